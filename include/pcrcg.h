@@ -1,0 +1,175 @@
+/* pcrcg.h -- C ABI of libpcrcg_hip.so, the MI355X (gfx950) implementation of PCR-CG's
+ * feature-extraction hot path.
+ *
+ * The reference has no C-level FFI for this path: its native boundary is two CPython extension
+ * modules (NumPy C-API glue) and, for the model, stock PyTorch ops.  Every entry point below names
+ * the reference interface it replaces; INTEGRATION.md shows the binding a maintainer of the
+ * reference would add (a ctypes stub, since the reference's host language is Python).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is a DEVICE pointer unless the parameter
+ *     name starts with `h_`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued on
+ *     it and nothing synchronises unless documented;
+ *   - no hidden allocation: scratch memory is a caller-provided workspace whose size comes from the
+ *     matching *_ws_bytes() query; workspaces may be reused across calls on the same stream;
+ *   - return value: PCRCG_OK (0) or a negative PCRCG_E* code; pcrcg_last_error() gives the
+ *     message of the calling thread's last failure;
+ *   - index tables use the reference's batched-neighbour contract: int64, row-major [Nq, cols],
+ *     shadow (padding) value == number of stacked support points (ref:neighbors.cpp:319-325).
+ */
+#ifndef PCRCG_H
+#define PCRCG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCRCG_OK 0
+#define PCRCG_EBADARG (-1)   /* null pointer / negative size / unsupported shape */
+#define PCRCG_EWORKSPACE (-2) /* workspace too small */
+#define PCRCG_ELAUNCH (-3)   /* HIP runtime error while enqueuing */
+#define PCRCG_ECAPACITY (-4) /* device-side capacity overflow reported by pcrcg_check_status */
+
+#define PCRCG_KPOINTS 15 /* kernel points per KPConv (ref:configs/test/indoor.yaml num_kernel_points) */
+
+const char* pcrcg_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int pcrcg_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Front end: grid subsampling
+ * Replaces cpp_wrappers.cpp_subsampling.grid_subsampling.subsample_batch(points, batches,
+ * sampleDl=, max_p=) (zip:cpp_subsampling/wrapper.cpp:62-330) whose core is batch_grid_subsampling
+ * (zip:cpp_subsampling/grid_subsampling/grid_subsampling.cpp:109-211).
+ *   pts      [n,3] f32 stacked clouds           len      [nb] i32 points per cloud
+ *   out_pts  [n,3] f32 (capacity n rows)        out_len  [nb] i32 cells kept per cloud
+ *   out_m    [1]   i32 total rows written (= sum(out_len)); read it back after the stream drains
+ * Output rows are the cell barycentres in the exact order the reference emits them (libstdc++
+ * unordered_map iteration order per cloud), bit-identical in fp32.
+ * ---------------------------------------------------------------------------------------------- */
+size_t pcrcg_grid_subsample_ws_bytes(int n, int nb);
+int pcrcg_grid_subsample_batch(const float* pts, int n, const int* len, int nb, float dl, int max_p,
+                               float* out_pts, int* out_len, int* out_m, void* ws, size_t ws_bytes,
+                               void* stream);
+
+/* Iteration order of a libstdc++ std::unordered_map<size_t,T> (identity hash) after inserting the
+ * m DISTINCT keys in order; order[j] = insertion rank of the j-th visited element.  This is the
+ * ordering step of the subsampling above, exported for unit tests
+ * (zip:.../grid_subsampling.cpp:48,59-61,85).  keys [m] u64, order [m] i32. */
+size_t pcrcg_umap_order_ws_bytes(int m);
+int pcrcg_umap_order(const uint64_t* keys, int m, int* order, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Front end: radius neighbours
+ * Replaces cpp_wrappers.cpp_neighbors.radius_neighbors.batch_query(queries, supports, q_batches,
+ * s_batches, radius=) (ref:cpp_wrappers/cpp_neighbors/wrapper.cpp:58-238) whose core is
+ * batch_nanoflann_neighbors (ref:cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:211-333), plus
+ * the `[:, :max_neighbors]` truncation and `.long()` cast of batch_neighbors_kpconv
+ * (ref:datasets/dataloader.py:54-69, 347-349).
+ *
+ * The search structure (a hashed uniform cell grid over the supports, cell edge = radius) is built
+ * once per support set and can serve several query sets of the same radius: in the KPConv pyramid
+ * the conv, pool and upsample searches over one level all use that level's radius
+ * (ref:datasets/dataloader.py:273,298,301).
+ *   sup [ns,3] f32, slen [nb] i32, grid = workspace of pcrcg_cellgrid_ws_bytes(ns, nb) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+size_t pcrcg_cellgrid_ws_bytes(int ns, int nb);
+int pcrcg_cellgrid_build(const float* sup, int ns, const int* slen, int nb, float radius, void* grid,
+                         size_t grid_bytes, void* stream);
+/*   q [nq,3] f32, qlen [nb] i32; out_idx [nq, cols] i64: row = supports with d2 < radius^2 (fp32,
+ *   unfused) in ascending (d2, index) order, truncated to `cols`, padded with ns;
+ *   out_count [nq] i32 (may be NULL) = untruncated list length per query;
+ *   out_max_count [1] i32 = max over queries (the reference's column count), accumulated with
+ *   atomicMax: zero it (or let pcrcg_radius_neighbors_batch do so) before the first query call;
+ *   status [1] i32 (may be NULL): set non-zero if a list exceeded the kernel's staging capacity. */
+int pcrcg_radius_query(const float* q, int nq, const int* qlen, int ns, const int* slen, int nb,
+                       float radius, const void* grid, int cols, int64_t* out_idx, int* out_count,
+                       int* out_max_count, int* status, void* stream);
+/* Convenience: zero out_max_count/status, build the grid in `ws`, run one query. */
+size_t pcrcg_radius_neighbors_ws_bytes(int ns, int nb);
+int pcrcg_radius_neighbors_batch(const float* q, int nq, const float* sup, int ns, const int* qlen,
+                                 const int* slen, int nb, float radius, int cols, int64_t* out_idx,
+                                 int* out_count, int* out_max_count, int* status, void* ws,
+                                 size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * KPConv (rigid, linear influence, sum aggregation) -- replaces KPConv.forward
+ * (ref:models/blocks.py:229-374):
+ *   out[q,:] = (1/n_q) * sum_k ( sum_h max(0, 1 - |s[idx[q,h]] - q_pts[q] - kp[k]| / extent)
+ *                                 * x[idx[q,h],:] ) @ W[k]
+ *   n_q = max(1, #{h : sum_c x[idx[q,h],c] > 0}); idx == ns addresses the shadow support
+ *   (point 1e6,1e6,1e6; feature 0).
+ * Stage 1 (this call) gathers and aggregates:  wf [nq, 15*cin] f32 (kernel-point major: column
+ * k*cin + c) and inv_n [nq] f32 = 1/n_q.  Stage 2 is the dense contraction wf @ W[15*cin, cout]
+ * scaled per row by inv_n (pcrcg_gemm_f32 with row_scale).
+ *   q_pts [nq,3], s_pts [ns,3], idx [nq, h] i64 (row stride ld_idx elements), x [ns, cin] f32,
+ *   kp [15,3] f32.
+ * ---------------------------------------------------------------------------------------------- */
+size_t pcrcg_kpconv_ws_bytes(int ns);
+int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx,
+                           int h, int ld_idx, const float* x, int cin, const float* kp, float extent,
+                           float* wf, float* inv_n, void* ws, size_t ws_bytes, void* stream);
+
+/* C[m,n] = (A[m,k] @ B[k,n]) * row_scale[m] + bias[n]   (fp32 in, fp32 MFMA accumulate; row_scale
+ * and bias may be NULL).  Row-major with leading dimensions in elements.  Replaces the
+ * torch.matmul / nn.Linear / 1x1 nn.Conv1d contractions of the path (ref:models/blocks.py:361-366,
+ * 487; ref:models/architectures.py:528,538-539). */
+int pcrcg_gemm_f32(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n,
+                   int k, const float* row_scale, const float* bias, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Point-wise blocks
+ * ---------------------------------------------------------------------------------------------- */
+/* max_pool (ref:models/blocks.py:86-102): out[q,c] = max_h xpad[idx[q,h],c], shadow row = 0. */
+int pcrcg_gather_max(const float* x, int ns, int c, const int64_t* idx, int nq, int h, int ld_idx,
+                     float* out, void* stream);
+/* closest_pool (ref:models/blocks.py:71-83): out[q,:] = xpad[idx[q,0],:]; writes into a row-major
+ * destination with leading dimension ld_out (so it can fill the left part of a concat buffer). */
+int pcrcg_gather_first(const float* x, int ns, int c, const int64_t* idx, int nq, int ld_idx, float* out,
+                       int ld_out, void* stream);
+/* InstanceNorm over all rows + LeakyReLU (BatchNormBlock/UnaryBlock/ResnetBottleneckBlock,
+ * ref:models/blocks.py:433-470, 493-500, 650-678):
+ *   stats[2*c] receives per-channel (mean, 1/sqrt(var+eps)) of x [n,c] (biased variance);
+ *   y = lrelu( (x - mean_x) * rstd_x + res_term, slope )
+ *   res_term = 0                                   if res == NULL
+ *            = res                                 if res_stats == NULL
+ *            = (res - mean_r) * rstd_r             otherwise (res_stats from a previous call)
+ * x, res, y are row-major with leading dimensions ldx, ldr, ldy.  slope 1.0 = no activation.
+ * ws: pcrcg_instnorm_ws_bytes(c) bytes. */
+size_t pcrcg_instnorm_ws_bytes(int c);
+int pcrcg_instnorm_stats(const float* x, int n, int c, int ldx, float eps, float* stats, void* ws,
+                         size_t ws_bytes, void* stream);
+int pcrcg_instnorm_apply(const float* x, int n, int c, int ldx, const float* stats, const float* res,
+                         int ldr, const float* res_stats, float slope, float* y, int ldy, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GNN head helpers (ref:models/gcn.py)
+ * ---------------------------------------------------------------------------------------------- */
+/* get_graph_feature's kNN (ref:models/gcn.py:15-34,48-51): dist = -2ab + a^2 + b^2 clamped at 1e-12,
+ * the k+1 smallest by (dist, index), first dropped.  coords [n,3] f32 -> idx [n,k] i32. */
+int pcrcg_knn(const float* coords, int n, int k, int* idx, void* stream);
+/* DGCNN edge conv after splitting the 1x1 conv over cat(f_i, f_j - f_i) into a centre term and a
+ * neighbour term (ref:models/gcn.py:61-62,123-129):  e[i,j,c] = ctr[i,c] + nbr[idx[i,j],c];
+ *   emax[i,c] = max_j e[i,j,c];  stats[2*c] = (mean, rstd) of e over all (i,j) (InstanceNorm2d).
+ * The caller finishes with pcrcg_instnorm_apply(emax, stats, slope 0.2) -- max commutes with the
+ * monotone normalise + LeakyReLU.  ctr/nbr/emax row-major [n,c] with leading dims. */
+size_t pcrcg_edgeconv_ws_bytes(int c);
+int pcrcg_edgeconv_reduce(const float* ctr, int ld_ctr, const float* nbr, int ld_nbr, const int* idx,
+                          int n, int k, int c, float eps, float* emax, int ld_emax, float* stats,
+                          void* ws, size_t ws_bytes, void* stream);
+/* Row softmax in place: x [rows, cols] (ld), x = softmax(x * scale) (ref:models/gcn.py:151-155,
+ * ref:models/architectures.py:562-563). */
+int pcrcg_softmax_rows(float* x, int rows, int cols, int ld, float scale, void* stream);
+
+/* Copy a device status word to the host after draining `stream`; returns PCRCG_ECAPACITY if it is
+ * non-zero. */
+int pcrcg_check_status(const int* status, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCRCG_H */

@@ -1,0 +1,73 @@
+"""ctypes binding of libpcrcg_hip.so (the C ABI declared in include/pcrcg.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.  The
+product path never imports anything from ``oracle/``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcrcg_hip.so")
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pcrcg.h one to one
+SIGNATURES = {
+    "pcrcg_last_error": (ctypes.c_char_p, []),
+    "pcrcg_abi_version": (c_int, []),
+    "pcrcg_check_status": (c_int, [c_void_p, c_void_p]),
+    "pcrcg_grid_subsample_ws_bytes": (c_size_t, [c_int, c_int]),
+    "pcrcg_grid_subsample_batch": (c_int, [c_void_p, c_int, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_umap_order_ws_bytes": (c_size_t, [c_int]),
+    "pcrcg_umap_order": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_cellgrid_ws_bytes": (c_size_t, [c_int, c_int]),
+    "pcrcg_cellgrid_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_radius_query": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcrcg_radius_neighbors_ws_bytes": (c_size_t, [c_int, c_int]),
+    "pcrcg_radius_neighbors_batch": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float,
+                                             c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                             c_void_p]),
+    "pcrcg_kpconv_ws_bytes": (c_size_t, [c_int]),
+    "pcrcg_kpconv_aggregate": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                       c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                               c_void_p, c_void_p]),
+    "pcrcg_gather_max": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pcrcg_gather_first": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "pcrcg_instnorm_ws_bytes": (c_size_t, [c_int]),
+    "pcrcg_instnorm_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_instnorm_apply": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float,
+                                     c_void_p, c_int, c_void_p]),
+    "pcrcg_knn": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "pcrcg_edgeconv_ws_bytes": (c_size_t, [c_int]),
+    "pcrcg_edgeconv_reduce": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float,
+                                      c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_softmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libpcrcg_hip.so once; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C pcrcg_amd/csrc` "
+                "(or __graft_entry__.build()).  pcrcg_amd has no CPU or PyTorch fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().pcrcg_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

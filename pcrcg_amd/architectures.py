@@ -1,0 +1,146 @@
+"""KPFCNN on the MI355X -- host-side mirror of ref:models/architectures.py:37-174 (constructor) and
+:181-191, :516-610 (forward, geometry-only branch).  Same constructor argument, same forward
+signature and result dict, same state_dict keys and shapes; the forward pass runs in the HIP kernels
+behind pcrcg_amd.ops."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .blocks import block_decider
+from .config import as_config
+from .gcn import GCN
+
+
+class KPFCNN(nn.Module):
+
+    def __init__(self, config):
+        super().__init__()
+        config = as_config(config)
+        if config.get("image_feature", False) or config.get("node_overlap", False) or config.get("quaternion", False):
+            raise NotImplementedError("pcrcg_amd.KPFCNN: the 2-D image branch and the node-overlap / quaternion "
+                                      "heads are outside the accelerated path (SURVEY.md 8f)")
+        layer = 0
+        r = config.first_subsampling_dl * config.conv_radius
+        in_dim = config.in_feats_dim
+        out_dim = config.first_feats_dim
+        self.K = config.num_kernel_points
+        self.epsilon = torch.nn.Parameter(torch.tensor(-5.0))
+        self.final_feats_dim = config.final_feats_dim
+
+        # encoder (:58-100)
+        self.encoder_blocks = nn.ModuleList()
+        self.encoder_skip_dims = []
+        self.encoder_skips = []
+        for block_i, block in enumerate(config.architecture):
+            if ("equivariant" in block) and (not out_dim % 3 == 0):
+                raise ValueError("Equivariant block but features dimension is not a factor of 3")
+            if np.any([tmp in block for tmp in ["pool", "strided", "upsample", "global"]]):
+                self.encoder_skips.append(block_i)
+                self.encoder_skip_dims.append(in_dim)
+            if "upsample" in block:
+                break
+            self.encoder_blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
+            in_dim = out_dim // 2 if "simple" in block else out_dim
+            if "pool" in block or "strided" in block:
+                layer += 1
+                r *= 2
+                out_dim *= 2
+
+        # bottleneck + GNN (:102-111)
+        gnn_feats_dim = config.gnn_feats_dim
+        self.bottle = nn.Conv1d(in_dim, gnn_feats_dim, kernel_size=1, bias=True)
+        self.gnn = GCN(config.num_head, gnn_feats_dim, config.dgcnn_k, config.nets)
+        self.proj_gnn = nn.Conv1d(gnn_feats_dim, gnn_feats_dim, kernel_size=1, bias=True)
+        self.proj_score = nn.Conv1d(gnn_feats_dim, 1, kernel_size=1, bias=True)
+
+        # decoder (:113-153)
+        out_dim = gnn_feats_dim + 2
+        self.decoder_blocks = nn.ModuleList()
+        self.decoder_concats = []
+        start_i = 0
+        for block_i, block in enumerate(config.architecture):
+            if "upsample" in block:
+                start_i = block_i
+                break
+        for block_i, block in enumerate(config.architecture[start_i:]):
+            if block_i > 0 and "upsample" in config.architecture[start_i + block_i - 1]:
+                in_dim += self.encoder_skip_dims[layer]
+                self.decoder_concats.append(block_i)
+            self.decoder_blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
+            in_dim = out_dim
+            if "upsample" in block:
+                layer -= 1
+                r *= 0.5
+                out_dim = out_dim // 2
+        self._eps_cache = None
+
+    def regular_score(self, score):
+        """ref:models/architectures.py:176-179."""
+        score = torch.where(torch.isnan(score), torch.zeros_like(score), score)
+        score = torch.where(torch.isinf(score), torch.zeros_like(score), score)
+        return score
+
+    def _temperature(self):
+        key = (self.epsilon._version, self.epsilon.data_ptr())
+        if self._eps_cache is None or self._eps_cache[0] != key:
+            self._eps_cache = (key, float(torch.exp(self.epsilon.detach()).item()) + 0.03)
+        return self._eps_cache[1]
+
+    @staticmethod
+    def _conv1x1(layer, x):
+        return ops.gemm(x, layer.weight.data.squeeze(-1).t(), bias=layer.bias.data)
+
+    def forward(self, batch, backbone2d=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("pcrcg_amd.KPFCNN: forward-only in this round -- call under torch.no_grad()")
+        x = batch["features"].clone().detach()                                   # :183
+        if "stack_lengths_host" in batch:
+            len_src_c = int(batch["stack_lengths_host"][-1][0])
+        else:
+            len_src_c = int(batch["stack_lengths"][-1][0])                       # :187
+        pcd_c = batch["points"][-1]
+        src_pcd_c, tgt_pcd_c = pcd_c[:len_src_c], pcd_c[len_src_c:]
+
+        # 1. joint encoder (:519-524)
+        skip_x = []
+        for block_i, block_op in enumerate(self.encoder_blocks):
+            if block_i in self.encoder_skips:
+                skip_x.append(x)
+            x = block_op(x, batch)
+
+        # 2. bottleneck projection (:527-528), row-major [N, C]
+        feats_c = self._conv1x1(self.bottle, x)
+
+        # 3. GNN (:532-536)
+        src_f, tgt_f = self.gnn(src_pcd_c, tgt_pcd_c, feats_c[:len_src_c], feats_c[len_src_c:])
+        feats_c = torch.cat([src_f, tgt_f], 0)
+        feats_c = self._conv1x1(self.proj_gnn, feats_c)                          # :538
+        scores_c = self._conv1x1(self.proj_score, feats_c)                       # :539  [N, 1]
+        feats_norm = F.normalize(feats_c, p=2, dim=1)                            # :541
+
+        # 4. cross-cloud saliency (:556-565)
+        src_n, tgt_n = feats_norm[:len_src_c], feats_norm[len_src_c:]
+        inv_t = 1.0 / self._temperature()
+        p_st = ops.softmax_rows_(ops.gemm(src_n, tgt_n.t().contiguous()), inv_t)
+        p_ts = ops.softmax_rows_(ops.gemm(tgt_n, src_n.t().contiguous()), inv_t)
+        s1 = ops.gemm(p_st, scores_c[len_src_c:])
+        s2 = ops.gemm(p_ts, scores_c[:len_src_c])
+        x = torch.cat([scores_c, torch.cat([s1, s2], 0), feats_c], 1)
+
+        # decoder (:567-570)
+        for block_i, block_op in enumerate(self.decoder_blocks):
+            if block_i in self.decoder_concats:
+                x = torch.cat([x, skip_x.pop()], 1)
+            x = block_op(x, batch)
+        fd = self.final_feats_dim
+        feats_f = x[:, :fd]
+        scores_overlap = x[:, fd]
+        scores_saliency = x[:, fd + 1]
+        scores_overlap = torch.clamp(torch.sigmoid(scores_overlap.view(-1)), min=0, max=1)     # :576-577
+        scores_saliency = torch.clamp(torch.sigmoid(scores_saliency.view(-1)), min=0, max=1)
+        scores_overlap = self.regular_score(scores_overlap)
+        scores_saliency = self.regular_score(scores_saliency)
+        feats_f = F.normalize(feats_f, p=2, dim=1)                                             # :582
+        return {"feats_f": feats_f, "scores_overlap": scores_overlap, "scores_saliency": scores_saliency}

@@ -1,0 +1,42 @@
+"""MI355X replacement for the reference extension module ``radius_neighbors``
+(ref:cpp_wrappers/cpp_neighbors/wrapper.cpp:25-29: method ``batch_query``)."""
+import torch
+
+from ... import ops
+from .._common import as_tensor, to_device
+
+_FIRST_GUESS_COLS = 128
+
+
+def batch_query(queries, supports, q_batches, s_batches, *, radius=0.1):
+    """-> int32 [Nq, max_count]: per query the supports of the same batch element within `radius`,
+    ascending distance, padded with the total support count
+    (ref:cpp_wrappers/cpp_neighbors/wrapper.cpp:58-238, neighbors.cpp:211-333).
+    numpy in -> numpy out; device tensors in -> device tensor out."""
+    q, was_numpy = as_tensor(queries, torch.float32, "Error converting query points to numpy arrays of type float32")
+    s, _ = as_tensor(supports, torch.float32, "Error converting support points to numpy arrays of type float32")
+    qb, _ = as_tensor(q_batches, torch.int32, "Error converting query batches to numpy arrays of type int32")
+    sb, _ = as_tensor(s_batches, torch.int32, "Error converting support batches to numpy arrays of type int32")
+    if q.dim() != 2 or q.shape[1] != 3:
+        raise RuntimeError("Wrong dimensions : query.shape is not (N, 3)")
+    if s.dim() != 2 or s.shape[1] != 3:
+        raise RuntimeError("Wrong dimensions : support.shape is not (N, 3)")
+    if qb.dim() > 1:
+        raise RuntimeError("Wrong dimensions : queries_batches.shape is not (B,) ")
+    if sb.dim() > 1:
+        raise RuntimeError("Wrong dimensions : supports_batches.shape is not (B,) ")
+    if qb.shape[0] != sb.shape[0]:
+        raise RuntimeError("Wrong number of batch elements: different for queries and supports ")
+    q, s, qb, sb = to_device(q), to_device(s), to_device(qb), to_device(sb)
+    grid = ops.CellGrid(s, sb, float(radius))
+    idx, meta = grid.query(q, qb, _FIRST_GUESS_COLS)
+    max_count, status = (int(v) for v in meta.tolist())
+    if max_count > _FIRST_GUESS_COLS and status == 0:
+        idx, meta = grid.query(q, qb, max_count)
+        max_count, status = (int(v) for v in meta.tolist())
+    if status != 0:
+        raise RuntimeError("pcrcg_amd: radius search capacity exceeded (status %d)" % status)
+    if q.shape[0] * max_count < 1:  # wrapper.cpp:201-205
+        raise RuntimeError("Error")
+    out = idx[:, :max_count].to(torch.int32)
+    return out.cpu().numpy() if was_numpy else out.contiguous()

@@ -1,0 +1,75 @@
+// common.h -- shared host-side helpers of libpcrcg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "pcrcg.h"
+
+namespace pcrcg {
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Bump allocator over the caller's workspace; every carve is 256-byte aligned.
+struct Carver {
+    char* base;
+    size_t cap;
+    size_t off = 0;
+    Carver(void* ws, size_t bytes) : base(static_cast<char*>(ws)), cap(bytes) {}
+    template <typename T>
+    T* take(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+        T* p = reinterpret_cast<T*>(base + off);
+        off += bytes;
+        return p;
+    }
+    bool ok() const { return off <= cap; }
+};
+inline size_t carve_bytes(size_t count, size_t elem) { return (count * elem + 255) & ~size_t(255); }
+
+// Exclusive prefix sum of int32 (device-wide, any n >= 0).  out may alias in.  If total != nullptr
+// the grand total is stored there.  ws: scan_ws_bytes(n).
+size_t scan_ws_bytes(int n);
+int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hipStream_t stream);
+
+constexpr int kWave = 64;
+
+}  // namespace pcrcg
+
+#define PCRCG_CHECK_ARG(cond)                                                        \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            pcrcg::set_error("%s: bad argument: %s", __func__, #cond);               \
+            return PCRCG_EBADARG;                                                    \
+        }                                                                            \
+    } while (0)
+
+#define PCRCG_CHECK_WS(carver)                                                                     \
+    do {                                                                                           \
+        if (!(carver).ok()) {                                                                      \
+            pcrcg::set_error("%s: workspace too small (%zu needed, %zu given)", __func__,          \
+                             (carver).off, (carver).cap);                                          \
+            return PCRCG_EWORKSPACE;                                                               \
+        }                                                                                          \
+    } while (0)
+
+#define PCRCG_CHECK_HIP(expr)                                                                  \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            pcrcg::set_error("%s: %s failed: %s", __func__, #expr, hipGetErrorString(e_));     \
+            return PCRCG_ELAUNCH;                                                              \
+        }                                                                                      \
+    } while (0)
+
+#define PCRCG_CHECK_LAUNCH() PCRCG_CHECK_HIP(hipGetLastError())
+
+#define PCRCG_PROPAGATE(expr)      \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != PCRCG_OK) return rc_; \
+    } while (0)

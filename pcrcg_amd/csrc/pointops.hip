@@ -1,0 +1,202 @@
+// pointops.hip -- HBM-bound point-wise blocks of the KPConv encoder/decoder on gfx950:
+//   gather-max pooling      (max_pool,      ref:models/blocks.py:86-102)
+//   nearest upsampling      (closest_pool,  ref:models/blocks.py:71-83)
+//   InstanceNorm over all stacked points + LeakyReLU (+ residual)
+//                           (BatchNormBlock/UnaryBlock/ResnetBottleneckBlock, ref:models/blocks.py:433-470,
+//                            493-500, 650-678)
+// Every kernel keeps channels on the fastest-moving lanes so that a wavefront reads and writes
+// contiguous 256-byte (float) or 1-KiB (float4) segments of a feature row.
+#include "common.h"
+
+namespace pcrcg {
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+
+// one wavefront per query row, lanes over channels (float4 when the row allows it)
+template <bool VEC4>
+__global__ void __launch_bounds__(kWavesPerBlock * 64) k_gather_max(const float* __restrict__ x, int ns, int c,
+                                                                     const long long* __restrict__ idx, int nq, int h,
+                                                                     int ld_idx, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const long long* row = idx + (long)q * ld_idx;
+    if (VEC4) {
+        const int c4 = c >> 2;
+        for (int cb = lane; cb < c4; cb += 64) {
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool any = false;
+            for (int j = 0; j < h; ++j) {
+                const long long i = row[j];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);   // shadow row = zeros  (:95)
+                if (i >= 0 && i < ns) v = reinterpret_cast<const float4*>(x + i * c)[cb];
+                if (!any) { m = v; any = true; }
+                else { m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
+            }
+            reinterpret_cast<float4*>(out + (long)q * c)[cb] = m;
+        }
+    } else {
+        for (int cc = lane; cc < c; cc += 64) {
+            float m = 0.f;
+            bool any = false;
+            for (int j = 0; j < h; ++j) {
+                const long long i = row[j];
+                const float v = (i >= 0 && i < ns) ? x[i * c + cc] : 0.f;
+                m = any ? fmaxf(m, v) : v;
+                any = true;
+            }
+            out[(long)q * c + cc] = m;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gather_first(const float* __restrict__ x, int ns, int c,
+                                                       const long long* __restrict__ idx, int nq, int ld_idx,
+                                                       float* __restrict__ out, int ld_out) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const long long i = idx[(long)q * ld_idx];
+    const bool real = i >= 0 && i < ns;
+    for (int cc = lane; cc < c; cc += 64) out[(long)q * ld_out + cc] = real ? x[i * c + cc] : 0.f;
+}
+
+// ---- InstanceNorm statistics: deterministic two-stage column reduction in fp64 -----------------
+constexpr int kStatChunks = 128;   // row chunks (= partial sums per channel)
+
+__global__ void __launch_bounds__(256) k_colstats_partial(const float* __restrict__ x, int n, int c, int ldx,
+                                                           double* __restrict__ partial /* [chunks][2][c] */) {
+    __shared__ double s_sum[4][64], s_sq[4][64];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int ch = blockIdx.y * 64 + lane;
+    const int chunk = blockIdx.x, nchunks = gridDim.x;
+    const long rows_per = ((long)n + nchunks - 1) / nchunks;
+    const long r0 = chunk * rows_per, r1 = min((long)n, r0 + rows_per);
+    double s = 0.0, sq = 0.0;
+    if (ch < c)
+        for (long r = r0 + rl; r < r1; r += 4) {
+            const double v = (double)x[r * ldx + ch];
+            s += v;
+            sq += v * v;
+        }
+    s_sum[rl][lane] = s;
+    s_sq[rl][lane] = sq;
+    __syncthreads();
+    if (rl == 0 && ch < c) {
+        s = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
+        sq = (s_sq[0][lane] + s_sq[1][lane]) + (s_sq[2][lane] + s_sq[3][lane]);
+        partial[((long)chunk * 2 + 0) * c + ch] = s;
+        partial[((long)chunk * 2 + 1) * c + ch] = sq;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_colstats_final(const double* __restrict__ partial, int nchunks, int c,
+                                                         double count, float eps, float* __restrict__ stats) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0, sq = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+        s += partial[((long)k * 2 + 0) * c + ch];
+        sq += partial[((long)k * 2 + 1) * c + ch];
+    }
+    const double mean = s / count;
+    double var = sq / count - mean * mean;   // biased variance (InstanceNorm)
+    if (var < 0.0) var = 0.0;
+    stats[2 * ch] = (float)mean;
+    stats[2 * ch + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ void __launch_bounds__(256) k_instnorm_apply(const float* __restrict__ x, int n, int c, int ldx,
+                                                         const float* __restrict__ stats, const float* __restrict__ res,
+                                                         int ldr, const float* __restrict__ res_stats, float slope,
+                                                         float* __restrict__ y, int ldy) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)n * c) return;
+    const long r = e / c;
+    const int ch = (int)(e - r * c);
+    float v = (x[r * ldx + ch] - stats[2 * ch]) * stats[2 * ch + 1];
+    if (res) {
+        float rv = res[r * ldr + ch];
+        if (res_stats) rv = (rv - res_stats[2 * ch]) * res_stats[2 * ch + 1];
+        v += rv;
+    }
+    y[r * ldy + ch] = v >= 0.f ? v : v * slope;
+}
+
+}  // namespace
+
+size_t colstats_ws_bytes(int c) { return carve_bytes((size_t)kStatChunks * 2 * (size_t)(c > 0 ? c : 1), sizeof(double)); }
+
+// shared with gnn.hip: finish a [chunks][2][c] fp64 partial buffer into (mean, rstd) pairs
+int colstats_finalize(const double* partial, int nchunks, int c, double count, float eps, float* stats,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(k_colstats_final, dim3((c + 255) / 256), dim3(256), 0, st, partial, nchunks, c, count, eps,
+                       stats);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+int colstats_chunks() { return kStatChunks; }
+
+}  // namespace pcrcg
+
+using namespace pcrcg;
+
+extern "C" {
+
+int pcrcg_gather_max(const float* x, int ns, int c, const int64_t* idx, int nq, int h, int ld_idx,
+                     float* out, void* stream) {
+    PCRCG_CHECK_ARG(ns >= 0 && c >= 1 && nq >= 0 && h >= 1 && ld_idx >= h);
+    if (nq == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(x && idx && out);
+    const long long* idx_ll = reinterpret_cast<const long long*>(idx);
+    const int blocks = (nq + kWavesPerBlock - 1) / kWavesPerBlock;
+    const bool vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(k_gather_max<true>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, as_stream(stream), x, ns, c,
+                           idx_ll, nq, h, ld_idx, out);
+    else
+        hipLaunchKernelGGL(k_gather_max<false>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, as_stream(stream), x, ns,
+                           c, idx_ll, nq, h, ld_idx, out);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+int pcrcg_gather_first(const float* x, int ns, int c, const int64_t* idx, int nq, int ld_idx, float* out,
+                       int ld_out, void* stream) {
+    PCRCG_CHECK_ARG(ns >= 0 && c >= 1 && nq >= 0 && ld_idx >= 1 && ld_out >= c);
+    if (nq == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(x && idx && out);
+    hipLaunchKernelGGL(k_gather_first, dim3((nq + 3) / 4), dim3(256), 0, as_stream(stream), x, ns, c,
+                       reinterpret_cast<const long long*>(idx), nq, ld_idx, out, ld_out);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+size_t pcrcg_instnorm_ws_bytes(int c) { return colstats_ws_bytes(c); }
+
+int pcrcg_instnorm_stats(const float* x, int n, int c, int ldx, float eps, float* stats, void* ws,
+                         size_t ws_bytes, void* stream) {
+    PCRCG_CHECK_ARG(n >= 1 && c >= 1 && ldx >= c && x && stats && ws);
+    Carver cv(ws, ws_bytes);
+    double* partial = cv.take<double>((size_t)kStatChunks * 2 * c);
+    PCRCG_CHECK_WS(cv);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(k_colstats_partial, dim3(kStatChunks, (c + 63) / 64), dim3(256), 0, st, x, n, c, ldx, partial);
+    return colstats_finalize(partial, kStatChunks, c, (double)n, eps, stats, st);
+}
+
+int pcrcg_instnorm_apply(const float* x, int n, int c, int ldx, const float* stats, const float* res,
+                         int ldr, const float* res_stats, float slope, float* y, int ldy, void* stream) {
+    PCRCG_CHECK_ARG(n >= 0 && c >= 1 && ldx >= c && ldy >= c);
+    if (n == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(x && stats && y);
+    PCRCG_CHECK_ARG(!res || ldr >= c);
+    const long total = (long)n * c;
+    hipLaunchKernelGGL(k_instnorm_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), x, n,
+                       c, ldx, stats, res, ldr, res_stats, slope, y, ldy);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+}

@@ -1,0 +1,152 @@
+// scan.hip -- library plumbing: error string, status check and a device-wide int32 exclusive scan.
+#include <cstring>
+
+#include "common.h"
+
+namespace pcrcg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;                            // consecutive items per thread
+constexpr int kScanTile = kScanThreads * kScanItems;     // items per block
+
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Exclusive scan of one value per thread across a block of kScanThreads; returns the exclusive
+// prefix and stores the block total in *total (valid in all threads).
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* smem /* [kScanThreads/64 + 1] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = wave_inclusive_scan(v, lane);
+    if (lane == 63) smem[wave] = inc;
+    __syncthreads();
+    int wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) {
+        int s = smem[w];
+        if (w < wave) wave_off += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return wave_off + inc - v;
+}
+
+__global__ void __launch_bounds__(kScanThreads) scan_tile_sums(const int* __restrict__ in, int n,
+                                                                int* __restrict__ partial) {
+    __shared__ int smem[kScanThreads / 64 + 1];
+    const long base = (long)blockIdx.x * kScanTile + (long)threadIdx.x * kScanItems;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i)
+        if (base + i < n) s += in[base + i];
+    int tot;
+    block_exclusive_scan(s, &tot, smem);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// One block scans the tile sums in place (looping with a carry) and publishes the grand total.
+__global__ void __launch_bounds__(kScanThreads) scan_partials(int* __restrict__ partial, int nt,
+                                                               int* __restrict__ total) {
+    __shared__ int smem[kScanThreads / 64 + 1];
+    int carry = 0;
+    for (int base = 0; base < nt; base += kScanThreads) {
+        int i = base + threadIdx.x;
+        int v = i < nt ? partial[i] : 0;
+        int tot;
+        int ex = block_exclusive_scan(v, &tot, smem);
+        if (i < nt) partial[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+
+__global__ void __launch_bounds__(kScanThreads) scan_apply(const int* in, int* out,
+                                                            int n, const int* __restrict__ partial,
+                                                            int* __restrict__ total_single) {
+    __shared__ int smem[kScanThreads / 64 + 1];
+    const long base = (long)blockIdx.x * kScanTile + (long)threadIdx.x * kScanItems;
+    int v[kScanItems];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        v[i] = base + i < n ? in[base + i] : 0;
+        s += v[i];
+    }
+    int tot;
+    int ex = block_exclusive_scan(s, &tot, smem) + (partial ? partial[blockIdx.x] : 0);
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        if (base + i < n) out[base + i] = ex;
+        ex += v[i];
+    }
+    if (total_single && threadIdx.x == 0) *total_single = tot;  // single-tile case only
+}
+
+__global__ void zero_int(int* p) { *p = 0; }
+
+}  // namespace
+
+size_t scan_ws_bytes(int n) {
+    int nt = n > 0 ? (n + kScanTile - 1) / kScanTile : 1;
+    return carve_bytes((size_t)nt, sizeof(int));
+}
+
+int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hipStream_t stream) {
+    if (n <= 0) {
+        if (total) hipLaunchKernelGGL(zero_int, dim3(1), dim3(1), 0, stream, total);
+        PCRCG_CHECK_LAUNCH();
+        return PCRCG_OK;
+    }
+    const int nt = (n + kScanTile - 1) / kScanTile;
+    if (nt == 1) {
+        hipLaunchKernelGGL(scan_apply, dim3(1), dim3(kScanThreads), 0, stream, in, out, n,
+                           (const int*)nullptr, total);
+        PCRCG_CHECK_LAUNCH();
+        return PCRCG_OK;
+    }
+    int* partial = static_cast<int*>(ws);
+    hipLaunchKernelGGL(scan_tile_sums, dim3(nt), dim3(kScanThreads), 0, stream, in, n, partial);
+    hipLaunchKernelGGL(scan_partials, dim3(1), dim3(kScanThreads), 0, stream, partial, nt, total);
+    hipLaunchKernelGGL(scan_apply, dim3(nt), dim3(kScanThreads), 0, stream, in, out, n,
+                       (const int*)partial, (int*)nullptr);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+}  // namespace pcrcg
+
+extern "C" {
+
+const char* pcrcg_last_error(void) { return pcrcg::g_err; }
+
+int pcrcg_abi_version(void) { return 1; }
+
+int pcrcg_check_status(const int* status, void* stream) {
+    PCRCG_CHECK_ARG(status != nullptr);
+    int h = 0;
+    PCRCG_CHECK_HIP(hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, pcrcg::as_stream(stream)));
+    PCRCG_CHECK_HIP(hipStreamSynchronize(pcrcg::as_stream(stream)));
+    if (h != 0) {
+        pcrcg::set_error("device status word = %d (capacity overflow)", h);
+        return PCRCG_ECAPACITY;
+    }
+    return PCRCG_OK;
+}
+}

@@ -1,0 +1,277 @@
+"""Tensor-level wrappers over the C ABI (include/pcrcg.h).  PyTorch is used only for device memory
+and streams; every computation below runs in the hand-written HIP kernels of libpcrcg_hip.so.
+All tensors must live on a HIP device -- there is no CPU path."""
+import torch
+
+from . import _lib
+
+_F32, _I32, _I64 = torch.float32, torch.int32, torch.int64
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"pcrcg_amd: `{name}` must be a tensor on a HIP device (no CPU fallback exists)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"pcrcg_amd: `{name}` must have dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def _rows(t, dtype, name):
+    """2-D tensor with unit inner stride; returns (tensor, leading dimension in elements)."""
+    _dev(t, dtype, name)
+    if t.dim() != 2:
+        raise RuntimeError(f"pcrcg_amd: `{name}` must be 2-D")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else t.shape[1]
+    if ld < t.shape[1]:  # e.g. an expanded (stride-0) tensor
+        t = t.contiguous()
+        ld = t.shape[1]
+    return t, max(ld, 1)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class _Workspaces:
+    """Grow-only scratch buffers keyed by (device, stream, tag): stream-ordered reuse is safe."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, tag, nbytes, device):
+        key = (device.index, _stream(), tag)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        return buf
+
+
+_ws = _Workspaces()
+
+
+# ------------------------------------------------------------------------------------------------
+# front end
+# ------------------------------------------------------------------------------------------------
+def grid_subsample(points, lengths, dl, max_p=0):
+    """batch_grid_subsampling on device.  points [N,3] f32, lengths [B] i32 ->
+    (sub_points [M,3] f32, sub_lengths [B] i32).  One host sync (to learn M)."""
+    L = _lib.lib()
+    points = _dev(points, _F32, "points").contiguous()
+    lengths = _dev(lengths, _I32, "lengths").contiguous()
+    n, nb = points.shape[0], lengths.shape[0]
+    out = torch.empty((max(n, 1), 3), dtype=_F32, device=points.device)
+    out_len = torch.empty(nb, dtype=_I32, device=points.device)
+    out_m = torch.zeros(1, dtype=_I32, device=points.device)
+    nbytes = L.pcrcg_grid_subsample_ws_bytes(n, nb)
+    ws = _ws.get("subsample", nbytes, points.device)
+    _lib.check(L.pcrcg_grid_subsample_batch(points.data_ptr(), n, lengths.data_ptr(), nb, float(dl), int(max_p),
+                                            out.data_ptr(), out_len.data_ptr(), out_m.data_ptr(), ws.data_ptr(),
+                                            nbytes, _stream()), "pcrcg_grid_subsample_batch")
+    m = int(out_m.item())
+    return out[:m], out_len
+
+
+def umap_order(keys):
+    """libstdc++ unordered_map iteration order of distinct uint64 keys (given as int64 bit patterns)."""
+    L = _lib.lib()
+    keys = _dev(keys, _I64, "keys").contiguous()
+    m = keys.shape[0]
+    order = torch.empty(m, dtype=_I32, device=keys.device)
+    nbytes = L.pcrcg_umap_order_ws_bytes(m)
+    ws = _ws.get("umap", nbytes, keys.device)
+    _lib.check(L.pcrcg_umap_order(keys.data_ptr(), m, order.data_ptr(), ws.data_ptr(), nbytes, _stream()),
+               "pcrcg_umap_order")
+    return order
+
+
+class CellGrid:
+    """Hashed uniform cell grid over one level's supports; serves every query set of that radius."""
+
+    def __init__(self, supports, lengths, radius):
+        L = _lib.lib()
+        self.supports = _dev(supports, _F32, "supports").contiguous()
+        self.lengths = _dev(lengths, _I32, "s_batches").contiguous()
+        self.radius = float(radius)
+        self.ns, self.nb = self.supports.shape[0], self.lengths.shape[0]
+        self.nbytes = L.pcrcg_cellgrid_ws_bytes(self.ns, self.nb)
+        self.grid = torch.empty(self.nbytes, dtype=torch.uint8, device=self.supports.device)
+        _lib.check(L.pcrcg_cellgrid_build(self.supports.data_ptr(), self.ns, self.lengths.data_ptr(), self.nb,
+                                          self.radius, self.grid.data_ptr(), self.nbytes, _stream()),
+                   "pcrcg_cellgrid_build")
+
+    def query(self, queries, q_lengths, cols, want_counts=False):
+        """-> (idx [Nq, cols] i64, max_count [1] i32 device, status [1] i32 device[, counts [Nq] i32])."""
+        L = _lib.lib()
+        queries = _dev(queries, _F32, "queries").contiguous()
+        q_lengths = _dev(q_lengths, _I32, "q_batches").contiguous()
+        if q_lengths.shape[0] != self.nb:
+            raise RuntimeError("Wrong number of batch elements: different for queries and supports ")
+        nq = queries.shape[0]
+        idx = torch.empty((nq, int(cols)), dtype=_I64, device=queries.device)
+        meta = torch.zeros(2, dtype=_I32, device=queries.device)  # [max_count, status]
+        counts = torch.empty(nq, dtype=_I32, device=queries.device) if want_counts else None
+        _lib.check(L.pcrcg_radius_query(queries.data_ptr(), nq, q_lengths.data_ptr(), self.ns,
+                                        self.lengths.data_ptr(), self.nb, self.radius, self.grid.data_ptr(),
+                                        int(cols), idx.data_ptr(), _ptr(counts), meta[0:1].data_ptr(),
+                                        meta[1:2].data_ptr(), _stream()), "pcrcg_radius_query")
+        if want_counts:
+            return idx, meta, counts
+        return idx, meta
+
+
+# ------------------------------------------------------------------------------------------------
+# model kernels
+# ------------------------------------------------------------------------------------------------
+def gemm(a, b, row_scale=None, bias=None, out=None):
+    """out[m,n] = (a[m,k] @ b[k,n]) * row_scale[m] + bias[n] on the fp32 matrix cores."""
+    L = _lib.lib()
+    a, lda = _rows(a, _F32, "a")
+    b, ldb = _rows(b, _F32, "b")
+    m, k = a.shape
+    k2, n = b.shape
+    if k != k2:
+        raise RuntimeError(f"pcrcg_amd.gemm: inner dimensions differ ({k} vs {k2})")
+    if out is None:
+        out = torch.empty((m, n), dtype=_F32, device=a.device)
+    out_, ldc = _rows(out, _F32, "out")
+    if out_.data_ptr() != out.data_ptr():
+        raise RuntimeError("pcrcg_amd.gemm: `out` must have unit inner stride")
+    if row_scale is not None:
+        row_scale = _dev(row_scale, _F32, "row_scale").contiguous()
+    if bias is not None:
+        bias = _dev(bias, _F32, "bias").contiguous()
+    _lib.check(L.pcrcg_gemm_f32(a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), ldc, m, n, k,
+                                _ptr(row_scale), _ptr(bias), _stream()), "pcrcg_gemm_f32")
+    return out
+
+
+def kpconv(q_pts, s_pts, idx, x, kernel_points, weights, extent):
+    """KPConv.forward (rigid / linear / sum): aggregate kernel + MFMA contraction with 1/n row scale.
+    weights: [15, cin, cout] as stored in the reference state_dict."""
+    L = _lib.lib()
+    q_pts = _dev(q_pts, _F32, "q_pts").contiguous()
+    s_pts = _dev(s_pts, _F32, "s_pts").contiguous()
+    idx, ld_idx = _rows(idx, _I64, "neighb_inds")
+    x = _dev(x, _F32, "x").contiguous()
+    kp = _dev(kernel_points, _F32, "kernel_points").contiguous()
+    nq, h = idx.shape
+    ns, cin = x.shape
+    kdim = kp.shape[0]
+    if kdim != 15:
+        raise RuntimeError("pcrcg_amd.kpconv: only 15 kernel points are supported")
+    wf = torch.empty((nq, kdim * cin), dtype=_F32, device=x.device)
+    inv_n = torch.empty(nq, dtype=_F32, device=x.device)
+    nbytes = L.pcrcg_kpconv_ws_bytes(ns)
+    ws = _ws.get("kpconv", nbytes, x.device)
+    _lib.check(L.pcrcg_kpconv_aggregate(q_pts.data_ptr(), nq, s_pts.data_ptr(), ns, idx.data_ptr(), h, ld_idx,
+                                        x.data_ptr(), cin, kp.data_ptr(), float(extent), wf.data_ptr(),
+                                        inv_n.data_ptr(), ws.data_ptr(), nbytes, _stream()),
+               "pcrcg_kpconv_aggregate")
+    w2 = _dev(weights, _F32, "weights").reshape(kdim * cin, -1)
+    return gemm(wf, w2, row_scale=inv_n)
+
+
+def gather_max(x, idx):
+    L = _lib.lib()
+    x = _dev(x, _F32, "x").contiguous()
+    idx, ld_idx = _rows(idx, _I64, "inds")
+    ns, c = x.shape
+    nq, h = idx.shape
+    out = torch.empty((nq, c), dtype=_F32, device=x.device)
+    _lib.check(L.pcrcg_gather_max(x.data_ptr(), ns, c, idx.data_ptr(), nq, h, ld_idx, out.data_ptr(), _stream()),
+               "pcrcg_gather_max")
+    return out
+
+
+def gather_first(x, idx, out=None):
+    """closest_pool; `out` may be a column slice [nq, c] of a wider row-major buffer."""
+    L = _lib.lib()
+    x = _dev(x, _F32, "x").contiguous()
+    idx, ld_idx = _rows(idx, _I64, "inds")
+    ns, c = x.shape
+    nq = idx.shape[0]
+    if out is None:
+        out = torch.empty((nq, c), dtype=_F32, device=x.device)
+    ld_out = out.stride(0) if nq > 1 else max(c, out.stride(0))
+    if out.stride(1) != 1 and c > 1:
+        raise RuntimeError("pcrcg_amd.gather_first: `out` must have unit inner stride")
+    _lib.check(L.pcrcg_gather_first(x.data_ptr(), ns, c, idx.data_ptr(), nq, ld_idx, out.data_ptr(), ld_out,
+                                    _stream()), "pcrcg_gather_first")
+    return out
+
+
+def instnorm_stats(x, eps=1e-5):
+    L = _lib.lib()
+    x, ldx = _rows(x, _F32, "x")
+    n, c = x.shape
+    stats = torch.empty(2 * c, dtype=_F32, device=x.device)
+    nbytes = L.pcrcg_instnorm_ws_bytes(c)
+    ws = _ws.get("instnorm", nbytes, x.device)
+    _lib.check(L.pcrcg_instnorm_stats(x.data_ptr(), n, c, ldx, float(eps), stats.data_ptr(), ws.data_ptr(), nbytes,
+                                      _stream()), "pcrcg_instnorm_stats")
+    return stats
+
+
+def instnorm_apply(x, stats, slope=1.0, res=None, res_stats=None, out=None):
+    L = _lib.lib()
+    x, ldx = _rows(x, _F32, "x")
+    n, c = x.shape
+    ldr = 0
+    if res is not None:
+        res, ldr = _rows(res, _F32, "res")
+    if out is None:
+        out = torch.empty((n, c), dtype=_F32, device=x.device)
+    ldy = out.stride(0) if n > 1 else max(c, out.stride(0))
+    _lib.check(L.pcrcg_instnorm_apply(x.data_ptr(), n, c, ldx, stats.data_ptr(), _ptr(res), ldr, _ptr(res_stats),
+                                      float(slope), out.data_ptr(), ldy, _stream()), "pcrcg_instnorm_apply")
+    return out
+
+
+def instnorm_lrelu(x, slope, eps=1e-5):
+    """InstanceNorm over rows followed by LeakyReLU(slope); slope 1.0 = identity."""
+    return instnorm_apply(x, instnorm_stats(x, eps), slope)
+
+
+def knn(coords, k):
+    L = _lib.lib()
+    coords = _dev(coords, _F32, "coords").contiguous()
+    n = coords.shape[0]
+    idx = torch.empty((n, k), dtype=_I32, device=coords.device)
+    _lib.check(L.pcrcg_knn(coords.data_ptr(), n, int(k), idx.data_ptr(), _stream()), "pcrcg_knn")
+    return idx
+
+
+def edgeconv_reduce(ctr, nbr, idx, eps=1e-5):
+    """-> (emax [n,c], stats [2c]) for e[i,j,:] = ctr[i,:] + nbr[idx[i,j],:]."""
+    L = _lib.lib()
+    ctr, ld_ctr = _rows(ctr, _F32, "ctr")
+    nbr, ld_nbr = _rows(nbr, _F32, "nbr")
+    idx = _dev(idx, _I32, "idx").contiguous()
+    n, c = ctr.shape
+    k = idx.shape[1]
+    emax = torch.empty((n, c), dtype=_F32, device=ctr.device)
+    stats = torch.empty(2 * c, dtype=_F32, device=ctr.device)
+    nbytes = L.pcrcg_edgeconv_ws_bytes(c)
+    ws = _ws.get("edgeconv", nbytes, ctr.device)
+    _lib.check(L.pcrcg_edgeconv_reduce(ctr.data_ptr(), ld_ctr, nbr.data_ptr(), ld_nbr, idx.data_ptr(), n, k, c,
+                                       float(eps), emax.data_ptr(), c, stats.data_ptr(), ws.data_ptr(), nbytes,
+                                       _stream()), "pcrcg_edgeconv_reduce")
+    return emax, stats
+
+
+def softmax_rows_(x, scale=1.0):
+    """In-place softmax(x * scale) over the last dimension of a 2-D tensor."""
+    L = _lib.lib()
+    x_, ld = _rows(x, _F32, "x")
+    if x_.data_ptr() != x.data_ptr():
+        raise RuntimeError("pcrcg_amd.softmax_rows_: tensor must have unit inner stride")
+    _lib.check(L.pcrcg_softmax_rows(x.data_ptr(), x.shape[0], x.shape[1], ld, float(scale), _stream()),
+               "pcrcg_softmax_rows")
+    return x

@@ -1,0 +1,187 @@
+"""Point-pyramid builder on the MI355X: the device-resident counterpart of the reference's
+``collate_fn_descriptor`` (ref:datasets/dataloader.py:203-400), ``batch_grid_subsampling_kpconv``
+(:14-52), ``batch_neighbors_kpconv`` (:54-69) and ``calibrate_neighbors`` (:402-434).
+
+The reference runs this on the CPU inside DataLoader workers and ships ten index tables to the GPU;
+here the stacked cloud is uploaded once and every table is produced in HBM.  Per level the supports
+are binned once and the conv / pool / upsample searches reuse that grid (all three use the level's
+radius, :273,:298,:301)."""
+import numpy as np
+import torch
+
+from . import ops
+from .config import as_config
+
+_I32 = torch.int32
+
+
+def _layer_plan(config):
+    """Walk config.architecture like ref:datasets/dataloader.py:252-359 and return one entry per
+    pyramid level: (radius, has_conv, pooled, dl_next)."""
+    arch = config.architecture
+    r_normal = config.first_subsampling_dl * config.conv_radius
+    levels, layer_blocks = [], []
+    for i, block in enumerate(arch):
+        if "global" in block or "upsample" in block:
+            break
+        if not ("pool" in block or "strided" in block):
+            layer_blocks.append(block)
+            if i < len(arch) - 1 and "upsample" not in arch[i + 1]:
+                continue
+        deform_conv = any("deformable" in b for b in layer_blocks[:-1])
+        r_conv = r_normal * config.deform_radius / config.conv_radius if deform_conv else r_normal
+        pooled = "pool" in block or "strided" in block
+        r_pool = r_normal * config.deform_radius / config.conv_radius if "deformable" in block else r_normal
+        levels.append(dict(r_conv=r_conv, has_conv=bool(layer_blocks), pooled=pooled, r_pool=r_pool,
+                           dl=2 * r_normal / config.conv_radius))
+        r_normal *= 2
+        layer_blocks = []
+    return levels
+
+
+def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=False):
+    """points [N0,3] f32 and lengths [B] i32 on the device -> the reference's batch dict
+    (ref:datasets/dataloader.py:363-380) restricted to the keys KPFCNN.forward reads, all on the
+    device: points, neighbors, pools, upsamples (int64, shadow = support count), stack_lengths,
+    features (ones).  Extra keys: 'stack_lengths_host' (list of python int lists) and, if
+    want_counts, 'neighbor_counts' (untruncated list lengths of the conv tables, for calibration)."""
+    config = as_config(config)
+    if not points.is_cuda:
+        raise RuntimeError("pcrcg_amd.build_pyramid: points must be on a HIP device (no CPU path)")
+    pts = points.to(torch.float32).contiguous()
+    lens = lengths.to(_I32).contiguous()
+    plan = _layer_plan(config)
+    in_points, in_neighbors, in_pools, in_ups, in_lens = [], [], [], [], []
+    metas, tables, counts_out = [], [], []
+    empty_idx = torch.zeros((0, 1), dtype=torch.int64, device=pts.device)
+    carried = None   # grid over the current level's points built for the previous level's upsample search
+    for layer, lv in enumerate(plan):
+        limit = int(neighborhood_limits[layer])
+        grid = None
+        if lv["has_conv"]:
+            grid = carried if carried is not None and carried.radius == float(lv["r_conv"]) else \
+                ops.CellGrid(pts, lens, lv["r_conv"])
+            if want_counts:
+                conv_i, meta, cnt = grid.query(pts, lens, limit, want_counts=True)
+                counts_out.append(cnt)
+            else:
+                conv_i, meta = grid.query(pts, lens, limit)
+            metas.append(meta)
+            tables.append(("neighbors", layer))
+        else:
+            conv_i = empty_idx
+        if lv["pooled"]:
+            pool_p, pool_b = ops.grid_subsample(pts, lens, lv["dl"])      # one host sync (row count)
+            if grid is None or grid.radius != float(lv["r_pool"]):
+                grid = carried if carried is not None and carried.radius == float(lv["r_pool"]) else \
+                    ops.CellGrid(pts, lens, lv["r_pool"])
+            pool_i, meta = grid.query(pool_p, pool_b, limit)
+            metas.append(meta)
+            tables.append(("pools", layer))
+            up_grid = ops.CellGrid(pool_p, pool_b, 2 * lv["r_pool"])
+            up_i, meta = up_grid.query(pts, lens, limit)
+            metas.append(meta)
+            tables.append(("upsamples", layer))
+            # the next level's conv and pool searches use these supports with this radius: hand it on
+            carried = up_grid
+        else:
+            pool_i, up_i = empty_idx, empty_idx
+            pool_p = torch.zeros((0, 3), dtype=torch.float32, device=pts.device)
+            pool_b = torch.zeros((0,), dtype=torch.int64, device=pts.device)
+            carried = None
+        in_points.append(pts)
+        in_neighbors.append(conv_i)
+        in_pools.append(pool_i)
+        in_ups.append(up_i)
+        in_lens.append(lens)
+        pts, lens = pool_p, pool_b
+    out = {"points": in_points, "neighbors": in_neighbors, "pools": in_pools, "upsamples": in_ups,
+           "stack_lengths": in_lens}
+    # one host round trip for all tables: column counts (neighbors[:, :limit] keeps FEWER columns
+    # when the longest list is shorter than the limit, ref:datasets/dataloader.py:65-67) and status
+    meta_h = torch.stack(metas).cpu().tolist() if metas else []
+    for (key, layer), (max_count, status) in zip(tables, meta_h):
+        if status != 0:
+            raise RuntimeError(f"pcrcg_amd.build_pyramid: radius search capacity exceeded ({key}[{layer}])")
+        t = out[key][layer]
+        if max_count < t.shape[1]:
+            out[key][layer] = t[:, :max(max_count, 0)]
+    out["features"] = torch.ones((in_points[0].shape[0], 1), dtype=torch.float32, device=points.device)
+    lens_h = torch.stack([l.to(_I32) for l in in_lens]).cpu().tolist()
+    out["stack_lengths_host"] = lens_h
+    if want_counts:
+        out["neighbor_counts"] = counts_out
+    return out
+
+
+def _point2node(nodes, points):
+    """ref:datasets/dataloader.py:90-105: nearest node of every point (dense distances)."""
+    d = -2.0 * points @ nodes.t()
+    d = d + (points ** 2).sum(-1, keepdim=True) + (nodes ** 2).sum(-1)[None, :]
+    return torch.clamp(d, min=1e-12).argmin(1)
+
+
+def _node_visibility(nodes, points, visible_idx):
+    """ref:datasets/dataloader.py:107-152: fraction of each node's points that have a correspondence."""
+    p2n = _point2node(nodes, points)
+    tot = torch.ones(nodes.shape[0], device=nodes.device)
+    idx, cts = torch.unique(p2n, return_counts=True)
+    tot[idx] = cts.float()
+    vis_mask = torch.zeros(points.shape[0], device=nodes.device)
+    vis_mask[visible_idx] = 1.0
+    vis_pts = vis_mask.nonzero().squeeze(1)
+    vis = torch.zeros(nodes.shape[0], device=nodes.device)
+    idx_, cts_ = torch.unique(p2n[vis_pts], return_counts=True)
+    vis[idx_] = cts_.float()
+    return vis / tot, p2n
+
+
+def collate_fn_descriptor(list_data, config, neighborhood_limits, device=None):
+    """Same contract as ref:datasets/dataloader.py:203-400 (one pair per batch, :207), with the result
+    already on the device.  Image-feature keys (:383-398) are passed through untouched."""
+    assert len(list_data) == 1
+    device = torch.device(device if device is not None else "cuda")
+    item = list_data[0]
+    src = torch.as_tensor(np.asarray(item["src_pcd"]), dtype=torch.float32).to(device)
+    tgt = torch.as_tensor(np.asarray(item["tgt_pcd"]), dtype=torch.float32).to(device)
+    points = torch.cat([src, tgt], 0)
+    lengths = torch.tensor([src.shape[0], tgt.shape[0]], dtype=_I32, device=device)
+    out = build_pyramid(points, lengths, config, neighborhood_limits)
+    feats = np.concatenate([np.asarray(item["src_feats"]), np.asarray(item["tgt_feats"])], 0)
+    out["features"] = torch.as_tensor(feats, dtype=torch.float32).to(device)
+    out["rot"] = torch.as_tensor(np.asarray(item["rot"])).to(device)
+    out["trans"] = torch.as_tensor(np.asarray(item["trans"])).to(device)
+    corr = item["correspondences"]
+    out["correspondences"] = corr
+    out["src_pcd_raw"], out["tgt_pcd_raw"] = src, tgt
+    out["sample"] = item.get("sample")
+    # node-overlap labels of the coarsest level (:309-322): training labels, plain dense torch math
+    nodes = out["points"][-1]
+    n_src = out["stack_lengths_host"][-1][0]
+    corr_t = torch.as_tensor(np.asarray(corr)).to(device).long()
+    src_vis, src_p2n = _node_visibility(nodes[:n_src], src, corr_t[:, 0])
+    tgt_vis, tgt_p2n = _node_visibility(nodes[n_src:], tgt, corr_t[:, 1])
+    out["node_overlap_gt"] = torch.cat([src_vis, tgt_vis])
+    out["points2node"] = torch.cat([src_p2n, tgt_p2n])
+    for key in item.keys():
+        if key not in out and key not in ("src_pcd", "tgt_pcd", "src_feats", "tgt_feats"):
+            out[key] = item[key]
+    return out
+
+
+def calibrate_neighbors(pairs, config, keep_ratio=0.8, samples_threshold=2000):
+    """ref:datasets/dataloader.py:402-434: limits[l] = #{h : cumhist_l(h) < keep_ratio * total_l} over
+    the histograms of untruncated neighbour counts.  `pairs` yields (points [N,3], lengths [B]) device
+    tensors."""
+    config = as_config(config)
+    hist_n = int(np.ceil(4 / 3 * np.pi * (config.deform_radius + 1) ** 3))
+    hists = np.zeros((config.num_layers, hist_n), dtype=np.int64)
+    for points, lengths in pairs:
+        b = build_pyramid(points, lengths, config, [hist_n] * config.num_layers, want_counts=True)
+        for l, cnt in enumerate(b["neighbor_counts"]):
+            c = torch.clamp(cnt.long(), max=hist_n)   # the reference sees at most hist_n columns
+            hists[l] += torch.bincount(c, minlength=hist_n + 1)[:hist_n].cpu().numpy()
+        if hists.sum(1).min() > samples_threshold:
+            break
+    cumsum = np.cumsum(hists.T, axis=0)
+    return np.sum(cumsum < (keep_ratio * cumsum[hist_n - 1, :]), axis=0)

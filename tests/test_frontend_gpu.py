@@ -1,0 +1,220 @@
+"""Parity of the HIP front end (through the C ABI) with the CPU oracle and the committed golden
+vectors.  Bar: bit-exact subsampled points and order; neighbour tables identical up to the order
+inside groups of exactly equal fp32 distance (tests/tieutil.py)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend as OF
+from pcrcg_amd import ops, synthetic
+from pcrcg_amd.cpp_wrappers.cpp_neighbors import radius_neighbors
+from pcrcg_amd.cpp_wrappers.cpp_subsampling import grid_subsampling
+from tests.tieutil import assert_tables_equal_mod_ties, canonicalise_table, row_d2
+
+pytestmark = pytest.mark.gpu
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _stack(recipe, seed=0):
+    src, tgt = synthetic.pair(recipe, seed)
+    return np.concatenate([src, tgt]), np.array([len(src), len(tgt)], np.int32)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_umap_order_matches_libstdcxx_fixture(cuda, golden_dir):
+    g = np.load(os.path.join(golden_dir, "umap_order.npz"))
+    for n in (1, 2, 13, 14, 29, 30, 500, 6000):
+        keys = g[f"keys{n}"]
+        got = ops.umap_order(torch.from_numpy(keys.view(np.int64)).to(cuda)).cpu().numpy()
+        assert (got == g[f"order{n}"]).all(), f"n={n}"
+
+
+@pytest.mark.parametrize("n", [3, 100, 20000, 70000])
+def test_umap_order_matches_oracle_random(cuda, n):
+    rng = np.random.RandomState(n)
+    keys = np.unique(rng.randint(0, 1 << 45, size=2 * n).astype(np.uint64))
+    rng.shuffle(keys)
+    keys = keys[:n]
+    got = ops.umap_order(torch.from_numpy(keys.view(np.int64)).to(cuda)).cpu().numpy()
+    assert (got == OF.oracle_umap_order(keys)).all()
+
+
+def test_subsample_golden_mini(cuda, golden_dir):
+    g = np.load(os.path.join(golden_dir, "frontend_mini.npz"))
+    pts, lens = _stack("mini")
+    dl = 0.05
+    for l in range(3):
+        sp, sl = grid_subsampling.subsample_batch(pts, lens, sampleDl=dl)
+        assert sp.dtype == np.float32 and sl.dtype == np.int32
+        assert (sl == g[f"lens{l + 1}"]).all()
+        assert sp.shape == g[f"points{l + 1}"].shape
+        assert (_bits(sp) == _bits(g[f"points{l + 1}"])).all(), f"level {l}"
+        pts, lens, dl = sp, sl, dl * 2
+
+
+@pytest.mark.parametrize("recipe", ["C1", "S30k"])
+def test_subsample_digests_and_oracle(cuda, golden_dir, recipe):
+    dig = json.load(open(os.path.join(golden_dir, "frontend_digests.json")))[recipe]
+    pts, lens = _stack(recipe)
+    dl = 0.05
+    for l in range(3):
+        sp, sl = grid_subsampling.subsample_batch(pts, lens, sampleDl=dl)
+        op, ol = OF.oracle_subsample_batch(pts, lens, dl)
+        assert (sl == ol).all() and sp.shape == op.shape
+        assert (_bits(sp) == _bits(op)).all()
+        assert _sha(sp) == dig[f"points{l + 1}"]["sha256"]
+        assert _sha(sl) == dig[f"lens{l + 1}"]["sha256"]
+        pts, lens, dl = sp, sl, dl * 2
+
+
+def test_subsample_edge_cases(cuda):
+    rng = np.random.RandomState(5)
+    # ragged batch of three clouds incl. negative coordinates, a one-point cloud, duplicates
+    a = (rng.rand(700, 3) - 0.5).astype(np.float32) * 2
+    b = (rng.rand(1, 3)).astype(np.float32)
+    c = np.repeat((rng.rand(40, 3).astype(np.float32) - 3.0), 5, axis=0)
+    pts = np.concatenate([a, b, c])
+    lens = np.array([len(a), len(b), len(c)], np.int32)
+    for dl in (0.07, 0.3, 5.0):
+        sp, sl = grid_subsampling.subsample_batch(pts, lens, sampleDl=dl)
+        op, ol = OF.oracle_subsample_batch(pts, lens, dl)
+        assert (sl == ol).all()
+        assert (_bits(sp) == _bits(op)).all()
+    # max_p cap keeps the first max_p cells of every cloud (grid_subsampling.cpp:185-205)
+    sp, sl = grid_subsampling.subsample_batch(pts, lens, sampleDl=0.07, max_p=10)
+    op, ol = OF.oracle_subsample_batch(pts, lens, 0.07, max_p=10)
+    assert (sl == ol).all() and (_bits(sp) == _bits(op)).all()
+    # single-cloud entry point
+    s1 = grid_subsampling.subsample(a, sampleDl=0.1)
+    o1, _ = OF.oracle_subsample_batch(a, np.array([len(a)], np.int32), 0.1)
+    assert (_bits(s1) == _bits(o1)).all()
+    # device tensors in -> device tensors out
+    tp, tl = grid_subsampling.subsample_batch(torch.from_numpy(pts).to(cuda), torch.from_numpy(lens).to(cuda),
+                                              sampleDl=0.3)
+    assert tp.is_cuda and tl.is_cuda
+    with pytest.raises(RuntimeError):
+        grid_subsampling.subsample_batch(pts[:, :2], lens, sampleDl=0.1)
+    with pytest.raises(RuntimeError):
+        grid_subsampling.subsample_batch(pts, lens, sampleDl=0.1, method="nope")
+
+
+# ------------------------------------------------------------------------------------------------
+def _pyramid_tables(pts, lens, r0=0.0625, dl0=0.05, levels=4):
+    """Yield (name, queries, supports, q_len, s_len, radius) following ref:datasets/dataloader.py:252-359."""
+    r, dl = r0, dl0
+    for l in range(levels):
+        yield f"conv{l}", pts, pts, lens, lens, r
+        if l == levels - 1:
+            return
+        sp, sl = OF.oracle_subsample_batch(pts, lens, dl)
+        yield f"pool{l}", sp, pts, sl, lens, r
+        yield f"up{l}", pts, sp, lens, sl, 2 * r
+        pts, lens, r, dl = sp, sl, r * 2, dl * 2
+
+
+def test_batch_query_golden_mini(cuda, golden_dir):
+    g = np.load(os.path.join(golden_dir, "frontend_mini.npz"))
+    pts, lens = _stack("mini")
+    for name, q, s, ql, sl, r in _pyramid_tables(pts, lens):
+        got = radius_neighbors.batch_query(q, s, ql, sl, radius=r)
+        assert got.dtype == np.int32
+        assert_tables_equal_mod_ties(got, g[name], q, s)
+
+
+@pytest.mark.parametrize("recipe", ["C1", "S30k"])
+def test_batch_query_digests_and_oracle(cuda, golden_dir, recipe):
+    dig = json.load(open(os.path.join(golden_dir, "frontend_digests.json")))[recipe]
+    pts, lens = _stack(recipe)
+    for name, q, s, ql, sl, r in _pyramid_tables(pts, lens):
+        got = radius_neighbors.batch_query(q, s, ql, sl, radius=r)
+        assert list(got.shape) == dig[name]["shape"]
+        canon, _ = canonicalise_table(got, q, s)
+        assert (canon == got).all(), "HIP rows must already be in canonical (d2, index) order"
+        assert _sha(canon) == dig[name]["sha256_canonical"], name
+        exp = OF.oracle_batch_query(q, s, ql, sl, r)
+        assert (got == exp).all(), name  # oracle uses the same canonical order: exact equality
+
+
+def test_batch_query_edge_cases(cuda):
+    rng = np.random.RandomState(11)
+    # three ragged clouds; queries and supports differ; a cloud with a single support
+    s = np.concatenate([rng.rand(500, 3), rng.rand(1, 3) + 2, rng.rand(300, 3) - 1.5]).astype(np.float32)
+    sl = np.array([500, 1, 300], np.int32)
+    q = np.concatenate([rng.rand(40, 3), rng.rand(3, 3) + 2, rng.rand(77, 3) - 1.5]).astype(np.float32)
+    ql = np.array([40, 3, 77], np.int32)
+    for r in (0.05, 0.2, 0.9):
+        got = radius_neighbors.batch_query(q, s, ql, sl, radius=r)
+        exp = OF.oracle_batch_query(q, s, ql, sl, r)
+        assert got.shape == exp.shape and (got == exp).all()
+        assert ((got == len(s)) | (got < len(s))).all()
+    # exact ties: supports mirrored about the query must come out in ascending index order
+    q1 = np.zeros((1, 3), np.float32)
+    s1 = np.array([[0.1, 0, 0], [-0.1, 0, 0], [0, 0.1, 0], [0, -0.1, 0], [0.05, 0, 0]], np.float32)
+    got = radius_neighbors.batch_query(q1, s1, [1], [5], radius=0.5)
+    assert got.tolist() == [[4, 0, 1, 2, 3]]
+    # strict inequality d2 < r2 (nanoflann.hpp:249-253): a support at exactly r is excluded
+    s2 = np.array([[0.5, 0, 0], [0.25, 0, 0]], np.float32)
+    got = radius_neighbors.batch_query(q1, s2, [1], [2], radius=0.5)
+    assert got.tolist() == [[1]]
+    # no neighbour at all -> the reference raises RuntimeError("Error") (wrapper.cpp:201-205)
+    with pytest.raises(RuntimeError):
+        radius_neighbors.batch_query(q1, s2 + 10, [1], [2], radius=0.1)
+    with pytest.raises(RuntimeError):
+        radius_neighbors.batch_query(q1, s2, [1], [1, 1], radius=0.1)
+    # more neighbours than the first-guess width (128) of the shim
+    dense = (rng.rand(400, 3) * 0.1).astype(np.float32)
+    got = radius_neighbors.batch_query(dense, dense, [400], [400], radius=1.0)
+    exp = OF.oracle_batch_query(dense, dense, [400], [400], 1.0)
+    assert got.shape == (400, 400) and (got == exp).all()
+
+
+def test_truncation_and_counts(cuda):
+    pts, lens = _stack("C1")
+    tp, tl = torch.from_numpy(pts).to(cuda), torch.from_numpy(lens).to(cuda)
+    grid = ops.CellGrid(tp, tl, 0.0625)
+    idx, meta, cnt = grid.query(tp, tl, 24, want_counts=True)
+    full = OF.oracle_batch_query(pts, pts, lens, lens, 0.0625)
+    assert meta.tolist() == [full.shape[1], 0]
+    assert idx.dtype == torch.int64 and idx.shape == (len(pts), 24)
+    assert (idx.cpu().numpy() == full[:, :24]).all()
+    assert (cnt.cpu().numpy() == (full < len(pts)).sum(1)).all()
+
+
+def test_k120k_properties(cuda):
+    """KITTI-shaped stress (BASELINE.json configs[4]) checked through size-independent properties."""
+    src, tgt = synthetic.slab_pair(120000, 0)
+    pts = np.concatenate([src, tgt])
+    lens = np.array([len(src), len(tgt)], np.int32)
+    tp, tl = torch.from_numpy(pts).to(cuda), torch.from_numpy(lens).to(cuda)
+    r = 0.3 * 4.25
+    grid = ops.CellGrid(tp, tl, r)
+    idx, meta, cnt = grid.query(tp, tl, 62, want_counts=True)
+    assert meta[1].item() == 0
+    t = idx.cpu().numpy()
+    assert (t[:, 0] == np.arange(len(pts))).all()            # a point is its own nearest neighbour
+    sub = np.random.RandomState(0).choice(len(pts), 4000, replace=False)
+    d2 = row_d2(t[sub], pts[sub], pts)
+    d2 = np.where(t[sub] >= len(pts), np.inf, d2)
+    assert (np.diff(d2, axis=1)[np.isfinite(d2[:, 1:])] >= 0).all()   # ascending distance
+    assert (d2[np.isfinite(d2)] < np.float32(r) * np.float32(r)).all()
+    real = t < len(pts)
+    assert (real.sum(1) == np.minimum(cnt.cpu().numpy(), 62)).all()   # padding only after the real ones
+    same_cloud = (t[:len(src)][real[:len(src)]] < len(src)).all() and (t[len(src):][real[len(src):]] >= len(src)).all()
+    assert same_cloud
+    # subsampling: every cell barycentre is the mean of >= 1 points; lengths sum to rows; second run identical
+    sp, sl = ops.grid_subsample(tp, tl, 0.6)
+    sp2, sl2 = ops.grid_subsample(tp, tl, 0.6)
+    assert sp.shape[0] == int(sl.sum()) and torch.equal(sp, sp2) and torch.equal(sl, sl2)
+    op, ol = OF.oracle_subsample_batch(pts, lens, 0.6)
+    assert (sl.cpu().numpy() == ol).all() and (_bits(sp.cpu().numpy()) == _bits(op)).all()
