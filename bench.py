@@ -1,0 +1,177 @@
+"""bench.py -- fragment-pairs/s of the PCR-CG hot path on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one synthetic 3DMatch-shaped pair per GPU (configs[1]:
+2 x 30 000 points, indoor hyper-parameters, full-width KPFCNN + GCN, fp32): raw stacked points already
+resident in HBM -> point pyramid (3 grid subsamplings, 10 radius searches) -> KPFCNN+GCN forward ->
+per-point descriptors / overlap / saliency.  Independent pairs shard across ranks with no data-path
+collective: weak scaling, one pair per rank per step.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of the
+dominant kernel (the KPConv neighbour-gather/aggregate kernel) inside the timed region; `cpu_baseline`
+times the CPU oracle (oracle/: C front end + torch-CPU model, a restatement pinned against the
+reference) on a bounded sample on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from pcrcg_amd import indoor_config, ops, synthetic  # noqa: E402
+from pcrcg_amd.architectures import KPFCNN  # noqa: E402
+from pcrcg_amd.pyramid import build_pyramid  # noqa: E402
+from pcrcg_amd.sharding import pair_seeds_for_rank  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+RECIPE = "S30k"
+
+
+def kpconv_algorithmic_bytes(nq, h, cin, cout, e=4):
+    """no-reuse gather model of one KPConv call."""
+    return nq * h * (cin * e + 8 + 12) + nq * cout * e
+
+
+def cpu_baseline(cfg, state_dict, limits):
+    """CPU oracle on one S30k pair: front end single-threaded C, model torch-CPU on all cores."""
+    from oracle import frontend as OF
+    from oracle import model_ref as MR
+    src, tgt = synthetic.pair(RECIPE, 12345)
+    pts = np.concatenate([src, tgt])
+    lens = np.array([len(src), len(tgt)], np.int32)
+    t0 = time.perf_counter()
+    r, dl = cfg.first_subsampling_dl * cfg.conv_radius, 2 * cfg.first_subsampling_dl
+    batch = {"points": [], "neighbors": [], "pools": [], "upsamples": [], "stack_lengths": []}
+    empty = torch.zeros((0, 1), dtype=torch.int64)
+    for l in range(cfg.num_layers):
+        batch["points"].append(torch.from_numpy(pts))
+        batch["stack_lengths"].append(torch.from_numpy(lens))
+        batch["neighbors"].append(torch.from_numpy(OF.oracle_batch_query(pts, pts, lens, lens, r)[:, :limits[l]]).long())
+        if l == cfg.num_layers - 1:
+            batch["pools"].append(empty)
+            batch["upsamples"].append(empty)
+            break
+        sp, sl = OF.oracle_subsample_batch(pts, lens, dl)
+        batch["pools"].append(torch.from_numpy(OF.oracle_batch_query(sp, pts, sl, lens, r)[:, :limits[l]]).long())
+        batch["upsamples"].append(torch.from_numpy(OF.oracle_batch_query(pts, sp, lens, sl, 2 * r)[:, :limits[l]]).long())
+        pts, lens, r, dl = sp, sl, r * 2, dl * 2
+    batch["features"] = torch.ones((batch["points"][0].shape[0], 1))
+    t1 = time.perf_counter()
+    MR.kpfcnn_forward(state_dict, dict(cfg), batch)
+    t2 = time.perf_counter()
+    return {"value": round(1.0 / (t2 - t0), 4), "unit": "fragment-pairs/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"1 {RECIPE} pair: oracle C front end {t1 - t0:.2f}s (1 thread) + torch-CPU model "
+                      f"{t2 - t1:.2f}s ({torch.get_num_threads()} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = indoor_config()
+    limits = synthetic.LIMITS[RECIPE]
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = KPFCNN(cfg).eval()
+    state_dict = {k: v.clone() for k, v in net.state_dict().items()} if rank == 0 else None
+    net = net.to(dev)
+
+    # synthetic inputs, resident in HBM before the timed region; every step sees a different pair
+    total = args.warmup + args.steps
+    seeds = pair_seeds_for_rank(total, rank, world)
+    pool = {}
+    for s in sorted(set(seeds)):
+        src, tgt = synthetic.pair(RECIPE, s % 16)     # 16 distinct pairs per rank, cycled
+        if s % 16 not in pool:
+            pool[s % 16] = (torch.from_numpy(np.concatenate([src, tgt])).to(dev),
+                            torch.tensor([len(src), len(tgt)], dtype=torch.int32, device=dev))
+
+    def step(seed):
+        pts, lens = pool[seed % 16]
+        batch = build_pyramid(pts, lens, cfg, limits)
+        with torch.no_grad():
+            return net(batch)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(seeds[i])
+    fence()
+    ops.KPCONV_EVENTS = []            # HIP events around every KPConv aggregate launch from here on
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        out = step(seeds[i])
+    fence()
+    elapsed = time.perf_counter() - t0
+    events, ops.KPCONV_EVENTS = ops.KPCONV_EVENTS, None
+    assert out["feats_f"].shape[1] == cfg.final_feats_dim
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        k_ms = sum(a.elapsed_time(b) for a, b, _ in events)
+        k_bytes = sum(kpconv_algorithmic_bytes(*shape) for _, _, shape in events)
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        line = {
+            "metric": "fragment-pairs/s KPFCNN+GCN fwd, 30k-pt pairs",
+            "value": round(args.steps * world / elapsed, 3),
+            "unit": "fragment-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "S30k: 2x30000-pt shell pairs (3DMatch-shaped), pyramid build + KPFCNN+GCN "
+                                   "forward, indoor hyper-parameters, random-init full-width weights, 1 pair/GPU/step",
+                       "limits": limits, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "k_kpconv_aggregate (11 launches/pair)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_launch_us": round(k_ms * 1e3 / max(len(events), 1), 2),
+                         "algorithmic_bytes_per_pair": int(k_bytes / max(args.steps, 1))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, state_dict, limits)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,10 @@ class _Workspaces:
 
 _ws = _Workspaces()
 
+# bench.py sets this to a list to collect (start_event, end_event, (nq, h, cin, cout)) around every
+# KPConv gather/aggregate launch (HIP events on the stream the kernel runs on).
+KPCONV_EVENTS = None
+
 
 # ------------------------------------------------------------------------------------------------
 # front end
@@ -170,11 +174,18 @@ def kpconv(q_pts, s_pts, idx, x, kernel_points, weights, extent):
     inv_n = torch.empty(nq, dtype=_F32, device=x.device)
     nbytes = L.pcrcg_kpconv_ws_bytes(ns)
     ws = _ws.get("kpconv", nbytes, x.device)
+    w2 = _dev(weights, _F32, "weights").reshape(kdim * cin, -1)
+    ev = None
+    if KPCONV_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _lib.check(L.pcrcg_kpconv_aggregate(q_pts.data_ptr(), nq, s_pts.data_ptr(), ns, idx.data_ptr(), h, ld_idx,
                                         x.data_ptr(), cin, kp.data_ptr(), float(extent), wf.data_ptr(),
                                         inv_n.data_ptr(), ws.data_ptr(), nbytes, _stream()),
                "pcrcg_kpconv_aggregate")
-    w2 = _dev(weights, _F32, "weights").reshape(kdim * cin, -1)
+    if ev is not None:
+        ev[1].record()
+        KPCONV_EVENTS.append((ev[0], ev[1], (nq, h, cin, w2.shape[1])))
     return gemm(wf, w2, row_scale=inv_n)
 
 
