@@ -16,7 +16,7 @@ def main(db, out, steps=None):
         f.write("\n# durations in microseconds\n")
         f.write("calls,total_us,avg_us,percent,name\n")
         for name, calls, tot, avg, pct in rows:
-            short = name.split("(")[0].replace("void ", "").replace("pcrcg::(anonymous namespace)::", "")
+            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             if len(short) > 110:
                 short = short[:107] + "..."
             f.write(f"{calls},{tot:.1f},{avg:.2f},{pct:.2f},{short}\n")

@@ -1,0 +1,102 @@
+"""CPU: the oracle's C front end (oracle/front_end.c) against the golden vectors generated from the
+unmodified reference C++ (scripts/make_golden_frontend.py) and, when the prebuilt reference checker
+library oracle/_ref is present, against the reference itself."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import frontend as OF
+from pcrcg_amd import synthetic
+from tests.tieutil import assert_tables_equal_mod_ties, canonicalise_table
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _stack(recipe, seed=0):
+    src, tgt = synthetic.pair(recipe, seed)
+    return np.concatenate([src, tgt]), np.array([len(src), len(tgt)], np.int32)
+
+
+def test_umap_order_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "umap_order.npz"))
+    for n in (1, 2, 13, 14, 29, 30, 500, 6000):
+        assert (OF.oracle_umap_order(g[f"keys{n}"]) == g[f"order{n}"]).all(), n
+
+
+def test_mini_pyramid_full_vectors(golden_dir):
+    g = np.load(os.path.join(golden_dir, "frontend_mini.npz"))
+    pts, lens = _stack("mini")
+    r, dl = 0.0625, 0.05
+    for l in range(4):
+        assert_tables_equal_mod_ties(OF.oracle_batch_query(pts, pts, lens, lens, r), g[f"conv{l}"], pts, pts)
+        if l == 3:
+            break
+        sp, sl = OF.oracle_subsample_batch(pts, lens, dl)
+        assert (sl == g[f"lens{l + 1}"]).all()
+        assert (_bits(sp) == _bits(g[f"points{l + 1}"])).all()
+        assert_tables_equal_mod_ties(OF.oracle_batch_query(sp, pts, sl, lens, r), g[f"pool{l}"], sp, pts)
+        assert_tables_equal_mod_ties(OF.oracle_batch_query(pts, sp, lens, sl, 2 * r), g[f"up{l}"], pts, sp)
+        pts, lens, r, dl = sp, sl, r * 2, dl * 2
+
+
+@pytest.mark.parametrize("recipe", ["C1", "S30k"])
+def test_digests(golden_dir, recipe):
+    dig = json.load(open(os.path.join(golden_dir, "frontend_digests.json")))[recipe]
+    pts, lens = _stack(recipe)
+    r, dl = 0.0625, 0.05
+    for l in range(4):
+        t = OF.oracle_batch_query(pts, pts, lens, lens, r)
+        assert list(t.shape) == dig[f"conv{l}"]["shape"]
+        assert _sha(canonicalise_table(t, pts, pts)[0]) == dig[f"conv{l}"]["sha256_canonical"]
+        if l == 3:
+            break
+        sp, sl = OF.oracle_subsample_batch(pts, lens, dl)
+        assert _sha(sp) == dig[f"points{l + 1}"]["sha256"] and _sha(sl) == dig[f"lens{l + 1}"]["sha256"]
+        t = OF.oracle_batch_query(sp, pts, sl, lens, r)
+        assert _sha(canonicalise_table(t, sp, pts)[0]) == dig[f"pool{l}"]["sha256_canonical"]
+        t = OF.oracle_batch_query(pts, sp, lens, sl, 2 * r)
+        assert _sha(canonicalise_table(t, pts, sp)[0]) == dig[f"up{l}"]["sha256_canonical"]
+        pts, lens, r, dl = sp, sl, r * 2, dl * 2
+
+
+def test_properties_and_errors():
+    pts, lens = _stack("mini", 3)
+    t = OF.oracle_batch_query(pts, pts, lens, lens, 0.07)
+    assert (t[:, 0] == np.arange(len(pts))).all()             # self first
+    assert t.max() == len(pts)                                # pad value = supports.size() (neighbors.cpp:324)
+    sp, sl = OF.oracle_subsample_batch(pts, lens, 0.1)
+    assert sl.sum() == len(sp)
+    with pytest.raises(RuntimeError):
+        OF.oracle_batch_query(pts[:, :2], pts, lens, lens, 0.1)
+    with pytest.raises(RuntimeError):
+        OF.oracle_batch_query(pts, pts, lens, lens[:1], 0.1)
+
+
+@pytest.mark.skipif(not OF.have_ref(), reason="oracle/_ref (reference checker library) not built")
+def test_against_reference_library():
+    rng = np.random.RandomState(2)
+    for n in (1, 13, 14, 700, 30000):
+        k = np.unique(rng.randint(0, 1 << 50, size=2 * n).astype(np.uint64))
+        rng.shuffle(k)
+        assert (OF.oracle_umap_order(k[:n]) == OF.ref_umap_order(k[:n])).all()
+    a = (rng.rand(900, 3) - 0.5).astype(np.float32) * 3
+    b = (rng.rand(400, 3)).astype(np.float32) + 5
+    pts, lens = np.concatenate([a, b]), np.array([900, 400], np.int32)
+    for dl in (0.11, 0.4):
+        rp, rl = OF.ref_subsample_batch(pts, lens, dl)
+        op, ol = OF.oracle_subsample_batch(pts, lens, dl)
+        assert (rl == ol).all() and (_bits(rp) == _bits(op)).all()
+        assert_tables_equal_mod_ties(OF.oracle_batch_query(rp, pts, rl, lens, 2.5 * dl),
+                                     OF.ref_batch_query(rp, pts, rl, lens, 2.5 * dl), rp, pts)
+    rp, rl = OF.ref_subsample_batch(pts, lens, 0.11, max_p=50)
+    op, ol = OF.oracle_subsample_batch(pts, lens, 0.11, max_p=50)
+    assert (rl == ol).all() and (_bits(rp) == _bits(op)).all()
