@@ -84,8 +84,8 @@ __global__ void __launch_bounds__(256) k_edgeconv_reduce(const float* __restrict
     if (rl == 0 && ch < c) {
         s = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
         sq = (s_sq[0][lane] + s_sq[1][lane]) + (s_sq[2][lane] + s_sq[3][lane]);
-        partial[((long)chunk * 2 + 0) * c + ch] = s;
-        partial[((long)chunk * 2 + 1) * c + ch] = sq;
+        partial[(long)ch * nchunks + chunk] = s;                       // layout [2][c][nchunks]
+        partial[((long)c + ch) * nchunks + chunk] = sq;
     }
 }
 

@@ -88,9 +88,9 @@ __global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ pts, i
                 lo = min(lo, (unsigned)__shfl_xor((int)lo, s, 64));
                 hi = max(hi, (unsigned)__shfl_xor((int)hi, s, 64));
             }
-            if ((threadIdx.x & 63) == 0) {
-                atomicMin(&mm[b0 * 6 + d], lo);
-                atomicMax(&mm[b0 * 6 + 3 + d], hi);
+            if ((threadIdx.x & 63) == 0) {   // skip the contended atomics that cannot change the result
+                if (lo < (unsigned)aload((const int*)&mm[b0 * 6 + d])) atomicMin(&mm[b0 * 6 + d], lo);
+                if (hi > (unsigned)aload((const int*)&mm[b0 * 6 + 3 + d])) atomicMax(&mm[b0 * 6 + 3 + d], hi);
             }
         }
     } else if (valid) {

@@ -1,17 +1,27 @@
-// kpconv.hip -- KPConv gather + kernel-point aggregation on gfx950 (stage 1 of KPConv.forward,
-// ref:models/blocks.py:264-354,369-372).
+// kpconv.hip -- KPConv neighbour gather + kernel-point aggregation on gfx950 (stage 1 of
+// KPConv.forward, ref:models/blocks.py:264-354,369-372).  This is the dominant HBM-bound kernel of the
+// path (bench.py `roofline`).
 //
-// For every query q (one 64-lane wavefront per query):
-//   geometry  lanes = neighbours: load idx[q,h], the support point, and evaluate the 15 linear
-//             influence weights  w[h,k] = max(0, 1 - |s_h - q - kp_k| / extent)  (:272-289,328);
-//             weights and indices are staged in LDS
-//   aggregate lanes = channels: for each neighbour read the feature row x[idx,:] (coalesced 256-byte
-//             rows) once and accumulate all 15 kernel points from registers:
-//             wf[q,k,c] += w[h,k] * x[idx[q,h],c]   (:351-354)
-//   count     n_q = max(1, #{h : sum_c x[idx[q,h],c] > 0})   (:369-371) from per-support flags that a
-//             small pre-pass derives from x (the flag depends on the support only).
-// Shadow neighbours (idx == ns) have weight 0 and feature 0 in the reference (:269,:348) and are
-// skipped.  Output wf [nq, 15*cin] feeds the dense contraction (pcrcg_gemm_f32, row_scale = 1/n_q).
+//   wf[q,k,c] = sum_h w[q,h,k] * x[idx[q,h],c],   w[q,h,k] = max(0, 1 - |s[idx[q,h]] - q - kp[k]| / extent)
+//   n_q       = max(1, #{h : sum_c x[idx[q,h],c] > 0})                       (:369-371)
+//
+// Main kernel (k_kpconv_mfma): one wavefront per (query, channel chunk).  The aggregation is a
+// [16 kernel points] x [H neighbours] x [channels] contraction, done on the matrix cores with
+// v_mfma_f32_16x16x4_f32 (exact fp32).  Per step of 4 neighbours:
+//   * lane (hsub = lane>>4, j = lane&15) evaluates ONE influence weight -- neighbour h0+hsub against
+//     kernel point j -- which is exactly the A-operand element A[i=j][k=hsub] it must supply;
+//   * the same lane loads one float4 of feature row idx[h0+hsub] at channel 4j: 16 lanes read a whole
+//     256-byte row segment (coalesced), and the 4 components feed 4 MFMAs as B[k=hsub][col=j], so MFMA n
+//     accumulates channels {4j+n};
+//   * neighbour indices and centred neighbour coordinates are loaded once per 64 neighbours
+//     (lanes = neighbours) and broadcast with wave shuffles; nothing is staged through LDS.
+// The D layout (row = 4*(lane>>4)+r = kernel point, col = j) lets each lane store float4s of 4
+// consecutive channels of wf.
+// Shadow neighbours (idx == ns) have weight 0 and feature 0 in the reference (:269,:348): their weight
+// is forced to 0 and no row is read.
+//
+// Fallbacks: k_kpconv_c1 for Cin == 1 (first layer, features are a column of ones), and the scalar
+// k_kpconv_generic for channel counts that are not a multiple of 4.
 #include "common.h"
 
 namespace pcrcg {
@@ -19,6 +29,7 @@ namespace {
 
 constexpr int K = PCRCG_KPOINTS;
 constexpr int kWavesPerBlock = 4;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // pos[s] = (sum_c x[s,c] > 0); one wavefront per support row.
 __global__ void __launch_bounds__(256) k_row_positive(const float* __restrict__ x, int ns, int cin,
@@ -33,8 +44,145 @@ __global__ void __launch_bounds__(256) k_row_positive(const float* __restrict__ 
     if (lane == 0) pos[row] = s > 0.0f ? 1 : 0;
 }
 
-template <int J>  // channels handled per lane and pass: 64*J
-__global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_aggregate(
+template <int NB>  // 64-channel blocks handled per wavefront (one float4 per lane and block)
+__global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
+    const float* __restrict__ q_pts, int nq, const float* __restrict__ s_pts, int ns,
+    const long long* __restrict__ idx, int H, int ld_idx, const float* __restrict__ x, int cin,
+    const float* __restrict__ kp, float extent, const unsigned char* __restrict__ pos, float* __restrict__ wf,
+    float* __restrict__ inv_n, int nchunk) {
+    const int lane = threadIdx.x & 63;
+    const int hsub = lane >> 4, j = lane & 15;
+    const long gw = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long nw = (long)gridDim.x * kWavesPerBlock;
+    const long items = (long)nq * nchunk;
+    const bool jvalid = j < K;
+    const float kpx = jvalid ? kp[3 * j] : 0.f, kpy = jvalid ? kp[3 * j + 1] : 0.f, kpz = jvalid ? kp[3 * j + 2] : 0.f;
+    const float inv_extent = 1.0f / extent;
+
+    for (long item = gw; item < items; item += nw) {
+        const int q = (int)(item / nchunk), chunk = (int)(item - (long)q * nchunk);
+        const int c0 = chunk * 64 * NB;
+        const float qx = q_pts[3 * (long)q], qy = q_pts[3 * (long)q + 1], qz = q_pts[3 * (long)q + 2];
+        f32x4 acc[NB][4];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[b][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int npos = 0;
+        for (int hc = 0; hc < H; hc += 64) {
+            // lanes = neighbours: index + centred coordinates, once per 64 neighbours
+            const int h = hc + lane;
+            int i = -1;
+            if (h < H) {
+                const long long v = idx[(long)q * ld_idx + h];
+                i = (v >= 0 && v < ns) ? (int)v : -1;
+            }
+            float px = 0.f, py = 0.f, pz = 0.f;
+            if (i >= 0) {
+                px = s_pts[3 * (long)i] - qx;
+                py = s_pts[3 * (long)i + 1] - qy;
+                pz = s_pts[3 * (long)i + 2] - qz;
+            }
+            if (chunk == 0) npos += __popcll(__ballot(i >= 0 && pos[i >= 0 ? i : 0] != 0));
+            const int hn = H - hc < 64 ? H - hc : 64;
+#pragma unroll 2
+            for (int h0 = 0; h0 < hn; h0 += 4) {
+                const int src = h0 + hsub;
+                const int ii = __shfl(i, src, 64);
+                const float nx = __shfl(px, src, 64), ny = __shfl(py, src, 64), nz = __shfl(pz, src, 64);
+                const bool real = ii >= 0;
+                float w = 0.f;
+                if (real && jvalid) {
+                    const float dx = nx - kpx, dy = ny - kpy, dz = nz - kpz;
+                    w = fmaxf(1.0f - sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent, 0.0f);   // :285-289,328
+                }
+                const float4* xr = reinterpret_cast<const float4*>(x + (long)(real ? ii : 0) * cin + c0) + j;
+                float4 v[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (real && c0 + 64 * b + 4 * j < cin) v[b] = xr[16 * b];
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v[b].x, acc[b][0], 0, 0, 0);
+                    acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v[b].y, acc[b][1], 0, 0, 0);
+                    acc[b][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v[b].z, acc[b][2], 0, 0, 0);
+                    acc[b][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v[b].w, acc[b][3], 0, 0, 0);
+                }
+            }
+        }
+        // D layout: register r of lane (hsub, j) = kernel point 4*hsub + r, channel group j
+        float* o = wf + (long)q * K * cin + c0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int c = 64 * b + 4 * j;
+            if (c0 + c >= cin) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * hsub + r;
+                if (k < K)
+                    *reinterpret_cast<float4*>(o + (long)k * cin + c) =
+                        make_float4(acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]);
+            }
+        }
+        if (chunk == 0 && lane == 0) inv_n[q] = 1.0f / (float)(npos > 1 ? npos : 1);
+    }
+}
+
+// Cin == 1: wf[q,k] = sum_h w[q,h,k] * x[idx[q,h]]; lane (hsub, j) accumulates its own (neighbour
+// residue, kernel point) pair, the 4 residues are folded with two shuffles at the end.
+__global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_c1(
+    const float* __restrict__ q_pts, int nq, const float* __restrict__ s_pts, int ns,
+    const long long* __restrict__ idx, int H, int ld_idx, const float* __restrict__ x, const float* __restrict__ kp,
+    float extent, float* __restrict__ wf, float* __restrict__ inv_n) {
+    const int lane = threadIdx.x & 63;
+    const int hsub = lane >> 4, j = lane & 15;
+    const int gw = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nw = gridDim.x * kWavesPerBlock;
+    const bool jvalid = j < K;
+    const float kpx = jvalid ? kp[3 * j] : 0.f, kpy = jvalid ? kp[3 * j + 1] : 0.f, kpz = jvalid ? kp[3 * j + 2] : 0.f;
+    const float inv_extent = 1.0f / extent;
+    for (int q = gw; q < nq; q += nw) {
+        const float qx = q_pts[3 * (long)q], qy = q_pts[3 * (long)q + 1], qz = q_pts[3 * (long)q + 2];
+        float acc = 0.f;
+        int npos = 0;
+        for (int hc = 0; hc < H; hc += 64) {
+            const int h = hc + lane;
+            int i = -1;
+            if (h < H) {
+                const long long v = idx[(long)q * ld_idx + h];
+                i = (v >= 0 && v < ns) ? (int)v : -1;
+            }
+            float px = 0.f, py = 0.f, pz = 0.f, xv = 0.f;
+            if (i >= 0) {
+                px = s_pts[3 * (long)i] - qx;
+                py = s_pts[3 * (long)i + 1] - qy;
+                pz = s_pts[3 * (long)i + 2] - qz;
+                xv = x[i];
+            }
+            npos += __popcll(__ballot(i >= 0 && xv > 0.0f));
+            const int hn = H - hc < 64 ? H - hc : 64;
+            for (int h0 = 0; h0 < hn; h0 += 4) {
+                const int src = h0 + hsub;
+                const int ii = __shfl(i, src, 64);
+                const float nx = __shfl(px, src, 64), ny = __shfl(py, src, 64), nz = __shfl(pz, src, 64);
+                const float xs = __shfl(xv, src, 64);
+                if (ii >= 0 && jvalid) {
+                    const float dx = nx - kpx, dy = ny - kpy, dz = nz - kpz;
+                    acc = fmaf(fmaxf(1.0f - sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent, 0.0f), xs, acc);
+                }
+            }
+        }
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        if (lane < K) wf[(long)q * K + lane] = acc;
+        if (lane == 0) inv_n[q] = 1.0f / (float)(npos > 1 ? npos : 1);
+    }
+}
+
+// Scalar fallback for channel counts that are not a multiple of 4: weights staged in LDS, lanes =
+// channels.
+__global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_generic(
     const float* __restrict__ q_pts, int nq, const float* __restrict__ s_pts, int ns,
     const long long* __restrict__ idx, int H, int ld_idx, const float* __restrict__ x, int cin,
     const float* __restrict__ kp, float extent, const unsigned char* __restrict__ pos, float* __restrict__ wf,
@@ -43,77 +191,47 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_aggregate(
     __shared__ int s_idx[kWavesPerBlock][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = blockIdx.x * kWavesPerBlock + wave, nw = gridDim.x * kWavesPerBlock;
-    float kpx[K], kpy[K], kpz[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) { kpx[k] = kp[3 * k]; kpy[k] = kp[3 * k + 1]; kpz[k] = kp[3 * k + 2]; }
     const float inv_extent = 1.0f / extent;
-
     for (int q = gw; q < nq; q += nw) {
         const float qx = q_pts[3 * (long)q], qy = q_pts[3 * (long)q + 1], qz = q_pts[3 * (long)q + 2];
         int npos = 0;
-        for (int cbase = 0; cbase < cin; cbase += 64 * J) {
-            float acc[K][J];
+        for (int cbase = 0; cbase < cin; cbase += 64) {
+            float acc[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k)
-#pragma unroll
-                for (int j = 0; j < J; ++j) acc[k][j] = 0.0f;
+            for (int k = 0; k < K; ++k) acc[k] = 0.0f;
             for (int hc = 0; hc < H; hc += 64) {
-                // ---- geometry: lanes = neighbours
                 const int h = hc + lane;
-                int i = ns;
-                if (h < H) i = (int)idx[(long)q * ld_idx + h];
-                const bool real = i >= 0 && i < ns;
-                float w[16];
-                if (real) {
+                int i = -1;
+                if (h < H) {
+                    const long long v = idx[(long)q * ld_idx + h];
+                    i = (v >= 0 && v < ns) ? (int)v : -1;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (i >= 0) {
                     const float nx = s_pts[3 * (long)i] - qx, ny = s_pts[3 * (long)i + 1] - qy,
                                 nz = s_pts[3 * (long)i + 2] - qz;
-#pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const float dx = nx - kpx[k], dy = ny - kpy[k], dz = nz - kpz[k];
-                        const float d2 = dx * dx + dy * dy + dz * dz;
-                        w[k] = fmaxf(1.0f - sqrtf(d2) * inv_extent, 0.0f);
+                        const float dx = nx - kp[3 * k], dy = ny - kp[3 * k + 1], dz = nz - kp[3 * k + 2];
+                        s_w[wave][lane][k] = fmaxf(1.0f - sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent, 0.0f);
                     }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) w[k] = 0.0f;
                 }
-                w[15] = 0.0f;
+                s_idx[wave][lane] = i;
+                if (cbase == 0) npos += __popcll(__ballot(i >= 0 && pos[i >= 0 ? i : 0] != 0));
                 __builtin_amdgcn_wave_barrier();
-                float4* dst = reinterpret_cast<float4*>(&s_w[wave][lane][0]);
-                dst[0] = make_float4(w[0], w[1], w[2], w[3]);
-                dst[1] = make_float4(w[4], w[5], w[6], w[7]);
-                dst[2] = make_float4(w[8], w[9], w[10], w[11]);
-                dst[3] = make_float4(w[12], w[13], w[14], w[15]);
-                s_idx[wave][lane] = real ? i : -1;
-                if (cbase == 0) npos += __popcll(__ballot(real && pos[real ? i : 0] != 0));
-                __builtin_amdgcn_wave_barrier();
-                // ---- aggregate: lanes = channels
                 const int hn = H - hc < 64 ? H - hc : 64;
+                const int c = cbase + lane;
                 for (int hh = 0; hh < hn; ++hh) {
                     const int ii = s_idx[wave][hh];
-                    if (ii < 0) continue;  // wave-uniform
-                    const float4* src = reinterpret_cast<const float4*>(&s_w[wave][hh][0]);
-                    const float4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
-                    const float wk[K] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
-                                         w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z};
-                    const float* xr = x + (long)ii * cin + cbase;
+                    if (ii < 0) continue;
+                    const float xv = c < cin ? x[(long)ii * cin + c] : 0.0f;
 #pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        const int c = lane + 64 * j;
-                        const float xv = cbase + c < cin ? xr[c] : 0.0f;
-#pragma unroll
-                        for (int k = 0; k < K; ++k) acc[k][j] = fmaf(wk[k], xv, acc[k][j]);
-                    }
+                    for (int k = 0; k < K; ++k) acc[k] = fmaf(s_w[wave][hh][k], xv, acc[k]);
                 }
             }
-            float* o = wf + (long)q * K * cin + cbase;
+            const int c = cbase + lane;
+            if (c < cin)
 #pragma unroll
-            for (int k = 0; k < K; ++k)
-#pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    const int c = lane + 64 * j;
-                    if (cbase + c < cin) o[(long)k * cin + c] = acc[k][j];
-                }
+                for (int k = 0; k < K; ++k) wf[(long)q * K * cin + (long)k * cin + c] = acc[k];
         }
         if (lane == 0) inv_n[q] = 1.0f / (float)(npos > 1 ? npos : 1);
     }
@@ -139,16 +257,39 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
     unsigned char* pos = cv.take<unsigned char>((size_t)ns + 1);
     PCRCG_CHECK_WS(cv);
     hipStream_t st = as_stream(stream);
-    if (ns > 0) hipLaunchKernelGGL(k_row_positive, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, pos);
-    int blocks = (nq + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (blocks > 256 * 32) blocks = 256 * 32;
     const long long* idx_ll = reinterpret_cast<const long long*>(idx);
-#define LAUNCH(J)                                                                                             \
-    hipLaunchKernelGGL(k_kpconv_aggregate<J>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, st, q_pts, nq, s_pts, \
-                       ns, idx_ll, h, ld_idx, x, cin, kp, extent, pos, wf, inv_n)
-    if (cin <= 64) LAUNCH(1);
-    else if (cin <= 128) LAUNCH(2);
-    else LAUNCH(4);
+    const int max_blocks = 256 * 32;
+    auto blocks_for = [&](long waves) {
+        long b = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+        return (int)(b > max_blocks ? max_blocks : b);
+    };
+    if (cin == 1) {
+        hipLaunchKernelGGL(k_kpconv_c1, dim3(blocks_for(nq)), dim3(kWavesPerBlock * 64), 0, st, q_pts, nq, s_pts, ns,
+                           idx_ll, h, ld_idx, x, kp, extent, wf, inv_n);
+        PCRCG_CHECK_LAUNCH();
+        return PCRCG_OK;
+    }
+    if (ns > 0) hipLaunchKernelGGL(k_row_positive, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, pos);
+    const bool aligned = (cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(wf) & 15) == 0);
+    if (!aligned) {
+        hipLaunchKernelGGL(k_kpconv_generic, dim3(blocks_for(nq)), dim3(kWavesPerBlock * 64), 0, st, q_pts, nq, s_pts,
+                           ns, idx_ll, h, ld_idx, x, cin, kp, extent, pos, wf, inv_n);
+        PCRCG_CHECK_LAUNCH();
+        return PCRCG_OK;
+    }
+    // channel blocks of 64 per wavefront: as many as possible while keeping >= ~16k wavefronts in the grid
+    const int nblk = (cin + 63) / 64;
+    int nb = nblk >= 4 ? 4 : (nblk >= 2 ? 2 : 1);
+    while (nb > 1 && ((long)nq * ((nblk + nb - 1) / nb) < 16384 || nblk % nb != 0)) nb >>= 1;
+    const int nchunk = (nblk + nb - 1) / nb;
+    const int blocks = blocks_for((long)nq * nchunk);
+#define LAUNCH(NBV)                                                                                             \
+    hipLaunchKernelGGL(k_kpconv_mfma<NBV>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, st, q_pts, nq, s_pts, ns, \
+                       idx_ll, h, ld_idx, x, cin, kp, extent, pos, wf, inv_n, nchunk)
+    if (nb == 4) LAUNCH(4);
+    else if (nb == 2) LAUNCH(2);
+    else LAUNCH(1);
 #undef LAUNCH
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;

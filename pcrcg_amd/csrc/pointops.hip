@@ -13,41 +13,43 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 
-// one wavefront per query row, lanes over channels (float4 when the row allows it)
+// one wavefront per (query row, block of 64 lanes x float4 | float channels)
 template <bool VEC4>
 __global__ void __launch_bounds__(kWavesPerBlock * 64) k_gather_max(const float* __restrict__ x, int ns, int c,
                                                                      const long long* __restrict__ idx, int nq, int h,
-                                                                     int ld_idx, float* __restrict__ out) {
+                                                                     int ld_idx, float* __restrict__ out, int nchunk) {
     const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (q >= nq) return;
+    const long item = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (item >= (long)nq * nchunk) return;
+    const int q = (int)(item / nchunk), chunk = (int)(item - (long)q * nchunk);
     const long long* row = idx + (long)q * ld_idx;
     if (VEC4) {
-        const int c4 = c >> 2;
-        for (int cb = lane; cb < c4; cb += 64) {
-            float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-            bool any = false;
-            for (int j = 0; j < h; ++j) {
-                const long long i = row[j];
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);   // shadow row = zeros  (:95)
-                if (i >= 0 && i < ns) v = reinterpret_cast<const float4*>(x + i * c)[cb];
-                if (!any) { m = v; any = true; }
-                else { m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
-            }
-            reinterpret_cast<float4*>(out + (long)q * c)[cb] = m;
+        const int cb = chunk * 64 + lane;
+        if (cb >= (c >> 2)) return;
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);   // the shadow row is all zeros  (:95)
+        bool any = false;
+#pragma unroll 4
+        for (int j = 0; j < h; ++j) {
+            const long long i = row[j];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i >= 0 && i < ns) v = reinterpret_cast<const float4*>(x + i * c)[cb];
+            if (!any) { m = v; any = true; }
+            else { m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
         }
+        reinterpret_cast<float4*>(out + (long)q * c)[cb] = m;
     } else {
-        for (int cc = lane; cc < c; cc += 64) {
-            float m = 0.f;
-            bool any = false;
-            for (int j = 0; j < h; ++j) {
-                const long long i = row[j];
-                const float v = (i >= 0 && i < ns) ? x[i * c + cc] : 0.f;
-                m = any ? fmaxf(m, v) : v;
-                any = true;
-            }
-            out[(long)q * c + cc] = m;
+        const int cc = chunk * 64 + lane;
+        if (cc >= c) return;
+        float m = 0.f;
+        bool any = false;
+#pragma unroll 4
+        for (int j = 0; j < h; ++j) {
+            const long long i = row[j];
+            const float v = (i >= 0 && i < ns) ? x[i * c + cc] : 0.f;
+            m = any ? fmaxf(m, v) : v;
+            any = true;
         }
+        out[(long)q * c + cc] = m;
     }
 }
 
@@ -86,20 +88,28 @@ __global__ void __launch_bounds__(256) k_colstats_partial(const float* __restric
     if (rl == 0 && ch < c) {
         s = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
         sq = (s_sq[0][lane] + s_sq[1][lane]) + (s_sq[2][lane] + s_sq[3][lane]);
-        partial[((long)chunk * 2 + 0) * c + ch] = s;
-        partial[((long)chunk * 2 + 1) * c + ch] = sq;
+        partial[(long)ch * nchunks + chunk] = s;                       // layout [2][c][nchunks]
+        partial[((long)c + ch) * nchunks + chunk] = sq;
     }
 }
 
+// one wavefront per channel: lanes over the (<= 128) chunk partials, fixed-order butterfly
 __global__ void __launch_bounds__(256) k_colstats_final(const double* __restrict__ partial, int nchunks, int c,
                                                          double count, float eps, float* __restrict__ stats) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ch >= c) return;
     double s = 0.0, sq = 0.0;
-    for (int k = 0; k < nchunks; ++k) {
-        s += partial[((long)k * 2 + 0) * c + ch];
-        sq += partial[((long)k * 2 + 1) * c + ch];
+    for (int k = lane; k < nchunks; k += 64) {
+        s += partial[(long)ch * nchunks + k];
+        sq += partial[((long)c + ch) * nchunks + k];
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s += __shfl_xor(s, d, 64);
+        sq += __shfl_xor(sq, d, 64);
+    }
+    if (lane != 0) return;
     const double mean = s / count;
     double var = sq / count - mean * mean;   // biased variance (InstanceNorm)
     if (var < 0.0) var = 0.0;
@@ -131,8 +141,7 @@ size_t colstats_ws_bytes(int c) { return carve_bytes((size_t)kStatChunks * 2 * (
 // shared with gnn.hip: finish a [chunks][2][c] fp64 partial buffer into (mean, rstd) pairs
 int colstats_finalize(const double* partial, int nchunks, int c, double count, float eps, float* stats,
                       hipStream_t st) {
-    hipLaunchKernelGGL(k_colstats_final, dim3((c + 255) / 256), dim3(256), 0, st, partial, nchunks, c, count, eps,
-                       stats);
+    hipLaunchKernelGGL(k_colstats_final, dim3((c + 3) / 4), dim3(256), 0, st, partial, nchunks, c, count, eps, stats);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -150,15 +159,18 @@ int pcrcg_gather_max(const float* x, int ns, int c, const int64_t* idx, int nq, 
     if (nq == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(x && idx && out);
     const long long* idx_ll = reinterpret_cast<const long long*>(idx);
-    const int blocks = (nq + kWavesPerBlock - 1) / kWavesPerBlock;
     const bool vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    const int per_wave = vec ? 256 : 64;
+    const int nchunk = (c + per_wave - 1) / per_wave;
+    const long items = (long)nq * nchunk;
+    const unsigned blocks = (unsigned)((items + kWavesPerBlock - 1) / kWavesPerBlock);
     if (vec)
         hipLaunchKernelGGL(k_gather_max<true>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, as_stream(stream), x, ns, c,
-                           idx_ll, nq, h, ld_idx, out);
+                           idx_ll, nq, h, ld_idx, out, nchunk);
     else
         hipLaunchKernelGGL(k_gather_max<false>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, as_stream(stream), x, ns,
-                           c, idx_ll, nq, h, ld_idx, out);
+                           c, idx_ll, nq, h, ld_idx, out, nchunk);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

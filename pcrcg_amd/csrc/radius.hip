@@ -229,7 +229,8 @@ __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
         wave_max = nhit > wave_max ? nhit : wave_max;
         __builtin_amdgcn_wave_barrier();
     }
-    if (lane == 0 && wave_max > 0) atomicMax(out_max, wave_max);
+    // one contended word: only the few waves that actually raise the maximum issue an atomic
+    if (lane == 0 && wave_max > aload(out_max)) atomicMax(out_max, wave_max);
 }
 
 __global__ void k_zero2(int* a, int* b) {
