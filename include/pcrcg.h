@@ -114,12 +114,14 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
                            int h, int ld_idx, const float* x, int cin, const float* kp, float extent,
                            float* wf, float* inv_n, void* ws, size_t ws_bytes, void* stream);
 
-/* C[m,n] = (A[m,k] @ B[k,n]) * row_scale[m] + bias[n]   (fp32 in, fp32 MFMA accumulate; row_scale
- * and bias may be NULL).  Row-major with leading dimensions in elements.  Replaces the
- * torch.matmul / nn.Linear / 1x1 nn.Conv1d contractions of the path (ref:models/blocks.py:361-366,
- * 487; ref:models/architectures.py:528,538-539). */
-int pcrcg_gemm_f32(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n,
-                   int k, const float* row_scale, const float* bias, void* stream);
+/* C[m,n] = (A[m,k] @ Bop[k,n]) * row_scale[m] + bias[n]   (fp32 in, fp32 MFMA accumulate; row_scale
+ * and bias may be NULL).  Row-major with leading dimensions in elements.
+ *   trans_b = 0: b is [k,n] (ldb >= n), Bop = b      -- KPConv weights [15*cin, cout], P @ V
+ *   trans_b = 1: b is [n,k] (ldb >= k), Bop = b^T    -- nn.Linear / 1x1 conv weights [out,in], Q @ K^T
+ * Replaces the torch.matmul / nn.Linear / 1x1 nn.Conv1d contractions of the path
+ * (ref:models/blocks.py:361-366, 487; ref:models/architectures.py:528,538-539; ref:models/gcn.py:123-173). */
+int pcrcg_gemm_f32(const float* a, int lda, const float* b, int ldb, int trans_b, float* c, int ldc, int m,
+                   int n, int k, const float* row_scale, const float* bias, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Point-wise blocks

@@ -32,8 +32,8 @@ SIGNATURES = {
     "pcrcg_kpconv_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_kpconv_aggregate": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                        c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "pcrcg_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
-                               c_void_p, c_void_p]),
+    "pcrcg_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                               c_void_p, c_void_p, c_void_p]),
     "pcrcg_gather_max": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pcrcg_gather_first": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "pcrcg_instnorm_ws_bytes": (c_size_t, [c_int]),

@@ -123,8 +123,8 @@ class KPFCNN(nn.Module):
         # 4. cross-cloud saliency (:556-565)
         src_n, tgt_n = feats_norm[:len_src_c], feats_norm[len_src_c:]
         inv_t = 1.0 / self._temperature()
-        p_st = ops.softmax_rows_(ops.gemm(src_n, tgt_n.t().contiguous()), inv_t)
-        p_ts = ops.softmax_rows_(ops.gemm(tgt_n, src_n.t().contiguous()), inv_t)
+        p_st = ops.softmax_rows_(ops.gemm(src_n, tgt_n.t()), inv_t)
+        p_ts = ops.softmax_rows_(ops.gemm(tgt_n, src_n.t()), inv_t)
         s1 = ops.gemm(p_st, scores_c[len_src_c:])
         s2 = ops.gemm(p_ts, scores_c[:len_src_c])
         x = torch.cat([scores_c, torch.cat([s1, s2], 0), feats_c], 1)

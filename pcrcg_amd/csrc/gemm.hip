@@ -2,45 +2,61 @@
 // bit-for-bit an fmaf chain -- MI355X guide section 3), with the per-row scale / bias epilogues the
 // KPConv contraction and the 1x1 convolutions need:
 //
-//   C[m,n] = (sum_k A[m,k] * B[k,n]) * row_scale[m] + bias[n]
+//   C[m,n] = (sum_k A[m,k] * Bop[k,n]) * row_scale[m] + bias[n]
+//   Bop = B        (B  is [K,N] row-major: KPConv weights [15*Cin, Cout], P @ V)        trans_b = 0
+//   Bop = B^T      (B  is [N,K] row-major: nn.Linear / 1x1 conv weights, Q @ K^T)       trans_b = 1
 //
 // Replaces torch.matmul(weighted_features, self.weights).sum(0) / neighbor_num
 // (ref:models/blocks.py:361-372), nn.Linear (ref:models/blocks.py:487) and the 1x1 nn.Conv1d layers
-// (ref:models/architectures.py:528,538-539; ref:models/gcn.py).
+// (ref:models/architectures.py:528,538-539; ref:models/gcn.py:123-132,165-173).
 //
-// Tiling: 256 threads = 4 wavefronts; block tile BM x BN x 16; A and B tiles are staged through
-// registers into k-major LDS images so that the 32 lanes of an MFMA operand row read consecutive
-// words (conflict-free ds_read_b32); the next tile's global loads are issued before the current
-// tile's MFMAs.  Split-K (grid.z) with fp32 atomics fills the chip when M*N is small and K is large
-// (coarse KPConv levels: M = 763, K = 7680).
+// Structure: 256 threads = 4 wavefronts; block tile BM x BN x 32, two LDS stages (dynamic LDS).
+//   * A (and B when trans_b) is copied row-major into LDS as float4s with rows padded to 36 floats: a
+//     wavefront's ds_read_b128 of 4 consecutive k for 32 consecutive rows is bank-conflict free
+//     (36*r mod 64 enumerates all 16 four-bank slots).  The k index is permuted inside each group of
+//     8 (MFMA t of a group sums k = 8g+t and 8g+4+t) identically for A and B, so one b128 read per
+//     operand tile feeds four MFMAs.
+//   * per k-step: tile s is consumed from LDS[s&1] while tile s+1 (already in registers) is written
+//     to LDS[(s+1)&1] and tile s+2 is requested from HBM; ONE barrier per step.
+//   * interior blocks (full tile, 16-byte aligned operands) use unguarded float4 loads; edge blocks
+//     use branch-free clamped loads (a per-element "load or zero" branch makes hipcc wait vmcnt(0)
+//     inside every branch).
+//   * split-K (grid.z) with fp32 atomics only when even the smallest tile leaves the chip idle.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace pcrcg {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int BK = 16;
+constexpr int BK = 32;
+constexpr int KPAD = BK + 4;   // row stride of k-contiguous LDS images (floats)
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, bool TRANS_B>
+constexpr int stage_floats() { return BM * KPAD + (TRANS_B ? BN * KPAD : BK * (BN + 4)); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_B>
 __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                    int ldb, float* __restrict__ C, int ldc, int M, int N, int Kdim,
                                                    const float* __restrict__ row_scale, const float* __restrict__ bias,
-                                                   int k_per_split, int vec_a, int vec_b, int atomic_out) {
+                                                   int k_per_split, int vec_ok, int atomic_out) {
     static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per block");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // per-wave tile
     constexpr int TM = WM / 32, TN = WN / 32;            // 32x32 MFMA tiles per wave
-    constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
-    constexpr int A_ITERS = BM * BK / 4 / 256;           // float4 loads per thread
+    constexpr int NPAD = BN + 4;
+    constexpr int A_ITERS = BM * BK / 4 / 256;           // float4 per thread and tile
     constexpr int B_ITERS = BN * BK / 4 / 256;
+    constexpr int STAGE = stage_floats<BM, BN, TRANS_B>();
     static_assert(A_ITERS >= 1 && B_ITERS >= 1, "tile too small");
-    __shared__ __attribute__((aligned(16))) float As[BK][LDA_S];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][LDB_S];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int k_begin = blockIdx.z * k_per_split;
     const int k_end = min(Kdim, k_begin + k_per_split);
+    const bool interior = vec_ok && (m0 + BM <= M) && (n0 + BN <= N);   // block-uniform
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -51,106 +67,195 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     float4 ra[A_ITERS], rb[B_ITERS];
+
+    // rows row0.. of a [rows, K] row-major matrix, columns k0..k0+31 (k-contiguous operand)
+    auto kmajor_fast = [&](const float* __restrict__ P, int ld, int row0, int k0, int it) {
+        const int e = tid + it * 256;
+        const int r = e / (BK / 4), k4 = (e % (BK / 4)) * 4;
+        return *reinterpret_cast<const float4*>(P + (long)(row0 + r) * ld + k0 + k4);
+    };
+    auto kmajor_edge = [&](const float* __restrict__ P, int ld, int row0, int rows, int k0, int it) {
+        const int e = tid + it * 256;
+        const int r = e / (BK / 4), k4 = (e % (BK / 4)) * 4;
+        const int gr = row0 + r, gk = k0 + k4, ke = k_end - 1;
+        const float* p = P + (long)min(gr, rows - 1) * ld;     // always a valid address
+        const bool rok = gr < rows;
+        float4 v;
+        v.x = p[min(gk, ke)];
+        v.y = p[min(gk + 1, ke)];
+        v.z = p[min(gk + 2, ke)];
+        v.w = p[min(gk + 3, ke)];
+        v.x = (rok && gk < k_end) ? v.x : 0.f;
+        v.y = (rok && gk + 1 < k_end) ? v.y : 0.f;
+        v.z = (rok && gk + 2 < k_end) ? v.z : 0.f;
+        v.w = (rok && gk + 3 < k_end) ? v.w : 0.f;
+        return v;
+    };
     auto load_tiles = [&](int k0) {
+        const bool fast = interior && (k0 + BK <= k_end);
+        if (fast) {
 #pragma unroll
-        for (int it = 0; it < A_ITERS; ++it) {
-            const int e = tid + it * 256;            // float4 index in the BM x (BK/4) tile
-            const int row = e / (BK / 4), k4 = (e % (BK / 4)) * 4;
-            const int gm = m0 + row, gk = k0 + k4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gm < M) {
-                const float* p = A + (long)gm * lda + gk;
-                if (vec_a && gk + 3 < k_end) v = *reinterpret_cast<const float4*>(p);
-                else {
-                    if (gk < k_end) v.x = p[0];
-                    if (gk + 1 < k_end) v.y = p[1];
-                    if (gk + 2 < k_end) v.z = p[2];
-                    if (gk + 3 < k_end) v.w = p[3];
+            for (int it = 0; it < A_ITERS; ++it) ra[it] = kmajor_fast(A, lda, m0, k0, it);
+#pragma unroll
+            for (int it = 0; it < B_ITERS; ++it) {
+                if (TRANS_B) {
+                    rb[it] = kmajor_fast(B, ldb, n0, k0, it);
+                } else {
+                    const int e = tid + it * 256;            // float4 index in the BK x (BN/4) tile
+                    const int kr = e / (BN / 4), n4 = (e % (BN / 4)) * 4;
+                    rb[it] = *reinterpret_cast<const float4*>(B + (long)(k0 + kr) * ldb + n0 + n4);
                 }
             }
-            ra[it] = v;
-        }
+        } else {
 #pragma unroll
-        for (int it = 0; it < B_ITERS; ++it) {
-            const int e = tid + it * 256;            // float4 index in the BK x (BN/4) tile
-            const int kr = e / (BN / 4), n4 = (e % (BN / 4)) * 4;
-            const int gk = k0 + kr, gn = n0 + n4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gk < k_end) {
-                const float* p = B + (long)gk * ldb + gn;
-                if (vec_b && gn + 3 < N) v = *reinterpret_cast<const float4*>(p);
-                else {
-                    if (gn < N) v.x = p[0];
-                    if (gn + 1 < N) v.y = p[1];
-                    if (gn + 2 < N) v.z = p[2];
-                    if (gn + 3 < N) v.w = p[3];
+            for (int it = 0; it < A_ITERS; ++it) ra[it] = kmajor_edge(A, lda, m0, M, k0, it);
+#pragma unroll
+            for (int it = 0; it < B_ITERS; ++it) {
+                if (TRANS_B) {
+                    rb[it] = kmajor_edge(B, ldb, n0, N, k0, it);
+                } else {
+                    const int e = tid + it * 256;
+                    const int kr = e / (BN / 4), n4 = (e % (BN / 4)) * 4;
+                    const int gk = k0 + kr, gn = n0 + n4, ne = N - 1;
+                    const float* p = B + (long)min(gk, k_end - 1) * ldb;
+                    const bool kok = gk < k_end;
+                    float4 v;
+                    v.x = p[min(gn, ne)];
+                    v.y = p[min(gn + 1, ne)];
+                    v.z = p[min(gn + 2, ne)];
+                    v.w = p[min(gn + 3, ne)];
+                    v.x = (kok && gn < N) ? v.x : 0.f;
+                    v.y = (kok && gn + 1 < N) ? v.y : 0.f;
+                    v.z = (kok && gn + 2 < N) ? v.z : 0.f;
+                    v.w = (kok && gn + 3 < N) ? v.w : 0.f;
+                    rb[it] = v;
                 }
             }
-            rb[it] = v;
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](float* As, float* Bs) {
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) {
             const int e = tid + it * 256;
-            const int row = e / (BK / 4), k4 = (e % (BK / 4)) * 4;
-            As[k4 + 0][row] = ra[it].x;
-            As[k4 + 1][row] = ra[it].y;
-            As[k4 + 2][row] = ra[it].z;
-            As[k4 + 3][row] = ra[it].w;
+            const int r = e / (BK / 4), k4 = (e % (BK / 4)) * 4;
+            *reinterpret_cast<float4*>(&As[r * KPAD + k4]) = ra[it];
         }
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
             const int e = tid + it * 256;
-            const int kr = e / (BN / 4), n4 = (e % (BN / 4)) * 4;
-            *reinterpret_cast<float4*>(&Bs[kr][n4]) = rb[it];
+            if (TRANS_B) {
+                const int r = e / (BK / 4), k4 = (e % (BK / 4)) * 4;
+                *reinterpret_cast<float4*>(&Bs[r * KPAD + k4]) = rb[it];
+            } else {
+                const int kr = e / (BN / 4), n4 = (e % (BN / 4)) * 4;
+                *reinterpret_cast<float4*>(&Bs[kr * NPAD + n4]) = rb[it];
+            }
         }
     };
 
-    if (k_begin < k_end) load_tiles(k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        __syncthreads();   // previous tile fully consumed
-        store_tiles();
-        __syncthreads();
-        if (k0 + BK < k_end) load_tiles(k0 + BK);   // overlaps with the MFMAs below
-        const int half = lane >> 5, l31 = lane & 31;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nsteps = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
+    if (nsteps > 0) {
+        load_tiles(k_begin);
+        store_tiles(smem, smem + BM * KPAD);
+        if (nsteps > 1) load_tiles(k_begin + BK);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const float* As = smem + (s & 1) * STAGE;
+        const float* Bs = As + BM * KPAD;
+        float* An = smem + ((s + 1) & 1) * STAGE;
+        if (s + 1 < nsteps) store_tiles(An, An + BM * KPAD);          // tile s+1: registers -> other stage
+        if (s + 2 < nsteps) load_tiles(k_begin + (s + 2) * BK);       // tile s+2: HBM -> registers
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[kk + half][wm * WM + i * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[kk + half][wn * WN + j * 32 + l31];
+        for (int g = 0; g < BK / 8; ++g) {
+            float4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + l31) * KPAD + g * 8 + 4 * half]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+                if (TRANS_B) {
+                    b[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + l31) * KPAD + g * 8 + 4 * half]);
+                } else {
+                    const float* bp = &Bs[(g * 8 + 4 * half) * NPAD + wn * WN + j * 32 + l31];
+                    b[j] = make_float4(bp[0], bp[NPAD], bp[2 * NPAD], bp[3 * NPAD]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            t == 0 ? a[i].x : (t == 1 ? a[i].y : (t == 2 ? a[i].z : a[i].w)),
+                            t == 0 ? b[j].x : (t == 1 ? b[j].y : (t == 2 ? b[j].z : b[j].w)), acc[i][j], 0, 0, 0);
         }
+        __syncthreads();   // stage s fully read, stage s+1 fully written
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int l31 = lane & 31, half = lane >> 5;
+    // (all row scales / biases are fetched up front with clamped indices: a load inside the per-element
+    // branches would be waited for element by element)
     const bool first_split = blockIdx.z == 0;
+    float rs[TM][16], bv[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            rs[i][r] = row_scale ? row_scale[min(gm, M - 1)] : 1.0f;
+        }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int gn = n0 + wn * WN + j * 32 + l31;
+        bv[j] = (bias && first_split) ? bias[min(gn, N - 1)] : 0.0f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int gn = n0 + wn * WN + j * 32 + l31;
-            if (gn >= N) continue;
-            const float bv = (bias && first_split) ? bias[gn] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int gm = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (gm >= M) continue;
-                float v = acc[i][j][r];
-                if (row_scale) v *= row_scale[gm];
-                v += bv;
-                float* dst = C + (long)gm * ldc + gn;
-                if (atomic_out) atomicAdd(dst, v);
-                else *dst = v;
+                const float v = acc[i][j][r] * rs[i][r] + bv[j];
+                if (gm < M && gn < N) {
+                    float* dst = C + (long)gm * ldc + gn;
+                    if (atomic_out) atomicAdd(dst, v);
+                    else *dst = v;
+                }
             }
         }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_B>
+int launch_one(dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m,
+               int n, int k, const float* row_scale, const float* bias, int k_per_split, int vec_ok, int atomic_out) {
+    constexpr size_t lds = 2 * sizeof(float) * stage_floats<BM, BN, TRANS_B>();
+    auto kern = k_gemm_f32<BM, BN, WAVES_M, WAVES_N, TRANS_B>;
+    static bool configured = false;   // > 64 KiB of dynamic LDS must be requested once per kernel
+    if (!configured) {
+        PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split,
+                       vec_ok, atomic_out);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch(bool trans_b, dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c,
+           int ldc, int m, int n, int k, const float* row_scale, const float* bias, int k_per_split, int vec_ok,
+           int atomic_out) {
+    if (trans_b)
+        return launch_one<BM, BN, WAVES_M, WAVES_N, true>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
+                                                          k_per_split, vec_ok, atomic_out);
+    return launch_one<BM, BN, WAVES_M, WAVES_N, false>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
+                                                       k_per_split, vec_ok, atomic_out);
 }
 
 }  // namespace
@@ -158,22 +263,34 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
 
 using namespace pcrcg;
 
-extern "C" int pcrcg_gemm_f32(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n,
-                              int k, const float* row_scale, const float* bias, void* stream) {
+extern "C" int pcrcg_gemm_f32(const float* a, int lda, const float* b, int ldb, int trans_b, float* c, int ldc,
+                              int m, int n, int k, const float* row_scale, const float* bias, void* stream) {
     PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 0);
     if (m == 0 || n == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(a && b && c);
-    PCRCG_CHECK_ARG(lda >= k && ldb >= n && ldc >= n);
+    PCRCG_CHECK_ARG(lda >= k && ldc >= n);
+    PCRCG_CHECK_ARG(trans_b ? ldb >= k : ldb >= n);
     hipStream_t st = as_stream(stream);
-    const int vec_a = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
-    const int vec_b = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
-    const bool narrow = n <= 64;
-    const int BM = 128, BN = narrow ? 64 : 128;
+    const int vec_ok = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && (ldb % 4 == 0) &&
+                       ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+    // Tile / split selection (sweep in scripts/gemm_tune.py on the path's shapes): these GEMMs are skinny
+    // (N = 64..2048, K up to 7680) and each block streams its own slice of A from HBM, so many small
+    // blocks beat few large ones: 128x128 only when that still yields >= 1024 blocks, otherwise 64x64
+    // (128x64 for N <= 64 with a long M), with K split until ~1024 blocks are in flight.
+    struct Tile { int bm, bn; };
+    static const Tile tiles[4] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    auto ntiles = [&](int t) {
+        return (long)((m + tiles[t].bm - 1) / tiles[t].bm) * ((n + tiles[t].bn - 1) / tiles[t].bn);
+    };
+    int pick = -1;
+    if (const char* e = getenv("PCRCG_GEMM_TILE")) pick = atoi(e);          // tuning aid
+    if (pick < 0 || pick > 3) pick = (n > 64 && ntiles(0) >= 1024) ? 0 : 3;
+    const int BM = tiles[pick].bm, BN = tiles[pick].bn;
     const int gx = (n + BN - 1) / BN, gy = (m + BM - 1) / BM;
-    // split K until the grid covers the 256 CUs about twice
     int splits = 1;
     const int ktiles = (k + BK - 1) / BK;
-    while (gx * gy * splits < 384 && splits * 2 <= ktiles / 8 && splits < 32) splits *= 2;
+    while ((long)gx * gy * splits < 1024 && k / (2 * splits) >= 192 && splits < 32) splits *= 2;
+    if (const char* e = getenv("PCRCG_GEMM_SPLITK")) splits = atoi(e) > 0 ? atoi(e) : splits;   // tuning aid
     int k_per_split = ((ktiles + splits - 1) / splits) * BK;
     if (k_per_split < BK) k_per_split = BK;
     splits = k > 0 ? (k + k_per_split - 1) / k_per_split : 1;
@@ -184,12 +301,12 @@ extern "C" int pcrcg_gemm_f32(const float* a, int lda, const float* b, int ldb, 
         else PCRCG_CHECK_HIP(hipMemset2DAsync(c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), m, st));
     }
     dim3 grid(gx, gy, splits);
-    if (narrow)
-        hipLaunchKernelGGL((k_gemm_f32<128, 64, 4, 1>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m, n, k,
-                           row_scale, bias, k_per_split, vec_a, vec_b, atomic_out);
-    else
-        hipLaunchKernelGGL((k_gemm_f32<128, 128, 2, 2>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m, n, k,
-                           row_scale, bias, k_per_split, vec_a, vec_b, atomic_out);
-    PCRCG_CHECK_LAUNCH();
-    return PCRCG_OK;
+#define GO(BMV, BNV, WMV, WNV)                                                                                   \
+    return launch<BMV, BNV, WMV, WNV>(trans_b != 0, grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, \
+                                      k_per_split, vec_ok, atomic_out)
+    if (pick == 0) GO(128, 128, 2, 2);
+    if (pick == 1) GO(128, 64, 4, 1);
+    if (pick == 2) GO(64, 128, 2, 2);
+    GO(64, 64, 2, 2);
+#undef GO
 }

@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
     const long long* __restrict__ idx, int H, int ld_idx, const float* __restrict__ x, int cin,
     const float* __restrict__ kp, float extent, const unsigned char* __restrict__ pos, float* __restrict__ wf,
     float* __restrict__ inv_n, int nchunk) {
+    constexpr int STEPS = NB >= 4 ? 4 : 8;   // groups of 4 neighbours whose row reads are in flight together
     const int lane = threadIdx.x & 63;
     const int hsub = lane >> 4, j = lane & 15;
     const long gw = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -72,44 +73,48 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
         for (int hc = 0; hc < H; hc += 64) {
             // lanes = neighbours: index + centred coordinates, once per 64 neighbours
             const int h = hc + lane;
-            int i = -1;
-            if (h < H) {
-                const long long v = idx[(long)q * ld_idx + h];
-                i = (v >= 0 && v < ns) ? (int)v : -1;
-            }
-            float px = 0.f, py = 0.f, pz = 0.f;
-            if (i >= 0) {
-                px = s_pts[3 * (long)i] - qx;
-                py = s_pts[3 * (long)i + 1] - qy;
-                pz = s_pts[3 * (long)i + 2] - qz;
-            }
-            if (chunk == 0) npos += __popcll(__ballot(i >= 0 && pos[i >= 0 ? i : 0] != 0));
+            const long long iv = idx[(long)q * ld_idx + (h < H ? h : H - 1)];   // branch-free, clamped
+            const int i = (h < H && iv >= 0 && iv < ns) ? (int)iv : -1;
+            const long ic = i >= 0 ? i : 0;
+            const float px = s_pts[3 * ic] - qx, py = s_pts[3 * ic + 1] - qy, pz = s_pts[3 * ic + 2] - qz;
+            if (chunk == 0) npos += __popcll(__ballot(i >= 0 && pos[ic] != 0));
             const int hn = H - hc < 64 ? H - hc : 64;
-#pragma unroll 2
-            for (int h0 = 0; h0 < hn; h0 += 4) {
-                const int src = h0 + hsub;
-                const int ii = __shfl(i, src, 64);
-                const float nx = __shfl(px, src, 64), ny = __shfl(py, src, 64), nz = __shfl(pz, src, 64);
-                const bool real = ii >= 0;
-                float w = 0.f;
-                if (real && jvalid) {
-                    const float dx = nx - kpx, dy = ny - kpy, dz = nz - kpz;
-                    w = fmaxf(1.0f - sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent, 0.0f);   // :285-289,328
-                }
-                const float4* xr = reinterpret_cast<const float4*>(x + (long)(real ? ii : 0) * cin + c0) + j;
-                float4 v[NB];
+            // STEPS groups of 4 neighbours at a time: all their row reads are issued before the first
+            // MFMA needs one (STEPS x NB KiB in flight per wavefront)
+            for (int h0 = 0; h0 < hn; h0 += 4 * STEPS) {
+                float w[STEPS];
+                float4 v[STEPS][NB];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (real && c0 + 64 * b + 4 * j < cin) v[b] = xr[16 * b];
+                for (int s = 0; s < STEPS; ++s) {
+                    const int src = h0 + 4 * s + hsub;            // <= 63
+                    const int ii = __shfl(i, src, 64);
+                    const float nx = __shfl(px, src, 64), ny = __shfl(py, src, 64), nz = __shfl(pz, src, 64);
+                    const bool real = ii >= 0 && h0 + 4 * s < hn;
+                    w[s] = 0.f;
+                    if (real && jvalid) {
+                        const float dx = nx - kpx, dy = ny - kpy, dz = nz - kpz;
+                        w[s] = fmaxf(1.0f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent, 0.0f);
+                    }
+                    // unconditional loads from clamped (always valid) addresses, zeroed by select: a load
+                    // inside a divergent branch would be waited for one by one
+                    const float* xrow = x + (long)(real ? ii : 0) * cin;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const int c = c0 + 64 * b + 4 * j;
+                        const float4 t = *reinterpret_cast<const float4*>(xrow + (c < cin ? c : cin - 4));
+                        const bool ok = real && c < cin;
+                        v[s][b] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+                    }
                 }
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v[b].x, acc[b][0], 0, 0, 0);
-                    acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v[b].y, acc[b][1], 0, 0, 0);
-                    acc[b][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v[b].z, acc[b][2], 0, 0, 0);
-                    acc[b][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, v[b].w, acc[b][3], 0, 0, 0);
-                }
+                for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], v[s][b].x, acc[b][0], 0, 0, 0);
+                        acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], v[s][b].y, acc[b][1], 0, 0, 0);
+                        acc[b][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], v[s][b].z, acc[b][2], 0, 0, 0);
+                        acc[b][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], v[s][b].w, acc[b][3], 0, 0, 0);
+                    }
             }
         }
         // D layout: register r of lane (hsub, j) = kernel point 4*hsub + r, channel group j
@@ -253,6 +258,7 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
     PCRCG_CHECK_ARG(extent > 0.0f);
     if (nq == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(q_pts && s_pts && idx && x && kp && wf && inv_n && ws);
+    PCRCG_CHECK_ARG(ns >= 1);
     Carver cv(ws, ws_bytes);
     unsigned char* pos = cv.take<unsigned char>((size_t)ns + 1);
     PCRCG_CHECK_WS(cv);

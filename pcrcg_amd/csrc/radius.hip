@@ -191,22 +191,19 @@ __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
         int nhit = 0;
         for (int base = 0; base < total; base += 64) {
             const int t = base + lane;
-            bool hit = false;
-            u64 packed = 0;
-            if (t < total) {
-                int lo = 0;   // largest j in [0,27) with excl[j] <= t  (5-step binary search over 32 entries)
+            const int tc = t < total ? t : total - 1;   // clamped: loads stay branch-free
+            int lo = 0;   // largest j in [0,27) with excl[j] <= tc  (5-step binary search over 32 entries)
 #pragma unroll
-                for (int step = 16; step >= 1; step >>= 1)
-                    if (s_excl[wave][lo + step] <= t) lo += step;
-                const float4 p = g.spts[s_start[wave][lo] + (t - s_excl[wave][lo])];
-                const float d0 = qx - p.x, d1 = qy - p.y, d2c = qz - p.z;
-                float d2 = 0.0f;
-                d2 += d0 * d0;
-                d2 += d1 * d1;
-                d2 += d2c * d2c;
-                hit = d2 < r2;
-                packed = ((u64)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p.w);
-            }
+            for (int step = 16; step >= 1; step >>= 1)
+                if (s_excl[wave][lo + step] <= tc) lo += step;
+            const float4 p = g.spts[s_start[wave][lo] + (tc - s_excl[wave][lo])];
+            const float d0 = qx - p.x, d1 = qy - p.y, d2c = qz - p.z;
+            float d2 = 0.0f;
+            d2 += d0 * d0;
+            d2 += d1 * d1;
+            d2 += d2c * d2c;
+            const bool hit = t < total && d2 < r2;
+            const u64 packed = ((u64)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p.w);
             const u64 mask = __ballot(hit);
             const int pos = nhit + __popcll(mask & ((1ull << lane) - 1ull));
             if (hit && pos < kListCap) list[pos] = packed;

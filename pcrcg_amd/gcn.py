@@ -92,18 +92,17 @@ class MultiHeadedAttention(nn.Module):
         proj = []
         for layer, x in zip(self.proj, (query, key, value)):
             w = layer.weight.data.squeeze(-1)[perm]      # rows = output channels, head-major
-            proj.append(ops.gemm(x, w.t().contiguous(), bias=layer.bias.data[perm].contiguous()))
+            proj.append(ops.gemm(x, w.t(), bias=layer.bias.data[perm].contiguous()))
         q, kk, v = proj
-        kt = kk.t().contiguous()                         # [C, M]
         n, m = q.shape[0], kk.shape[0]
         msg = torch.empty((n, c), dtype=torch.float32, device=dev)
         scores = torch.empty((n, m), dtype=torch.float32, device=dev)
         for i in range(h):
-            ops.gemm(q[:, i * d:(i + 1) * d], kt[i * d:(i + 1) * d], out=scores)      # :152
+            ops.gemm(q[:, i * d:(i + 1) * d], kk[:, i * d:(i + 1) * d].t(), out=scores)   # :152
             ops.softmax_rows_(scores, 1.0 / d ** 0.5)                                 # :153
             ops.gemm(scores, v[:, i * d:(i + 1) * d], out=msg[:, i * d:(i + 1) * d])  # :154
         wm = self.merge.weight.data.squeeze(-1)[:, perm]
-        return ops.gemm(msg, wm.t().contiguous(), bias=self.merge.bias.data)          # :173
+        return ops.gemm(msg, wm.t(), bias=self.merge.bias.data)                       # :173
 
 
 class AttentionalPropagation(nn.Module):

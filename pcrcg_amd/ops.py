@@ -133,11 +133,26 @@ class CellGrid:
 # ------------------------------------------------------------------------------------------------
 # model kernels
 # ------------------------------------------------------------------------------------------------
+def _operand_b(b):
+    """[k, n] operand -> (tensor, ld, trans_b).  A transposed view of a row-major [n, k] matrix (e.g.
+    `linear.weight.t()`) is passed as it is with trans_b = 1: no copy."""
+    _dev(b, _F32, "b")
+    if b.dim() != 2:
+        raise RuntimeError("pcrcg_amd: `b` must be 2-D")
+    k, n = b.shape
+    if b.stride(1) == 1 and (k == 1 or b.stride(0) >= n):
+        return b, (b.stride(0) if k > 1 else n), 0
+    if b.stride(0) == 1 and (n == 1 or b.stride(1) >= k):
+        return b, (b.stride(1) if n > 1 else k), 1
+    b = b.contiguous()
+    return b, n, 0
+
+
 def gemm(a, b, row_scale=None, bias=None, out=None):
     """out[m,n] = (a[m,k] @ b[k,n]) * row_scale[m] + bias[n] on the fp32 matrix cores."""
     L = _lib.lib()
     a, lda = _rows(a, _F32, "a")
-    b, ldb = _rows(b, _F32, "b")
+    b, ldb, trans_b = _operand_b(b)
     m, k = a.shape
     k2, n = b.shape
     if k != k2:
@@ -151,7 +166,7 @@ def gemm(a, b, row_scale=None, bias=None, out=None):
         row_scale = _dev(row_scale, _F32, "row_scale").contiguous()
     if bias is not None:
         bias = _dev(bias, _F32, "bias").contiguous()
-    _lib.check(L.pcrcg_gemm_f32(a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), ldc, m, n, k,
+    _lib.check(L.pcrcg_gemm_f32(a.data_ptr(), lda, b.data_ptr(), ldb, trans_b, out.data_ptr(), ldc, m, n, k,
                                 _ptr(row_scale), _ptr(bias), _stream()), "pcrcg_gemm_f32")
     return out
 

@@ -38,9 +38,9 @@ def test_workspace_queries():
 
 def test_bad_arguments_are_rejected_before_any_launch():
     lib = _lib.lib()
-    rc = lib.pcrcg_gemm_f32(None, 4, None, 4, None, 4, 4, 4, 4, None, None, None)
+    rc = lib.pcrcg_gemm_f32(None, 4, None, 4, 0, None, 4, 4, 4, 4, None, None, None)
     assert rc == -1 and b"bad argument" in lib.pcrcg_last_error()
-    rc = lib.pcrcg_gemm_f32(ctypes.c_void_p(16), 2, ctypes.c_void_p(16), 4, ctypes.c_void_p(16), 4, 4, 4, 4, None,
+    rc = lib.pcrcg_gemm_f32(ctypes.c_void_p(16), 2, ctypes.c_void_p(16), 4, 0, ctypes.c_void_p(16), 4, 4, 4, 4, None,
                             None, None)
     assert rc == -1  # lda < k
     rc = lib.pcrcg_grid_subsample_batch(None, 10, None, 1, 0.1, 0, None, None, None, None, 0, None)
