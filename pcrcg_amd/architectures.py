@@ -8,7 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .blocks import block_decider
+from .blocks import NearestUpsampleBlock, block_decider
 from .config import as_config
 from .gcn import GCN
 
@@ -130,10 +130,12 @@ class KPFCNN(nn.Module):
         x = torch.cat([scores_c, torch.cat([s1, s2], 0), feats_c], 1)
 
         # decoder (:567-570)
+        fused_concat = False
         for block_i, block_op in enumerate(self.decoder_blocks):
-            if block_i in self.decoder_concats:
+            if block_i in self.decoder_concats and not fused_concat:
                 x = torch.cat([x, skip_x.pop()], 1)
-            x = block_op(x, batch)
+            fused_concat = isinstance(block_op, NearestUpsampleBlock) and (block_i + 1) in self.decoder_concats
+            x = block_op(x, batch, skip_x.pop()) if fused_concat else block_op(x, batch)
         fd = self.final_feats_dim
         feats_f = x[:, :fd]
         scores_overlap = x[:, fd]

@@ -21,6 +21,27 @@ def _no_autograd(*tensors):
                            "torch.no_grad() (backward kernels are listed as next in DESIGN.md)")
 
 
+_PADDED = {}
+
+
+def aligned_weight(weight):
+    """[out, in] weight whose rows start on 16-byte boundaries: a cached copy with the leading
+    dimension padded to a multiple of 4 when `in` is not one (decoder widths 1538 and 769), so the GEMM
+    can use float4 loads.  The returned tensor is a [out, in] view."""
+    w = weight.data
+    k = w.shape[1]
+    if k % 4 == 0:
+        return w
+    key = (w.data_ptr(), weight._version, tuple(w.shape))
+    hit = _PADDED.get(id(weight))
+    if hit is None or hit[0] != key:
+        buf = torch.zeros((w.shape[0], (k + 3) // 4 * 4), dtype=w.dtype, device=w.device)
+        buf[:, :k].copy_(w)
+        hit = (key, buf)
+        _PADDED[id(weight)] = hit
+    return hit[1][:, :k]
+
+
 def gather(x, idx, method=2):
     """ref:models/blocks.py:27-58 (row gather); kept for API parity."""
     return x[idx]
@@ -124,7 +145,7 @@ class UnaryBlock(nn.Module):
 
     def linear(self, x):
         _no_autograd(x, self.mlp.weight)
-        return ops.gemm(x, self.mlp.weight.data.t())
+        return ops.gemm(x, aligned_weight(self.mlp.weight).t())
 
     def forward(self, x, batch=None):
         return self.batch_norm(self.linear(x), 1.0 if self.no_relu else 0.1)
@@ -145,7 +166,7 @@ class LastUnaryBlock(nn.Module):
 
     def forward(self, x, batch=None):
         _no_autograd(x, self.mlp.weight)
-        return ops.gemm(x, self.mlp.weight.data.t())
+        return ops.gemm(x, aligned_weight(self.mlp.weight).t())
 
     def __repr__(self):
         return "LastUnaryBlock(in_feat: {:d}, out_feat: {:d})".format(self.in_dim, self.out_dim)
@@ -242,8 +263,17 @@ class NearestUpsampleBlock(nn.Module):
         super().__init__()
         self.layer_ind = layer_ind
 
-    def forward(self, x, batch):
-        return closest_pool(x, batch["upsamples"][self.layer_ind - 1])
+    def forward(self, x, batch, skip=None):
+        """With `skip`, returns cat([upsampled x, skip], 1) built in place in a buffer whose rows are
+        16-byte aligned (the concat of ref:models/architectures.py:568-569 fused with the upsample)."""
+        inds = batch["upsamples"][self.layer_ind - 1]
+        if skip is None:
+            return closest_pool(x, inds)
+        c, cs = x.shape[1], skip.shape[1]
+        buf = torch.empty((inds.shape[0], (c + cs + 3) // 4 * 4), dtype=x.dtype, device=x.device)
+        ops.gather_first(x, inds, out=buf[:, :c])
+        buf[:, c:c + cs].copy_(skip)
+        return buf[:, :c + cs]
 
     def __repr__(self):
         return "NearestUpsampleBlock(layer: {:d} -> {:d})".format(self.layer_ind, self.layer_ind - 1)

@@ -40,7 +40,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_B>
 __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                    int ldb, float* __restrict__ C, int ldc, int M, int N, int Kdim,
                                                    const float* __restrict__ row_scale, const float* __restrict__ bias,
-                                                   int k_per_split, int vec_ok, int atomic_out) {
+                                                   int k_per_split, int vec_a, int vec_b, int atomic_out) {
     static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per block");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // per-wave tile
     constexpr int TM = WM / 32, TN = WN / 32;            // 32x32 MFMA tiles per wave
@@ -56,7 +56,8 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int k_begin = blockIdx.z * k_per_split;
     const int k_end = min(Kdim, k_begin + k_per_split);
-    const bool interior = vec_ok && (m0 + BM <= M) && (n0 + BN <= N);   // block-uniform
+    const bool full_a = vec_a && (m0 + BM <= M);   // block-uniform: operand tile fully inside, 16-B aligned
+    const bool full_b = vec_b && (n0 + BN <= N);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -92,10 +93,15 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
         return v;
     };
     auto load_tiles = [&](int k0) {
-        const bool fast = interior && (k0 + BK <= k_end);
-        if (fast) {
+        const bool kfull = k0 + BK <= k_end;
+        if (full_a && kfull) {
 #pragma unroll
             for (int it = 0; it < A_ITERS; ++it) ra[it] = kmajor_fast(A, lda, m0, k0, it);
+        } else {
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) ra[it] = kmajor_edge(A, lda, m0, M, k0, it);
+        }
+        if (full_b && kfull) {
 #pragma unroll
             for (int it = 0; it < B_ITERS; ++it) {
                 if (TRANS_B) {
@@ -107,8 +113,6 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
                 }
             }
         } else {
-#pragma unroll
-            for (int it = 0; it < A_ITERS; ++it) ra[it] = kmajor_edge(A, lda, m0, M, k0, it);
 #pragma unroll
             for (int it = 0; it < B_ITERS; ++it) {
                 if (TRANS_B) {
@@ -232,7 +236,8 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_B>
 int launch_one(dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m,
-               int n, int k, const float* row_scale, const float* bias, int k_per_split, int vec_ok, int atomic_out) {
+               int n, int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b,
+               int atomic_out) {
     constexpr size_t lds = 2 * sizeof(float) * stage_floats<BM, BN, TRANS_B>();
     auto kern = k_gemm_f32<BM, BN, WAVES_M, WAVES_N, TRANS_B>;
     static bool configured = false;   // > 64 KiB of dynamic LDS must be requested once per kernel
@@ -242,20 +247,20 @@ int launch_one(dim3 grid, hipStream_t st, const float* a, int lda, const float* 
         configured = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split,
-                       vec_ok, atomic_out);
+                       vec_a, vec_b, atomic_out);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch(bool trans_b, dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c,
-           int ldc, int m, int n, int k, const float* row_scale, const float* bias, int k_per_split, int vec_ok,
-           int atomic_out) {
+           int ldc, int m, int n, int k, const float* row_scale, const float* bias, int k_per_split, int vec_a,
+           int vec_b, int atomic_out) {
     if (trans_b)
         return launch_one<BM, BN, WAVES_M, WAVES_N, true>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
-                                                          k_per_split, vec_ok, atomic_out);
+                                                          k_per_split, vec_a, vec_b, atomic_out);
     return launch_one<BM, BN, WAVES_M, WAVES_N, false>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
-                                                       k_per_split, vec_ok, atomic_out);
+                                                       k_per_split, vec_a, vec_b, atomic_out);
 }
 
 }  // namespace
@@ -271,8 +276,8 @@ extern "C" int pcrcg_gemm_f32(const float* a, int lda, const float* b, int ldb, 
     PCRCG_CHECK_ARG(lda >= k && ldc >= n);
     PCRCG_CHECK_ARG(trans_b ? ldb >= k : ldb >= n);
     hipStream_t st = as_stream(stream);
-    const int vec_ok = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && (ldb % 4 == 0) &&
-                       ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+    const int vec_a = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+    const int vec_b = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
     // Tile / split selection (sweep in scripts/gemm_tune.py on the path's shapes): these GEMMs are skinny
     // (N = 64..2048, K up to 7680) and each block streams its own slice of A from HBM, so many small
     // blocks beat few large ones: 128x128 only when that still yields >= 1024 blocks, otherwise 64x64
@@ -289,7 +294,7 @@ extern "C" int pcrcg_gemm_f32(const float* a, int lda, const float* b, int ldb, 
     const int gx = (n + BN - 1) / BN, gy = (m + BM - 1) / BM;
     int splits = 1;
     const int ktiles = (k + BK - 1) / BK;
-    while ((long)gx * gy * splits < 1024 && k / (2 * splits) >= 192 && splits < 32) splits *= 2;
+    while ((long)gx * gy * splits < 768 && k / (2 * splits) >= 192 && splits < 32) splits *= 2;
     if (const char* e = getenv("PCRCG_GEMM_SPLITK")) splits = atoi(e) > 0 ? atoi(e) : splits;   // tuning aid
     int k_per_split = ((ktiles + splits - 1) / splits) * BK;
     if (k_per_split < BK) k_per_split = BK;
@@ -303,7 +308,7 @@ extern "C" int pcrcg_gemm_f32(const float* a, int lda, const float* b, int ldb, 
     dim3 grid(gx, gy, splits);
 #define GO(BMV, BNV, WMV, WNV)                                                                                   \
     return launch<BMV, BNV, WMV, WNV>(trans_b != 0, grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, \
-                                      k_per_split, vec_ok, atomic_out)
+                                      k_per_split, vec_a, vec_b, atomic_out)
     if (pick == 0) GO(128, 128, 2, 2);
     if (pick == 1) GO(128, 64, 4, 1);
     if (pick == 2) GO(64, 128, 2, 2);

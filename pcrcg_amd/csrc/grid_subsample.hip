@@ -55,13 +55,21 @@ __device__ __forceinline__ int cloud_of(const int* __restrict__ coff, int nb, in
     return lo;
 }
 
-__global__ void k_offsets(const int* __restrict__ len, int nb, int* __restrict__ coff, unsigned* __restrict__ mm) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+// cloud offsets, min/max seeds and every table reset in one launch (instead of a kernel and 5 memsets)
+__global__ void __launch_bounds__(256) k_init(const int* __restrict__ len, int nb, int* __restrict__ coff,
+                                               unsigned* __restrict__ mm, u64* __restrict__ tkey, int* __restrict__ tfirst,
+                                               int* __restrict__ tcnt, int* __restrict__ ccnt, int* __restrict__ cfill,
+                                               int* __restrict__ mtot, long n1) {
+    const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    if (t0 == 0) {
         int s = 0;
         for (int b = 0; b < nb; ++b) { coff[b] = s; s += len[b]; }
         coff[nb] = s;
+        *mtot = 0;
     }
-    for (int i = threadIdx.x; i < nb * 6; i += blockDim.x) mm[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
+    for (long i = t0; i < nb * 6; i += stride) mm[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
+    for (long i = t0; i < 2 * n1; i += stride) { tkey[i] = kEmptyKey; tfirst[i] = kInfIdx; tcnt[i] = 0; }
+    for (long i = t0; i < n1; i += stride) { ccnt[i] = 0; cfill[i] = 0; }
 }
 
 __global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ pts, int n, const int* __restrict__ coff,
@@ -450,12 +458,9 @@ int pcrcg_grid_subsample_batch(const float* pts, int n, const int* len, int nb, 
     PCRCG_CHECK_WS(cv);
 
     const int blocks = n > 0 ? (n + 255) / 256 : 1;
-    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(64), 0, st, len, nb, coff, mm);
-    PCRCG_CHECK_HIP(hipMemsetAsync(tkey, 0xFF, 2 * N * sizeof(u64), st));
-    PCRCG_CHECK_HIP(hipMemsetAsync(tfirst, 0x7F, 2 * N * sizeof(int), st));
-    PCRCG_CHECK_HIP(hipMemsetAsync(tcnt, 0, 2 * N * sizeof(int), st));
-    PCRCG_CHECK_HIP(hipMemsetAsync(ccnt, 0, N * sizeof(int), st));
-    PCRCG_CHECK_HIP(hipMemsetAsync(cfill, 0, N * sizeof(int), st));
+    const int init_blocks = (int)((2 * N + 255) / 256 < 1024 ? (2 * N + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_init, dim3(init_blocks), dim3(256), 0, st, len, nb, coff, mm, tkey, tfirst, tcnt, ccnt, cfill,
+                       mtot, (long)N);
     if (n > 0) {
         const float inv_dl = 1 / dl;  // (1/sampleDl): int/float -> fp32 division on the host (:27)
         hipLaunchKernelGGL(k_minmax, dim3(blocks), dim3(256), 0, st, pts, n, coff, nb, mm);
@@ -468,8 +473,6 @@ int pcrcg_grid_subsample_batch(const float* pts, int n, const int* len, int nb, 
         PCRCG_PROPAGATE(exclusive_scan_i32(ccnt, cstart, n, nullptr, scan_ws, st));
         hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, st, n, slot_of, trank, cstart, cfill, cidx);
         hipLaunchKernelGGL(k_barycentres, dim3(blocks), dim3(256), 0, st, pts, mtot, cstart, ccnt, cidx, cbary);
-    } else {
-        PCRCG_CHECK_HIP(hipMemsetAsync(mtot, 0, sizeof(int), st));
     }
     hipLaunchKernelGGL(k_order_emit, dim3(nb), dim3(kUmapThreads), 0, st, n, nb, coff, rank, mtot, ckey, cbary, ebase,
                        bbase, (long)es, (long)bs, max_p, out_pts, out_len, out_m);

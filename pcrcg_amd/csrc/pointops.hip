@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) k_gather_first(const float* __restrict__ 
 constexpr int kStatChunks = 128;   // row chunks (= partial sums per channel)
 
 __global__ void __launch_bounds__(256) k_colstats_partial(const float* __restrict__ x, int n, int c, int ldx,
-                                                           double* __restrict__ partial /* [chunks][2][c] */) {
+                                                           double* __restrict__ partial /* [2][c][chunks] */) {
     __shared__ double s_sum[4][64], s_sq[4][64];
     const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int ch = blockIdx.y * 64 + lane;
@@ -76,12 +76,20 @@ __global__ void __launch_bounds__(256) k_colstats_partial(const float* __restric
     const long rows_per = ((long)n + nchunks - 1) / nchunks;
     const long r0 = chunk * rows_per, r1 = min((long)n, r0 + rows_per);
     double s = 0.0, sq = 0.0;
-    if (ch < c)
-        for (long r = r0 + rl; r < r1; r += 4) {
+    if (ch < c) {
+        long r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {   // four independent row reads in flight per thread
+            const float v0 = x[r * ldx + ch], v1 = x[(r + 4) * ldx + ch], v2 = x[(r + 8) * ldx + ch],
+                        v3 = x[(r + 12) * ldx + ch];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+            sq += ((double)v0 * v0 + (double)v1 * v1) + ((double)v2 * v2 + (double)v3 * v3);
+        }
+        for (; r < r1; r += 4) {
             const double v = (double)x[r * ldx + ch];
             s += v;
             sq += v * v;
         }
+    }
     s_sum[rl][lane] = s;
     s_sq[rl][lane] = sq;
     __syncthreads();
@@ -132,6 +140,34 @@ __global__ void __launch_bounds__(256) k_instnorm_apply(const float* __restrict_
         v += rv;
     }
     y[r * ldy + ch] = v >= 0.f ? v : v * slope;
+}
+
+// float4 variant: c, ldx, ldr, ldy multiples of 4 and 16-byte aligned bases
+__global__ void __launch_bounds__(256) k_instnorm_apply4(const float* __restrict__ x, int n, int c4, int ldx,
+                                                          const float* __restrict__ stats, const float* __restrict__ res,
+                                                          int ldr, const float* __restrict__ res_stats, float slope,
+                                                          float* __restrict__ y, int ldy) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)n * c4) return;
+    const long r = e / c4;
+    const int q = (int)(e - r * c4);
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + 4 * q);
+    const float4 s0 = *reinterpret_cast<const float4*>(stats + 8 * q), s1 = *reinterpret_cast<const float4*>(stats + 8 * q + 4);
+    float4 v = make_float4((xv.x - s0.x) * s0.y, (xv.y - s0.z) * s0.w, (xv.z - s1.x) * s1.y, (xv.w - s1.z) * s1.w);
+    if (res) {
+        float4 rv = *reinterpret_cast<const float4*>(res + r * ldr + 4 * q);
+        if (res_stats) {
+            const float4 t0 = *reinterpret_cast<const float4*>(res_stats + 8 * q),
+                         t1 = *reinterpret_cast<const float4*>(res_stats + 8 * q + 4);
+            rv = make_float4((rv.x - t0.x) * t0.y, (rv.y - t0.z) * t0.w, (rv.z - t1.x) * t1.y, (rv.w - t1.z) * t1.w);
+        }
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+    }
+    v.x = v.x >= 0.f ? v.x : v.x * slope;
+    v.y = v.y >= 0.f ? v.y : v.y * slope;
+    v.z = v.z >= 0.f ? v.z : v.z * slope;
+    v.w = v.w >= 0.f ? v.w : v.w * slope;
+    *reinterpret_cast<float4*>(y + r * ldy + 4 * q) = v;
 }
 
 }  // namespace
@@ -205,9 +241,18 @@ int pcrcg_instnorm_apply(const float* x, int n, int c, int ldx, const float* sta
     if (n == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(x && stats && y);
     PCRCG_CHECK_ARG(!res || ldr >= c);
-    const long total = (long)n * c;
-    hipLaunchKernelGGL(k_instnorm_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), x, n,
-                       c, ldx, stats, res, ldr, res_stats, slope, y, ldy);
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && al16(x) && al16(y) && al16(stats) &&
+                     (!res || (ldr % 4 == 0 && al16(res))) && (!res_stats || al16(res_stats));
+    if (vec) {
+        const long total = (long)n * (c / 4);
+        hipLaunchKernelGGL(k_instnorm_apply4, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), x,
+                           n, c / 4, ldx, stats, res, ldr, res_stats, slope, y, ldy);
+    } else {
+        const long total = (long)n * c;
+        hipLaunchKernelGGL(k_instnorm_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), x,
+                           n, c, ldx, stats, res, ldr, res_stats, slope, y, ldy);
+    }
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

@@ -28,8 +28,10 @@ namespace {
 typedef unsigned long long u64;
 constexpr u64 kEmptyKey = ~0ull;
 constexpr int kCoordBias = 1 << 20;   // cell coordinates are stored biased, 21 bits each
-constexpr int kListCap = 1024;        // staged hits per query (reference bound: hist_n = 905,
+constexpr int kListCapFast = 256;     // staged hits per query in the first pass (8 KiB of LDS per workgroup)
+constexpr int kListCapFull = 1024;    // second pass for the rare longer lists (reference bound: hist_n = 905,
                                       // ref:datasets/dataloader.py:407)
+constexpr long long kRedoMark = -2;   // row[0] marker: list did not fit the first pass
 constexpr int kQueryWaves = 4;        // waves (= queries in flight) per workgroup
 
 struct GridHeader {   // first 256 bytes of the grid workspace
@@ -99,17 +101,22 @@ __device__ __forceinline__ u64 cell_key(int cx, int cy, int cz) {
     return (u64)(unsigned)cx | ((u64)(unsigned)cy << 21) | ((u64)(unsigned)cz << 42);
 }
 
-__global__ void k_grid_header(GridHeader* hdr, int* __restrict__ soff, const int* __restrict__ slen, int ns, int nb,
-                              double inv_cell) {
-    if (threadIdx.x == 0) {
+// header + cloud offsets + table reset in one launch (instead of a kernel and two memsets)
+__global__ void __launch_bounds__(256) k_grid_init(GridView g, const int* __restrict__ slen, int ns, int nb,
+                                                    double inv_cell, long nslots) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         int s = 0;
-        for (int b = 0; b < nb; ++b) { soff[b] = s; s += slen[b]; }
-        soff[nb] = s;
-        hdr->inv_cell = inv_cell;
-        hdr->ns = ns;
-        hdr->nb = nb;
-        hdr->cursor = 0;
-        hdr->overflow = 0;
+        for (int b = 0; b < nb; ++b) { g.soff[b] = s; s += slen[b]; }
+        g.soff[nb] = s;
+        g.hdr->inv_cell = inv_cell;
+        g.hdr->ns = ns;
+        g.hdr->nb = nb;
+        g.hdr->cursor = 0;
+        g.hdr->overflow = 0;
+    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (long)gridDim.x * blockDim.x) {
+        g.tkey[i] = kEmptyKey;
+        g.tcnt[i] = 0;
     }
 }
 
@@ -148,11 +155,13 @@ __global__ void __launch_bounds__(256) k_grid_scatter(const float* __restrict__ 
     g.spts[dst] = make_float4(sup[3 * (long)i], sup[3 * (long)i + 1], sup[3 * (long)i + 2], __int_as_float(i));
 }
 
-// One wavefront per query.
+// One wavefront per query.  Pass 1 (REDO = false) handles every query with a small LDS list; a query
+// whose list does not fit marks its row, and pass 2 (REDO = true, large list) redoes only marked rows.
+template <int CAP, bool REDO>
 __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
     const float* __restrict__ q, int nq, const int* __restrict__ qlen, int nb, float r2, GridView g, int cols,
     long long* __restrict__ out_idx, int* __restrict__ out_count, int* __restrict__ out_max, int* __restrict__ status) {
-    __shared__ u64 s_list[kQueryWaves][kListCap];
+    __shared__ u64 s_list[kQueryWaves][CAP];
     __shared__ int s_excl[kQueryWaves][32];
     __shared__ int s_start[kQueryWaves][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -161,7 +170,9 @@ __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
     const double inv_cell = g.hdr->inv_cell;
     u64* list = s_list[wave];
     int wave_max = 0;
+    if (REDO && blockIdx.x == 0 && threadIdx.x == 0 && g.hdr->overflow && status) *status = 2;
     for (int qi = gw; qi < nq; qi += nw) {
+        if (REDO && out_idx[(long)qi * cols] != kRedoMark) continue;   // wave-uniform
         // cloud of this query: walk the (few) query lengths
         int b = 0, qacc = 0;
         while (b < nb - 1 && qi >= qacc + qlen[b]) { qacc += qlen[b]; ++b; }
@@ -206,12 +217,17 @@ __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
             const u64 packed = ((u64)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p.w);
             const u64 mask = __ballot(hit);
             const int pos = nhit + __popcll(mask & ((1ull << lane) - 1ull));
-            if (hit && pos < kListCap) list[pos] = packed;
+            if (hit && pos < CAP) list[pos] = packed;
             nhit += __popcll(mask);
         }
         __builtin_amdgcn_wave_barrier();
-        const int nl = nhit < kListCap ? nhit : kListCap;
+        const int nl = nhit < CAP ? nhit : CAP;
         long long* row = out_idx + (long)qi * cols;
+        if (!REDO && nhit > CAP) {   // leave the row to pass 2
+            if (lane == 0) row[0] = kRedoMark;
+            wave_max = nhit > wave_max ? nhit : wave_max;
+            continue;
+        }
         for (int e = lane; e < nl; e += 64) {
             const u64 mine = list[e];
             int rank = 0;
@@ -221,7 +237,7 @@ __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
         for (int j = nl + lane; j < cols; j += 64) row[j] = (long long)ns;   // shadow index  (:324)
         if (lane == 0) {
             if (out_count) out_count[qi] = nhit;
-            if ((nhit > kListCap || !inrange) && status) *status = 1;
+            if ((nhit > CAP || !inrange) && status) *status = 1;
         }
         wave_max = nhit > wave_max ? nhit : wave_max;
         __builtin_amdgcn_wave_barrier();
@@ -233,10 +249,6 @@ __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
 __global__ void k_zero2(int* a, int* b) {
     if (a) *a = 0;
     if (b) *b = 0;
-}
-
-__global__ void k_copy_overflow(const GridHeader* hdr, int* status) {
-    if (hdr->overflow && status) *status = 2;
 }
 
 }  // namespace
@@ -262,9 +274,8 @@ int pcrcg_cellgrid_build(const float* sup, int ns, const int* slen, int nb, floa
     }
     const size_t N = (size_t)ns + 1;
     const double inv_cell = 1.0 / ((double)radius * (1.0 + 1e-5));
-    hipLaunchKernelGGL(k_grid_header, dim3(1), dim3(64), 0, st, g.hdr, g.soff, slen, ns, nb, inv_cell);
-    PCRCG_CHECK_HIP(hipMemsetAsync(g.tkey, 0xFF, 2 * N * sizeof(u64), st));
-    PCRCG_CHECK_HIP(hipMemsetAsync(g.tcnt, 0, 2 * N * sizeof(int), st));
+    const int init_blocks = (int)((2 * N + 255) / 256 < 1024 ? (2 * N + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_grid_init, dim3(init_blocks), dim3(256), 0, st, g, slen, ns, nb, inv_cell, (long)(2 * N));
     if (ns > 0) {
         const int blocks = (ns + 255) / 256;
         hipLaunchKernelGGL(k_grid_insert, dim3(blocks), dim3(256), 0, st, sup, ns, nb, g);
@@ -290,9 +301,11 @@ int pcrcg_radius_query(const float* q, int nq, const int* qlen, int ns, const in
     int blocks = (nq + kQueryWaves - 1) / kQueryWaves;
     const int max_blocks = 256 * 16;   // 256 CUs x a few workgroups each; waves loop over queries
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL(k_radius_query, dim3(blocks), dim3(kQueryWaves * 64), 0, st, q, nq, qlen, nb, r2, g, cols,
-                       reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status);
-    hipLaunchKernelGGL(k_copy_overflow, dim3(1), dim3(1), 0, st, g.hdr, status);
+    hipLaunchKernelGGL((k_radius_query<kListCapFast, false>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, q, nq, qlen,
+                       nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status);
+    const int redo_blocks = blocks < 512 ? blocks : 512;
+    hipLaunchKernelGGL((k_radius_query<kListCapFull, true>), dim3(redo_blocks), dim3(kQueryWaves * 64), 0, st, q, nq,
+                       qlen, nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
