@@ -114,6 +114,12 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
                            int h, int ld_idx, const float* x, int cin, const float* kp, float extent,
                            float* wf, float* inv_n, void* ws, size_t ws_bytes, void* stream);
 
+/* Measurement aid for bench.py: when enabled, every pcrcg_kpconv_aggregate call is bracketed by HIP
+ * events recorded on its own stream; _read waits for them and returns up to `cap` records
+ * (milliseconds and the nq / h / cin of the launch).  Not thread-safe; off by default. */
+void pcrcg_profile_kpconv(int enable);
+int pcrcg_profile_kpconv_read(float* ms, int* nq, int* h, int* cin, int cap);
+
 /* C[m,n] = (A[m,k] @ Bop[k,n]) * row_scale[m] + bias[n]   (fp32 in, fp32 MFMA accumulate; row_scale
  * and bias may be NULL).  Row-major with leading dimensions in elements.
  *   trans_b = 0: b is [k,n] (ldb >= n), Bop = b      -- KPConv weights [15*cin, cout], P @ V
@@ -170,6 +176,95 @@ int pcrcg_softmax_rows(float* x, int rows, int cols, int ld, float scale, void* 
 /* Copy a device status word to the host after draining `stream`; returns PCRCG_ECAPACITY if it is
  * non-zero. */
 int pcrcg_check_status(const int* status, void* stream);
+
+/* Small element-wise helpers used by the network runner (also exported for tests).
+ *   copy2d : dst[r, 0:cols] = src[r, 0:cols]                       (torch.cat pieces)
+ *   add    : dst = a + b                                          (residual of ref:models/gcn.py:213-214)
+ *   l2norm : dst[r,:] = src[r,:] / max(|src[r,:]|, 1e-12)          (F.normalize, ref:architectures.py:541,582)
+ *   scores : dst[r] = scrub(clamp(sigmoid(src[r*ld]), 0, 1))      (ref:architectures.py:176-179,576-579) */
+int pcrcg_copy2d(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, void* stream);
+int pcrcg_add(const float* a, const float* b, float* dst, long n, void* stream);
+int pcrcg_l2norm_rows(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, void* stream);
+int pcrcg_sigmoid_scores(const float* src, int ld_src, float* dst, int rows, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-network runner: KPFCNN.forward (ref:models/architectures.py:181-191, 516-610) enqueued by ONE
+ * call, so that the host cost per pair is a single FFI crossing instead of several hundred.
+ * The descriptors are plain C structs of device pointers and sizes; pcrcg_amd/runner.py builds them
+ * from the nn.Module tree (weights as stored in the reference state_dict, plus a few re-packed copies
+ * noted below).
+ * ---------------------------------------------------------------------------------------------- */
+#define PCRCG_MAX_LEVELS 8
+#define PCRCG_MAX_BLOCKS 32
+#define PCRCG_MAX_GNN 8
+
+enum { PCRCG_BLK_SIMPLE = 0, PCRCG_BLK_RESNETB = 1, PCRCG_BLK_UNARY = 2, PCRCG_BLK_LAST_UNARY = 3,
+       PCRCG_BLK_UPSAMPLE = 4 };
+
+typedef struct pcrcg_block {
+    int type;            /* PCRCG_BLK_* */
+    int layer;           /* layer_ind of the reference block */
+    int strided;         /* queries = level layer+1, table = pools[layer] */
+    int in_dim, out_dim; /* feature widths seen by the block (out_dim = produced width) */
+    int mid_dim;         /* KPConv width of a resnetb block (out_dim/4); KPConv output of a simple block */
+    float extent;        /* KP_extent of the block's KPConv */
+    const float* kp;     /* [15,3]  ...KPConv.kernel_points */
+    const float* kp_w;   /* [15*cin, cout]  ...KPConv.weights */
+    const float* unary1; /* [mid, in] or NULL (nn.Identity) */
+    const float* unary2; /* [out, mid] */
+    const float* shortcut; /* [out, in] or NULL (nn.Identity) */
+    const float* mlp;    /* unary / last_unary: [out, in] with leading dimension mlp_ld (rows 16-B aligned) */
+    int mlp_ld;
+} pcrcg_block;
+
+typedef struct pcrcg_gnn_layer {
+    int cross;             /* 0 = SelfAttention (ref:models/gcn.py:96-134), 1 = AttentionalPropagation (:176-185) */
+    /* self: 1x1 conv weights re-packed as [cin, 2*cout] = [(Wa-Wb)^T | Wb^T] (centre | neighbour term) */
+    const float* edge1;    /* [c, 2c] */
+    const float* edge2;    /* [c, 4c] */
+    const float* conv3;    /* [c, 4c] as stored ([out, in]) */
+    /* cross: projection weights with output channels permuted head-major, [c, c] as [out, in] */
+    const float *wq, *bq, *wk, *bk, *wv, *bv;
+    const float *wm, *bm;  /* merge, input channels permuted head-major */
+    const float *w0, *b0;  /* mlp.0 [2c, 2c] */
+    const float *w3, *b3;  /* mlp.3 [c, 2c] */
+} pcrcg_gnn_layer;
+
+typedef struct pcrcg_model {
+    int n_enc, n_dec, n_gnn;
+    pcrcg_block enc[PCRCG_MAX_BLOCKS];
+    pcrcg_block dec[PCRCG_MAX_BLOCKS];
+    pcrcg_gnn_layer gnn[PCRCG_MAX_GNN];
+    int enc_skip[PCRCG_MAX_BLOCKS];   /* 1 if the input of encoder block i is saved as a skip (:521-522) */
+    int dec_concat[PCRCG_MAX_BLOCKS]; /* 1 if decoder block i consumes cat([x, skip]) (:568-569) */
+    int enc_out_dim, gnn_dim, heads, knn_k, final_dim;
+    const float *bottle_w, *bottle_b;         /* [gnn, enc_out], [gnn] */
+    const float *proj_gnn_w, *proj_gnn_b;     /* [gnn, gnn], [gnn] */
+    const float *proj_score_w, *proj_score_b; /* [1, gnn], [1] */
+    float temperature;                        /* exp(epsilon) + 0.03 (:561) */
+} pcrcg_model;
+
+typedef struct pcrcg_table { const int64_t* idx; int rows, cols, ld; } pcrcg_table;
+
+typedef struct pcrcg_batch {
+    int n_levels;
+    const float* points[PCRCG_MAX_LEVELS];
+    int n_points[PCRCG_MAX_LEVELS];
+    pcrcg_table neighbors[PCRCG_MAX_LEVELS], pools[PCRCG_MAX_LEVELS], upsamples[PCRCG_MAX_LEVELS];
+    const float* features; /* [n_points[0], feat_dim] */
+    int feat_dim;
+    int len_src_c;         /* stack_lengths[-1][0] */
+} pcrcg_batch;
+
+typedef struct pcrcg_outputs {
+    float* feats_f;         /* [n0, final_dim] */
+    float* scores_overlap;  /* [n0] */
+    float* scores_saliency; /* [n0] */
+} pcrcg_outputs;
+
+size_t pcrcg_kpfcnn_ws_bytes(const pcrcg_model* model, const pcrcg_batch* batch);
+int pcrcg_kpfcnn_forward(const pcrcg_model* model, const pcrcg_batch* batch, const pcrcg_outputs* out, void* ws,
+                         size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

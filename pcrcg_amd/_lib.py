@@ -32,6 +32,8 @@ SIGNATURES = {
     "pcrcg_kpconv_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_kpconv_aggregate": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                        c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_profile_kpconv": (None, [c_int]),
+    "pcrcg_profile_kpconv_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "pcrcg_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                c_void_p, c_void_p, c_void_p]),
     "pcrcg_gather_max": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -45,6 +47,13 @@ SIGNATURES = {
     "pcrcg_edgeconv_reduce": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float,
                                       c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pcrcg_softmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "pcrcg_copy2d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "pcrcg_add": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p]),
+    "pcrcg_l2norm_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "pcrcg_sigmoid_scores": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    # struct-based entry points: pcrcg_amd/runner.py declares the ctypes.Structure mirrors
+    "pcrcg_kpfcnn_ws_bytes": (c_size_t, [c_void_p, c_void_p]),
+    "pcrcg_kpfcnn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

@@ -2,6 +2,8 @@
 :181-191, :516-610 (forward, geometry-only branch).  Same constructor argument, same forward
 signature and result dict, same state_dict keys and shapes; the forward pass runs in the HIP kernels
 behind pcrcg_amd.ops."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -75,6 +77,8 @@ class KPFCNN(nn.Module):
                 r *= 0.5
                 out_dim = out_dim // 2
         self._eps_cache = None
+        self._runner = None
+        self.use_runner = config.use_batch_norm and os.environ.get("PCRCG_PY_FORWARD", "0") != "1"
 
     def regular_score(self, score):
         """ref:models/architectures.py:176-179."""
@@ -95,6 +99,17 @@ class KPFCNN(nn.Module):
     def forward(self, batch, backbone2d=None):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise RuntimeError("pcrcg_amd.KPFCNN: forward-only in this round -- call under torch.no_grad()")
+        if self.use_runner:
+            # the whole forward below, enqueued by one call into the C++ runner (csrc/runner.hip)
+            if self._runner is None:
+                from .runner import Runner
+                self._runner = Runner(self)
+            return self._runner.forward(batch)
+        return self.forward_ops(batch)
+
+    def forward_ops(self, batch):
+        """Op-by-op forward through pcrcg_amd.ops (one FFI call per kernel); same kernels, same results
+        as the runner -- kept as the readable mirror of the reference's forward and for debugging."""
         x = batch["features"].clone().detach()                                   # :183
         if "stack_lengths_host" in batch:
             len_src_c = int(batch["stack_lengths_host"][-1][0])

@@ -1,0 +1,97 @@
+// elementwise.hip -- small element-wise helpers of the network runner: strided row copies (the pieces
+// of torch.cat), residual add, row L2 normalisation (F.normalize, ref:models/architectures.py:541,582)
+// and the score head (sigmoid + clamp + NaN/Inf scrub, ref:models/architectures.py:176-179,576-579).
+#include "common.h"
+
+namespace pcrcg {
+namespace {
+
+__global__ void __launch_bounds__(256) k_copy2d(const float* __restrict__ src, int ld_src, float* __restrict__ dst,
+                                                 int ld_dst, int rows, int cols) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)rows * cols) return;
+    const long r = e / cols;
+    const int c = (int)(e - r * cols);
+    dst[r * ld_dst + c] = src[r * ld_src + c];
+}
+
+__global__ void __launch_bounds__(256) k_add(const float* __restrict__ a, const float* __restrict__ b,
+                                              float* __restrict__ dst, long n) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) dst[e] = a[e] + b[e];
+}
+
+// one wavefront per row
+__global__ void __launch_bounds__(256) k_l2norm_rows(const float* __restrict__ src, int ld_src, float* __restrict__ dst,
+                                                      int ld_dst, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = src[(long)r * ld_src + c];
+        s += v * v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);   // F.normalize: x / max(||x||, eps)
+    for (int c = lane; c < cols; c += 64) dst[(long)r * ld_dst + c] = src[(long)r * ld_src + c] * inv;
+}
+
+__global__ void __launch_bounds__(256) k_sigmoid_scores(const float* __restrict__ src, int ld_src,
+                                                         float* __restrict__ dst, int rows) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float v = 1.0f / (1.0f + expf(-src[(long)r * ld_src]));
+    v = fminf(fmaxf(v, 0.0f), 1.0f);
+    if (isnan(v) || isinf(v)) v = 0.0f;
+    dst[r] = v;
+}
+
+}  // namespace
+}  // namespace pcrcg
+
+using namespace pcrcg;
+
+extern "C" {
+
+int pcrcg_copy2d(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, void* stream) {
+    PCRCG_CHECK_ARG(rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= cols);
+    if (rows == 0 || cols == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(src && dst);
+    const long total = (long)rows * cols;
+    hipLaunchKernelGGL(k_copy2d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), src, ld_src,
+                       dst, ld_dst, rows, cols);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+int pcrcg_add(const float* a, const float* b, float* dst, long n, void* stream) {
+    PCRCG_CHECK_ARG(n >= 0);
+    if (n == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(a && b && dst);
+    hipLaunchKernelGGL(k_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), a, b, dst, n);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+int pcrcg_l2norm_rows(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, void* stream) {
+    PCRCG_CHECK_ARG(rows >= 0 && cols >= 1 && ld_src >= cols && ld_dst >= cols);
+    if (rows == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(src && dst);
+    hipLaunchKernelGGL(k_l2norm_rows, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), src, ld_src, dst, ld_dst,
+                       rows, cols);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+int pcrcg_sigmoid_scores(const float* src, int ld_src, float* dst, int rows, void* stream) {
+    PCRCG_CHECK_ARG(rows >= 0 && ld_src >= 1);
+    if (rows == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(src && dst);
+    hipLaunchKernelGGL(k_sigmoid_scores, dim3((rows + 255) / 256), dim3(256), 0, as_stream(stream), src, ld_src, dst,
+                       rows);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+}

@@ -22,10 +22,17 @@
 //
 // Fallbacks: k_kpconv_c1 for Cin == 1 (first layer, features are a column of ones), and the scalar
 // k_kpconv_generic for channel counts that are not a multiple of 4.
+#include <vector>
+
 #include "common.h"
 
 namespace pcrcg {
 namespace {
+
+// optional HIP-event timing of every gather/aggregate launch (bench.py roofline)
+struct ProfRec { hipEvent_t a, b; int nq, h, cin; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
 
 constexpr int K = PCRCG_KPOINTS;
 constexpr int kWavesPerBlock = 4;
@@ -249,6 +256,25 @@ using namespace pcrcg;
 
 extern "C" {
 
+void pcrcg_profile_kpconv(int enable) {
+    for (auto& r : g_prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = enable != 0;
+}
+
+int pcrcg_profile_kpconv_read(float* ms, int* nq, int* h, int* cin, int cap) {
+    int n = 0;
+    for (auto& r : g_prof) {
+        if (n >= cap) break;
+        if (hipEventSynchronize(r.b) != hipSuccess) return -1;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return -1;
+        ms[n] = t; nq[n] = r.nq; h[n] = r.h; cin[n] = r.cin;
+        ++n;
+    }
+    return n;
+}
+
 size_t pcrcg_kpconv_ws_bytes(int ns) { return carve_bytes((size_t)(ns > 0 ? ns : 0) + 1, 1); }
 
 int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx,
@@ -263,6 +289,16 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
     unsigned char* pos = cv.take<unsigned char>((size_t)ns + 1);
     PCRCG_CHECK_WS(cv);
     hipStream_t st = as_stream(stream);
+    struct ProfScope {   // events on the stream the kernels run on
+        hipStream_t st; ProfRec r; bool on;
+        ProfScope(hipStream_t s, int nq, int h, int cin) : st(s), on(g_prof_on) {
+            if (!on) return;
+            r.nq = nq; r.h = h; r.cin = cin;
+            hipEventCreate(&r.a); hipEventCreate(&r.b);
+            hipEventRecord(r.a, st);
+        }
+        ~ProfScope() { if (on) { hipEventRecord(r.b, st); g_prof.push_back(r); } }
+    } prof_scope(st, nq, h, cin);
     const long long* idx_ll = reinterpret_cast<const long long*>(idx);
     const int max_blocks = 256 * 32;
     auto blocks_for = [&](long waves) {

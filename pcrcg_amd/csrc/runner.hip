@@ -1,0 +1,354 @@
+// runner.hip -- host-side network runner: enqueues the whole KPFCNN forward
+// (ref:models/architectures.py:181-191, 516-610; blocks ref:models/blocks.py:536-709; GNN
+// ref:models/gcn.py:96-217) from ONE C-ABI call.  It contains no device code of its own: it sequences
+// the kernels of this library (pcrcg_* entry points) over a caller-provided arena, exactly like the
+// Python mirror in pcrcg_amd/{blocks,gcn,architectures}.py does op by op -- the two are compared in
+// tests/test_model_gpu.py.  The point is host cost: several hundred kernel launches per fragment pair
+// cost one FFI crossing instead of several hundred.
+//
+// Memory: block outputs live until the end of the forward (skip connections need some of them and the
+// total is ~0.25 GB for a 2 x 30k-point pair); temporaries of a block are released when it returns
+// (stack discipline).  pcrcg_kpfcnn_ws_bytes runs the same code with launches disabled to size it.
+#include <vector>
+
+#include "common.h"
+
+namespace pcrcg {
+namespace {
+
+struct Mat {          // row-major fp32 matrix view
+    float* p = nullptr;
+    int rows = 0, cols = 0, ld = 0;
+};
+
+struct Ctx {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    hipStream_t st = nullptr;
+    bool dry = false;
+    int rc = PCRCG_OK;
+
+    void* raw(size_t bytes) {
+        bytes = (bytes + 255) & ~size_t(255);
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        if (off > peak) peak = off;
+        if (!dry && off > cap && rc == PCRCG_OK) {
+            set_error("pcrcg_kpfcnn_forward: workspace too small (%zu needed so far, %zu given)", off, cap);
+            rc = PCRCG_EWORKSPACE;
+        }
+        return p;
+    }
+    Mat mat(int rows, int cols, int ld = 0) {
+        Mat m;
+        m.rows = rows; m.cols = cols; m.ld = ld ? ld : cols;
+        m.p = static_cast<float*>(raw((size_t)(rows > 0 ? rows : 1) * m.ld * sizeof(float)));
+        return m;
+    }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+    bool live() const { return !dry && rc == PCRCG_OK; }
+    void check(int r) { if (r != PCRCG_OK && rc == PCRCG_OK) rc = r; }
+};
+
+inline int pad4(int v) { return (v + 3) & ~3; }
+inline Mat cols(const Mat& m, int c0, int n) { Mat r = m; r.p = m.p ? m.p + c0 : nullptr; r.cols = n; return r; }
+inline Mat rows(const Mat& m, int r0, int n) { Mat r = m; r.p = m.p ? m.p + (long)r0 * m.ld : nullptr; r.rows = n; return r; }
+
+// y = x @ w^T (+ bias); w is [out, in] with leading dimension ldw
+void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, const Mat& y) {
+    if (c.live())
+        c.check(pcrcg_gemm_f32(x.p, x.ld, w, ldw, 1, y.p, y.ld, x.rows, y.cols, x.cols, nullptr, bias, c.st));
+}
+
+// y = lrelu(IN(x) [+ IN(res) | + res], slope)
+void norm_act(Ctx& c, const Mat& x, float slope, const Mat& y, const Mat* res = nullptr, bool norm_res = false) {
+    const size_t m = c.mark();
+    float* stats = static_cast<float*>(c.raw(sizeof(float) * 2 * x.cols));
+    float* rstats = (res && norm_res) ? static_cast<float*>(c.raw(sizeof(float) * 2 * x.cols)) : nullptr;
+    const size_t wsb = pcrcg_instnorm_ws_bytes(x.cols);
+    void* ws = c.raw(wsb);
+    if (c.live()) {
+        c.check(pcrcg_instnorm_stats(x.p, x.rows, x.cols, x.ld, 1e-5f, stats, ws, wsb, c.st));
+        if (rstats) c.check(pcrcg_instnorm_stats(res->p, res->rows, res->cols, res->ld, 1e-5f, rstats, ws, wsb, c.st));
+        c.check(pcrcg_instnorm_apply(x.p, x.rows, x.cols, x.ld, stats, res ? res->p : nullptr, res ? res->ld : 0,
+                                     rstats, slope, y.p, y.ld, c.st));
+    }
+    c.release(m);
+}
+
+void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, const Mat& y) {
+    const int l = blk.layer;
+    const pcrcg_table& t = blk.strided ? b.pools[l] : b.neighbors[l];
+    const float* q = blk.strided ? b.points[l + 1] : b.points[l];
+    const int nq = blk.strided ? b.n_points[l + 1] : b.n_points[l];
+    const int ns = b.n_points[l];
+    const size_t m = c.mark();
+    Mat wf = c.mat(nq, PCRCG_KPOINTS * x.cols);
+    float* inv_n = static_cast<float*>(c.raw(sizeof(float) * (nq > 0 ? nq : 1)));
+    const size_t wsb = pcrcg_kpconv_ws_bytes(ns);
+    void* ws = c.raw(wsb);
+    if (c.live()) {
+        c.check(pcrcg_kpconv_aggregate(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, x.p, x.cols, blk.kp, blk.extent,
+                                       wf.p, inv_n, ws, wsb, c.st));
+        c.check(pcrcg_gemm_f32(wf.p, wf.ld, blk.kp_w, y.cols, 0, y.p, y.ld, nq, y.cols, wf.cols, inv_n, nullptr, c.st));
+    }
+    c.release(m);
+}
+
+int out_rows(const pcrcg_batch& b, const pcrcg_block& blk) {
+    return blk.strided ? b.n_points[blk.layer + 1] : b.n_points[blk.layer];
+}
+
+// SimpleBlock.forward (ref:models/blocks.py:578-590)
+Mat simple_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x) {
+    Mat y = c.mat(out_rows(b, blk), blk.mid_dim);
+    const size_t m = c.mark();
+    Mat t = c.mat(y.rows, y.cols);
+    kpconv(c, b, blk, x, t);
+    norm_act(c, t, 0.1f, y);
+    c.release(m);
+    return y;
+}
+
+// ResnetBottleneckBlock.forward (ref:models/blocks.py:650-678)
+Mat resnet_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& feats) {
+    const int nq = out_rows(b, blk);
+    Mat y = c.mat(nq, blk.out_dim);
+    const size_t m = c.mark();
+    Mat x = feats;
+    if (blk.unary1) {
+        Mat t = c.mat(feats.rows, blk.mid_dim), u = c.mat(feats.rows, blk.mid_dim);
+        linear(c, feats, blk.unary1, feats.cols, nullptr, t);
+        norm_act(c, t, 0.1f, u);
+        x = u;
+    }
+    Mat k = c.mat(nq, blk.mid_dim), kn = c.mat(nq, blk.mid_dim);
+    kpconv(c, b, blk, x, k);
+    norm_act(c, k, 0.1f, kn);
+    Mat u2 = c.mat(nq, blk.out_dim);
+    linear(c, kn, blk.unary2, blk.mid_dim, nullptr, u2);
+    Mat sc = feats;
+    if (blk.strided) {   // max_pool shortcut (:672-673)
+        const pcrcg_table& t = b.pools[blk.layer];
+        sc = c.mat(nq, feats.cols);
+        if (c.live())
+            c.check(pcrcg_gather_max(feats.p, feats.rows, feats.cols, t.idx, nq, t.cols, t.ld, sc.p, c.st));
+    }
+    if (blk.shortcut) {
+        Mat s2 = c.mat(nq, blk.out_dim);
+        linear(c, sc, blk.shortcut, sc.cols, nullptr, s2);
+        norm_act(c, u2, 0.1f, y, &s2, true);      // lrelu(IN(unary2) + IN(shortcut))
+    } else {
+        norm_act(c, u2, 0.1f, y, &sc, false);     // lrelu(IN(unary2) + shortcut)
+    }
+    c.release(m);
+    return y;
+}
+
+// SelfAttention.forward (ref:models/gcn.py:110-134) on row-major [n, ch]
+Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, const float* coords, const Mat& f) {
+    const int n = f.rows, ch = f.cols;
+    Mat y = c.mat(n, ch);
+    const size_t m = c.mark();
+    const int k = mdl.knn_k < n - 1 ? mdl.knn_k : n - 1;
+    int* idx = static_cast<int*>(c.raw(sizeof(int) * (size_t)n * (k > 0 ? k : 1)));
+    Mat cat = c.mat(n, 4 * ch);
+    const size_t wsb = pcrcg_edgeconv_ws_bytes(2 * ch);
+    void* ws = c.raw(wsb);
+    float* stats = static_cast<float*>(c.raw(sizeof(float) * 4 * ch));
+    Mat cn1 = c.mat(n, 2 * ch), e1 = c.mat(n, ch), cn2 = c.mat(n, 4 * ch), e2 = c.mat(n, 2 * ch), x3 = c.mat(n, ch);
+    if (c.live()) {
+        c.check(pcrcg_knn(coords, n, k, idx, c.st));
+        c.check(pcrcg_copy2d(f.p, f.ld, cat.p, cat.ld, n, ch, c.st));                                    // x0
+        // x1 = max_k lrelu(IN2d(conv1(cat(f_i, f_j - f_i))))  (:121-125)
+        c.check(pcrcg_gemm_f32(f.p, f.ld, g.edge1, 2 * ch, 0, cn1.p, cn1.ld, n, 2 * ch, ch, nullptr, nullptr, c.st));
+        c.check(pcrcg_edgeconv_reduce(cn1.p, cn1.ld, cn1.p + ch, cn1.ld, idx, n, k, ch, 1e-5f, e1.p, e1.ld, stats, ws,
+                                      wsb, c.st));
+        c.check(pcrcg_instnorm_apply(e1.p, n, ch, e1.ld, stats, nullptr, 0, nullptr, 0.2f, cat.p + ch, cat.ld, c.st));
+        // x2 from x1 with conv2 (:127-129)
+        c.check(pcrcg_gemm_f32(cat.p + ch, cat.ld, g.edge2, 4 * ch, 0, cn2.p, cn2.ld, n, 4 * ch, ch, nullptr, nullptr,
+                               c.st));
+        c.check(pcrcg_edgeconv_reduce(cn2.p, cn2.ld, cn2.p + 2 * ch, cn2.ld, idx, n, k, 2 * ch, 1e-5f, e2.p, e2.ld, stats,
+                                      ws, wsb, c.st));
+        c.check(pcrcg_instnorm_apply(e2.p, n, 2 * ch, e2.ld, stats, nullptr, 0, nullptr, 0.2f, cat.p + 2 * ch, cat.ld,
+                                     c.st));
+        // x3 = lrelu(IN(conv3(cat(x0,x1,x2))))  (:131-132)
+        c.check(pcrcg_gemm_f32(cat.p, cat.ld, g.conv3, 4 * ch, 1, x3.p, x3.ld, n, ch, 4 * ch, nullptr, nullptr, c.st));
+    }
+    norm_act(c, x3, 0.2f, y);
+    c.release(m);
+    return y;
+}
+
+// x + AttentionalPropagation(x, src)  (ref:models/gcn.py:151-185, 213-214)
+Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, const Mat& x, const Mat& src) {
+    const int n = x.rows, ms = src.rows, ch = x.cols, h = mdl.heads, d = ch / h;
+    Mat y = c.mat(n, ch);
+    const size_t m = c.mark();
+    Mat q = c.mat(n, ch), kk = c.mat(ms, ch), v = c.mat(ms, ch), msg = c.mat(n, ch), sc = c.mat(n, ms);
+    Mat cat = c.mat(n, 2 * ch), h0 = c.mat(n, 2 * ch), h1 = c.mat(n, 2 * ch), delta = c.mat(n, ch);
+    linear(c, x, g.wq, ch, g.bq, q);
+    linear(c, src, g.wk, ch, g.bk, kk);
+    linear(c, src, g.wv, ch, g.bv, v);
+    if (c.live()) {
+        for (int i = 0; i < h; ++i) {   // heads are contiguous column blocks after the weight permutation
+            c.check(pcrcg_gemm_f32(q.p + i * d, q.ld, kk.p + i * d, kk.ld, 1, sc.p, sc.ld, n, ms, d, nullptr, nullptr,
+                                   c.st));
+            c.check(pcrcg_softmax_rows(sc.p, n, ms, sc.ld, 1.0f / sqrtf((float)d), c.st));
+            c.check(pcrcg_gemm_f32(sc.p, sc.ld, v.p + i * d, v.ld, 0, msg.p + i * d, msg.ld, n, d, ms, nullptr, nullptr,
+                                   c.st));
+        }
+        c.check(pcrcg_copy2d(x.p, x.ld, cat.p, cat.ld, n, ch, c.st));
+    }
+    linear(c, msg, g.wm, ch, g.bm, cols(cat, ch, ch));       // merge, written next to x: cat([x, message])
+    linear(c, cat, g.w0, 2 * ch, g.b0, h0);
+    norm_act(c, h0, 0.0f, h1);                              // InstanceNorm1d + ReLU
+    linear(c, h1, g.w3, 2 * ch, g.b3, delta);
+    if (c.live()) c.check(pcrcg_add(x.p, delta.p, y.p, (long)n * ch, c.st));
+    c.release(m);
+    return y;
+}
+
+void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_outputs& out) {
+    const int L = b.n_levels;
+    Mat x;
+    x.p = const_cast<float*>(b.features);
+    x.rows = b.n_points[0];
+    x.cols = x.ld = b.feat_dim;
+    std::vector<Mat> skips;
+    // 1. encoder (:519-524)
+    for (int i = 0; i < mdl.n_enc; ++i) {
+        if (mdl.enc_skip[i]) skips.push_back(x);
+        const pcrcg_block& blk = mdl.enc[i];
+        x = blk.type == PCRCG_BLK_SIMPLE ? simple_block(c, b, blk, x) : resnet_block(c, b, blk, x);
+    }
+    // 2. bottleneck (:527-528) and 3. GNN (:532-536)
+    const int nc = b.n_points[L - 1], ns = b.len_src_c, nt = nc - ns, g = mdl.gnn_dim;
+    Mat fc = c.mat(nc, g);
+    linear(c, x, mdl.bottle_w, mdl.enc_out_dim, mdl.bottle_b, fc);
+    Mat d0 = rows(fc, 0, ns), d1 = rows(fc, ns, nt);
+    const float* c0 = b.points[L - 1];
+    const float* c1 = b.points[L - 1] + 3 * (long)ns;
+    for (int i = 0; i < mdl.n_gnn; ++i) {
+        const pcrcg_gnn_layer& gl = mdl.gnn[i];
+        if (gl.cross) {
+            d0 = cross_attention(c, mdl, gl, d0, d1);
+            d1 = cross_attention(c, mdl, gl, d1, d0);   // sees the updated d0 (:214)
+        } else {
+            d0 = self_attention(c, mdl, gl, c0, d0);
+            d1 = self_attention(c, mdl, gl, c1, d1);
+        }
+    }
+    // coarse features [score | saliency | proj_gnn feats] (:538-565), rows 16-byte aligned
+    const int wc = g + 2;
+    Mat xc = c.mat(nc, wc, pad4(wc));
+    {
+        const size_t m = c.mark();
+        Mat gcat = c.mat(nc, g), fn = c.mat(nc, g), pst = c.mat(ns, nt), pts = c.mat(nt, ns);
+        if (c.live()) {
+            c.check(pcrcg_copy2d(d0.p, d0.ld, gcat.p, gcat.ld, ns, g, c.st));
+            c.check(pcrcg_copy2d(d1.p, d1.ld, gcat.p + (long)ns * gcat.ld, gcat.ld, nt, g, c.st));
+        }
+        Mat feats = cols(xc, 2, g), score = cols(xc, 0, 1), sal = cols(xc, 1, 1);
+        linear(c, gcat, mdl.proj_gnn_w, g, mdl.proj_gnn_b, feats);           // :538
+        linear(c, feats, mdl.proj_score_w, g, mdl.proj_score_b, score);      // :539
+        if (c.live()) {
+            c.check(pcrcg_l2norm_rows(feats.p, feats.ld, fn.p, fn.ld, nc, g, c.st));   // :541
+            const float inv_t = 1.0f / mdl.temperature;
+            const float* fs = fn.p;
+            const float* ft = fn.p + (long)ns * fn.ld;
+            c.check(pcrcg_gemm_f32(fs, fn.ld, ft, fn.ld, 1, pst.p, pst.ld, ns, nt, g, nullptr, nullptr, c.st));
+            c.check(pcrcg_softmax_rows(pst.p, ns, nt, pst.ld, inv_t, c.st));
+            c.check(pcrcg_gemm_f32(ft, fn.ld, fs, fn.ld, 1, pts.p, pts.ld, nt, ns, g, nullptr, nullptr, c.st));
+            c.check(pcrcg_softmax_rows(pts.p, nt, ns, pts.ld, inv_t, c.st));
+            // s1 = softmax(inner/T) @ tgt_scores, s2 = softmax(inner^T/T) @ src_scores  (:562-563)
+            c.check(pcrcg_gemm_f32(pst.p, pst.ld, score.p + (long)ns * xc.ld, xc.ld, 0, sal.p, xc.ld, ns, 1, nt, nullptr,
+                                   nullptr, c.st));
+            c.check(pcrcg_gemm_f32(pts.p, pts.ld, score.p, xc.ld, 0, sal.p + (long)ns * xc.ld, xc.ld, nt, 1, ns, nullptr,
+                                   nullptr, c.st));
+        }
+        c.release(m);
+    }
+    x = xc;
+    // 4. decoder (:567-570)
+    for (int j = 0; j < mdl.n_dec; ++j) {
+        const pcrcg_block& blk = mdl.dec[j];
+        if (blk.type == PCRCG_BLK_UPSAMPLE) {
+            const pcrcg_table& t = b.upsamples[blk.layer - 1];
+            const bool concat = j + 1 < mdl.n_dec && mdl.dec_concat[j + 1];
+            const int cs = concat ? skips.back().cols : 0;
+            Mat y = c.mat(t.rows, x.cols + cs, pad4(x.cols + cs));
+            Mat xs = x;
+            if (x.ld != x.cols) {   // gather_first reads dense rows
+                xs = c.mat(x.rows, x.cols);
+                if (c.live()) c.check(pcrcg_copy2d(x.p, x.ld, xs.p, xs.ld, x.rows, x.cols, c.st));
+            }
+            if (c.live()) {
+                c.check(pcrcg_gather_first(xs.p, xs.rows, xs.cols, t.idx, t.rows, t.ld, y.p, y.ld, c.st));
+                if (concat) {
+                    const Mat& s = skips.back();
+                    c.check(pcrcg_copy2d(s.p, s.ld, y.p + x.cols, y.ld, s.rows, s.cols, c.st));
+                }
+            }
+            if (concat) skips.pop_back();
+            x = y;
+        } else if (blk.type == PCRCG_BLK_UNARY) {
+            Mat t = c.mat(x.rows, blk.out_dim), y = c.mat(x.rows, blk.out_dim);
+            linear(c, x, blk.mlp, blk.mlp_ld, nullptr, t);
+            norm_act(c, t, 0.1f, y);
+            x = y;
+        } else {   // last_unary
+            Mat y = c.mat(x.rows, blk.out_dim, pad4(blk.out_dim));
+            linear(c, x, blk.mlp, blk.mlp_ld, nullptr, y);
+            x = y;
+        }
+    }
+    // heads (:571-582)
+    if (c.live()) {
+        const int fd = mdl.final_dim;
+        c.check(pcrcg_l2norm_rows(x.p, x.ld, out.feats_f, fd, x.rows, fd, c.st));
+        c.check(pcrcg_sigmoid_scores(x.p + fd, x.ld, out.scores_overlap, x.rows, c.st));
+        c.check(pcrcg_sigmoid_scores(x.p + fd + 1, x.ld, out.scores_saliency, x.rows, c.st));
+    }
+}
+
+int validate(const pcrcg_model* m, const pcrcg_batch* b) {
+    PCRCG_CHECK_ARG(m && b);
+    PCRCG_CHECK_ARG(m->n_enc >= 1 && m->n_enc <= PCRCG_MAX_BLOCKS && m->n_dec >= 1 && m->n_dec <= PCRCG_MAX_BLOCKS);
+    PCRCG_CHECK_ARG(m->n_gnn >= 0 && m->n_gnn <= PCRCG_MAX_GNN);
+    PCRCG_CHECK_ARG(b->n_levels >= 1 && b->n_levels <= PCRCG_MAX_LEVELS);
+    PCRCG_CHECK_ARG(b->len_src_c >= 1 && b->len_src_c < b->n_points[b->n_levels - 1]);
+    PCRCG_CHECK_ARG(m->heads >= 1 && m->gnn_dim % m->heads == 0 && m->temperature > 0.0f);
+    for (int i = 0; i < m->n_enc; ++i) PCRCG_CHECK_ARG(m->enc[i].layer >= 0 && m->enc[i].layer + m->enc[i].strided < b->n_levels);
+    return PCRCG_OK;
+}
+
+}  // namespace
+}  // namespace pcrcg
+
+using namespace pcrcg;
+
+extern "C" {
+
+size_t pcrcg_kpfcnn_ws_bytes(const pcrcg_model* model, const pcrcg_batch* batch) {
+    if (validate(model, batch) != PCRCG_OK) return 0;
+    Ctx c;
+    c.dry = true;
+    pcrcg_outputs none = {nullptr, nullptr, nullptr};
+    forward(c, *model, *batch, none);
+    return c.peak + 4096;
+}
+
+int pcrcg_kpfcnn_forward(const pcrcg_model* model, const pcrcg_batch* batch, const pcrcg_outputs* out, void* ws,
+                         size_t ws_bytes, void* stream) {
+    PCRCG_PROPAGATE(validate(model, batch));
+    PCRCG_CHECK_ARG(out && out->feats_f && out->scores_overlap && out->scores_saliency && ws);
+    Ctx c;
+    c.base = static_cast<char*>(ws);
+    c.cap = ws_bytes;
+    c.st = as_stream(stream);
+    forward(c, *model, *batch, *out);
+    return c.rc;
+}
+}

@@ -55,9 +55,22 @@ class _Workspaces:
 
 _ws = _Workspaces()
 
-# bench.py sets this to a list to collect (start_event, end_event, (nq, h, cin, cout)) around every
-# KPConv gather/aggregate launch (HIP events on the stream the kernel runs on).
-KPCONV_EVENTS = None
+def kpconv_profile_start():
+    """Bracket every KPConv gather/aggregate launch with HIP events (on the launching stream)."""
+    _lib.lib().pcrcg_profile_kpconv(1)
+
+
+def kpconv_profile_stop(cap=1 << 16):
+    """-> list of (milliseconds, nq, h, cin) per launch since kpconv_profile_start()."""
+    import ctypes
+    L = _lib.lib()
+    ms = (ctypes.c_float * cap)()
+    nq, h, cin = (ctypes.c_int * cap)(), (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
+    n = L.pcrcg_profile_kpconv_read(ms, nq, h, cin, cap)
+    L.pcrcg_profile_kpconv(0)
+    if n < 0:
+        raise RuntimeError("pcrcg_profile_kpconv_read failed")
+    return [(ms[i], nq[i], h[i], cin[i]) for i in range(n)]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -190,17 +203,10 @@ def kpconv(q_pts, s_pts, idx, x, kernel_points, weights, extent):
     nbytes = L.pcrcg_kpconv_ws_bytes(ns)
     ws = _ws.get("kpconv", nbytes, x.device)
     w2 = _dev(weights, _F32, "weights").reshape(kdim * cin, -1)
-    ev = None
-    if KPCONV_EVENTS is not None:
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
     _lib.check(L.pcrcg_kpconv_aggregate(q_pts.data_ptr(), nq, s_pts.data_ptr(), ns, idx.data_ptr(), h, ld_idx,
                                         x.data_ptr(), cin, kp.data_ptr(), float(extent), wf.data_ptr(),
                                         inv_n.data_ptr(), ws.data_ptr(), nbytes, _stream()),
                "pcrcg_kpconv_aggregate")
-    if ev is not None:
-        ev[1].record()
-        KPCONV_EVENTS.append((ev[0], ev[1], (nq, h, cin, w2.shape[1])))
     return gemm(wf, w2, row_scale=inv_n)
 
 

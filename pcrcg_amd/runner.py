@@ -1,0 +1,242 @@
+"""Python side of the whole-network runner (pcrcg_kpfcnn_forward in include/pcrcg.h): builds the C
+descriptors (device pointers + sizes) from a pcrcg_amd.architectures.KPFCNN module and a batch dict,
+and enqueues the complete forward pass with ONE call into libpcrcg_hip.so.
+
+Weights are used in place as stored in the (reference-compatible) state_dict.  Three re-packed copies
+are made once per weight version and cached:
+  * DGCNN edge convs: [Cout, 2Cin] -> [Cin, 2Cout] = [(Wa-Wb)^T | Wb^T]   (centre | neighbour term)
+  * attention projections / merge: channels permuted head-major (the reference interleaves heads,
+    ref:models/gcn.py:170)
+  * decoder unary weights with 1538 / 769 input channels: rows padded to a multiple of 4 floats."""
+import ctypes
+
+import torch
+
+from . import _lib
+from .blocks import (LastUnaryBlock, NearestUpsampleBlock, ResnetBottleneckBlock, SimpleBlock, UnaryBlock,
+                     aligned_weight)
+from .gcn import AttentionalPropagation, SelfAttention
+
+MAX_LEVELS, MAX_BLOCKS, MAX_GNN = 8, 32, 8
+BLK_SIMPLE, BLK_RESNETB, BLK_UNARY, BLK_LAST_UNARY, BLK_UPSAMPLE = range(5)
+_fp = ctypes.c_void_p
+
+
+class Block(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_int), ("layer", ctypes.c_int), ("strided", ctypes.c_int),
+                ("in_dim", ctypes.c_int), ("out_dim", ctypes.c_int), ("mid_dim", ctypes.c_int),
+                ("extent", ctypes.c_float), ("kp", _fp), ("kp_w", _fp), ("unary1", _fp), ("unary2", _fp),
+                ("shortcut", _fp), ("mlp", _fp), ("mlp_ld", ctypes.c_int)]
+
+
+class GnnLayer(ctypes.Structure):
+    _fields_ = [("cross", ctypes.c_int), ("edge1", _fp), ("edge2", _fp), ("conv3", _fp),
+                ("wq", _fp), ("bq", _fp), ("wk", _fp), ("bk", _fp), ("wv", _fp), ("bv", _fp),
+                ("wm", _fp), ("bm", _fp), ("w0", _fp), ("b0", _fp), ("w3", _fp), ("b3", _fp)]
+
+
+class Model(ctypes.Structure):
+    _fields_ = [("n_enc", ctypes.c_int), ("n_dec", ctypes.c_int), ("n_gnn", ctypes.c_int),
+                ("enc", Block * MAX_BLOCKS), ("dec", Block * MAX_BLOCKS), ("gnn", GnnLayer * MAX_GNN),
+                ("enc_skip", ctypes.c_int * MAX_BLOCKS), ("dec_concat", ctypes.c_int * MAX_BLOCKS),
+                ("enc_out_dim", ctypes.c_int), ("gnn_dim", ctypes.c_int), ("heads", ctypes.c_int),
+                ("knn_k", ctypes.c_int), ("final_dim", ctypes.c_int),
+                ("bottle_w", _fp), ("bottle_b", _fp), ("proj_gnn_w", _fp), ("proj_gnn_b", _fp),
+                ("proj_score_w", _fp), ("proj_score_b", _fp), ("temperature", ctypes.c_float)]
+
+
+class Table(ctypes.Structure):
+    _fields_ = [("idx", _fp), ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("ld", ctypes.c_int)]
+
+
+class Batch(ctypes.Structure):
+    _fields_ = [("n_levels", ctypes.c_int), ("points", _fp * MAX_LEVELS), ("n_points", ctypes.c_int * MAX_LEVELS),
+                ("neighbors", Table * MAX_LEVELS), ("pools", Table * MAX_LEVELS), ("upsamples", Table * MAX_LEVELS),
+                ("features", _fp), ("feat_dim", ctypes.c_int), ("len_src_c", ctypes.c_int)]
+
+
+class Outputs(ctypes.Structure):
+    _fields_ = [("feats_f", _fp), ("scores_overlap", _fp), ("scores_saliency", _fp)]
+
+
+_bound = False
+
+
+def _bind():
+    global _bound
+    L = _lib.lib()
+    if not _bound:
+        _bound = True   # signatures are declared in _lib.SIGNATURES (struct pointers as void*)
+    return L
+
+
+def _dense(t):
+    t = t.detach()
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise RuntimeError("pcrcg_amd.runner: parameters must be float32 tensors on a HIP device")
+    return t.contiguous()
+
+
+class Runner:
+    """Descriptor cache for one KPFCNN module."""
+
+    def __init__(self, model):
+        self.model = model
+        self.sig = None
+        self.desc = None
+        self.keep = []      # tensors the descriptor points into
+        self.ws = {}
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+
+    def _w(self, t):
+        t = _dense(t)
+        self.keep.append(t)
+        return t.data_ptr()
+
+    def _fill_block(self, blk, mod):
+        if isinstance(mod, SimpleBlock):
+            blk.type, blk.layer, blk.strided = BLK_SIMPLE, mod.layer_ind, int("strided" in mod.block_name)
+            kp = mod.KPConv
+            blk.in_dim, blk.out_dim, blk.mid_dim = kp.in_channels, kp.out_channels, kp.out_channels
+            blk.extent = float(kp.KP_extent)
+            blk.kp, blk.kp_w = self._w(kp.kernel_points.data), self._w(kp.weights.data)
+        elif isinstance(mod, ResnetBottleneckBlock):
+            blk.type, blk.layer, blk.strided = BLK_RESNETB, mod.layer_ind, int("strided" in mod.block_name)
+            kp = mod.KPConv
+            blk.in_dim, blk.out_dim, blk.mid_dim = mod.in_dim, mod.out_dim, kp.out_channels
+            blk.extent = float(kp.KP_extent)
+            blk.kp, blk.kp_w = self._w(kp.kernel_points.data), self._w(kp.weights.data)
+            blk.unary1 = self._w(mod.unary1.mlp.weight.data) if isinstance(mod.unary1, UnaryBlock) else None
+            blk.unary2 = self._w(mod.unary2.mlp.weight.data)
+            blk.shortcut = (self._w(mod.unary_shortcut.mlp.weight.data)
+                            if isinstance(mod.unary_shortcut, UnaryBlock) else None)
+        elif isinstance(mod, (UnaryBlock, LastUnaryBlock)):
+            blk.type = BLK_UNARY if isinstance(mod, UnaryBlock) else BLK_LAST_UNARY
+            blk.in_dim, blk.out_dim = mod.in_dim, mod.out_dim
+            w = aligned_weight(mod.mlp.weight)          # [out, in] view, rows 16-byte aligned
+            self.keep.append(w)
+            blk.mlp, blk.mlp_ld = w.data_ptr(), (w.stride(0) if w.shape[0] > 1 else w.shape[1])
+        elif isinstance(mod, NearestUpsampleBlock):
+            blk.type, blk.layer = BLK_UPSAMPLE, mod.layer_ind
+        else:
+            raise RuntimeError(f"pcrcg_amd.runner: unsupported block {type(mod).__name__}")
+        if not getattr(mod, "use_bn", True):
+            raise RuntimeError("pcrcg_amd.runner: use_batch_norm=False is handled by the op-by-op path only")
+
+    def _fill_gnn(self, g, layer, heads):
+        if isinstance(layer, SelfAttention):
+            g.cross = 0
+
+            def pack(conv):
+                w = conv.weight.data.flatten(1)
+                cin = w.shape[1] // 2
+                wa, wb = w[:, :cin], w[:, cin:]
+                return self._w(torch.cat([(wa - wb).t(), wb.t()], 1))
+            g.edge1, g.edge2 = pack(layer.conv1), pack(layer.conv2)
+            g.conv3 = self._w(layer.conv3.weight.data.flatten(1))
+        elif isinstance(layer, AttentionalPropagation):
+            g.cross = 1
+            att = layer.attn
+            h, d = att.num_heads, att.dim
+            dev = att.merge.weight.device
+            perm = (torch.arange(h, device=dev)[:, None] + h * torch.arange(d, device=dev)[None, :]).reshape(-1)
+            for name, proj in zip("qkv", att.proj):
+                setattr(g, "w" + name, self._w(proj.weight.data.squeeze(-1)[perm]))
+                setattr(g, "b" + name, self._w(proj.bias.data[perm]))
+            g.wm = self._w(att.merge.weight.data.squeeze(-1)[:, perm])
+            g.bm = self._w(att.merge.bias.data)
+            g.w0, g.b0 = self._w(layer.mlp[0].weight.data.squeeze(-1)), self._w(layer.mlp[0].bias.data)
+            g.w3, g.b3 = self._w(layer.mlp[3].weight.data.squeeze(-1)), self._w(layer.mlp[3].bias.data)
+        else:
+            raise RuntimeError(f"pcrcg_amd.runner: unsupported GNN layer {type(layer).__name__}")
+
+    def descriptor(self):
+        sig = self._signature()
+        if self.desc is not None and sig == self.sig:
+            return self.desc
+        m = self.model
+        self.keep = []
+        d = Model()
+        d.n_enc, d.n_dec, d.n_gnn = len(m.encoder_blocks), len(m.decoder_blocks), len(m.gnn.layers)
+        if d.n_enc > MAX_BLOCKS or d.n_dec > MAX_BLOCKS or d.n_gnn > MAX_GNN:
+            raise RuntimeError("pcrcg_amd.runner: architecture too deep for the descriptor")
+        for i, mod in enumerate(m.encoder_blocks):
+            self._fill_block(d.enc[i], mod)
+            d.enc_skip[i] = int(i in m.encoder_skips)
+        for j, mod in enumerate(m.decoder_blocks):
+            self._fill_block(d.dec[j], mod)
+            d.dec_concat[j] = int(j in m.decoder_concats)
+        heads = None
+        for i, layer in enumerate(m.gnn.layers):
+            self._fill_gnn(d.gnn[i], layer, heads)
+            if isinstance(layer, AttentionalPropagation):
+                heads = layer.attn.num_heads
+            else:
+                d.knn_k = layer.k
+        d.heads = heads or 1
+        d.enc_out_dim, d.gnn_dim, d.final_dim = m.bottle.in_channels, m.bottle.out_channels, m.final_feats_dim
+        d.bottle_w, d.bottle_b = self._w(m.bottle.weight.data.squeeze(-1)), self._w(m.bottle.bias.data)
+        d.proj_gnn_w, d.proj_gnn_b = self._w(m.proj_gnn.weight.data.squeeze(-1)), self._w(m.proj_gnn.bias.data)
+        d.proj_score_w, d.proj_score_b = (self._w(m.proj_score.weight.data.squeeze(-1)),
+                                          self._w(m.proj_score.bias.data))
+        d.temperature = float(torch.exp(m.epsilon.detach()).item()) + 0.03
+        self.desc, self.sig = d, sig
+        return d
+
+    @staticmethod
+    def _table(dst, t, keep):
+        if t.numel() == 0:
+            dst.idx, dst.rows, dst.cols, dst.ld = None, int(t.shape[0]), 0, 1
+            return
+        if t.dtype != torch.int64 or not t.is_cuda:
+            raise RuntimeError("pcrcg_amd.runner: index tables must be int64 tensors on the device")
+        if t.shape[1] > 1 and t.stride(1) != 1:
+            t = t.contiguous()
+        keep.append(t)
+        dst.idx, dst.rows, dst.cols = t.data_ptr(), int(t.shape[0]), int(t.shape[1])
+        dst.ld = int(t.stride(0)) if t.shape[0] > 1 else int(t.shape[1])
+
+    def forward(self, batch):
+        L = _bind()
+        desc = self.descriptor()
+        keep = []
+        b = Batch()
+        pts = batch["points"]
+        b.n_levels = len(pts)
+        for l, p in enumerate(pts):
+            p = p.contiguous()
+            if p.dtype != torch.float32 or not p.is_cuda:
+                raise RuntimeError("pcrcg_amd.runner: points must be float32 tensors on the device")
+            keep.append(p)
+            b.points[l], b.n_points[l] = p.data_ptr(), int(p.shape[0])
+            self._table(b.neighbors[l], batch["neighbors"][l], keep)
+            self._table(b.pools[l], batch["pools"][l], keep)
+            self._table(b.upsamples[l], batch["upsamples"][l], keep)
+        feats = batch["features"].to(torch.float32).contiguous()
+        keep.append(feats)
+        b.features, b.feat_dim = feats.data_ptr(), int(feats.shape[1])
+        if "stack_lengths_host" in batch:
+            b.len_src_c = int(batch["stack_lengths_host"][-1][0])
+        else:
+            b.len_src_c = int(batch["stack_lengths"][-1][0])
+        dev = feats.device
+        n0 = b.n_points[0]
+        out = {"feats_f": torch.empty((n0, desc.final_dim), dtype=torch.float32, device=dev),
+               "scores_overlap": torch.empty(n0, dtype=torch.float32, device=dev),
+               "scores_saliency": torch.empty(n0, dtype=torch.float32, device=dev)}
+        o = Outputs(out["feats_f"].data_ptr(), out["scores_overlap"].data_ptr(), out["scores_saliency"].data_ptr())
+        nbytes = L.pcrcg_kpfcnn_ws_bytes(ctypes.byref(desc), ctypes.byref(b))
+        if nbytes == 0:
+            raise RuntimeError("pcrcg_kpfcnn_ws_bytes rejected the descriptors: "
+                               + (L.pcrcg_last_error() or b"").decode())
+        stream = torch.cuda.current_stream().cuda_stream
+        key = (dev.index, stream)
+        ws = self.ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)
+            self.ws[key] = ws
+        _lib.check(L.pcrcg_kpfcnn_forward(ctypes.byref(desc), ctypes.byref(b), ctypes.byref(o), ws.data_ptr(),
+                                          ws.numel(), stream), "pcrcg_kpfcnn_forward")
+        return out

@@ -190,14 +190,18 @@ def test_kpfcnn_golden_mini(cuda, golden_dir, mini):
     hooks = [net.encoder_blocks[i].register_forward_hook(lambda m, a, o, i=i: inter.__setitem__(f"enc{i}", o))
              for i in (0, 1, 2, 10)]
     with torch.no_grad():
-        out = net(dbatch)
+        out_ops = net.forward_ops(dbatch)     # op-by-op mirror (one FFI call per kernel), fires the hooks
+        out = net(dbatch)                     # C++ runner: the whole forward in one call
     for h in hooks:
         h.remove()
+    assert net.use_runner and sorted(inter) == ["enc0", "enc1", "enc10", "enc2"]
     for k, v in inter.items():
         assert rel(v, mm["intermediates"][k]) < TOL, k
     for k in ("feats_f", "scores_overlap", "scores_saliency"):
         assert out[k].shape == mm["outputs"][k].shape
         assert rel(out[k], mm["outputs"][k]) < TOL, k
+        assert rel(out_ops[k], mm["outputs"][k]) < TOL, k
+        assert rel(out[k], out_ops[k]) < 1e-5, k
     # and the CPU oracle agrees with both
     oo = MR.kpfcnn_forward(mm["state_dict"], mm["config"], batch)
     for k in ("feats_f", "scores_overlap", "scores_saliency"):
@@ -242,6 +246,9 @@ def test_end_to_end_c1_vs_oracle(cuda):
     with torch.no_grad():
         out = net(batch)
         out2 = net(batch)
+        out3 = net.forward_ops(batch)
+    for k in ("feats_f", "scores_overlap", "scores_saliency"):
+        assert rel(out3[k], out[k]) < 1e-5, k
     cpu_batch = {k: [t.cpu() for t in v] if isinstance(v, list) and isinstance(v[0], torch.Tensor) else v
                  for k, v in batch.items()}
     cpu_batch["features"] = batch["features"].cpu()
@@ -278,3 +285,34 @@ def test_full_size_s30k_properties(cuda):
     with torch.no_grad():
         out2 = net(batch)
     assert rel(out2["feats_f"], out["feats_f"]) < 1e-5
+
+
+def test_two_stream_pipeline_matches_sequential(cuda):
+    """The front-end/model stream overlap must not change any result (race check over several pairs)."""
+    from pcrcg_amd.pipeline import PairPipeline
+    cfg = indoor_config(first_feats_dim=64, gnn_feats_dim=128)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = KPFCNN(cfg).to(cuda).eval()
+    limits = synthetic.LIMITS["C1"]
+    pairs = []
+    for seed in range(6):
+        src, tgt = synthetic.pair("C1", seed)
+        pairs.append((torch.from_numpy(np.concatenate([src, tgt])).to(cuda),
+                      torch.tensor([len(src), len(tgt)], dtype=torch.int32, device=cuda)))
+    ref = []
+    with torch.no_grad():
+        for pts, lens in pairs:
+            ref.append(net(build_pyramid(pts, lens, cfg, limits)))
+    torch.cuda.synchronize()
+    pipe = PairPipeline(net, cfg, limits, cuda)
+    outs = []
+    prepared = pipe.prepare(*pairs[0])
+    for i in range(len(pairs)):
+        out = pipe.run(prepared)
+        prepared = pipe.prepare(*pairs[(i + 1) % len(pairs)])
+        outs.append(out)
+    pipe.synchronize()
+    for a, b in zip(outs, ref):
+        for k in ("feats_f", "scores_overlap", "scores_saliency"):
+            assert rel(a[k], b[k]) < 1e-5, k
