@@ -147,12 +147,31 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        # output widths of the KPConv layers in launch order (the aggregate kernel itself never sees Cout)
+        # KPConv kernels bracketed by HIP events on their own stream (pcrcg_profile_kpconv): kind 0 =
+        # gather/aggregate kernel of the two-stage path, kind 1 = fused gather+aggregate+contraction kernel.
+        # Algorithmic bytes: SURVEY.md 8d no-reuse gather model of one KPConv call.
         couts = [blk.KPConv.out_channels for blk in net.encoder_blocks]
-        k_ms = sum(e[0] for e in events)
-        k_bytes = sum(kpconv_algorithmic_bytes(nq, h, cin, couts[i % len(couts)])
-                      for i, (_, nq, h, cin) in enumerate(events))
+        gather = {"ms": 0.0, "bytes": 0, "n": 0}
+        fused = {"ms": 0.0, "bytes": 0, "flops": 0, "n": 0}
+        per_pair = len(couts)
+        for i, (ms, nq, h, cin, cout, kind) in enumerate(events):
+            co = cout if kind == 1 else couts[i % per_pair]
+            d = fused if kind == 1 else gather
+            d["ms"] += ms
+            d["bytes"] += kpconv_algorithmic_bytes(nq, h, cin, co)
+            d["n"] += 1
+            if kind == 1:
+                d["flops"] += 2 * nq * 15 * cin * (h + co)
+        k_bytes = gather["bytes"] + fused["bytes"]
+        k_ms = gather["ms"] + fused["ms"]
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        g_gbs = gather["bytes"] / (gather["ms"] * 1e-3) / 1e9 if gather["ms"] > 0 else 0.0
+        f_gbs = fused["bytes"] / (fused["ms"] * 1e-3) / 1e9 if fused["ms"] > 0 else 0.0
+        f_tf = fused["flops"] / (fused["ms"] * 1e-3) / 1e12 if fused["ms"] > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(REPO, "profiles", "r01_pmc_kpconv.json")
+        if os.path.exists(pmc_path):        # HBM bytes per launch from the committed rocprofv3 PMC passes
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
         line = {
             "metric": "fragment-pairs/s KPFCNN+GCN fwd, 30k-pt pairs",
             "value": round(args.steps * world / elapsed, 3),
@@ -171,11 +190,19 @@ def main():
                                    "forward, indoor hyper-parameters, random-init full-width weights, 1 pair/GPU/step; "
                                    "pyramid of pair i+1 overlaps the forward of pair i on a second HIP stream",
                        "limits": limits, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_kpconv_aggregate (11 launches/pair)",
+            "roofline": {"bound": "hbm", "kernel": "KPConv neighbour-gather kernels (k_kpconv_mfma / k_kpconv_c1 / "
+                                                     "k_kpconv_fused), %d launches/pair" % per_pair,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "avg_launch_us": round(k_ms * 1e3 / max(len(events), 1), 2),
-                         "algorithmic_bytes_per_pair": int(k_bytes / max(args.steps, 1))},
+                         "algorithmic_bytes_per_pair": int(k_bytes / max(args.steps, 1)),
+                         "gather_only_kernels": {"launches_per_pair": gather["n"] // max(args.steps, 1),
+                                                 "achieved_GBs": round(g_gbs, 1),
+                                                 "frac": round(g_gbs / HBM_PEAK_GBS, 4)},
+                         "fused_kernels": {"launches_per_pair": fused["n"] // max(args.steps, 1),
+                                           "achieved_GBs": round(f_gbs, 1), "frac_hbm": round(f_gbs / HBM_PEAK_GBS, 4),
+                                           "achieved_TFLOPs_f32_mfma": round(f_tf, 1),
+                                           "frac_mfma_f32_157TF": round(f_tf / 157.3, 4)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, state_dict, limits)

@@ -114,11 +114,23 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
                            int h, int ld_idx, const float* x, int cin, const float* kp, float extent,
                            float* wf, float* inv_n, void* ws, size_t ws_bytes, void* stream);
 
-/* Measurement aid for bench.py: when enabled, every pcrcg_kpconv_aggregate call is bracketed by HIP
- * events recorded on its own stream; _read waits for them and returns up to `cap` records
- * (milliseconds and the nq / h / cin of the launch).  Not thread-safe; off by default. */
+/* The same operator in ONE kernel (gather + aggregate + contraction + 1/n scaling) for layers whose
+ * [nq, 15*cin] intermediate would dominate HBM traffic: the aggregated tile of 16 queries stays in LDS
+ * and is contracted on the matrix cores against wt, a K-contiguous copy of the layer's weights
+ * (wt [cout, 15*cin] = weights.reshape(15*cin, cout)^T).  Supported when cin % 64 == 0 and
+ * cout in {64, 128, 256} (pcrcg_kpconv_fused_supported); ws as for pcrcg_kpconv_aggregate. */
+int pcrcg_kpconv_fused_supported(int nq, int cin, int cout);
+int pcrcg_kpconv_fused(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h,
+                       int ld_idx, const float* x, int cin, const float* kp, float extent, const float* wt,
+                       int cout, float* out, int ld_out, void* ws, size_t ws_bytes, void* stream);
+
+/* Measurement aid for bench.py: when enabled, the gather/aggregate kernel of every
+ * pcrcg_kpconv_aggregate call (kind 0) and the fused kernel of every pcrcg_kpconv_fused call (kind 1)
+ * are bracketed by HIP events recorded on their own stream; _read waits for them and returns up to
+ * `cap` records (milliseconds, nq / h / cin of the launch, cout for kind 1).  Not thread-safe; off by
+ * default. */
 void pcrcg_profile_kpconv(int enable);
-int pcrcg_profile_kpconv_read(float* ms, int* nq, int* h, int* cin, int cap);
+int pcrcg_profile_kpconv_read(float* ms, int* nq, int* h, int* cin, int* cout, int* kind, int cap);
 
 /* C[m,n] = (A[m,k] @ Bop[k,n]) * row_scale[m] + bias[n]   (fp32 in, fp32 MFMA accumulate; row_scale
  * and bias may be NULL).  Row-major with leading dimensions in elements.
@@ -210,6 +222,7 @@ typedef struct pcrcg_block {
     float extent;        /* KP_extent of the block's KPConv */
     const float* kp;     /* [15,3]  ...KPConv.kernel_points */
     const float* kp_w;   /* [15*cin, cout]  ...KPConv.weights */
+    const float* kp_wt;  /* [cout, 15*cin]  K-contiguous copy for pcrcg_kpconv_fused, or NULL */
     const float* unary1; /* [mid, in] or NULL (nn.Identity) */
     const float* unary2; /* [out, mid] */
     const float* shortcut; /* [out, in] or NULL (nn.Identity) */

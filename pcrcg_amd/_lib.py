@@ -32,8 +32,11 @@ SIGNATURES = {
     "pcrcg_kpconv_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_kpconv_aggregate": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                        c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_kpconv_fused_supported": (c_int, [c_int, c_int, c_int]),
+    "pcrcg_kpconv_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                   c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "pcrcg_profile_kpconv": (None, [c_int]),
-    "pcrcg_profile_kpconv_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "pcrcg_profile_kpconv_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "pcrcg_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                c_void_p, c_void_p, c_void_p]),
     "pcrcg_gather_max": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

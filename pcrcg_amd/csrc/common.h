@@ -38,6 +38,17 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
 
 constexpr int kWave = 64;
 
+// Optional HIP-event bracket around a KPConv kernel launch (bench.py roofline); see
+// pcrcg_profile_kpconv in include/pcrcg.h.  kind 0 = gather/aggregate kernel, 1 = fused kernel.
+struct KpProfScope {
+    hipStream_t st;
+    hipEvent_t a, b;
+    int nq, h, cin, cout, kind;
+    bool on;
+    KpProfScope(hipStream_t s, int nq, int h, int cin, int cout, int kind);
+    ~KpProfScope();
+};
+
 }  // namespace pcrcg
 
 #define PCRCG_CHECK_ARG(cond)                                                        \

@@ -27,12 +27,26 @@
 #include "common.h"
 
 namespace pcrcg {
-namespace {
 
-// optional HIP-event timing of every gather/aggregate launch (bench.py roofline)
-struct ProfRec { hipEvent_t a, b; int nq, h, cin; };
-bool g_prof_on = false;
-std::vector<ProfRec> g_prof;
+// optional HIP-event timing of every KPConv launch (bench.py roofline)
+struct ProfRec { hipEvent_t a, b; int nq, h, cin, cout, kind; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+KpProfScope::KpProfScope(hipStream_t s, int nq_, int h_, int cin_, int cout_, int kind_)
+    : st(s), nq(nq_), h(h_), cin(cin_), cout(cout_), kind(kind_), on(g_prof_on) {
+    if (!on) return;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    hipEventRecord(a, st);
+}
+KpProfScope::~KpProfScope() {
+    if (!on) return;
+    hipEventRecord(b, st);
+    g_prof.push_back({a, b, nq, h, cin, cout, kind});
+}
+
+namespace {
 
 constexpr int K = PCRCG_KPOINTS;
 constexpr int kWavesPerBlock = 4;
@@ -142,54 +156,42 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
     }
 }
 
-// Cin == 1: wf[q,k] = sum_h w[q,h,k] * x[idx[q,h]]; lane (hsub, j) accumulates its own (neighbour
-// residue, kernel point) pair, the 4 residues are folded with two shuffles at the end.
-__global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_c1(
+// Cin == 1 (first layer: the feature is a column of ones): wf[q,k] = sum_h w[q,h,k] * x[idx[q,h]].
+// There is no channel dimension to spread over lanes, so one THREAD owns a query: 15 accumulators in
+// registers, kernel points in SGPRs, neighbours streamed with branch-free clamped loads.
+__global__ void __launch_bounds__(256) k_kpconv_c1(
     const float* __restrict__ q_pts, int nq, const float* __restrict__ s_pts, int ns,
     const long long* __restrict__ idx, int H, int ld_idx, const float* __restrict__ x, const float* __restrict__ kp,
     float extent, float* __restrict__ wf, float* __restrict__ inv_n) {
-    const int lane = threadIdx.x & 63;
-    const int hsub = lane >> 4, j = lane & 15;
-    const int gw = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nw = gridDim.x * kWavesPerBlock;
-    const bool jvalid = j < K;
-    const float kpx = jvalid ? kp[3 * j] : 0.f, kpy = jvalid ? kp[3 * j + 1] : 0.f, kpz = jvalid ? kp[3 * j + 2] : 0.f;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float kpx[K], kpy[K], kpz[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { kpx[k] = kp[3 * k]; kpy[k] = kp[3 * k + 1]; kpz[k] = kp[3 * k + 2]; }
     const float inv_extent = 1.0f / extent;
-    for (int q = gw; q < nq; q += nw) {
-        const float qx = q_pts[3 * (long)q], qy = q_pts[3 * (long)q + 1], qz = q_pts[3 * (long)q + 2];
-        float acc = 0.f;
-        int npos = 0;
-        for (int hc = 0; hc < H; hc += 64) {
-            const int h = hc + lane;
-            int i = -1;
-            if (h < H) {
-                const long long v = idx[(long)q * ld_idx + h];
-                i = (v >= 0 && v < ns) ? (int)v : -1;
-            }
-            float px = 0.f, py = 0.f, pz = 0.f, xv = 0.f;
-            if (i >= 0) {
-                px = s_pts[3 * (long)i] - qx;
-                py = s_pts[3 * (long)i + 1] - qy;
-                pz = s_pts[3 * (long)i + 2] - qz;
-                xv = x[i];
-            }
-            npos += __popcll(__ballot(i >= 0 && xv > 0.0f));
-            const int hn = H - hc < 64 ? H - hc : 64;
-            for (int h0 = 0; h0 < hn; h0 += 4) {
-                const int src = h0 + hsub;
-                const int ii = __shfl(i, src, 64);
-                const float nx = __shfl(px, src, 64), ny = __shfl(py, src, 64), nz = __shfl(pz, src, 64);
-                const float xs = __shfl(xv, src, 64);
-                if (ii >= 0 && jvalid) {
-                    const float dx = nx - kpx, dy = ny - kpy, dz = nz - kpz;
-                    acc = fmaf(fmaxf(1.0f - sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent, 0.0f), xs, acc);
-                }
-            }
+    const float qx = q_pts[3 * (long)q], qy = q_pts[3 * (long)q + 1], qz = q_pts[3 * (long)q + 2];
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    int npos = 0;
+    const long long* row = idx + (long)q * ld_idx;
+#pragma unroll 4
+    for (int h = 0; h < H; ++h) {
+        const long long iv = row[h];
+        const bool real = iv >= 0 && iv < ns;
+        const long ic = real ? iv : 0;
+        const float nx = s_pts[3 * ic] - qx, ny = s_pts[3 * ic + 1] - qy, nz = s_pts[3 * ic + 2] - qz;
+        const float xv = real ? x[ic] : 0.f;
+        npos += (real && xv > 0.0f) ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float dx = nx - kpx[k], dy = ny - kpy[k], dz = nz - kpz[k];
+            acc[k] = fmaf(fmaxf(1.0f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent, 0.0f), xv, acc[k]);
         }
-        acc += __shfl_xor(acc, 16, 64);
-        acc += __shfl_xor(acc, 32, 64);
-        if (lane < K) wf[(long)q * K + lane] = acc;
-        if (lane == 0) inv_n[q] = 1.0f / (float)(npos > 1 ? npos : 1);
     }
+#pragma unroll
+    for (int k = 0; k < K; ++k) wf[(long)q * K + k] = acc[k];
+    inv_n[q] = 1.0f / (float)(npos > 1 ? npos : 1);
 }
 
 // Scalar fallback for channel counts that are not a multiple of 4: weights staged in LDS, lanes =
@@ -262,14 +264,14 @@ void pcrcg_profile_kpconv(int enable) {
     g_prof_on = enable != 0;
 }
 
-int pcrcg_profile_kpconv_read(float* ms, int* nq, int* h, int* cin, int cap) {
+int pcrcg_profile_kpconv_read(float* ms, int* nq, int* h, int* cin, int* cout, int* kind, int cap) {
     int n = 0;
     for (auto& r : g_prof) {
         if (n >= cap) break;
         if (hipEventSynchronize(r.b) != hipSuccess) return -1;
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return -1;
-        ms[n] = t; nq[n] = r.nq; h[n] = r.h; cin[n] = r.cin;
+        ms[n] = t; nq[n] = r.nq; h[n] = r.h; cin[n] = r.cin; cout[n] = r.cout; kind[n] = r.kind;
         ++n;
     }
     return n;
@@ -289,16 +291,6 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
     unsigned char* pos = cv.take<unsigned char>((size_t)ns + 1);
     PCRCG_CHECK_WS(cv);
     hipStream_t st = as_stream(stream);
-    struct ProfScope {   // events on the stream the kernels run on
-        hipStream_t st; ProfRec r; bool on;
-        ProfScope(hipStream_t s, int nq, int h, int cin) : st(s), on(g_prof_on) {
-            if (!on) return;
-            r.nq = nq; r.h = h; r.cin = cin;
-            hipEventCreate(&r.a); hipEventCreate(&r.b);
-            hipEventRecord(r.a, st);
-        }
-        ~ProfScope() { if (on) { hipEventRecord(r.b, st); g_prof.push_back(r); } }
-    } prof_scope(st, nq, h, cin);
     const long long* idx_ll = reinterpret_cast<const long long*>(idx);
     const int max_blocks = 256 * 32;
     auto blocks_for = [&](long waves) {
@@ -306,12 +298,14 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
         return (int)(b > max_blocks ? max_blocks : b);
     };
     if (cin == 1) {
-        hipLaunchKernelGGL(k_kpconv_c1, dim3(blocks_for(nq)), dim3(kWavesPerBlock * 64), 0, st, q_pts, nq, s_pts, ns,
-                           idx_ll, h, ld_idx, x, kp, extent, wf, inv_n);
+        KpProfScope prof_scope(st, nq, h, cin, 0, 0);
+        hipLaunchKernelGGL(k_kpconv_c1, dim3((nq + 255) / 256), dim3(256), 0, st, q_pts, nq, s_pts, ns, idx_ll, h,
+                           ld_idx, x, kp, extent, wf, inv_n);
         PCRCG_CHECK_LAUNCH();
         return PCRCG_OK;
     }
     if (ns > 0) hipLaunchKernelGGL(k_row_positive, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, pos);
+    KpProfScope prof_scope(st, nq, h, cin, 0, 0);   // brackets the gather/aggregate kernel only
     const bool aligned = (cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(wf) & 15) == 0);
     if (!aligned) {

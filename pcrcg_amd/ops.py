@@ -61,16 +61,17 @@ def kpconv_profile_start():
 
 
 def kpconv_profile_stop(cap=1 << 16):
-    """-> list of (milliseconds, nq, h, cin) per launch since kpconv_profile_start()."""
+    """-> list of (milliseconds, nq, h, cin, cout, kind) per KPConv kernel launch since
+    kpconv_profile_start(); kind 0 = gather/aggregate kernel (cout unknown: 0), 1 = fused kernel."""
     import ctypes
     L = _lib.lib()
     ms = (ctypes.c_float * cap)()
-    nq, h, cin = (ctypes.c_int * cap)(), (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
-    n = L.pcrcg_profile_kpconv_read(ms, nq, h, cin, cap)
+    arr = [(ctypes.c_int * cap)() for _ in range(5)]
+    n = L.pcrcg_profile_kpconv_read(ms, *arr, cap)
     L.pcrcg_profile_kpconv(0)
     if n < 0:
         raise RuntimeError("pcrcg_profile_kpconv_read failed")
-    return [(ms[i], nq[i], h[i], cin[i]) for i in range(n)]
+    return [(ms[i],) + tuple(a[i] for a in arr) for i in range(n)]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -208,6 +209,30 @@ def kpconv(q_pts, s_pts, idx, x, kernel_points, weights, extent):
                                         inv_n.data_ptr(), ws.data_ptr(), nbytes, _stream()),
                "pcrcg_kpconv_aggregate")
     return gemm(wf, w2, row_scale=inv_n)
+
+
+def kpconv_fused(q_pts, s_pts, idx, x, kernel_points, weights, extent):
+    """KPConv.forward in one kernel (no [nq, 15*cin] intermediate); needs cin % 64 == 0 and
+    cout in {64, 128, 256}."""
+    L = _lib.lib()
+    q_pts = _dev(q_pts, _F32, "q_pts").contiguous()
+    s_pts = _dev(s_pts, _F32, "s_pts").contiguous()
+    idx, ld_idx = _rows(idx, _I64, "neighb_inds")
+    x = _dev(x, _F32, "x").contiguous()
+    kp = _dev(kernel_points, _F32, "kernel_points").contiguous()
+    nq, h = idx.shape
+    ns, cin = x.shape
+    cout = weights.shape[-1]
+    if not L.pcrcg_kpconv_fused_supported(nq, cin, cout):
+        raise RuntimeError(f"pcrcg_amd.kpconv_fused: unsupported widths {cin}->{cout}")
+    wt = _dev(weights, _F32, "weights").reshape(-1, cout).t().contiguous()
+    out = torch.empty((nq, cout), dtype=_F32, device=x.device)
+    nbytes = L.pcrcg_kpconv_ws_bytes(ns)
+    ws = _ws.get("kpconv", nbytes, x.device)
+    _lib.check(L.pcrcg_kpconv_fused(q_pts.data_ptr(), nq, s_pts.data_ptr(), ns, idx.data_ptr(), h, ld_idx,
+                                    x.data_ptr(), cin, kp.data_ptr(), float(extent), wt.data_ptr(), cout,
+                                    out.data_ptr(), cout, ws.data_ptr(), nbytes, _stream()), "pcrcg_kpconv_fused")
+    return out
 
 
 def gather_max(x, idx):

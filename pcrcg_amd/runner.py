@@ -25,7 +25,7 @@ _fp = ctypes.c_void_p
 class Block(ctypes.Structure):
     _fields_ = [("type", ctypes.c_int), ("layer", ctypes.c_int), ("strided", ctypes.c_int),
                 ("in_dim", ctypes.c_int), ("out_dim", ctypes.c_int), ("mid_dim", ctypes.c_int),
-                ("extent", ctypes.c_float), ("kp", _fp), ("kp_w", _fp), ("unary1", _fp), ("unary2", _fp),
+                ("extent", ctypes.c_float), ("kp", _fp), ("kp_w", _fp), ("kp_wt", _fp), ("unary1", _fp), ("unary2", _fp),
                 ("shortcut", _fp), ("mlp", _fp), ("mlp_ld", ctypes.c_int)]
 
 
@@ -95,6 +95,12 @@ class Runner:
         self.keep.append(t)
         return t.data_ptr()
 
+    def _kp_wt(self, kp):
+        """K-contiguous copy [cout, 15*cin] of the KPConv weights for the fused kernel (or NULL)."""
+        if not _lib.lib().pcrcg_kpconv_fused_supported(1, kp.in_channels, kp.out_channels):
+            return None
+        return self._w(kp.weights.data.reshape(-1, kp.out_channels).t())
+
     def _fill_block(self, blk, mod):
         if isinstance(mod, SimpleBlock):
             blk.type, blk.layer, blk.strided = BLK_SIMPLE, mod.layer_ind, int("strided" in mod.block_name)
@@ -102,12 +108,14 @@ class Runner:
             blk.in_dim, blk.out_dim, blk.mid_dim = kp.in_channels, kp.out_channels, kp.out_channels
             blk.extent = float(kp.KP_extent)
             blk.kp, blk.kp_w = self._w(kp.kernel_points.data), self._w(kp.weights.data)
+            blk.kp_wt = self._kp_wt(kp)
         elif isinstance(mod, ResnetBottleneckBlock):
             blk.type, blk.layer, blk.strided = BLK_RESNETB, mod.layer_ind, int("strided" in mod.block_name)
             kp = mod.KPConv
             blk.in_dim, blk.out_dim, blk.mid_dim = mod.in_dim, mod.out_dim, kp.out_channels
             blk.extent = float(kp.KP_extent)
             blk.kp, blk.kp_w = self._w(kp.kernel_points.data), self._w(kp.weights.data)
+            blk.kp_wt = self._kp_wt(kp)
             blk.unary1 = self._w(mod.unary1.mlp.weight.data) if isinstance(mod.unary1, UnaryBlock) else None
             blk.unary2 = self._w(mod.unary2.mlp.weight.data)
             blk.shortcut = (self._w(mod.unary_shortcut.mlp.weight.data)
