@@ -112,14 +112,18 @@ def main():
             pool[s % 16] = (torch.from_numpy(np.concatenate([src, tgt])).to(dev),
                             torch.tensor([len(src), len(tgt)], dtype=torch.int32, device=dev))
 
-    # Two-stream pipeline: a step enqueues the forward of pair i and builds the pyramid of pair i+1, so
-    # the timed region contains exactly K forwards and K pyramid builds (the pyramid of the first timed
-    # pair is built during warm-up, the one built in the last step is for a pair that is never run).
+    # Multi-stream pipeline (pcrcg_amd/pipeline.py): a step enqueues the forward of pair i and requests the
+    # pyramid of pair i+DEPTH from the front-end worker, so the timed region contains exactly K forwards
+    # and K pyramid builds (the first DEPTH pyramids are requested before the clock starts, the last
+    # DEPTH requested inside the timed region are waited for -- not run -- before the clock stops).
+    DEPTH = 2
     pipe = PairPipeline(net, cfg, limits, dev)
 
-    def step(prepared, next_seed):
+    def step(i):
+        prepared = pipe.next_prepared()
         out = pipe.run(prepared)
-        return out, pipe.prepare(*pool[next_seed % 16])
+        pipe.request(*pool[seeds[(i + DEPTH) % total] % 16])
+        return out
 
     def fence():
         pipe.synchronize()
@@ -127,19 +131,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    prepared = pipe.prepare(*pool[seeds[0] % 16])
+    for i in range(DEPTH):
+        pipe.request(*pool[seeds[i] % 16])
     for i in range(args.warmup):
-        out, prepared = step(prepared, seeds[i + 1])
+        out = step(i)
     fence()
     ops.kpconv_profile_start()        # HIP events around every KPConv gather/aggregate launch from here on
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
-        out, prepared = step(prepared, seeds[(i + 1) % total])
+        out = step(i)
     submit = time.perf_counter() - t0      # host time to enqueue everything (GPU may still be busy)
+    pipe.drain()                           # the DEPTH pyramids requested last must be finished too
     fence()
     elapsed = time.perf_counter() - t0
     events = ops.kpconv_profile_stop()
     assert out["feats_f"].shape[1] == cfg.final_feats_dim
+
+    # the same kernels once more WITHOUT any concurrent stream: the roofline of the gather kernel in isolation
+    iso = None
+    if rank == 0:
+        pipe.request(*pool[seeds[0] % 16])
+        batch_iso, _ = pipe.next_prepared()
+        pipe.synchronize()
+        ops.kpconv_profile_start()
+        with torch.no_grad():
+            for _ in range(3):
+                net(batch_iso)
+        torch.cuda.synchronize()
+        iso = ops.kpconv_profile_stop()
+    pipe.close()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -168,6 +188,10 @@ def main():
         g_gbs = gather["bytes"] / (gather["ms"] * 1e-3) / 1e9 if gather["ms"] > 0 else 0.0
         f_gbs = fused["bytes"] / (fused["ms"] * 1e-3) / 1e9 if fused["ms"] > 0 else 0.0
         f_tf = fused["flops"] / (fused["ms"] * 1e-3) / 1e12 if fused["ms"] > 0 else 0.0
+        iso_ms = sum(e[0] for e in iso)
+        iso_bytes = sum(kpconv_algorithmic_bytes(nq, h, cin, couts[i % per_pair])
+                        for i, (_, nq, h, cin, _, _) in enumerate(iso))
+        iso_gbs = iso_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
         traffic = None
         pmc_path = os.path.join(REPO, "profiles", "r01_pmc_kpconv.json")
         if os.path.exists(pmc_path):        # HBM bytes per launch from the committed rocprofv3 PMC passes
@@ -188,7 +212,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "S30k: 2x30000-pt shell pairs (3DMatch-shaped), pyramid build + KPFCNN+GCN "
                                    "forward, indoor hyper-parameters, random-init full-width weights, 1 pair/GPU/step; "
-                                   "pyramid of pair i+1 overlaps the forward of pair i on a second HIP stream",
+                                   "pyramids are built by a front-end thread on its own HIP stream while forwards alternate "
+                                   "between two model streams",
                        "limits": limits, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "KPConv neighbour-gather kernels (k_kpconv_mfma / k_kpconv_c1 / "
                                                      "k_kpconv_fused), %d launches/pair" % per_pair,
@@ -196,6 +221,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "avg_launch_us": round(k_ms * 1e3 / max(len(events), 1), 2),
                          "algorithmic_bytes_per_pair": int(k_bytes / max(args.steps, 1)),
+                         "note": "achieved/frac are measured inside the timed region, where three HIP streams share "
+                                 "the GPU; `isolated` is the same 11 launches run alone right after it",
+                         "isolated": {"achieved": round(iso_gbs, 1), "frac": round(iso_gbs / HBM_PEAK_GBS, 4),
+                                      "avg_launch_us": round(iso_ms * 1e3 / max(len(iso), 1), 2)},
                          "gather_only_kernels": {"launches_per_pair": gather["n"] // max(args.steps, 1),
                                                  "achieved_GBs": round(g_gbs, 1),
                                                  "frac": round(g_gbs / HBM_PEAK_GBS, 4)},

@@ -322,14 +322,18 @@ def test_two_stream_pipeline_matches_sequential(cuda):
         for pts, lens in pairs:
             ref.append(net(build_pyramid(pts, lens, cfg, limits)))
     torch.cuda.synchronize()
-    pipe = PairPipeline(net, cfg, limits, cuda)
-    outs = []
-    prepared = pipe.prepare(*pairs[0])
-    for i in range(len(pairs)):
-        out = pipe.run(prepared)
-        prepared = pipe.prepare(*pairs[(i + 1) % len(pairs)])
-        outs.append(out)
-    pipe.synchronize()
-    for a, b in zip(outs, ref):
-        for k in ("feats_f", "scores_overlap", "scores_saliency"):
-            assert rel(a[k], b[k]) < 1e-5, k
+    for threaded in (False, True):
+        pipe = PairPipeline(net, cfg, limits, cuda, threaded=threaded)
+        outs = []
+        for i in range(2):
+            pipe.request(*pairs[i])
+        for i in range(len(pairs)):
+            out = pipe.run(pipe.next_prepared())
+            if i + 2 < len(pairs):
+                pipe.request(*pairs[i + 2])
+            outs.append(out)
+        pipe.drain()
+        pipe.close()
+        for a, b in zip(outs, ref):
+            for k in ("feats_f", "scores_overlap", "scores_saliency"):
+                assert rel(a[k], b[k]) < 1e-5, (threaded, k)
