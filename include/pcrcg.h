@@ -140,6 +140,16 @@ int pcrcg_profile_kpconv_read(float* ms, int* nq, int* h, int* cin, int* cout, i
  * (ref:models/blocks.py:361-366, 487; ref:models/architectures.py:528,538-539; ref:models/gcn.py:123-173). */
 int pcrcg_gemm_f32(const float* a, int lda, const float* b, int ldb, int trans_b, float* c, int ldc, int m,
                    int n, int k, const float* row_scale, const float* bias, void* stream);
+/* Same GEMM; additionally, when every output element is written exactly once (no split-K), the
+ * epilogue leaves per-column partial sums / sums of squares of C in `colstats`
+ * (pcrcg_gemm_colstats_bytes(m, n) bytes, layout [2][n][chunks] fp64) and stores the chunk count in the
+ * HOST integer *h_chunks; otherwise *h_chunks = 0 and the caller computes the statistics with
+ * pcrcg_instnorm_stats.  Every GEMM of the path feeds an InstanceNorm (ref:models/blocks.py:456-463), so
+ * this saves one full read of C per layer. */
+size_t pcrcg_gemm_colstats_bytes(int m, int n);
+int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, int ldb, int trans_b, float* c, int ldc,
+                            int m, int n, int k, const float* row_scale, const float* bias, void* colstats,
+                            size_t colstats_bytes, int* h_chunks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Point-wise blocks
@@ -161,6 +171,10 @@ int pcrcg_gather_first(const float* x, int ns, int c, const int64_t* idx, int nq
  * x, res, y are row-major with leading dimensions ldx, ldr, ldy.  slope 1.0 = no activation.
  * ws: pcrcg_instnorm_ws_bytes(c) bytes. */
 size_t pcrcg_instnorm_ws_bytes(int c);
+/* (mean, rstd) pairs from [2][c][chunks] fp64 partial sums over `count` rows (see
+ * pcrcg_gemm_f32_colstats); fixed summation order, deterministic. */
+int pcrcg_instnorm_stats_from_partials(const void* partials, int chunks, int c, double count, float eps,
+                                       float* stats, void* stream);
 int pcrcg_instnorm_stats(const float* x, int n, int c, int ldx, float eps, float* stats, void* ws,
                          size_t ws_bytes, void* stream);
 int pcrcg_instnorm_apply(const float* x, int n, int c, int ldx, const float* stats, const float* res,

@@ -40,7 +40,8 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_B>
 __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                    int ldb, float* __restrict__ C, int ldc, int M, int N, int Kdim,
                                                    const float* __restrict__ row_scale, const float* __restrict__ bias,
-                                                   int k_per_split, int vec_a, int vec_b, int atomic_out) {
+                                                   int k_per_split, int vec_a, int vec_b, int atomic_out,
+                                                   double* __restrict__ colp, int colp_chunks) {
     static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per block");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // per-wave tile
     constexpr int TM = WM / 32, TN = WN / 32;            // 32x32 MFMA tiles per wave
@@ -216,6 +217,9 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
         const int gn = n0 + wn * WN + j * 32 + l31;
         bv[j] = (bias && first_split) ? bias[min(gn, N - 1)] : 0.0f;
     }
+    float cs[TN], cq[TN];   // per-column sum / sum of squares over this wavefront's rows (InstanceNorm partials)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -229,15 +233,31 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
                     float* dst = C + (long)gm * ldc + gn;
                     if (atomic_out) atomicAdd(dst, v);
                     else *dst = v;
+                    cs[j] += v;
+                    cq[j] += v * v;
                 }
             }
         }
+    // Column statistics of the stored tile, one chunk per (block row, wavefront row): layout
+    // [2][N][chunks] fp64, finished by pcrcg_instnorm_stats_from_partials (deterministic, no atomics).
+    if (colp) {
+        const int chunk = blockIdx.y * WAVES_M + wm;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float s = cs[j] + __shfl_xor(cs[j], 32, 64), q2 = cq[j] + __shfl_xor(cq[j], 32, 64);
+            const int gn = n0 + wn * WN + j * 32 + l31;
+            if (half == 0 && gn < N) {
+                colp[(long)gn * colp_chunks + chunk] = (double)s;
+                colp[((long)N + gn) * colp_chunks + chunk] = (double)q2;
+            }
+        }
+    }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_B>
 int launch_one(dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m,
                int n, int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b,
-               int atomic_out) {
+               int atomic_out, double* colp, int colp_chunks) {
     constexpr size_t lds = 2 * sizeof(float) * stage_floats<BM, BN, TRANS_B>();
     auto kern = k_gemm_f32<BM, BN, WAVES_M, WAVES_N, TRANS_B>;
     static bool configured = false;   // > 64 KiB of dynamic LDS must be requested once per kernel
@@ -247,7 +267,7 @@ int launch_one(dim3 grid, hipStream_t st, const float* a, int lda, const float* 
         configured = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split,
-                       vec_a, vec_b, atomic_out);
+                       vec_a, vec_b, atomic_out, colp, colp_chunks);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -255,12 +275,12 @@ int launch_one(dim3 grid, hipStream_t st, const float* a, int lda, const float* 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch(bool trans_b, dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c,
            int ldc, int m, int n, int k, const float* row_scale, const float* bias, int k_per_split, int vec_a,
-           int vec_b, int atomic_out) {
+           int vec_b, int atomic_out, double* colp, int colp_chunks) {
     if (trans_b)
         return launch_one<BM, BN, WAVES_M, WAVES_N, true>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
-                                                          k_per_split, vec_a, vec_b, atomic_out);
+                                                          k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks);
     return launch_one<BM, BN, WAVES_M, WAVES_N, false>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
-                                                       k_per_split, vec_a, vec_b, atomic_out);
+                                                       k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks);
 }
 
 }  // namespace
@@ -268,8 +288,21 @@ int launch(bool trans_b, dim3 grid, hipStream_t st, const float* a, int lda, con
 
 using namespace pcrcg;
 
+extern "C" size_t pcrcg_gemm_colstats_bytes(int m, int n) {
+    const size_t chunks = (size_t)((m > 0 ? m : 1) + 31) / 32 + 4;
+    return carve_bytes(2 * (size_t)(n > 0 ? n : 1) * chunks, sizeof(double));
+}
+
 extern "C" int pcrcg_gemm_f32(const float* a, int lda, const float* b, int ldb, int trans_b, float* c, int ldc,
                               int m, int n, int k, const float* row_scale, const float* bias, void* stream) {
+    return pcrcg_gemm_f32_colstats(a, lda, b, ldb, trans_b, c, ldc, m, n, k, row_scale, bias, nullptr, 0, nullptr,
+                                   stream);
+}
+
+extern "C" int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, int ldb, int trans_b, float* c,
+                                       int ldc, int m, int n, int k, const float* row_scale, const float* bias,
+                                       void* colstats, size_t colstats_bytes, int* h_chunks, void* stream) {
+    if (h_chunks) *h_chunks = 0;
     PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 0);
     if (m == 0 || n == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(a && b && c);
@@ -306,9 +339,21 @@ extern "C" int pcrcg_gemm_f32(const float* a, int lda, const float* b, int ldb, 
         else PCRCG_CHECK_HIP(hipMemset2DAsync(c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), m, st));
     }
     dim3 grid(gx, gy, splits);
+    // column statistics ride along only when every output element is written exactly once
+    double* colp = nullptr;
+    int colp_chunks = 0;
+    if (colstats && h_chunks && !atomic_out) {
+        colp_chunks = gy * (pick == 1 ? 4 : 2);   // WAVES_M of the chosen tile
+        if (carve_bytes(2 * (size_t)n * colp_chunks, sizeof(double)) <= colstats_bytes) {
+            colp = static_cast<double*>(colstats);
+            *h_chunks = colp_chunks;
+        } else {
+            colp_chunks = 0;
+        }
+    }
 #define GO(BMV, BNV, WMV, WNV)                                                                                   \
     return launch<BMV, BNV, WMV, WNV>(trans_b != 0, grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, \
-                                      k_per_split, vec_a, vec_b, atomic_out)
+                                      k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks)
     if (pick == 0) GO(128, 128, 2, 2);
     if (pick == 1) GO(128, 64, 4, 1);
     if (pick == 2) GO(64, 128, 2, 2);

@@ -224,6 +224,12 @@ int pcrcg_gather_first(const float* x, int ns, int c, const int64_t* idx, int nq
 
 size_t pcrcg_instnorm_ws_bytes(int c) { return colstats_ws_bytes(c); }
 
+int pcrcg_instnorm_stats_from_partials(const void* partials, int chunks, int c, double count, float eps,
+                                       float* stats, void* stream) {
+    PCRCG_CHECK_ARG(partials && stats && chunks >= 1 && c >= 1 && count >= 1.0);
+    return colstats_finalize(static_cast<const double*>(partials), chunks, c, count, eps, stats, as_stream(stream));
+}
+
 int pcrcg_instnorm_stats(const float* x, int n, int c, int ldx, float eps, float* stats, void* ws,
                          size_t ws_bytes, void* stream) {
     PCRCG_CHECK_ARG(n >= 1 && c >= 1 && ldx >= c && x && stats && ws);

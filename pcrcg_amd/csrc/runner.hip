@@ -61,29 +61,57 @@ inline int pad4(int v) { return (v + 3) & ~3; }
 inline Mat cols(const Mat& m, int c0, int n) { Mat r = m; r.p = m.p ? m.p + c0 : nullptr; r.cols = n; return r; }
 inline Mat rows(const Mat& m, int r0, int n) { Mat r = m; r.p = m.p ? m.p + (long)r0 * m.ld : nullptr; r.rows = n; return r; }
 
-// y = x @ w^T (+ bias); w is [out, in] with leading dimension ldw
-void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, const Mat& y) {
-    if (c.live())
-        c.check(pcrcg_gemm_f32(x.p, x.ld, w, ldw, 1, y.p, y.ld, x.rows, y.cols, x.cols, nullptr, bias, c.st));
+struct Stat;
+// y = x @ w^T (+ bias); w is [out, in] with leading dimension ldw; optionally leaves the column
+// partials of y for the InstanceNorm that follows
+void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, const Mat& y, Stat* st = nullptr);
+
+// A GEMM output together with the InstanceNorm column partials its epilogue may have produced.
+struct Stat {
+    void* partials = nullptr;   // [2][cols][chunks] fp64, valid when chunks > 0
+    size_t bytes = 0;
+    int chunks = 0;
+};
+
+Stat stat_buffer(Ctx& c, int rows, int cols) {
+    Stat s;
+    s.bytes = pcrcg_gemm_colstats_bytes(rows, cols);
+    s.partials = c.raw(s.bytes);
+    return s;
+}
+
+// (mean, rstd) of x: from the producing GEMM's partials when it left some, else by a pass over x
+void col_stats(Ctx& c, const Mat& x, const Stat* s, float* stats, void* ws, size_t wsb) {
+    if (s && s->chunks > 0)
+        c.check(pcrcg_instnorm_stats_from_partials(s->partials, s->chunks, x.cols, (double)x.rows, 1e-5f, stats, c.st));
+    else
+        c.check(pcrcg_instnorm_stats(x.p, x.rows, x.cols, x.ld, 1e-5f, stats, ws, wsb, c.st));
 }
 
 // y = lrelu(IN(x) [+ IN(res) | + res], slope)
-void norm_act(Ctx& c, const Mat& x, float slope, const Mat& y, const Mat* res = nullptr, bool norm_res = false) {
+void norm_act(Ctx& c, const Mat& x, float slope, const Mat& y, const Stat* xs = nullptr, const Mat* res = nullptr,
+              bool norm_res = false, const Stat* rs = nullptr) {
     const size_t m = c.mark();
     float* stats = static_cast<float*>(c.raw(sizeof(float) * 2 * x.cols));
     float* rstats = (res && norm_res) ? static_cast<float*>(c.raw(sizeof(float) * 2 * x.cols)) : nullptr;
     const size_t wsb = pcrcg_instnorm_ws_bytes(x.cols);
     void* ws = c.raw(wsb);
     if (c.live()) {
-        c.check(pcrcg_instnorm_stats(x.p, x.rows, x.cols, x.ld, 1e-5f, stats, ws, wsb, c.st));
-        if (rstats) c.check(pcrcg_instnorm_stats(res->p, res->rows, res->cols, res->ld, 1e-5f, rstats, ws, wsb, c.st));
+        col_stats(c, x, xs, stats, ws, wsb);
+        if (rstats) col_stats(c, *res, rs, rstats, ws, wsb);
         c.check(pcrcg_instnorm_apply(x.p, x.rows, x.cols, x.ld, stats, res ? res->p : nullptr, res ? res->ld : 0,
                                      rstats, slope, y.p, y.ld, c.st));
     }
     c.release(m);
 }
 
-void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, const Mat& y) {
+void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, const Mat& y, Stat* st) {
+    if (!c.live()) return;
+    c.check(pcrcg_gemm_f32_colstats(x.p, x.ld, w, ldw, 1, y.p, y.ld, x.rows, y.cols, x.cols, nullptr, bias,
+                                    st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr, c.st));
+}
+
+void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, const Mat& y, Stat* st = nullptr) {
     const int l = blk.layer;
     const pcrcg_table& t = blk.strided ? b.pools[l] : b.neighbors[l];
     const float* q = blk.strided ? b.points[l + 1] : b.points[l];
@@ -108,7 +136,9 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
     if (c.live()) {
         c.check(pcrcg_kpconv_aggregate(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, x.p, x.cols, blk.kp, blk.extent,
                                        wf.p, inv_n, ws, wsb, c.st));
-        c.check(pcrcg_gemm_f32(wf.p, wf.ld, blk.kp_w, y.cols, 0, y.p, y.ld, nq, y.cols, wf.cols, inv_n, nullptr, c.st));
+        c.check(pcrcg_gemm_f32_colstats(wf.p, wf.ld, blk.kp_w, y.cols, 0, y.p, y.ld, nq, y.cols, wf.cols, inv_n, nullptr,
+                                        st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr,
+                                        c.st));
     }
     c.release(m);
 }
@@ -122,8 +152,9 @@ Mat simple_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat
     Mat y = c.mat(out_rows(b, blk), blk.mid_dim);
     const size_t m = c.mark();
     Mat t = c.mat(y.rows, y.cols);
-    kpconv(c, b, blk, x, t);
-    norm_act(c, t, 0.1f, y);
+    Stat ts = stat_buffer(c, t.rows, t.cols);
+    kpconv(c, b, blk, x, t, &ts);
+    norm_act(c, t, 0.1f, y, &ts);
     c.release(m);
     return y;
 }
@@ -136,15 +167,18 @@ Mat resnet_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat
     Mat x = feats;
     if (blk.unary1) {
         Mat t = c.mat(feats.rows, blk.mid_dim), u = c.mat(feats.rows, blk.mid_dim);
-        linear(c, feats, blk.unary1, feats.cols, nullptr, t);
-        norm_act(c, t, 0.1f, u);
+        Stat ts = stat_buffer(c, t.rows, t.cols);
+        linear(c, feats, blk.unary1, feats.cols, nullptr, t, &ts);
+        norm_act(c, t, 0.1f, u, &ts);
         x = u;
     }
     Mat k = c.mat(nq, blk.mid_dim), kn = c.mat(nq, blk.mid_dim);
-    kpconv(c, b, blk, x, k);
-    norm_act(c, k, 0.1f, kn);
+    Stat ks = stat_buffer(c, nq, blk.mid_dim);
+    kpconv(c, b, blk, x, k, &ks);
+    norm_act(c, k, 0.1f, kn, &ks);
     Mat u2 = c.mat(nq, blk.out_dim);
-    linear(c, kn, blk.unary2, blk.mid_dim, nullptr, u2);
+    Stat u2s = stat_buffer(c, nq, blk.out_dim);
+    linear(c, kn, blk.unary2, blk.mid_dim, nullptr, u2, &u2s);
     Mat sc = feats;
     if (blk.strided) {   // max_pool shortcut (:672-673)
         const pcrcg_table& t = b.pools[blk.layer];
@@ -154,10 +188,11 @@ Mat resnet_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat
     }
     if (blk.shortcut) {
         Mat s2 = c.mat(nq, blk.out_dim);
-        linear(c, sc, blk.shortcut, sc.cols, nullptr, s2);
-        norm_act(c, u2, 0.1f, y, &s2, true);      // lrelu(IN(unary2) + IN(shortcut))
+        Stat s2s = stat_buffer(c, nq, blk.out_dim);
+        linear(c, sc, blk.shortcut, sc.cols, nullptr, s2, &s2s);
+        norm_act(c, u2, 0.1f, y, &u2s, &s2, true, &s2s);      // lrelu(IN(unary2) + IN(shortcut))
     } else {
-        norm_act(c, u2, 0.1f, y, &sc, false);     // lrelu(IN(unary2) + shortcut)
+        norm_act(c, u2, 0.1f, y, &u2s, &sc, false);           // lrelu(IN(unary2) + shortcut)
     }
     c.release(m);
     return y;
@@ -312,8 +347,9 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
             x = y;
         } else if (blk.type == PCRCG_BLK_UNARY) {
             Mat t = c.mat(x.rows, blk.out_dim), y = c.mat(x.rows, blk.out_dim);
-            linear(c, x, blk.mlp, blk.mlp_ld, nullptr, t);
-            norm_act(c, t, 0.1f, y);
+            Stat ts = stat_buffer(c, t.rows, t.cols);
+            linear(c, x, blk.mlp, blk.mlp_ld, nullptr, t, &ts);
+            norm_act(c, t, 0.1f, y, &ts);
             x = y;
         } else {   // last_unary
             Mat y = c.mat(x.rows, blk.out_dim, pad4(blk.out_dim));
