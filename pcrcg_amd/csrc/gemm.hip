@@ -30,13 +30,11 @@ namespace pcrcg {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int BK = 32;
-constexpr int KPAD = BK + 4;   // row stride of k-contiguous LDS images (floats)
+// k-step: 32, or 64 for long-K GEMMs (256 contiguous bytes per operand row and step)
+template <int BM, int BN, bool TRANS_B, int BK>
+constexpr int stage_floats() { return BM * (BK + 4) + (TRANS_B ? BN * (BK + 4) : BK * (BN + 4)); }
 
-template <int BM, int BN, bool TRANS_B>
-constexpr int stage_floats() { return BM * KPAD + (TRANS_B ? BN * KPAD : BK * (BN + 4)); }
-
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_B>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_B, int BK>
 __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                    int ldb, float* __restrict__ C, int ldc, int M, int N, int Kdim,
                                                    const float* __restrict__ row_scale, const float* __restrict__ bias,
@@ -45,10 +43,11 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
     static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per block");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // per-wave tile
     constexpr int TM = WM / 32, TN = WN / 32;            // 32x32 MFMA tiles per wave
+    constexpr int KPAD = BK + 4;   // row stride of k-contiguous LDS images (floats); = 4 mod 64
     constexpr int NPAD = BN + 4;
     constexpr int A_ITERS = BM * BK / 4 / 256;           // float4 per thread and tile
     constexpr int B_ITERS = BN * BK / 4 / 256;
-    constexpr int STAGE = stage_floats<BM, BN, TRANS_B>();
+    constexpr int STAGE = stage_floats<BM, BN, TRANS_B, BK>();
     static_assert(A_ITERS >= 1 && B_ITERS >= 1, "tile too small");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -254,12 +253,12 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_B>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_B, int BK>
 int launch_one(dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m,
                int n, int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b,
                int atomic_out, double* colp, int colp_chunks) {
-    constexpr size_t lds = 2 * sizeof(float) * stage_floats<BM, BN, TRANS_B>();
-    auto kern = k_gemm_f32<BM, BN, WAVES_M, WAVES_N, TRANS_B>;
+    constexpr size_t lds = 2 * sizeof(float) * stage_floats<BM, BN, TRANS_B, BK>();
+    auto kern = k_gemm_f32<BM, BN, WAVES_M, WAVES_N, TRANS_B, BK>;
     static bool configured = false;   // > 64 KiB of dynamic LDS must be requested once per kernel
     if (!configured) {
         PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -272,14 +271,14 @@ int launch_one(dim3 grid, hipStream_t st, const float* a, int lda, const float* 
     return PCRCG_OK;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
 int launch(bool trans_b, dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c,
            int ldc, int m, int n, int k, const float* row_scale, const float* bias, int k_per_split, int vec_a,
            int vec_b, int atomic_out, double* colp, int colp_chunks) {
     if (trans_b)
-        return launch_one<BM, BN, WAVES_M, WAVES_N, true>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
+        return launch_one<BM, BN, WAVES_M, WAVES_N, true, BK>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
                                                           k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks);
-    return launch_one<BM, BN, WAVES_M, WAVES_N, false>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
+    return launch_one<BM, BN, WAVES_M, WAVES_N, false, BK>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
                                                        k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks);
 }
 
@@ -325,6 +324,7 @@ extern "C" int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, 
     if (pick < 0 || pick > 3) pick = (n > 64 && ntiles(0) >= 1024) ? 0 : 3;
     const int BM = tiles[pick].bm, BN = tiles[pick].bn;
     const int gx = (n + BN - 1) / BN, gy = (m + BM - 1) / BM;
+    constexpr int BK = 32;   // a 64-deep k-step (2 blocks/CU) measured 12 % slower on the path's shapes
     int splits = 1;
     const int ktiles = (k + BK - 1) / BK;
     while ((long)gx * gy * splits < 768 && k / (2 * splits) >= 192 && splits < 32) splits *= 2;
@@ -352,11 +352,11 @@ extern "C" int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, 
         }
     }
 #define GO(BMV, BNV, WMV, WNV)                                                                                   \
-    return launch<BMV, BNV, WMV, WNV>(trans_b != 0, grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, \
+    return launch<BMV, BNV, WMV, WNV, BK>(trans_b != 0, grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, \
                                       k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks)
-    if (pick == 0) GO(128, 128, 2, 2);
-    if (pick == 1) GO(128, 64, 4, 1);
-    if (pick == 2) GO(64, 128, 2, 2);
+    if (pick == 0) { GO(128, 128, 2, 2); }
+    if (pick == 1) { GO(128, 64, 4, 1); }
+    if (pick == 2) { GO(64, 128, 2, 2); }
     GO(64, 64, 2, 2);
 #undef GO
 }
