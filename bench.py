@@ -116,8 +116,8 @@ def main():
     # pyramid of pair i+DEPTH from the front-end worker, so the timed region contains exactly K forwards
     # and K pyramid builds (the first DEPTH pyramids are requested before the clock starts, the last
     # DEPTH requested inside the timed region are waited for -- not run -- before the clock stops).
-    DEPTH = 2
-    pipe = PairPipeline(net, cfg, limits, dev)
+    DEPTH = int(os.environ.get("PCRCG_PIPE_DEPTH", "2"))
+    pipe = PairPipeline(net, cfg, limits, dev, model_streams=int(os.environ.get("PCRCG_MODEL_STREAMS", "2")))
 
     def step(i):
         prepared = pipe.next_prepared()

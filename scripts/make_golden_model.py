@@ -9,6 +9,7 @@
   kpconv_mini.pt  : reference KPConv.forward (ref:models/blocks.py:229-374) on the mini tables for
                     (Cin,Cout) in {(1,16),(8,8) plain and strided,(64,64)}
   gcn_mini.pt     : reference GCN.forward (ref:models/gcn.py:208-217) on N=(96,80), C=64
+  calibration.json: reference calibrate_neighbors (ref:datasets/dataloader.py:402-434) limits
 """
 import os
 import sys
@@ -39,7 +40,8 @@ def ref_collate(src, tgt, cfg, limits):
 
 
 def slim(batch):
-    keep = ("points", "neighbors", "pools", "upsamples", "features", "stack_lengths")
+    keep = ("points", "neighbors", "pools", "upsamples", "features", "stack_lengths", "node_overlap_gt",
+            "points2node", "correspondences")
     return {k: batch[k] for k in keep}
 
 
@@ -111,6 +113,24 @@ def main():
     torch.save(dict(state_dict={k: v.clone() for k, v in gnn.state_dict().items()}, c0=c0[0].t().clone(),
                     c1=c1[0].t().clone(), d0=d0[0].t().clone(), d1=d1[0].t().clone(), o0=o0[0].t().clone(),
                     o1=o1[0].t().clone()), os.path.join(OUT, "gcn_mini.pt"))
+    # calibrate_neighbors (ref:datasets/dataloader.py:402-434) on one synthetic pair per recipe
+    import json
+    from datasets.dataloader import calibrate_neighbors, collate_fn_descriptor
+    full = ref_import.indoor_config()
+    lim = {}
+    for rec in ("mini", "C1", "S30k"):
+        s_, t_ = S.pair(rec, 0)
+        corr = torch.stack([torch.arange(0, 50), torch.arange(0, 50)], 1)
+        item = dict(rot=np.eye(3, dtype=np.float32), trans=np.zeros((3, 1), np.float32), correspondences=corr,
+                    sample=0, src_pcd=s_, tgt_pcd=t_, src_feats=np.ones((len(s_), 1), np.float32),
+                    tgt_feats=np.ones((len(t_), 1), np.float32))
+
+        class DS(list):
+            config = full
+        lim[rec] = [int(v) for v in calibrate_neighbors(DS([item]), full, collate_fn_descriptor,
+                                                        samples_threshold=10 ** 9)]
+    json.dump({"_doc": "reference calibrate_neighbors (keep_ratio 0.8) on one synthetic pair per recipe, seed 0",
+               "limits": lim}, open(os.path.join(OUT, "calibration.json"), "w"), indent=1)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

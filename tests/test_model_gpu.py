@@ -337,3 +337,60 @@ def test_two_stream_pipeline_matches_sequential(cuda):
         for a, b in zip(outs, ref):
             for k in ("feats_f", "scores_overlap", "scores_saliency"):
                 assert rel(a[k], b[k]) < 1e-5, (threaded, k)
+
+
+def test_collate_fn_descriptor_matches_reference(cuda, mini):
+    """Full collate contract incl. the node-overlap labels (ref:datasets/dataloader.py:309-322,363-380)."""
+    from pcrcg_amd.pyramid import collate_fn_descriptor
+    batch, limits = mini
+    cfg = indoor_config(first_feats_dim=32, gnn_feats_dim=64)
+    src, tgt = synthetic.pair("mini", 0)
+    item = dict(rot=np.eye(3, dtype=np.float32), trans=np.zeros((3, 1), np.float32),
+                correspondences=batch["correspondences"], sample=0, src_pcd=src, tgt_pcd=tgt,
+                src_feats=np.ones((len(src), 1), np.float32), tgt_feats=np.ones((len(tgt), 1), np.float32))
+    got = collate_fn_descriptor([item], cfg, limits, device=cuda)
+    for key in ("points", "neighbors", "pools", "upsamples", "features", "stack_lengths", "rot", "trans",
+                "correspondences", "src_pcd_raw", "tgt_pcd_raw", "sample", "node_overlap_gt", "points2node"):
+        assert key in got, key
+    assert torch.equal(got["points"][-1].cpu(), batch["points"][-1])
+    assert torch.allclose(got["node_overlap_gt"].cpu(), batch["node_overlap_gt"], atol=1e-6)
+    # nearest-node assignment: identical except where two nodes are equidistant within fp32 rounding
+    same = (got["points2node"].cpu() == batch["points2node"]).float().mean()
+    assert same > 0.999
+
+
+def test_calibrate_neighbors_reproduces_reference_limits(cuda, golden_dir):
+    """calibrate_neighbors (ref:datasets/dataloader.py:402-434) against the limits the imported reference
+    computes on the same synthetic pairs (tests/golden/calibration.json)."""
+    import json
+    from pcrcg_amd.pyramid import calibrate_neighbors
+    cfg = indoor_config()
+    golden = json.load(open(os.path.join(golden_dir, "calibration.json")))["limits"]
+    assert golden["S30k"] == synthetic.LIMITS["S30k"]
+    for recipe, expect in golden.items():
+        src, tgt = synthetic.pair(recipe, 0)
+        pts = torch.from_numpy(np.concatenate([src, tgt])).to(cuda)
+        lens = torch.tensor([len(src), len(tgt)], dtype=torch.int32, device=cuda)
+        got = calibrate_neighbors([(pts, lens)], cfg, samples_threshold=0)
+        assert list(got) == expect, (recipe, list(got))
+
+
+def test_kitti_shaped_k120k_forward_properties(cuda):
+    """BASELINE.json configs[4]: 2 x 120k-point outdoor slab, KITTI hyper-parameters, full width."""
+    from pcrcg_amd import kitti_config
+    cfg = kitti_config()
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = KPFCNN(cfg).to(cuda).eval()
+    src, tgt = synthetic.slab_pair(120000, 0)
+    pts = torch.from_numpy(np.concatenate([src, tgt])).to(cuda)
+    lens = torch.tensor([len(src), len(tgt)], dtype=torch.int32, device=cuda)
+    batch = build_pyramid(pts, lens, cfg, synthetic.LIMITS["K120k"])
+    sizes = [p.shape[0] for p in batch["points"]]
+    assert sizes[0] == 240000 and sizes[1] > sizes[2] > sizes[3] > 1000
+    with torch.no_grad():
+        out = net(batch)
+    assert out["feats_f"].shape == (240000, 32) and torch.isfinite(out["feats_f"]).all()
+    assert (out["feats_f"].norm(dim=1) - 1).abs().max() < 1e-4
+    for k in ("scores_overlap", "scores_saliency"):
+        assert out[k].min() >= 0 and out[k].max() <= 1
