@@ -53,7 +53,15 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dispatched round-robin over the 8 XCDs (private L2s), so the
+    // linear id is remapped such that each XCD walks a CONTIGUOUS range of tiles (n fastest): the n-tiles
+    // that share a row panel of A then hit the same L2.  Placement only affects speed.
+    const int gx = gridDim.x, ntile = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gx * blockIdx.y;
+    const int xq = ntile >> 3, xr = ntile & 7, xcd = lin & 7, slot = lin >> 3;
+    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;   // bijective
+    const int tile_x = tile % gx, tile_y = tile / gx;
+    const int m0 = tile_y * BM, n0 = tile_x * BN;
     const int k_begin = blockIdx.z * k_per_split;
     const int k_end = min(Kdim, k_begin + k_per_split);
     const bool full_a = vec_a && (m0 + BM <= M);   // block-uniform: operand tile fully inside, 16-B aligned
@@ -240,7 +248,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
     // Column statistics of the stored tile, one chunk per (block row, wavefront row): layout
     // [2][N][chunks] fp64, finished by pcrcg_instnorm_stats_from_partials (deterministic, no atomics).
     if (colp) {
-        const int chunk = blockIdx.y * WAVES_M + wm;
+        const int chunk = tile_y * WAVES_M + wm;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const float s = cs[j] + __shfl_xor(cs[j], 32, 64), q2 = cq[j] + __shfl_xor(cq[j], 32, 64);
