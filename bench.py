@@ -195,6 +195,11 @@ def main():
         iso_bytes = sum(kpconv_algorithmic_bytes(nq, h, cin, couts[i % per_pair])
                         for i, (_, nq, h, cin, _, _) in enumerate(iso))
         iso_gbs = iso_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
+        iso_rows = []                        # the last isolated forward, launch by launch
+        for i, (ms, nq, h, cin, _, _) in enumerate(iso[-per_pair:]):
+            b = kpconv_algorithmic_bytes(nq, h, cin, couts[i % per_pair])
+            iso_rows.append({"nq": nq, "h": h, "cin": cin, "cout": couts[i % per_pair], "us": round(ms * 1e3, 1),
+                             "GBs": round(b / (ms * 1e-3) / 1e9, 0) if ms > 0 else None})
         traffic = None
         pmc_path = os.path.join(REPO, "profiles", "r01_pmc_kpconv.json")
         if os.path.exists(pmc_path):        # HBM bytes per launch from the committed rocprofv3 PMC passes
@@ -227,7 +232,8 @@ def main():
                          "note": "achieved/frac are measured inside the timed region, where three HIP streams share "
                                  "the GPU; `isolated` is the same 11 launches run alone right after it",
                          "isolated": {"achieved": round(iso_gbs, 1), "frac": round(iso_gbs / HBM_PEAK_GBS, 4),
-                                      "avg_launch_us": round(iso_ms * 1e3 / max(len(iso), 1), 2)},
+                                      "avg_launch_us": round(iso_ms * 1e3 / max(len(iso), 1), 2),
+                                      "per_launch": iso_rows},
                          "gather_only_kernels": {"launches_per_pair": gather["n"] // max(args.steps, 1),
                                                  "achieved_GBs": round(g_gbs, 1),
                                                  "frac": round(g_gbs / HBM_PEAK_GBS, 4)},

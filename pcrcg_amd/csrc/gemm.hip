@@ -335,7 +335,9 @@ extern "C" int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, 
     constexpr int BK = 32;   // a 64-deep k-step (2 blocks/CU) measured 12 % slower on the path's shapes
     int splits = 1;
     const int ktiles = (k + BK - 1) / BK;
-    while ((long)gx * gy * splits < 768 && k / (2 * splits) >= 192 && splits < 32) splits *= 2;
+    int split_target = 768;
+    if (const char* e = getenv("PCRCG_GEMM_SPLIT_TARGET")) split_target = atoi(e);   // tuning aid
+    while ((long)gx * gy * splits < split_target && k / (2 * splits) >= 192 && splits < 32) splits *= 2;
     if (const char* e = getenv("PCRCG_GEMM_SPLITK")) splits = atoi(e) > 0 ? atoi(e) : splits;   // tuning aid
     int k_per_split = ((ktiles + splits - 1) / splits) * BK;
     if (k_per_split < BK) k_per_split = BK;
@@ -347,6 +349,10 @@ extern "C" int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, 
         else PCRCG_CHECK_HIP(hipMemset2DAsync(c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), m, st));
     }
     dim3 grid(gx, gy, splits);
+    static const bool log_shapes = getenv("PCRCG_GEMM_LOG") != nullptr;   // tuning aid
+    if (log_shapes)
+        fprintf(stderr, "pcrcg_gemm m=%d n=%d k=%d lda=%d ldb=%d ldc=%d tb=%d grid=%dx%dx%d rs=%d bias=%d stats=%d\n", m, n,
+                k, lda, ldb, ldc, trans_b, gx, gy, splits, row_scale != nullptr, bias != nullptr, colstats != nullptr);
     // column statistics ride along only when every output element is written exactly once
     double* colp = nullptr;
     int colp_chunks = 0;

@@ -20,7 +20,7 @@
 // Shadow neighbours (idx == ns) have weight 0 and feature 0 in the reference (:269,:348): their weight
 // is forced to 0 and no row is read.
 //
-// Fallbacks: k_kpconv_c1 for Cin == 1 (first layer, features are a column of ones), and the scalar
+// Fallbacks: k_kpconv_c1 for Cin == 1 (first layer, features are a column of ones; four lanes per query), and the scalar
 // k_kpconv_generic for channel counts that are not a multiple of 4.
 #include <vector>
 
@@ -157,14 +157,21 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
 }
 
 // Cin == 1 (first layer: the feature is a column of ones): wf[q,k] = sum_h w[q,h,k] * x[idx[q,h]].
-// There is no channel dimension to spread over lanes, so one THREAD owns a query: 15 accumulators in
-// registers, kernel points in SGPRs, neighbours streamed with branch-free clamped loads.
+// There is no channel dimension to spread over lanes and only Nq/64 wavefronts of thread-per-query work
+// (fewer than the chip has SIMDs), so the kernel is bound by the idx -> coordinate load chain.  Four
+// lanes share a query: each takes every fourth neighbour, C1_BATCH of them at a time with all index
+// loads, then all gathers, in flight together; the 15 partial sums are combined with two butterfly
+// shuffles.  Kernel points live in SGPRs, loads are branch-free (clamped addresses + select).
+constexpr int C1_PARTS = 4, C1_BATCH = 6;
+struct __attribute__((packed, aligned(4))) P3 { float x, y, z; };
 __global__ void __launch_bounds__(256) k_kpconv_c1(
     const float* __restrict__ q_pts, int nq, const float* __restrict__ s_pts, int ns,
     const long long* __restrict__ idx, int H, int ld_idx, const float* __restrict__ x, const float* __restrict__ kp,
     float extent, float* __restrict__ wf, float* __restrict__ inv_n) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int part = t & (C1_PARTS - 1);
+    const int qraw = t / C1_PARTS;
+    const int q = qraw < nq ? qraw : nq - 1;          // surplus lanes shadow the last query (shuffles stay uniform)
     float kpx[K], kpy[K], kpz[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { kpx[k] = kp[3 * k]; kpy[k] = kp[3 * k + 1]; kpz[k] = kp[3 * k + 2]; }
@@ -175,23 +182,48 @@ __global__ void __launch_bounds__(256) k_kpconv_c1(
     for (int k = 0; k < K; ++k) acc[k] = 0.f;
     int npos = 0;
     const long long* row = idx + (long)q * ld_idx;
-#pragma unroll 4
-    for (int h = 0; h < H; ++h) {
-        const long long iv = row[h];
-        const bool real = iv >= 0 && iv < ns;
-        const long ic = real ? iv : 0;
-        const float nx = s_pts[3 * ic] - qx, ny = s_pts[3 * ic + 1] - qy, nz = s_pts[3 * ic + 2] - qz;
-        const float xv = real ? x[ic] : 0.f;
-        npos += (real && xv > 0.0f) ? 1 : 0;
+    for (int h0 = 0; h0 < H; h0 += C1_PARTS * C1_BATCH) {
+        long long iv[C1_BATCH];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float dx = nx - kpx[k], dy = ny - kpy[k], dz = nz - kpz[k];
-            acc[k] = fmaf(fmaxf(1.0f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent, 0.0f), xv, acc[k]);
+        for (int b = 0; b < C1_BATCH; ++b) {
+            const int h = h0 + b * C1_PARTS + part;
+            iv[b] = row[h < H ? h : H - 1];
+        }
+        float nx[C1_BATCH], ny[C1_BATCH], nz[C1_BATCH], xv[C1_BATCH];
+#pragma unroll
+        for (int b = 0; b < C1_BATCH; ++b) {
+            const int h = h0 + b * C1_PARTS + part;
+            const bool real = h < H && iv[b] >= 0 && iv[b] < ns;
+            const long ic = real ? iv[b] : 0;
+            const P3 p = *reinterpret_cast<const P3*>(s_pts + 3 * ic);   // one global_load_dwordx3
+            nx[b] = p.x - qx;
+            ny[b] = p.y - qy;
+            nz[b] = p.z - qz;
+            const float v = x[ic];
+            xv[b] = real ? v : 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < C1_BATCH; ++b) {
+            npos += xv[b] > 0.0f ? 1 : 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float dx = nx[b] - kpx[k], dy = ny[b] - kpy[k], dz = nz[b] - kpz[k];
+                acc[k] = fmaf(fmaxf(1.0f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent, 0.0f),
+                              xv[b], acc[k]);
+            }
         }
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) wf[(long)q * K + k] = acc[k];
-    inv_n[q] = 1.0f / (float)(npos > 1 ? npos : 1);
+    for (int d = 1; d < C1_PARTS; d <<= 1) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += __shfl_xor(acc[k], d, 64);
+        npos += __shfl_xor(npos, d, 64);
+    }
+    if (qraw >= nq) return;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if ((k & (C1_PARTS - 1)) == part) wf[(long)q * K + k] = acc[k];
+    if (part == 0) inv_n[q] = 1.0f / (float)(npos > 1 ? npos : 1);
 }
 
 // Scalar fallback for channel counts that are not a multiple of 4: weights staged in LDS, lanes =
@@ -299,7 +331,7 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
     };
     if (cin == 1) {
         KpProfScope prof_scope(st, nq, h, cin, 0, 0);
-        hipLaunchKernelGGL(k_kpconv_c1, dim3((nq + 255) / 256), dim3(256), 0, st, q_pts, nq, s_pts, ns, idx_ll, h,
+        hipLaunchKernelGGL(k_kpconv_c1, dim3((int)(((long)nq * C1_PARTS + 255) / 256)), dim3(256), 0, st, q_pts, nq, s_pts, ns, idx_ll, h,
                            ld_idx, x, kp, extent, wf, inv_n);
         PCRCG_CHECK_LAUNCH();
         return PCRCG_OK;
