@@ -21,8 +21,13 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The pipeline
+# uses a front-end stream + three model streams (+ the default stream): with 4 queues two of them share
+# one and serialise (measured: 260 vs 338 pairs/s).  Must be set before the first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -78,8 +83,8 @@ def cpu_baseline(cfg, state_dict, limits):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -115,36 +120,35 @@ def main():
             pool[s % 16] = (torch.from_numpy(np.concatenate([src, tgt])).to(dev),
                             torch.tensor([len(src), len(tgt)], dtype=torch.int32, device=dev))
 
-    # Multi-stream pipeline (pcrcg_amd/pipeline.py): a step enqueues the forward of pair i and requests the
-    # pyramid of pair i+DEPTH from the front-end worker, so the timed region contains exactly K forwards
-    # and K pyramid builds (the first DEPTH pyramids are requested before the clock starts, the last
-    # DEPTH requested inside the timed region are waited for -- not run -- before the clock stops).
-    DEPTH = int(os.environ.get("PCRCG_PIPE_DEPTH", "2"))
-    pipe = PairPipeline(net, cfg, limits, dev, model_streams=int(os.environ.get("PCRCG_MODEL_STREAMS", "2")))
+    # Multi-stream pipeline (pcrcg_amd/pipeline.py): pairs are submitted up to DEPTH ahead; a front-end
+    # thread builds their pyramids on its own stream and one forward-worker thread per model stream
+    # enqueues the forwards.  The timed region starts from an EMPTY pipeline and ends with it empty again:
+    # all K pyramid builds and all K forwards are submitted, executed and finished inside it.
+    DEPTH = int(os.environ.get("PCRCG_PIPE_DEPTH", "4"))
+    pipe = PairPipeline(net, cfg, limits, dev, model_streams=int(os.environ.get("PCRCG_MODEL_STREAMS", "3")))
 
-    def step(i):
-        prepared = pipe.next_prepared()
-        out = pipe.run(prepared)
-        pipe.request(*pool[seeds[(i + DEPTH) % total] % 16])
+    def run_pairs(first, count):
+        """Push pairs first..first+count-1 through the pipeline, at most DEPTH in flight."""
+        out, submitted = None, 0
+        for i in range(count):
+            while submitted < min(count, i + DEPTH):
+                pipe.submit(*pool[seeds[first + submitted] % 16])
+                submitted += 1
+            out = pipe.result()
         return out
 
     def fence():
-        pipe.synchronize()
+        pipe.drain()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(DEPTH):
-        pipe.request(*pool[seeds[i] % 16])
-    for i in range(args.warmup):
-        out = step(i)
+    out = run_pairs(0, args.warmup)
     fence()
     ops.kpconv_profile_start()        # HIP events around every KPConv gather/aggregate launch from here on
     t0 = time.perf_counter()
-    for i in range(args.warmup, total):
-        out = step(i)
-    submit = time.perf_counter() - t0      # host time to enqueue everything (GPU may still be busy)
-    pipe.drain()                           # the DEPTH pyramids requested last must be finished too
+    out = run_pairs(args.warmup, args.steps)
+    submit = time.perf_counter() - t0      # host time until the last forward was enqueued (GPU may still be busy)
     fence()
     elapsed = time.perf_counter() - t0
     events = ops.kpconv_profile_stop()
@@ -153,8 +157,7 @@ def main():
     # the same kernels once more WITHOUT any concurrent stream: the roofline of the gather kernel in isolation
     iso = None
     if rank == 0:
-        pipe.request(*pool[seeds[0] % 16])
-        batch_iso, _ = pipe.next_prepared()
+        batch_iso, _ = pipe.prepare(*pool[seeds[0] % 16])
         pipe.synchronize()
         ops.kpconv_profile_start()
         with torch.no_grad():
@@ -173,12 +176,15 @@ def main():
         # KPConv kernels bracketed by HIP events on their own stream (pcrcg_profile_kpconv): kind 0 =
         # gather/aggregate kernel of the two-stage path, kind 1 = fused gather+aggregate+contraction kernel.
         # Algorithmic bytes: SURVEY.md 8d no-reuse gather model of one KPConv call.
+        # (forwards are enqueued by several threads, so records of different pairs interleave: the output width
+        # of a launch is looked up by its input width, which is unique per KPConv in this architecture)
         couts = [blk.KPConv.out_channels for blk in net.encoder_blocks]
+        cout_of = {blk.KPConv.in_channels: blk.KPConv.out_channels for blk in net.encoder_blocks}
         gather = {"ms": 0.0, "bytes": 0, "n": 0}
         fused = {"ms": 0.0, "bytes": 0, "flops": 0, "n": 0}
         per_pair = len(couts)
         for i, (ms, nq, h, cin, cout, kind) in enumerate(events):
-            co = cout if kind == 1 else couts[i % per_pair]
+            co = cout if kind == 1 else cout_of[cin]
             d = fused if kind == 1 else gather
             d["ms"] += ms
             d["bytes"] += kpconv_algorithmic_bytes(nq, h, cin, co)
@@ -192,13 +198,12 @@ def main():
         f_gbs = fused["bytes"] / (fused["ms"] * 1e-3) / 1e9 if fused["ms"] > 0 else 0.0
         f_tf = fused["flops"] / (fused["ms"] * 1e-3) / 1e12 if fused["ms"] > 0 else 0.0
         iso_ms = sum(e[0] for e in iso)
-        iso_bytes = sum(kpconv_algorithmic_bytes(nq, h, cin, couts[i % per_pair])
-                        for i, (_, nq, h, cin, _, _) in enumerate(iso))
+        iso_bytes = sum(kpconv_algorithmic_bytes(nq, h, cin, cout_of[cin]) for (_, nq, h, cin, _, _) in iso)
         iso_gbs = iso_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
         iso_rows = []                        # the last isolated forward, launch by launch
         for i, (ms, nq, h, cin, _, _) in enumerate(iso[-per_pair:]):
-            b = kpconv_algorithmic_bytes(nq, h, cin, couts[i % per_pair])
-            iso_rows.append({"nq": nq, "h": h, "cin": cin, "cout": couts[i % per_pair], "us": round(ms * 1e3, 1),
+            b = kpconv_algorithmic_bytes(nq, h, cin, cout_of[cin])
+            iso_rows.append({"nq": nq, "h": h, "cin": cin, "cout": cout_of[cin], "us": round(ms * 1e3, 1),
                              "GBs": round(b / (ms * 1e-3) / 1e9, 0) if ms > 0 else None})
         traffic = None
         pmc_path = os.path.join(REPO, "profiles", "r01_pmc_kpconv.json")
@@ -220,8 +225,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "S30k: 2x30000-pt shell pairs (3DMatch-shaped), pyramid build + KPFCNN+GCN "
                                    "forward, indoor hyper-parameters, random-init full-width weights, 1 pair/GPU/step; "
-                                   "pyramids are built by a front-end thread on its own HIP stream while forwards alternate "
-                                   "between two model streams",
+                                   "pyramids are built by a front-end thread on its own HIP stream, forwards are enqueued by "
+                                   "one worker thread per model stream (3 streams); the timed region starts and ends with "
+                                   "an empty pipeline",
                        "limits": limits, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "KPConv neighbour-gather kernels (k_kpconv_mfma / k_kpconv_c1 / "
                                                      "k_kpconv_fused), %d launches/pair" % per_pair,
@@ -229,7 +235,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "avg_launch_us": round(k_ms * 1e3 / max(len(events), 1), 2),
                          "algorithmic_bytes_per_pair": int(k_bytes / max(args.steps, 1)),
-                         "note": "achieved/frac are measured inside the timed region, where three HIP streams share "
+                         "note": "achieved/frac are measured inside the timed region, where four HIP streams share "
                                  "the GPU; `isolated` is the same 11 launches run alone right after it",
                          "isolated": {"achieved": round(iso_gbs, 1), "frac": round(iso_gbs / HBM_PEAK_GBS, 4),
                                       "avg_launch_us": round(iso_ms * 1e3 / max(len(iso), 1), 2),

@@ -22,6 +22,7 @@
 //
 // Fallbacks: k_kpconv_c1 for Cin == 1 (first layer, features are a column of ones; four lanes per query), and the scalar
 // k_kpconv_generic for channel counts that are not a multiple of 4.
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -32,6 +33,7 @@ namespace pcrcg {
 struct ProfRec { hipEvent_t a, b; int nq, h, cin, cout, kind; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;   // forwards may be enqueued from several host threads
 
 KpProfScope::KpProfScope(hipStream_t s, int nq_, int h_, int cin_, int cout_, int kind_)
     : st(s), nq(nq_), h(h_), cin(cin_), cout(cout_), kind(kind_), on(g_prof_on) {
@@ -43,6 +45,7 @@ KpProfScope::KpProfScope(hipStream_t s, int nq_, int h_, int cin_, int cout_, in
 KpProfScope::~KpProfScope() {
     if (!on) return;
     hipEventRecord(b, st);
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof.push_back({a, b, nq, h, cin, cout, kind});
 }
 
@@ -291,12 +294,14 @@ using namespace pcrcg;
 extern "C" {
 
 void pcrcg_profile_kpconv(int enable) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& r : g_prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     g_prof.clear();
     g_prof_on = enable != 0;
 }
 
 int pcrcg_profile_kpconv_read(float* ms, int* nq, int* h, int* cin, int* cout, int* kind, int cap) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     int n = 0;
     for (auto& r : g_prof) {
         if (n >= cap) break;

@@ -337,6 +337,22 @@ def test_two_stream_pipeline_matches_sequential(cuda):
         for a, b in zip(outs, ref):
             for k in ("feats_f", "scores_overlap", "scores_saliency"):
                 assert rel(a[k], b[k]) < 1e-5, (threaded, k)
+    # submit()/result(): forwards enqueued by one worker thread per model stream, results in order
+    for threaded, streams in ((False, 2), (True, 3)):
+        pipe = PairPipeline(net, cfg, limits, cuda, model_streams=streams, threaded=threaded)
+        outs, submitted = [], 0
+        for i in range(2 * len(pairs)):
+            while submitted < min(2 * len(pairs), i + 4):
+                pipe.submit(*pairs[submitted % len(pairs)])
+                submitted += 1
+            outs.append(pipe.result())
+        pipe.drain()
+        pipe.close()
+        with pytest.raises(RuntimeError):
+            pipe.result()
+        for i, a in enumerate(outs):
+            for k in ("feats_f", "scores_overlap", "scores_saliency"):
+                assert rel(a[k], ref[i % len(pairs)][k]) < 1e-5, (threaded, i, k)
 
 
 def test_collate_fn_descriptor_matches_reference(cuda, mini):
