@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libpcrcg_hip.so")
 
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
-# name -> (restype, argtypes); mirrors include/pcrcg.h one to one
+# name -> (restype, argtypes); mirrors include/pcrcg.h and include/pcrcg_train.h one to one
 SIGNATURES = {
     "pcrcg_last_error": (ctypes.c_char_p, []),
     "pcrcg_abi_version": (c_int, []),
@@ -62,6 +62,9 @@ SIGNATURES = {
     # struct-based entry points: pcrcg_amd/runner.py declares the ctypes.Structure mirrors
     "pcrcg_kpfcnn_ws_bytes": (c_size_t, [c_void_p, c_void_p]),
     "pcrcg_kpfcnn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    # include/pcrcg_train.h -- the "next" rows
+    "pcrcg_feature_argmax": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                     c_void_p]),
 }
 
 _lib = None

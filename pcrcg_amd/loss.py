@@ -1,0 +1,164 @@
+"""MetricLoss of the train / test step on the device (mirror of
+ref:lib/loss.py:46-252 -- same constructor, same method names, same keys in the returned dict).
+
+What differs from the reference, on purpose:
+  * device-agnostic: every tensor lives where the inputs live (the reference hard-codes
+    torch.device('cuda') for one label vector and builds two on the CPU, :194-198);
+  * the saliency labels need arg-max over the src x tgt descriptor similarity of ALL points in the overlap
+    region (:209-213); the reference materialises that matrix with torch.matmul, here the fused HIP kernel
+    pcrcg_feature_argmax produces the arg-max without it;
+  * precision / recall are computed on the device with the definition sklearn's
+    precision_recall_fscore_support(average='binary') uses (:131-133), and returned as 0-dim tensors
+    (no host round trip inside the step);
+  * `set(...)` of the correspondence columns (:159-160) becomes torch.unique -- the set's iteration order is
+    irrelevant to every output (all consumers are order-invariant sums or means).
+The remaining small dense math (<= max_points^2 matrices, BCE over N points) is plain torch on the device
+and differentiable by autograd; the descriptors / scores it is fed come from the HIP path."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def square_distance(src, dst, normalised=False):
+    """ref:lib/utils.py:78-97."""
+    dist = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    if normalised:
+        dist += 2
+    else:
+        dist += torch.sum(src ** 2, dim=-1)[:, :, None]
+        dist += torch.sum(dst ** 2, dim=-1)[:, None, :]
+    return torch.clamp(dist, min=1e-12, max=None)
+
+
+class MetricLoss(torch.nn.Module):
+    """Circle loss + overlap / saliency weighted BCE + feature-match recall (ref:lib/loss.py:46-70)."""
+
+    def __init__(self, configs, log_scale=16, pos_optimal=0.1, neg_optimal=1.4):
+        super().__init__()
+        # NB the yaml's `log_scale` is NOT read by the reference either (ref:main.py:100)
+        self.log_scale, self.pos_optimal, self.neg_optimal = log_scale, pos_optimal, neg_optimal
+        self.image_feature = configs.get("image_feature", False)
+        self.node_overlap = configs.get("node_overlap", False)
+        self.quaternion = configs.get("quaternion", False)
+        self.pos_margin, self.neg_margin = configs["pos_margin"], configs["neg_margin"]
+        self.max_points = configs["max_points"]
+        self.safe_radius = configs["safe_radius"]
+        self.matchability_radius = configs["matchability_radius"]
+        self.pos_radius = configs["pos_radius"]
+
+    def get_circle_loss(self, coords_dist, feats_dist):
+        """ref:lib/loss.py:71-104."""
+        pos_mask = coords_dist < self.pos_radius
+        neg_mask = coords_dist > self.safe_radius
+        row_sel = ((pos_mask.sum(-1) > 0) * (neg_mask.sum(-1) > 0)).detach()
+        col_sel = ((pos_mask.sum(-2) > 0) * (neg_mask.sum(-2) > 0)).detach()
+
+        pos_weight = feats_dist - 1e5 * (~pos_mask).float()
+        pos_weight = pos_weight - self.pos_optimal
+        pos_weight = torch.max(torch.zeros_like(pos_weight), pos_weight).detach()
+        neg_weight = feats_dist + 1e5 * (~neg_mask).float()
+        neg_weight = self.neg_optimal - neg_weight
+        neg_weight = torch.max(torch.zeros_like(neg_weight), neg_weight).detach()
+
+        lse_pos_row = torch.logsumexp(self.log_scale * (feats_dist - self.pos_margin) * pos_weight, dim=-1)
+        lse_pos_col = torch.logsumexp(self.log_scale * (feats_dist - self.pos_margin) * pos_weight, dim=-2)
+        lse_neg_row = torch.logsumexp(self.log_scale * (self.neg_margin - feats_dist) * neg_weight, dim=-1)
+        lse_neg_col = torch.logsumexp(self.log_scale * (self.neg_margin - feats_dist) * neg_weight, dim=-2)
+
+        loss_row = F.softplus(lse_pos_row + lse_neg_row) / self.log_scale
+        loss_col = F.softplus(lse_pos_col + lse_neg_col) / self.log_scale
+        return (loss_row[row_sel].mean() + loss_col[col_sel].mean()) / 2
+
+    def get_recall(self, coords_dist, feats_dist):
+        """ref:lib/loss.py:106-116."""
+        pos_mask = coords_dist < self.pos_radius
+        has_pos = pos_mask.sum(-1) > 0
+        n_gt_pos = has_pos.float().sum() + 1e-12
+        _, sel_idx = torch.min(feats_dist, -1)
+        sel_dist = torch.gather(coords_dist, dim=-1, index=sel_idx[:, None])[has_pos]
+        n_pred_pos = (sel_dist < self.pos_radius).float().sum()
+        return n_pred_pos / n_gt_pos
+
+    def get_weighted_bce_loss(self, prediction, gt):
+        """ref:lib/loss.py:118-135 -> (loss, precision, recall)."""
+        class_loss = F.binary_cross_entropy(prediction, gt, reduction="none")
+        w_negative = gt.sum() / gt.size(0)
+        w_positive = 1 - w_negative
+        weights = torch.where(gt >= 0.5, w_positive, w_negative)
+        w_class_loss = torch.mean(weights * class_loss)
+        # binary precision / recall of the rounded prediction (0/0 -> 0, as sklearn reports it)
+        pred = prediction.detach().round() > 0.5
+        true = gt.round() > 0.5
+        tp = (pred & true).sum().float()
+        n_pred, n_true = pred.sum().float(), true.sum().float()
+        zero = torch.zeros((), device=prediction.device)
+        precision = torch.where(n_pred > 0, tp / n_pred.clamp(min=1), zero)
+        recall = torch.where(n_true > 0, tp / n_true.clamp(min=1), zero)
+        return w_class_loss, precision, recall
+
+    def forward(self, inputs):
+        """ref:lib/loss.py:139-252.  inputs: rot [3,3], trans [3,1], src_feats [N,C], tgt_feats [M,C],
+        src_pcd_raw [N,3], tgt_pcd_raw [M,3], correspondences [K,2] int64, scores_overlap / scores_saliency
+        [N+M] -- all on one device."""
+        rot, trans = inputs["rot"], inputs["trans"]
+        src_feats, tgt_feats = inputs["src_feats"], inputs["tgt_feats"]
+        src_pcd, tgt_pcd = inputs["src_pcd_raw"], inputs["tgt_pcd_raw"]
+        correspondence = inputs["correspondences"].to(src_pcd.device).long()
+        scores_overlap, scores_saliency = inputs["scores_overlap"], inputs["scores_saliency"]
+        dev = src_pcd.device
+        stats = dict()
+
+        src_pcd = (torch.matmul(rot, src_pcd.transpose(0, 1)) + trans).transpose(0, 1)
+        src_idx = torch.unique(correspondence[:, 0])
+        tgt_idx = torch.unique(correspondence[:, 1])
+
+        if self.node_overlap:
+            loss, a, b = self.get_weighted_bce_loss(inputs["node_overlap_score_pred"], inputs["node_overlap_gt"])
+            stats["node_overlap_loss"], stats["node_overlap_recall"], stats["node_overlap_precision"] = loss, a, b
+        if self.quaternion:
+            q = F.mse_loss(inputs["quaternion_pred"], inputs["quaternion_gt"], reduction="sum")
+            t = F.mse_loss(inputs["trans_pred"], inputs["trans_gt"], reduction="sum")
+            stats["pose_loss"] = q + t
+
+        # overlap BCE: a point is "in the overlap" iff it appears in a correspondence (:193-203)
+        src_gt = torch.zeros(src_pcd.size(0), device=dev)
+        src_gt[src_idx] = 1.
+        tgt_gt = torch.zeros(tgt_pcd.size(0), device=dev)
+        tgt_gt[tgt_idx] = 1.
+        gt_labels = torch.cat((src_gt, tgt_gt))
+        class_loss, cls_precision, cls_recall = self.get_weighted_bce_loss(scores_overlap, gt_labels)
+        stats["overlap_loss"], stats["overlap_recall"], stats["overlap_precision"] = class_loss, cls_recall, cls_precision
+
+        # saliency BCE, supervised in the overlap region only (:205-225): a point is matchable iff its nearest
+        # descriptor on the other side lies within matchability_radius
+        src_feats_sel, src_pcd_sel = src_feats[src_idx], src_pcd[src_idx]
+        tgt_feats_sel, tgt_pcd_sel = tgt_feats[tgt_idx], tgt_pcd[tgt_idx]
+        with torch.no_grad():
+            idx12 = ops.feature_argmax(src_feats_sel.detach().float(), tgt_feats_sel.detach().float())
+            idx21 = ops.feature_argmax(tgt_feats_sel.detach().float(), src_feats_sel.detach().float())
+        distance_1 = torch.norm(src_pcd_sel - tgt_pcd_sel[idx12], p=2, dim=1)
+        distance_2 = torch.norm(tgt_pcd_sel - src_pcd_sel[idx21], p=2, dim=1)
+        gt_labels = torch.cat(((distance_1 < self.matchability_radius).float(),
+                               (distance_2 < self.matchability_radius).float()))
+        saliency = torch.cat((scores_saliency[:src_pcd.size(0)][src_idx], scores_saliency[src_pcd.size(0):][tgt_idx]))
+        class_loss, cls_precision, cls_recall = self.get_weighted_bce_loss(saliency, gt_labels)
+        stats["saliency_loss"], stats["saliency_recall"], stats["saliency_precision"] = class_loss, cls_recall, cls_precision
+
+        # correspondences closer than pos_radius, capped to max_points with the HOST numpy generator exactly as
+        # the reference does (:227-233): same draws for the same np.random state
+        c_dist = torch.norm(src_pcd[correspondence[:, 0]] - tgt_pcd[correspondence[:, 1]], dim=1)
+        correspondence = correspondence[c_dist < self.pos_radius - 0.001]
+        if correspondence.size(0) > self.max_points:
+            choice = np.random.permutation(correspondence.size(0))[:self.max_points]
+            correspondence = correspondence[torch.from_numpy(choice).to(dev)]
+        src_sel, tgt_sel = correspondence[:, 0], correspondence[:, 1]
+        src_pcd, tgt_pcd = src_pcd[src_sel], tgt_pcd[tgt_sel]
+        src_feats, tgt_feats = src_feats[src_sel], tgt_feats[tgt_sel]
+        coords_dist = torch.sqrt(square_distance(src_pcd[None], tgt_pcd[None]).squeeze(0))
+        feats_dist = torch.sqrt(square_distance(src_feats[None], tgt_feats[None], normalised=True)).squeeze(0)
+
+        stats["circle_loss"] = self.get_circle_loss(coords_dist, feats_dist)
+        stats["recall"] = self.get_recall(coords_dist, feats_dist)
+        return stats

@@ -332,3 +332,25 @@ def softmax_rows_(x, scale=1.0):
     _lib.check(L.pcrcg_softmax_rows(x.data_ptr(), x.shape[0], x.shape[1], ld, float(scale), _stream()),
                "pcrcg_softmax_rows")
     return x
+
+
+# ------------------------------------------------------------------------------------------------
+# training-side rows (include/pcrcg_train.h)
+# ------------------------------------------------------------------------------------------------
+def feature_argmax(a, b, want_best=False):
+    """argmax_j <a_i, b_j> for every row of a [n,c] over the rows of b [m,c] (int64 [n]); the n x m score
+    matrix of `torch.matmul(a, b.T).max(1)` (ref:lib/loss.py:209-213) is never materialised."""
+    L = _lib.lib()
+    a, lda = _rows(a, _F32, "a")
+    b, ldb = _rows(b, _F32, "b")
+    n, c = a.shape
+    m = b.shape[0]
+    if b.shape[1] != c:
+        raise RuntimeError("pcrcg_amd.feature_argmax: feature widths differ")
+    if m == 0:
+        raise RuntimeError("pcrcg_amd.feature_argmax: `b` has no rows")
+    arg = torch.empty(n, dtype=_I64, device=a.device)
+    best = torch.empty(n, dtype=_F32, device=a.device) if want_best else None
+    _lib.check(L.pcrcg_feature_argmax(a.data_ptr(), lda, n, b.data_ptr(), ldb, m, c, arg.data_ptr(), _ptr(best),
+                                      _stream()), "pcrcg_feature_argmax")
+    return (arg, best) if want_best else arg

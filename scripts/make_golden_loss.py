@@ -1,0 +1,103 @@
+"""Generate tests/golden/loss_mini.pt from the UNMODIFIED reference MetricLoss (ref:lib/loss.py:46-252,
+imported through scripts/ref_import.py).  Runs only in the build container.
+
+Contents: a small 3DLoMatch-shaped pair (synthetic.lomatch_pair('mini', ...)), its ground-truth
+correspondences (all src/tgt pairs closer than overlap_radius after applying (rot, trans), the definition of
+ref:lib/benchmark_utils.py:121-134), fixed random descriptors / scores, and
+
+  * the reference's three pure sub-methods called on CPU (get_circle_loss, get_recall,
+    get_weighted_bce_loss) on the exact matrices the reference's forward builds;
+  * the reference's full MetricLoss.forward.  Its body moves one label vector to torch.device('cuda')
+    (ref:lib/loss.py:198); there is no GPU here, so `torch.device` is patched for the duration of that
+    one call to hand back the CPU device -- the reference source itself is untouched.
+
+Two cases: `capped` has more correspondences than max_points (exercises the np.random.permutation
+cap, seeded), `all` has fewer.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+REPO = ref_import.REPO
+OUT = os.path.join(REPO, "tests", "golden")
+
+LOSS_CFG = dict(pos_margin=0.1, neg_margin=1.4, log_scale=24, pos_radius=0.0375, safe_radius=0.1,
+                overlap_radius=0.0375, matchability_radius=0.05, max_points=256)   # ref:configs/train/indoor.yaml:52-63
+
+
+def correspondences(src, tgt, rot, trans, radius):
+    """All (i, j) with |rot*src_i + trans - tgt_j| < radius, i-major, j by increasing distance."""
+    moved = (rot.astype(np.float64) @ src.astype(np.float64).T + trans.astype(np.float64)).T
+    out = []
+    for i in range(len(moved)):
+        d = np.sqrt(((tgt.astype(np.float64) - moved[i]) ** 2).sum(1))
+        js = np.nonzero(d < radius)[0]
+        js = js[np.argsort(d[js], kind="stable")]
+        out.extend((i, j) for j in js)
+    return np.asarray(out, np.int64).reshape(-1, 2)
+
+
+def one_case(MetricLoss, cfg, seed, n_keep_corr):
+    from pcrcg_amd import synthetic as S
+    src, tgt, rot, trans = S.lomatch_pair("mini", seed, overlap=0.3)
+    corr = correspondences(src, tgt, rot, trans, cfg["overlap_radius"])
+    rng = np.random.RandomState(100 + seed)
+    if n_keep_corr and len(corr) > n_keep_corr:
+        corr = corr[np.sort(rng.permutation(len(corr))[:n_keep_corr])]
+    g = torch.Generator().manual_seed(seed)
+    n = len(src) + len(tgt)
+    feats = torch.nn.functional.normalize(torch.randn(n, 32, generator=g), dim=1)
+    # make descriptors of corresponding points similar so that recall / saliency labels are non-trivial
+    c = torch.from_numpy(corr)
+    feats[len(src) + c[:, 1]] = torch.nn.functional.normalize(
+        feats[c[:, 0]] + 0.35 * torch.randn(len(c), 32, generator=g), dim=1)
+    scores_overlap = torch.rand(n, generator=g) * 0.98 + 0.01
+    scores_saliency = torch.rand(n, generator=g) * 0.98 + 0.01
+    inputs = dict(rot=torch.from_numpy(rot), trans=torch.from_numpy(trans), src_feats=feats[:len(src)],
+                  tgt_feats=feats[len(src):], src_pcd_raw=torch.from_numpy(src), tgt_pcd_raw=torch.from_numpy(tgt),
+                  correspondences=c, scores_overlap=scores_overlap, scores_saliency=scores_saliency)
+
+    loss = MetricLoss(ref_import.AttrDict(cfg, image_feature=False, node_overlap=False, quaternion=False))
+    real_device = torch.device
+    np.random.seed(7)
+    torch.device = lambda *a, **k: real_device("cpu")          # see module docstring
+    try:
+        stats = loss(dict(inputs))
+    finally:
+        torch.device = real_device
+    expected = {k: torch.as_tensor(v, dtype=torch.float64) for k, v in stats.items()}
+
+    # the pure sub-methods on the matrices of a fixed selection (no RNG involved)
+    from lib.utils import square_distance
+    moved = (inputs["rot"] @ inputs["src_pcd_raw"].T + inputs["trans"]).T
+    sel = c[:200]
+    coords_dist = torch.sqrt(square_distance(moved[sel[:, 0]][None], inputs["tgt_pcd_raw"][sel[:, 1]][None]).squeeze(0))
+    feats_dist = torch.sqrt(square_distance(inputs["src_feats"][sel[:, 0]][None], inputs["tgt_feats"][sel[:, 1]][None],
+                                            normalised=True)).squeeze(0)
+    gt = (torch.rand(n, generator=g) < 0.3).float()
+    bce, prec, rec = loss.get_weighted_bce_loss(scores_overlap, gt)
+    sub = dict(coords_dist=coords_dist, feats_dist=feats_dist, circle_loss=loss.get_circle_loss(coords_dist, feats_dist),
+               recall=loss.get_recall(coords_dist, feats_dist), bce_gt=gt, bce_loss=bce,
+               bce_precision=torch.tensor(float(prec)), bce_recall=torch.tensor(float(rec)))
+    return dict(inputs=inputs, expected=expected, sub=sub, numpy_seed=7)
+
+
+def main():
+    ref_import.setup()
+    from lib.loss import MetricLoss
+    os.makedirs(OUT, exist_ok=True)
+    cases = {"capped": one_case(MetricLoss, LOSS_CFG, 3, 0), "all": one_case(MetricLoss, LOSS_CFG, 4, 180)}
+    for name, cs in cases.items():
+        print(name, "correspondences", tuple(cs["inputs"]["correspondences"].shape),
+              {k: round(float(v), 6) for k, v in cs["expected"].items()})
+    torch.save({"config": LOSS_CFG, "cases": cases}, os.path.join(OUT, "loss_mini.pt"))
+
+
+if __name__ == "__main__":
+    main()

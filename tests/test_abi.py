@@ -1,5 +1,5 @@
-"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/pcrcg.h
-declares; argument validation works without a GPU (no compute is launched here)."""
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/pcrcg.h and
+include/pcrcg_train.h declare; argument validation works without a GPU (no compute is launched here)."""
 import ctypes
 import os
 import re
@@ -10,9 +10,12 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    text = open(os.path.join(REPO, "include", "pcrcg.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(pcrcg_\w+)\s*\(", text)))
+    names = set()
+    for header in ("pcrcg.h", "pcrcg_train.h"):
+        text = open(os.path.join(REPO, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names.update(re.findall(r"\b(pcrcg_\w+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_whole_header():
@@ -20,7 +23,7 @@ def test_library_exports_whole_header():
     names = _declared()
     assert len(names) >= 24
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/pcrcg.h but not exported"
+        assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "pcrcg_amd/_lib.py must bind exactly the declared ABI"
     assert lib.pcrcg_abi_version() == 1
 
