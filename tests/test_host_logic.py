@@ -105,3 +105,21 @@ def test_synthetic_recipes_are_reproducible():
     assert (a1 == a2).all() and (b1 == b2).all() and not (a1 == b1).all()
     s, t, rot, trans = synthetic.lomatch_pair("mini", 1, 0.2)
     assert s.shape == t.shape and abs(np.linalg.det(rot) - 1) < 1e-5
+
+
+def test_probabilistic_sample_draws_like_the_reference():
+    """Same host generator, same call as ref:lib/tester.py:155-158 -> same indices."""
+    import numpy as np
+    import torch
+    from pcrcg_amd.tester import probabilistic_sample
+    g = torch.Generator().manual_seed(0)
+    pcd, feats = torch.rand(700, 3, generator=g), torch.rand(700, 32, generator=g)
+    scores = torch.rand(700, generator=g) * torch.rand(700, generator=g)
+    np.random.seed(11)
+    p2, f2, idx = probabilistic_sample(pcd, feats, scores, 200)
+    np.random.seed(11)
+    want = np.random.choice(np.arange(700), size=200, replace=False, p=(scores / scores.sum()).numpy().flatten())
+    assert np.array_equal(idx, want) and len(set(idx.tolist())) == 200
+    assert torch.equal(p2, pcd[want]) and torch.equal(f2, feats[want])
+    p3, f3, none = probabilistic_sample(pcd, feats, scores, 700)
+    assert none is None and p3 is pcd and f3 is feats

@@ -71,3 +71,65 @@ def test_metric_loss_is_differentiable(cuda, golden_dir):
     for k in ("src_feats", "tgt_feats", "scores_overlap", "scores_saliency"):
         g = inputs[k].grad
         assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+
+
+def _tsfm(rot, trans):
+    t = np.eye(4)
+    t[:3, :3], t[:3, 3] = rot, trans.flatten()
+    return t
+
+
+@pytest.mark.parametrize("recipe,seed,K", [("mini", 3, None), ("mini", 5, 3), ("C1", 1, None)])
+def test_get_correspondences_matches_oracle(cuda, recipe, seed, K):
+    """Device get_correspondences == float64 brute force (oracle/correspondences.py), pair for pair."""
+    from oracle.correspondences import get_correspondences as oracle_corr
+    from pcrcg_amd import synthetic
+    from pcrcg_amd.correspondences import get_correspondences
+    src, tgt, rot, trans = synthetic.lomatch_pair(recipe, seed, overlap=0.3)
+    got = get_correspondences(torch.from_numpy(src).to(cuda), torch.from_numpy(tgt).to(cuda), _tsfm(rot, trans),
+                              0.0375, K=K)
+    want = oracle_corr(src, tgt, _tsfm(rot, trans), 0.0375, K=K)
+    assert got.dtype == torch.int64 and tuple(got.shape) == want.shape and len(want) > 1000
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_get_correspondences_edge_cases(cuda):
+    from pcrcg_amd.correspondences import get_correspondences
+    pts = torch.rand(100, 3, device=cuda)
+    eye = np.eye(4)
+    far = eye.copy()
+    far[:3, 3] = 50.0
+    assert get_correspondences(pts, pts, far, 0.05).shape == (0, 2)           # no overlap at all
+    assert get_correspondences(pts[:0], pts, eye, 0.05).shape == (0, 2)       # empty cloud
+    same = get_correspondences(pts, pts, eye, 1e-6)                           # identity: every point finds itself
+    assert torch.equal(same, torch.arange(100, device=cuda)[:, None].repeat(1, 2))
+    dense = get_correspondences(pts, pts, eye, 10.0)                          # radius covers everything: N*N pairs
+    assert dense.shape == (100 * 100, 2) and torch.equal(dense[::100, 1], torch.arange(100, device=cuda))
+    with pytest.raises(RuntimeError):
+        get_correspondences(pts.cpu(), pts.cpu(), eye, 0.05)
+
+
+def test_evaluate_pair_record_and_recall(cuda):
+    """Tester loop body: forward -> MetricLoss recall -> the dict the reference dumps per pair."""
+    from pcrcg_amd import indoor_config, synthetic
+    from pcrcg_amd.architectures import KPFCNN
+    from pcrcg_amd.correspondences import get_correspondences
+    from pcrcg_amd.pyramid import collate_fn_descriptor
+    from pcrcg_amd.tester import evaluate_pair
+    cfg = indoor_config(first_feats_dim=64, gnn_feats_dim=128)
+    torch.manual_seed(0)
+    net = KPFCNN(cfg).to(cuda).eval()
+    src, tgt, rot, trans = synthetic.lomatch_pair("mini", 2, overlap=0.3)
+    corr = get_correspondences(torch.from_numpy(src).to(cuda), torch.from_numpy(tgt).to(cuda), _tsfm(rot, trans), 0.0375)
+    item = dict(src_pcd=src, tgt_pcd=tgt, src_feats=np.ones((len(src), 1), np.float32),
+                tgt_feats=np.ones((len(tgt), 1), np.float32), rot=rot, trans=trans, correspondences=corr.cpu(), sample=0)
+    inputs = collate_fn_descriptor([item], cfg, [20, 26, 30, 32], device=cuda)
+    loss = MetricLoss(Config(pos_margin=0.1, neg_margin=1.4, pos_radius=0.0375, safe_radius=0.1,
+                             matchability_radius=0.05, max_points=256))
+    np.random.seed(0)
+    rec, stats = evaluate_pair(net, loss, inputs)
+    n = len(src) + len(tgt)
+    assert rec["pcd"].shape == (n, 3) and rec["feats"].shape == (n, 32) and rec["len_src"] == len(src)
+    assert not rec["feats"].is_cuda and rec["overlaps"].shape == (n,) and rec["saliency"].shape == (n,)
+    assert torch.equal(rec["rot"], torch.from_numpy(rot)) and rec["trans"].shape == (3, 1)
+    assert 0.0 <= float(stats["recall"]) <= 1.0 and torch.isfinite(stats["circle_loss"])
