@@ -18,6 +18,14 @@ extern "C" {
 int pcrcg_feature_argmax(const float* a, int lda, int n, const float* b, int ldb, int m, int c, int64_t* arg,
                          float* best, void* stream);
 
+/* pcrcg_gemm_f32 with an optionally transposed A:  C = (Aop * Bop) * row_scale[m] + bias[n],
+ * Aop = A ([M,K] row-major, lda >= K) or A^T (A stored [K,M] row-major, lda >= M) when trans_a.
+ * The weight gradients dW = X^T * dY of nn.Linear / the 1x1 convolutions / the KPConv contraction
+ * (autograd of ref:models/blocks.py:361-372,487) reduce over the points: K = N_points, split over up to
+ * 256 blocks with fp32 atomics. */
+int pcrcg_gemm_f32_ex(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc,
+                      int m, int n, int k, const float* row_scale, const float* bias, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

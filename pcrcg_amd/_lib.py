@@ -63,6 +63,8 @@ SIGNATURES = {
     "pcrcg_kpfcnn_ws_bytes": (c_size_t, [c_void_p, c_void_p]),
     "pcrcg_kpfcnn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     # include/pcrcg_train.h -- the "next" rows
+    "pcrcg_gemm_f32_ex": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_void_p, c_void_p, c_void_p]),
     "pcrcg_feature_argmax": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_void_p]),
 }

@@ -25,16 +25,19 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "pcrcg_train.h"
 
 namespace pcrcg {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // k-step: 32, or 64 for long-K GEMMs (256 contiguous bytes per operand row and step)
-template <int BM, int BN, bool TRANS_B, int BK>
-constexpr int stage_floats() { return BM * (BK + 4) + (TRANS_B ? BN * (BK + 4) : BK * (BN + 4)); }
+template <int BM, int BN, bool TRANS_A, bool TRANS_B, int BK>
+constexpr int stage_floats() {
+    return (TRANS_A ? BK * (BM + 4) : BM * (BK + 4)) + (TRANS_B ? BN * (BK + 4) : BK * (BN + 4));
+}
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_B, int BK>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_A, bool TRANS_B, int BK>
 __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                    int ldb, float* __restrict__ C, int ldc, int M, int N, int Kdim,
                                                    const float* __restrict__ row_scale, const float* __restrict__ bias,
@@ -45,9 +48,11 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
     constexpr int TM = WM / 32, TN = WN / 32;            // 32x32 MFMA tiles per wave
     constexpr int KPAD = BK + 4;   // row stride of k-contiguous LDS images (floats); = 4 mod 64
     constexpr int NPAD = BN + 4;
+    constexpr int MPAD = BM + 4;   // row stride of the k-major A image (TRANS_A: A is stored [K, M])
+    constexpr int A_FLOATS = TRANS_A ? BK * MPAD : BM * KPAD;
     constexpr int A_ITERS = BM * BK / 4 / 256;           // float4 per thread and tile
     constexpr int B_ITERS = BN * BK / 4 / 256;
-    constexpr int STAGE = stage_floats<BM, BN, TRANS_B, BK>();
+    constexpr int STAGE = stage_floats<BM, BN, TRANS_A, TRANS_B, BK>();
     static_assert(A_ITERS >= 1 && B_ITERS >= 1, "tile too small");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -65,6 +70,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
     const int k_begin = blockIdx.z * k_per_split;
     const int k_end = min(Kdim, k_begin + k_per_split);
     const bool full_a = vec_a && (m0 + BM <= M);   // block-uniform: operand tile fully inside, 16-B aligned
+    // (TRANS_A: rows of the stored matrix are k, the tile spans columns m0..m0+BM -- same condition)
     const bool full_b = vec_b && (n0 + BN <= N);
 
     f32x16 acc[TM][TN];
@@ -102,7 +108,30 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
     };
     auto load_tiles = [&](int k0) {
         const bool kfull = k0 + BK <= k_end;
-        if (full_a && kfull) {
+        if (TRANS_A) {           // stored [K, M]: tile rows are k, float4s run along m
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) {
+                const int e = tid + it * 256;
+                const int kr = e / (BM / 4), m4 = (e % (BM / 4)) * 4;
+                if (full_a && kfull) {
+                    ra[it] = *reinterpret_cast<const float4*>(A + (long)(k0 + kr) * lda + m0 + m4);
+                } else {
+                    const int gk = k0 + kr, gm = m0 + m4, me = M - 1;
+                    const float* p = A + (long)min(gk, k_end - 1) * lda;
+                    const bool kok = gk < k_end;
+                    float4 v;
+                    v.x = p[min(gm, me)];
+                    v.y = p[min(gm + 1, me)];
+                    v.z = p[min(gm + 2, me)];
+                    v.w = p[min(gm + 3, me)];
+                    v.x = (kok && gm < M) ? v.x : 0.f;
+                    v.y = (kok && gm + 1 < M) ? v.y : 0.f;
+                    v.z = (kok && gm + 2 < M) ? v.z : 0.f;
+                    v.w = (kok && gm + 3 < M) ? v.w : 0.f;
+                    ra[it] = v;
+                }
+            }
+        } else if (full_a && kfull) {
 #pragma unroll
             for (int it = 0; it < A_ITERS; ++it) ra[it] = kmajor_fast(A, lda, m0, k0, it);
         } else {
@@ -149,8 +178,13 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) {
             const int e = tid + it * 256;
-            const int r = e / (BK / 4), k4 = (e % (BK / 4)) * 4;
-            *reinterpret_cast<float4*>(&As[r * KPAD + k4]) = ra[it];
+            if (TRANS_A) {
+                const int kr = e / (BM / 4), m4 = (e % (BM / 4)) * 4;
+                *reinterpret_cast<float4*>(&As[kr * MPAD + m4]) = ra[it];
+            } else {
+                const int r = e / (BK / 4), k4 = (e % (BK / 4)) * 4;
+                *reinterpret_cast<float4*>(&As[r * KPAD + k4]) = ra[it];
+            }
         }
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
@@ -169,22 +203,28 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
     const int nsteps = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
     if (nsteps > 0) {
         load_tiles(k_begin);
-        store_tiles(smem, smem + BM * KPAD);
+        store_tiles(smem, smem + A_FLOATS);
         if (nsteps > 1) load_tiles(k_begin + BK);
     }
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const float* As = smem + (s & 1) * STAGE;
-        const float* Bs = As + BM * KPAD;
+        const float* Bs = As + A_FLOATS;
         float* An = smem + ((s + 1) & 1) * STAGE;
-        if (s + 1 < nsteps) store_tiles(An, An + BM * KPAD);          // tile s+1: registers -> other stage
+        if (s + 1 < nsteps) store_tiles(An, An + A_FLOATS);          // tile s+1: registers -> other stage
         if (s + 2 < nsteps) load_tiles(k_begin + (s + 2) * BK);       // tile s+2: HBM -> registers
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
             float4 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + l31) * KPAD + g * 8 + 4 * half]);
+            for (int i = 0; i < TM; ++i) {
+                if (TRANS_A) {
+                    const float* ap = &As[(g * 8 + 4 * half) * MPAD + wm * WM + i * 32 + l31];
+                    a[i] = make_float4(ap[0], ap[MPAD], ap[2 * MPAD], ap[3 * MPAD]);
+                } else {
+                    a[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + l31) * KPAD + g * 8 + 4 * half]);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (TRANS_B) {
@@ -261,12 +301,12 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_B, int BK>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS_A, bool TRANS_B, int BK>
 int launch_one(dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m,
                int n, int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b,
                int atomic_out, double* colp, int colp_chunks) {
-    constexpr size_t lds = 2 * sizeof(float) * stage_floats<BM, BN, TRANS_B, BK>();
-    auto kern = k_gemm_f32<BM, BN, WAVES_M, WAVES_N, TRANS_B, BK>;
+    constexpr size_t lds = 2 * sizeof(float) * stage_floats<BM, BN, TRANS_A, TRANS_B, BK>();
+    auto kern = k_gemm_f32<BM, BN, WAVES_M, WAVES_N, TRANS_A, TRANS_B, BK>;
     static bool configured = false;   // > 64 KiB of dynamic LDS must be requested once per kernel
     if (!configured) {
         PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -284,9 +324,9 @@ int launch(bool trans_b, dim3 grid, hipStream_t st, const float* a, int lda, con
            int ldc, int m, int n, int k, const float* row_scale, const float* bias, int k_per_split, int vec_a,
            int vec_b, int atomic_out, double* colp, int colp_chunks) {
     if (trans_b)
-        return launch_one<BM, BN, WAVES_M, WAVES_N, true, BK>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
+        return launch_one<BM, BN, WAVES_M, WAVES_N, false, true, BK>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
                                                           k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks);
-    return launch_one<BM, BN, WAVES_M, WAVES_N, false, BK>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
+    return launch_one<BM, BN, WAVES_M, WAVES_N, false, false, BK>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
                                                        k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks);
 }
 
@@ -294,6 +334,10 @@ int launch(bool trans_b, dim3 grid, hipStream_t st, const float* a, int lda, con
 }  // namespace pcrcg
 
 using namespace pcrcg;
+
+static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc,
+                         int m, int n, int k, const float* row_scale, const float* bias, void* colstats,
+                         size_t colstats_bytes, int* h_chunks, void* stream);
 
 extern "C" size_t pcrcg_gemm_colstats_bytes(int m, int n) {
     const size_t chunks = (size_t)((m > 0 ? m : 1) + 31) / 32 + 4;
@@ -309,11 +353,25 @@ extern "C" int pcrcg_gemm_f32(const float* a, int lda, const float* b, int ldb, 
 extern "C" int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, int ldb, int trans_b, float* c,
                                        int ldc, int m, int n, int k, const float* row_scale, const float* bias,
                                        void* colstats, size_t colstats_bytes, int* h_chunks, void* stream) {
+    return gemm_dispatch(a, lda, 0, b, ldb, trans_b, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks,
+                         stream);
+}
+
+// Aop = A^T when trans_a (A stored [K, M] row-major): the weight-gradient products dW = X^T * dY of the
+// training rows (include/pcrcg_train.h), whose reduction dimension is the number of points.
+extern "C" int pcrcg_gemm_f32_ex(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c,
+                                 int ldc, int m, int n, int k, const float* row_scale, const float* bias, void* stream) {
+    return gemm_dispatch(a, lda, trans_a, b, ldb, trans_b, c, ldc, m, n, k, row_scale, bias, nullptr, 0, nullptr, stream);
+}
+
+static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc,
+                         int m, int n, int k, const float* row_scale, const float* bias, void* colstats,
+                         size_t colstats_bytes, int* h_chunks, void* stream) {
     if (h_chunks) *h_chunks = 0;
     PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 0);
     if (m == 0 || n == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(a && b && c);
-    PCRCG_CHECK_ARG(lda >= k && ldc >= n);
+    PCRCG_CHECK_ARG((trans_a ? lda >= m : lda >= k) && ldc >= n);
     PCRCG_CHECK_ARG(trans_b ? ldb >= k : ldb >= n);
     hipStream_t st = as_stream(stream);
     const int vec_a = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
@@ -330,6 +388,7 @@ extern "C" int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, 
     int pick = -1;
     if (const char* e = getenv("PCRCG_GEMM_TILE")) pick = atoi(e);          // tuning aid
     if (pick < 0 || pick > 3) pick = (n > 64 && ntiles(0) >= 1024) ? 0 : 3;
+    if (trans_a) pick = 3;                                                   // only the 64x64 tile is built for A^T
     const int BM = tiles[pick].bm, BN = tiles[pick].bn;
     const int gx = (n + BN - 1) / BN, gy = (m + BM - 1) / BM;
     constexpr int BK = 32;   // a 64-deep k-step (2 blocks/CU) measured 12 % slower on the path's shapes
@@ -337,7 +396,8 @@ extern "C" int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, 
     const int ktiles = (k + BK - 1) / BK;
     int split_target = 768;
     if (const char* e = getenv("PCRCG_GEMM_SPLIT_TARGET")) split_target = atoi(e);   // tuning aid
-    while ((long)gx * gy * splits < split_target && k / (2 * splits) >= 192 && splits < 32) splits *= 2;
+    const int max_splits = trans_a ? 256 : 32;   // A^T products reduce over the points: few tiles, very long K
+    while ((long)gx * gy * splits < split_target && k / (2 * splits) >= 192 && splits < max_splits) splits *= 2;
     if (const char* e = getenv("PCRCG_GEMM_SPLITK")) splits = atoi(e) > 0 ? atoi(e) : splits;   // tuning aid
     int k_per_split = ((ktiles + splits - 1) / splits) * BK;
     if (k_per_split < BK) k_per_split = BK;
@@ -368,6 +428,13 @@ extern "C" int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, 
 #define GO(BMV, BNV, WMV, WNV)                                                                                   \
     return launch<BMV, BNV, WMV, WNV, BK>(trans_b != 0, grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, \
                                       k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks)
+    if (trans_a) {
+        if (trans_b)
+            return launch_one<64, 64, 2, 2, true, true, BK>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
+                                                            k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks);
+        return launch_one<64, 64, 2, 2, true, false, BK>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
+                                                         k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks);
+    }
     if (pick == 0) { GO(128, 128, 2, 2); }
     if (pick == 1) { GO(128, 64, 4, 1); }
     if (pick == 2) { GO(64, 128, 2, 2); }

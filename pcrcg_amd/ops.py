@@ -162,10 +162,25 @@ def _operand_b(b):
     return b, n, 0
 
 
+def _operand_a(a):
+    """[m, k] operand -> (tensor, ld, trans_a): a transposed view of a row-major [k, m] matrix (`x.t()`) is
+    passed as it is with trans_a = 1 (the weight-gradient products X^T dY)."""
+    _dev(a, _F32, "a")
+    if a.dim() != 2:
+        raise RuntimeError("pcrcg_amd: `a` must be 2-D")
+    m, k = a.shape
+    if a.stride(1) == 1 and (m == 1 or a.stride(0) >= k):
+        return a, (a.stride(0) if m > 1 else k), 0
+    if a.stride(0) == 1 and (k == 1 or a.stride(1) >= m):
+        return a, (a.stride(1) if k > 1 else m), 1
+    return a.contiguous(), k, 0
+
+
 def gemm(a, b, row_scale=None, bias=None, out=None):
-    """out[m,n] = (a[m,k] @ b[k,n]) * row_scale[m] + bias[n] on the fp32 matrix cores."""
+    """out[m,n] = (a[m,k] @ b[k,n]) * row_scale[m] + bias[n] on the fp32 matrix cores.  Transposed views
+    of row-major matrices are consumed in place (no copies) for either operand."""
     L = _lib.lib()
-    a, lda = _rows(a, _F32, "a")
+    a, lda, trans_a = _operand_a(a)
     b, ldb, trans_b = _operand_b(b)
     m, k = a.shape
     k2, n = b.shape
@@ -180,6 +195,10 @@ def gemm(a, b, row_scale=None, bias=None, out=None):
         row_scale = _dev(row_scale, _F32, "row_scale").contiguous()
     if bias is not None:
         bias = _dev(bias, _F32, "bias").contiguous()
+    if trans_a:
+        _lib.check(L.pcrcg_gemm_f32_ex(a.data_ptr(), lda, 1, b.data_ptr(), ldb, trans_b, out.data_ptr(), ldc, m, n, k,
+                                       _ptr(row_scale), _ptr(bias), _stream()), "pcrcg_gemm_f32_ex")
+        return out
     _lib.check(L.pcrcg_gemm_f32(a.data_ptr(), lda, b.data_ptr(), ldb, trans_b, out.data_ptr(), ldc, m, n, k,
                                 _ptr(row_scale), _ptr(bias), _stream()), "pcrcg_gemm_f32")
     return out

@@ -133,3 +133,21 @@ def test_evaluate_pair_record_and_recall(cuda):
     assert not rec["feats"].is_cuda and rec["overlaps"].shape == (n,) and rec["saliency"].shape == (n,)
     assert torch.equal(rec["rot"], torch.from_numpy(rot)) and rec["trans"].shape == (3, 1)
     assert 0.0 <= float(stats["recall"]) <= 1.0 and torch.isfinite(stats["circle_loss"])
+
+
+@pytest.mark.parametrize("m,n,k,tb", [(64, 64, 6000, 0), (960, 64, 15433, 0), (130, 70, 999, 1), (256, 1, 777, 0),
+                                       (1, 33, 50, 1), (2048, 512, 379, 0)])
+def test_gemm_transposed_a(cuda, m, n, k, tb):
+    """dW-shaped products: A^T given as a transposed view of a row-major [k, m] matrix (no copy)."""
+    g = torch.Generator().manual_seed(m * 7 + n)
+    at = torch.randn(k, m, generator=g).to(cuda)
+    b = torch.randn(n, k, generator=g).to(cuda).t() if tb else torch.randn(k, n, generator=g).to(cuda)
+    got = ops.gemm(at.t(), b)
+    ref = at.double().t() @ b.double()
+    assert rel(got, ref) < 2e-5
+    scale, bias = torch.rand(m, generator=g).to(cuda), torch.randn(n, generator=g).to(cuda)
+    got = ops.gemm(at.t(), b, row_scale=scale, bias=bias)
+    assert rel(got, ref * scale.double()[:, None] + bias.double()) < 2e-5
+    # a column slice of a wider matrix as A^T (lda > m, unaligned start)
+    wide = torch.randn(k, m + 5, generator=g).to(cuda)
+    assert rel(ops.gemm(wide[:, 1:m + 1].t(), b), wide[:, 1:m + 1].double().t() @ b.double()) < 2e-5
