@@ -26,6 +26,40 @@ int pcrcg_feature_argmax(const float* a, int lda, int n, const float* b, int ldb
 int pcrcg_gemm_f32_ex(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc,
                       int m, int n, int k, const float* row_scale, const float* bias, void* stream);
 
+/* ---- backward kernels (autograd of the hot path) -------------------------------
+ * Gradients flow to features and parameters only: geometry (points, influence weights) and the neighbour-count
+ * normaliser carry none (ref:models/blocks.py:264-372).  Scatter kernels ACCUMULATE into dx with hardware fp32
+ * atomics; the caller provides dx zero-initialised ([ns, c] row-major, shadow row not included). */
+
+/* KPConv: dx[idx[q,h], c] += sum_k w[q,h,k] * d_wf[q,k,c]; d_wf [nq, 15*cin] = (dy * 1/n_q) @ W^T comes from
+ * pcrcg_gemm_f32 (row_scale = inv_n), the weight gradient dW = wf^T @ (dy * 1/n_q) from pcrcg_gemm_f32_ex. */
+int pcrcg_kpconv_backward_dx(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h,
+                             int ld_idx, const float* d_wf, int cin, const float* kp, float extent, float* dx,
+                             void* stream);
+/* max_pool (ref:models/blocks.py:86-102): dx[idx[q,h*], c] += dy[q,c], h* = first neighbour attaining y[q,c]. */
+int pcrcg_gather_max_backward(const float* x, int ns, int c, const int64_t* idx, int nq, int h, int ld_idx,
+                              const float* y, const float* dy, float* dx, void* stream);
+/* closest_pool (ref:models/blocks.py:71-83): dx[idx[q,0], :] += dy[q, :]. */
+int pcrcg_gather_first_backward(const float* dy, int ld_dy, int c, const int64_t* idx, int nq, int ld_idx, int ns,
+                                float* dx, void* stream);
+/* InstanceNorm over the rows + LeakyReLU(slope) (ref:models/blocks.py:448-462): with xhat = (x-mean)*rstd
+ * (stats = pcrcg_instnorm_stats layout) and g = dy * (xhat > 0 ? 1 : slope):
+ *   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)). */
+size_t pcrcg_instnorm_backward_ws_bytes(int c);
+int pcrcg_instnorm_backward(const float* x, int n, int c, int ldx, const float* stats, const float* dy, int ld_dy,
+                            float slope, float* dx, int ld_dx, void* ws, size_t ws_bytes, void* stream);
+/* Row softmax p = softmax(s * scale): ds = scale * p * (dp - sum_j p*dp) (ref:models/gcn.py:151-155). */
+int pcrcg_softmax_rows_backward(const float* p, int ld_p, const float* dp, int ld_dp, int rows, int cols, float scale,
+                                float* ds, int ld_ds, void* stream);
+
+/* DGCNN edge conv of the GNN head (ref:models/gcn.py:37-64,121-129; forward = pcrcg_edgeconv_reduce +
+ * pcrcg_instnorm_apply): y[i,c] = lrelu(max_j IN2d(ctr[i,c] + nbr[idx[i,j],c])), statistics over all n*k edges.
+ * ctr, nbr, dy, dctr, dnbr are contiguous [n,c]; idx int32 [n,k]; dnbr must be zeroed by the caller. */
+size_t pcrcg_edgeconv_backward_ws_bytes(int c);
+int pcrcg_edgeconv_backward(const float* ctr, const float* nbr, const int* idx, int n, int k, int c, const float* stats,
+                            const float* dy, float slope, float* dctr, float* dnbr, void* ws, size_t ws_bytes,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

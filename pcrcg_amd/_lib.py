@@ -65,6 +65,19 @@ SIGNATURES = {
     # include/pcrcg_train.h -- the "next" rows
     "pcrcg_gemm_f32_ex": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p]),
+    "pcrcg_kpconv_backward_dx": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                         c_void_p, c_float, c_void_p, c_void_p]),
+    "pcrcg_gather_max_backward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_void_p]),
+    "pcrcg_gather_first_backward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pcrcg_instnorm_backward_ws_bytes": (c_size_t, [c_int]),
+    "pcrcg_instnorm_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p,
+                                        c_int, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_softmax_rows_backward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
+                                            c_void_p]),
+    "pcrcg_edgeconv_backward_ws_bytes": (c_size_t, [c_int]),
+    "pcrcg_edgeconv_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+                                        c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pcrcg_feature_argmax": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_void_p]),
 }

@@ -63,6 +63,252 @@ __global__ void __launch_bounds__(256) k_feature_argmax_any(const float* __restr
     if (best) best[row] = bv;
 }
 
+
+// ---- KPConv backward w.r.t. the input features ---------------------------------------------------
+//   dx[idx[q,h], c] += sum_k w[q,h,k] * d_wf[q,k,c],   w as in kpconv.hip (rigid kernel, linear influence)
+// One wavefront per (query, 64-channel chunk): lanes = channels hold the 15 rows d_wf[q,k,c0+lane] in
+// registers; neighbours are taken four at a time -- lane (hsub, j) evaluates the influence of neighbour
+// h0+hsub on kernel point j, exactly the forward's assignment -- and the 15 weights of each neighbour are
+// broadcast through SGPRs (v_readlane).  The scatter uses hardware fp32 atomics: a support point is a
+// neighbour of ~H queries, so its row receives ~H contributions in arbitrary order.
+constexpr int K = PCRCG_KPOINTS;
+
+__global__ void __launch_bounds__(256) k_kpconv_bwd_dx(const float* __restrict__ q_pts, int nq,
+                                                        const float* __restrict__ s_pts, int ns,
+                                                        const long long* __restrict__ idx, int H, int ld_idx,
+                                                        const float* __restrict__ d_wf, int cin,
+                                                        const float* __restrict__ kp, float extent,
+                                                        float* __restrict__ dx, int nchunk) {
+    const int lane = threadIdx.x & 63;
+    const int hsub = lane >> 4, j = lane & 15;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)nq * nchunk) return;
+    const int q = (int)(item / nchunk), chunk = (int)(item - (long)q * nchunk);
+    const int cc = chunk * 64 + lane;
+    const bool cok = cc < cin;
+    const bool jvalid = j < K;
+    const float kpx = jvalid ? kp[3 * j] : 0.f, kpy = jvalid ? kp[3 * j + 1] : 0.f, kpz = jvalid ? kp[3 * j + 2] : 0.f;
+    const float inv_extent = 1.0f / extent;
+    const float qx = q_pts[3 * (long)q], qy = q_pts[3 * (long)q + 1], qz = q_pts[3 * (long)q + 2];
+    float g[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) g[k] = d_wf[((long)q * K + k) * cin + (cok ? cc : cin - 1)];
+    for (int hc = 0; hc < H; hc += 64) {
+        const int h = hc + lane;
+        const long long iv = idx[(long)q * ld_idx + (h < H ? h : H - 1)];
+        const int i = (h < H && iv >= 0 && iv < ns) ? (int)iv : -1;
+        const long ic = i >= 0 ? i : 0;
+        const float px = s_pts[3 * ic] - qx, py = s_pts[3 * ic + 1] - qy, pz = s_pts[3 * ic + 2] - qz;
+        const int hn = H - hc < 64 ? H - hc : 64;
+        for (int h0 = 0; h0 < hn; h0 += 4) {
+            const int src = h0 + hsub;
+            const int ii = __shfl(i, src, 64);
+            const float nx = __shfl(px, src, 64), ny = __shfl(py, src, 64), nz = __shfl(pz, src, 64);
+            float w = 0.f;
+            if (ii >= 0 && src < hn && jvalid) {
+                const float ddx = nx - kpx, ddy = ny - kpy, ddz = nz - kpz;
+                w = fmaxf(1.0f - __builtin_amdgcn_sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) * inv_extent, 0.0f);
+            }
+            const int wi = __float_as_int(w);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int is = __shfl(i, h0 + s, 64);              // wave-uniform
+                if (h0 + s >= hn || is < 0) continue;
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(wi, s * 16 + k)), g[k], acc);
+                if (cok) atomicAdd(dx + (long)is * cin + cc, acc);
+            }
+        }
+    }
+}
+
+// ---- pooling backward ---------------------------------------------------------------------------
+// max_pool: the gradient of y[q,c] = max_h x[idx[q,h],c] goes to the FIRST neighbour attaining the maximum
+// (shadow neighbours contribute the value 0 and swallow the gradient when they win, ref:models/blocks.py:95).
+__global__ void __launch_bounds__(256) k_gather_max_bwd(const float* __restrict__ x, int ns, int c,
+                                                         const long long* __restrict__ idx, int nq, int h, int ld_idx,
+                                                         const float* __restrict__ y, const float* __restrict__ dy,
+                                                         float* __restrict__ dx, int nchunk) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)nq * nchunk) return;
+    const int q = (int)(item / nchunk), chunk = (int)(item - (long)q * nchunk);
+    const int cc = chunk * 64 + lane;
+    if (cc >= c) return;
+    const float m = y[(long)q * c + cc], gq = dy[(long)q * c + cc];
+    const long long* row = idx + (long)q * ld_idx;
+    for (int jn = 0; jn < h; ++jn) {
+        const long long i = row[jn];
+        const bool real = i >= 0 && i < ns;
+        const float v = real ? x[i * c + cc] : 0.f;
+        if (v == m) {
+            if (real) atomicAdd(dx + i * c + cc, gq);
+            break;
+        }
+    }
+}
+
+// closest_pool: dx[idx[q,0], :] += dy[q, :]
+__global__ void __launch_bounds__(256) k_gather_first_bwd(const float* __restrict__ dy, int ld_dy, int c,
+                                                           const long long* __restrict__ idx, int nq, int ld_idx, int ns,
+                                                           float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const long long i = idx[(long)q * ld_idx];
+    if (i < 0 || i >= ns) return;
+    for (int cc = lane; cc < c; cc += 64) atomicAdd(dx + i * c + cc, dy[(long)q * ld_dy + cc]);
+}
+
+// ---- InstanceNorm (+ LeakyReLU) backward ----------------------------------------------------------
+//   xhat = (x - mean) * rstd,  y = lrelu(xhat),  g = dy * (xhat > 0 ? 1 : slope)
+//   dx = rstd * (g - mean_n(g) - xhat * mean_n(g * xhat))
+// Column sums in fp64, two deterministic stages (layout [2][c][chunks], as the forward statistics).
+constexpr int kBwdChunks = 128;
+
+__global__ void __launch_bounds__(256) k_in_bwd_partial(const float* __restrict__ x, int n, int c, int ldx,
+                                                         const float* __restrict__ stats, const float* __restrict__ dy,
+                                                         int ld_dy, float slope, double* __restrict__ partial) {
+    __shared__ double s_a[4][64], s_b[4][64];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int ch = blockIdx.y * 64 + lane;
+    const int chunk = blockIdx.x, nchunks = gridDim.x;
+    const long rows_per = ((long)n + nchunks - 1) / nchunks;
+    const long r0 = chunk * rows_per, r1 = min((long)n, r0 + rows_per);
+    double a = 0.0, b = 0.0;
+    if (ch < c) {
+        const float mean = stats[2 * ch], rstd = stats[2 * ch + 1];
+        for (long r = r0 + rl; r < r1; r += 4) {
+            const float xh = (x[r * ldx + ch] - mean) * rstd;
+            const float g = dy[r * ld_dy + ch] * (xh > 0.f ? 1.0f : slope);
+            a += (double)g;
+            b += (double)g * (double)xh;
+        }
+    }
+    s_a[rl][lane] = a;
+    s_b[rl][lane] = b;
+    __syncthreads();
+    if (rl == 0 && ch < c) {
+        partial[(long)ch * nchunks + chunk] = (s_a[0][lane] + s_a[1][lane]) + (s_a[2][lane] + s_a[3][lane]);
+        partial[((long)c + ch) * nchunks + chunk] = (s_b[0][lane] + s_b[1][lane]) + (s_b[2][lane] + s_b[3][lane]);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_in_bwd_final(const double* __restrict__ partial, int nchunks, int c, double count,
+                                                       float* __restrict__ means /* [2c]: mean(g), mean(g*xhat) */) {
+    const int lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ch >= c) return;
+    double a = 0.0, b = 0.0;
+    for (int k = lane; k < nchunks; k += 64) {
+        a += partial[(long)ch * nchunks + k];
+        b += partial[((long)c + ch) * nchunks + k];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d, 64);
+        b += __shfl_xor(b, d, 64);
+    }
+    if (lane == 0) {
+        means[2 * ch] = (float)(a / count);
+        means[2 * ch + 1] = (float)(b / count);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_in_bwd_apply(const float* __restrict__ x, long total, int c, int ldx,
+                                                       const float* __restrict__ stats, const float* __restrict__ dy,
+                                                       int ld_dy, float slope, const float* __restrict__ means,
+                                                       float* __restrict__ dx, int ld_dx) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const long r = t / c;
+    const int ch = (int)(t - r * c);
+    const float rstd = stats[2 * ch + 1];
+    const float xh = (x[r * ldx + ch] - stats[2 * ch]) * rstd;
+    const float g = dy[r * ld_dy + ch] * (xh > 0.f ? 1.0f : slope);
+    dx[r * ld_dx + ch] = rstd * (g - means[2 * ch] - xh * means[2 * ch + 1]);
+}
+
+// ---- softmax backward: ds = scale * p * (dp - sum_j p*dp), one wavefront per row -----------------
+__global__ void __launch_bounds__(256) k_softmax_bwd(const float* __restrict__ p, int ld_p, const float* __restrict__ dp,
+                                                      int ld_dp, int rows, int cols, float scale, float* __restrict__ ds,
+                                                      int ld_ds) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float dot = 0.f;
+    for (int jn = lane; jn < cols; jn += 64) dot = fmaf(p[(long)r * ld_p + jn], dp[(long)r * ld_dp + jn], dot);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d, 64);
+    for (int jn = lane; jn < cols; jn += 64)
+        ds[(long)r * ld_ds + jn] = scale * p[(long)r * ld_p + jn] * (dp[(long)r * ld_dp + jn] - dot);
+}
+
+// ---- DGCNN edge conv backward (ref:models/gcn.py:37-64,121-129) ----------------------------------
+//   e[i,j,c] = ctr[i,c] + nbr[idx[i,j],c];  n = (e - mean) * rstd over all N*k edges;  y[i,c] = lrelu(max_j n[i,j,c])
+// With dn[i,c] = dy[i,c] * lrelu'(n_max[i,c]), S1[c] = sum_i dn, S2[c] = sum_i dn * n_max and E = N*k:
+//   de[i,j,c] = rstd * ([j == j*] dn[i,c] - S1/E - n[i,j,c] * S2/E)
+//   dctr[i,c] = sum_j de[i,j,c],   dnbr[s,c] = sum_{(i,j): idx[i,j] = s} de[i,j,c]        (fp32 atomics)
+// Stage 1 reduces S1, S2 (fp64 atomics into [2][c]; a few hundred points), stage 2 applies.
+__global__ void __launch_bounds__(256) k_edge_bwd_sums(const float* __restrict__ ctr, const float* __restrict__ nbr,
+                                                        const int* __restrict__ idx, int n, int k, int c,
+                                                        const float* __restrict__ stats, const float* __restrict__ dy,
+                                                        float slope, double* __restrict__ sums) {
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int ch = blockIdx.y * 64 + lane;
+    if (ch >= c) return;
+    const float mean = stats[2 * ch], rstd = stats[2 * ch + 1];
+    double a = 0.0, b = 0.0;
+    for (int r = blockIdx.x * 4 + rl; r < n; r += gridDim.x * 4) {
+        const float q = ctr[(long)r * c + ch];
+        float m = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const float v = q + nbr[(long)idx[(long)r * k + j] * c + ch];
+            m = j == 0 ? v : fmaxf(m, v);
+        }
+        const float nm = (m - mean) * rstd;
+        const float dn = dy[(long)r * c + ch] * (nm > 0.f ? 1.0f : slope);
+        a += (double)dn;
+        b += (double)dn * (double)nm;
+    }
+    atomicAdd(&sums[ch], a);
+    atomicAdd(&sums[c + ch], b);
+}
+
+__global__ void __launch_bounds__(256) k_edge_bwd_apply(const float* __restrict__ ctr, const float* __restrict__ nbr,
+                                                         const int* __restrict__ idx, int n, int k, int c,
+                                                         const float* __restrict__ stats, const float* __restrict__ dy,
+                                                         float slope, const double* __restrict__ sums,
+                                                         float* __restrict__ dctr, float* __restrict__ dnbr) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ch = blockIdx.y * 64 + lane;
+    if (r >= n || ch >= c) return;
+    const float mean = stats[2 * ch], rstd = stats[2 * ch + 1];
+    const double inv_e = 1.0 / ((double)n * (double)k);
+    const float s1 = (float)(sums[ch] * inv_e), s2 = (float)(sums[c + ch] * inv_e);
+    const float q = ctr[(long)r * c + ch];
+    float m = 0.f;
+    int jstar = 0;
+    for (int j = 0; j < k; ++j) {
+        const float v = q + nbr[(long)idx[(long)r * k + j] * c + ch];
+        if (j == 0 || v > m) { m = v; jstar = j; }        // first maximum wins
+    }
+    const float nm = (m - mean) * rstd;
+    const float dn = dy[(long)r * c + ch] * (nm > 0.f ? 1.0f : slope);
+    float acc = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const int s = idx[(long)r * k + j];
+        const float nv = (q + nbr[(long)s * c + ch] - mean) * rstd;
+        const float de = rstd * ((j == jstar ? dn : 0.f) - s1 - nv * s2);
+        acc += de;
+        atomicAdd(dnbr + (long)s * c + ch, de);
+    }
+    dctr[(long)r * c + ch] = acc;
+}
+
 }  // namespace
 }  // namespace pcrcg
 
@@ -79,6 +325,106 @@ extern "C" int pcrcg_feature_argmax(const float* a, int lda, int n, const float*
     if (c == 32) hipLaunchKernelGGL(k_feature_argmax<32>, grid, dim3(256), 0, st, a, lda, n, b, ldb, m, out, best);
     else if (c == 64) hipLaunchKernelGGL(k_feature_argmax<64>, grid, dim3(256), 0, st, a, lda, n, b, ldb, m, out, best);
     else hipLaunchKernelGGL(k_feature_argmax_any, grid, dim3(256), 0, st, a, lda, n, b, ldb, m, c, out, best);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+extern "C" int pcrcg_kpconv_backward_dx(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h,
+                                        int ld_idx, const float* d_wf, int cin, const float* kp, float extent, float* dx,
+                                        void* stream) {
+    PCRCG_CHECK_ARG(nq >= 0 && ns >= 1 && h >= 1 && ld_idx >= h && cin >= 1 && extent > 0.0f);
+    if (nq == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(q_pts && s_pts && idx && d_wf && kp && dx);
+    const int nchunk = (cin + 63) / 64;
+    const long items = (long)nq * nchunk;
+    hipLaunchKernelGGL(k_kpconv_bwd_dx, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), q_pts, nq,
+                       s_pts, ns, reinterpret_cast<const long long*>(idx), h, ld_idx, d_wf, cin, kp, extent, dx, nchunk);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+extern "C" int pcrcg_gather_max_backward(const float* x, int ns, int c, const int64_t* idx, int nq, int h, int ld_idx,
+                                         const float* y, const float* dy, float* dx, void* stream) {
+    PCRCG_CHECK_ARG(ns >= 0 && c >= 1 && nq >= 0 && h >= 1 && ld_idx >= h);
+    if (nq == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(x && idx && y && dy && dx);
+    const int nchunk = (c + 63) / 64;
+    const long items = (long)nq * nchunk;
+    hipLaunchKernelGGL(k_gather_max_bwd, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), x, ns, c,
+                       reinterpret_cast<const long long*>(idx), nq, h, ld_idx, y, dy, dx, nchunk);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+extern "C" int pcrcg_gather_first_backward(const float* dy, int ld_dy, int c, const int64_t* idx, int nq, int ld_idx,
+                                           int ns, float* dx, void* stream) {
+    PCRCG_CHECK_ARG(c >= 1 && nq >= 0 && ld_idx >= 1 && ld_dy >= c && ns >= 0);
+    if (nq == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(dy && idx && dx);
+    hipLaunchKernelGGL(k_gather_first_bwd, dim3((nq + 3) / 4), dim3(256), 0, as_stream(stream), dy, ld_dy, c,
+                       reinterpret_cast<const long long*>(idx), nq, ld_idx, ns, dx);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+extern "C" size_t pcrcg_instnorm_backward_ws_bytes(int c) {
+    return carve_bytes(2 * (size_t)(c > 0 ? c : 1) * kBwdChunks, sizeof(double)) + carve_bytes(2 * (size_t)(c > 0 ? c : 1), 4);
+}
+
+extern "C" int pcrcg_instnorm_backward(const float* x, int n, int c, int ldx, const float* stats, const float* dy,
+                                       int ld_dy, float slope, float* dx, int ld_dx, void* ws, size_t ws_bytes,
+                                       void* stream) {
+    PCRCG_CHECK_ARG(n >= 0 && c >= 1 && ldx >= c && ld_dy >= c && ld_dx >= c);
+    if (n == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(x && stats && dy && dx && ws);
+    Carver cv(ws, ws_bytes);
+    double* partial = cv.take<double>(2 * (size_t)c * kBwdChunks);
+    float* means = cv.take<float>(2 * (size_t)c);
+    PCRCG_CHECK_WS(cv);
+    hipStream_t st = as_stream(stream);
+    int chunks = (n + 255) / 256;
+    if (chunks > kBwdChunks) chunks = kBwdChunks;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(k_in_bwd_partial, dim3(chunks, (c + 63) / 64), dim3(256), 0, st, x, n, c, ldx, stats, dy, ld_dy,
+                       slope, partial);
+    hipLaunchKernelGGL(k_in_bwd_final, dim3((c + 3) / 4), dim3(256), 0, st, partial, chunks, c, (double)n, means);
+    const long total = (long)n * c;
+    hipLaunchKernelGGL(k_in_bwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, total, c, ldx, stats,
+                       dy, ld_dy, slope, means, dx, ld_dx);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+extern "C" int pcrcg_softmax_rows_backward(const float* p, int ld_p, const float* dp, int ld_dp, int rows, int cols,
+                                           float scale, float* ds, int ld_ds, void* stream) {
+    PCRCG_CHECK_ARG(rows >= 0 && cols >= 1 && ld_p >= cols && ld_dp >= cols && ld_ds >= cols);
+    if (rows == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(p && dp && ds);
+    hipLaunchKernelGGL(k_softmax_bwd, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), p, ld_p, dp, ld_dp, rows, cols,
+                       scale, ds, ld_ds);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+extern "C" size_t pcrcg_edgeconv_backward_ws_bytes(int c) { return carve_bytes(2 * (size_t)(c > 0 ? c : 1), sizeof(double)); }
+
+extern "C" int pcrcg_edgeconv_backward(const float* ctr, const float* nbr, const int* idx, int n, int k, int c,
+                                       const float* stats, const float* dy, float slope, float* dctr, float* dnbr,
+                                       void* ws, size_t ws_bytes, void* stream) {
+    PCRCG_CHECK_ARG(n >= 0 && k >= 1 && c >= 1);
+    if (n == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(ctr && nbr && idx && stats && dy && dctr && dnbr && ws);
+    Carver cv(ws, ws_bytes);
+    double* sums = cv.take<double>(2 * (size_t)c);
+    PCRCG_CHECK_WS(cv);
+    hipStream_t st = as_stream(stream);
+    PCRCG_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)c * sizeof(double), st));
+    int gx = (n + 3) / 4;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_edge_bwd_sums, dim3(gx, (c + 63) / 64), dim3(256), 0, st, ctr, nbr, idx, n, k, c, stats, dy, slope,
+                       sums);
+    hipLaunchKernelGGL(k_edge_bwd_apply, dim3((n + 3) / 4, (c + 63) / 64), dim3(256), 0, st, ctr, nbr, idx, n, k, c, stats,
+                       dy, slope, sums, dctr, dnbr);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

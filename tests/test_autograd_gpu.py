@@ -1,0 +1,143 @@
+"""GPU: gradients of the differentiable HIP ops (pcrcg_amd/autograd.py, kernels behind include/pcrcg_train.h)
+against torch autograd of the CPU oracle (oracle/model_ref.py) in float64.  Bar: 1e-4 relative per tensor."""
+import os
+
+import pytest
+import torch
+
+from oracle import model_ref as MR
+from pcrcg_amd import autograd as AG
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+@pytest.fixture(scope="module")
+def mini(golden_dir):
+    col = torch.load(os.path.join(golden_dir, "collate_mini.pt"))
+    return col["batch"]
+
+
+def _leaf(t, dev=None, dtype=None):
+    t = t.detach().clone()
+    if dtype is not None:
+        t = t.to(dtype)
+    if dev is not None:
+        t = t.to(dev)
+    return t.requires_grad_(True)
+
+
+@pytest.mark.parametrize("m,k,n,tb", [(300, 64, 48, 0), (1000, 33, 17, 1), (64, 512, 380, 1)])
+def test_matmul_grads(cuda, m, k, n, tb):
+    g = torch.Generator().manual_seed(m)
+    a, rs, bias = torch.randn(m, k, generator=g), torch.rand(m, generator=g) + 0.5, torch.randn(n, generator=g)
+    b = torch.randn(n, k, generator=g) if tb else torch.randn(k, n, generator=g)
+    dy = torch.randn(m, n, generator=g)
+    a1, b1, bias1 = _leaf(a, cuda), _leaf(b, cuda), _leaf(bias, cuda)
+    y = AG.matmul(a1, b1.t() if tb else b1, row_scale=rs.to(cuda), bias=bias1)
+    y.backward(dy.to(cuda))
+    a0, b0, bias0 = _leaf(a, dtype=torch.float64), _leaf(b, dtype=torch.float64), _leaf(bias, dtype=torch.float64)
+    y0 = (a0 @ (b0.t() if tb else b0)) * rs.double()[:, None] + bias0
+    y0.backward(dy.double())
+    assert rel(y, y0) < TOL
+    assert rel(a1.grad, a0.grad) < TOL and rel(b1.grad, b0.grad) < TOL and rel(bias1.grad, bias0.grad) < TOL
+
+
+@pytest.mark.parametrize("level,strided,cin,cout", [(0, False, 8, 16), (1, False, 64, 64), (0, True, 128, 32),
+                                                     (2, False, 1, 8), (1, True, 20, 12)])
+def test_kpconv_grads(cuda, mini, level, strided, cin, cout):
+    from pcrcg_amd.kernel_points import load_kernels
+    g = torch.Generator().manual_seed(level * 10 + cin)
+    s_pts = mini["points"][level]
+    q_pts = mini["points"][level + 1] if strided else s_pts
+    idx = mini["pools"][level] if strided else mini["neighbors"][level]
+    radius, extent = 0.0625 * 2 ** level, 0.05 * 2 ** level
+    kp = torch.tensor(load_kernels(radius, 15, dimension=3, fixed="center"), dtype=torch.float32)
+    x = torch.randn(s_pts.shape[0], cin, generator=g)
+    w = torch.randn(15, cin, cout, generator=g) * 0.2
+    dy = torch.randn(q_pts.shape[0], cout, generator=g)
+    x1, w1 = _leaf(x, cuda), _leaf(w, cuda)
+    y = AG.kpconv(x1, w1, q_pts.to(cuda), s_pts.to(cuda), idx.to(cuda), kp.to(cuda), extent)
+    y.backward(dy.to(cuda))
+    x0, w0 = _leaf(x, dtype=torch.float64), _leaf(w, dtype=torch.float64)
+    y0 = MR.kpconv(q_pts.double(), s_pts.double(), idx, x0, kp.double(), w0, extent)
+    y0.backward(dy.double())
+    assert rel(y, y0) < TOL
+    assert rel(w1.grad, w0.grad) < TOL
+    assert rel(x1.grad, x0.grad) < TOL
+
+
+@pytest.mark.parametrize("n,c,slope", [(500, 64, 0.1), (1000, 130, 1.0), (37, 8, 0.0), (4000, 32, 0.2)])
+def test_instnorm_lrelu_grads(cuda, n, c, slope):
+    g = torch.Generator().manual_seed(n + c)
+    x, dy = torch.randn(n, c, generator=g) * 2 + 0.3, torch.randn(n, c, generator=g)
+    x1 = _leaf(x, cuda)
+    y = AG.instnorm_lrelu(x1, slope)
+    y.backward(dy.to(cuda))
+    x0 = _leaf(x, dtype=torch.float64)
+    y0 = torch.nn.functional.leaky_relu(MR.instance_norm_rows(x0), slope)
+    y0.backward(dy.double())
+    assert rel(y, y0) < TOL and rel(x1.grad, x0.grad) < TOL
+
+
+def test_pool_grads(cuda, mini):
+    g = torch.Generator().manual_seed(5)
+    for c in (16, 70):
+        x = torch.randn(mini["points"][0].shape[0], c, generator=g)
+        pools, ups = mini["pools"][0], mini["upsamples"][0]
+        dy = torch.randn(pools.shape[0], c, generator=g)
+        x1 = _leaf(x, cuda)
+        y = AG.max_pool(x1, pools.to(cuda))
+        y.backward(dy.to(cuda))
+        x0 = _leaf(x, dtype=torch.float64)
+        y0 = MR.max_pool(x0, pools)
+        y0.backward(dy.double())
+        assert rel(y, y0) < 1e-6 and rel(x1.grad, x0.grad) < TOL
+        # nearest upsample: coarse features -> fine points
+        xc = torch.randn(mini["points"][1].shape[0], c, generator=g)
+        dyu = torch.randn(ups.shape[0], c, generator=g)
+        xc1 = _leaf(xc, cuda)
+        yu = AG.closest_pool(xc1, ups.to(cuda))
+        yu.backward(dyu.to(cuda))
+        xc0 = _leaf(xc, dtype=torch.float64)
+        yu0 = MR.closest_pool(xc0, ups)
+        yu0.backward(dyu.double())
+        assert rel(yu, yu0) < 1e-6 and rel(xc1.grad, xc0.grad) < TOL
+
+
+def test_softmax_rows_grads(cuda):
+    g = torch.Generator().manual_seed(9)
+    s, dp = torch.randn(190, 381, generator=g) * 3, torch.randn(190, 381, generator=g)
+    s1 = _leaf(s, cuda)
+    p = AG.softmax_rows(s1, 0.125)
+    p.backward(dp.to(cuda))
+    s0 = _leaf(s, dtype=torch.float64)
+    p0 = torch.softmax(s0 * 0.125, dim=1)
+    p0.backward(dp.double())
+    assert rel(p, p0) < TOL and rel(s1.grad, s0.grad) < TOL
+
+
+@pytest.mark.parametrize("n,c,k", [(96, 64, 10), (200, 130, 7)])
+def test_edge_conv_grads(cuda, n, c, k):
+    """DGCNN edge conv: InstanceNorm2d statistics over all n*k edges make every edge receive gradient."""
+    from pcrcg_amd import ops
+    g = torch.Generator().manual_seed(n)
+    coords = torch.rand(n, 3, generator=g)
+    ctr, nbr, dy = torch.randn(n, c, generator=g), torch.randn(n, c, generator=g), torch.randn(n, c, generator=g)
+    idx = ops.knn(coords.to(cuda), k)
+    c1, n1 = _leaf(ctr, cuda), _leaf(nbr, cuda)
+    y = AG.edge_conv(c1, n1, idx, 0.2)
+    y.backward(dy.to(cuda))
+    c0, n0 = _leaf(ctr, dtype=torch.float64), _leaf(nbr, dtype=torch.float64)
+    e = c0[:, None, :] + n0[idx.cpu().long()]                         # [n, k, c]
+    mean = e.mean((0, 1), keepdim=True)
+    var = e.var((0, 1), unbiased=False, keepdim=True)
+    y0 = torch.nn.functional.leaky_relu((e - mean) / torch.sqrt(var + 1e-5), 0.2).max(1)[0]
+    y0.backward(dy.double())
+    assert rel(y, y0) < TOL
+    assert rel(c1.grad, c0.grad) < TOL and rel(n1.grad, n0.grad) < TOL
