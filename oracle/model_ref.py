@@ -229,8 +229,17 @@ def gcn(sd, prefix, names, c0, c1, d0, d1, k, heads):
 # ------------------------------------------------------------------------------------------------
 # KPFCNN.forward, geometry-only branch (ref:models/architectures.py:181-191, 516-610)
 # ------------------------------------------------------------------------------------------------
+def kpfcnn_forward_with_grad(sd, cfg, batch, return_intermediates=False):
+    """The forward below with autograd recording (reference gradients for the training-row tests)."""
+    return _kpfcnn_forward(sd, cfg, batch, return_intermediates)
+
+
 @torch.no_grad()
 def kpfcnn_forward(sd, cfg, batch, return_intermediates=False):
+    return _kpfcnn_forward(sd, cfg, batch, return_intermediates)
+
+
+def _kpfcnn_forward(sd, cfg, batch, return_intermediates=False):
     pl = plan(cfg)
     use_bn = cfg.get("use_batch_norm", True)
     x = batch["features"].clone()

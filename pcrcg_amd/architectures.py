@@ -98,7 +98,9 @@ class KPFCNN(nn.Module):
 
     def forward(self, batch, backbone2d=None):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError("pcrcg_amd.KPFCNN: forward-only in this round -- call under torch.no_grad()")
+            # training: the differentiable composition of the same kernels (pcrcg_amd/train_forward.py)
+            from .train_forward import forward_train
+            return forward_train(self, batch)
         if self.use_runner:
             # the whole forward below, enqueued by one call into the C++ runner (csrc/runner.hip)
             if self._runner is None:

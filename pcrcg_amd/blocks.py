@@ -17,8 +17,9 @@ from .kernel_points import load_kernels
 
 def _no_autograd(*tensors):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise RuntimeError("pcrcg_amd: the HIP path is forward-only in this round; wrap the call in "
-                           "torch.no_grad() (backward kernels are listed as next in DESIGN.md)")
+        raise RuntimeError("pcrcg_amd: these module forwards are the inference path; wrap the call in "
+                           "torch.no_grad(), or train through KPFCNN.forward / pcrcg_amd.train_forward "
+                           "(differentiable composition of the same kernels)")
 
 
 _PADDED = {}

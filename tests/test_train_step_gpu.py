@@ -1,0 +1,130 @@
+"""GPU: the differentiable forward (pcrcg_amd/train_forward.py) and the train step (pcrcg_amd/trainer.py)
+against the CPU oracle (oracle/model_ref.py) under torch autograd, on the reduced-width reference model of
+tests/golden/model_mini.pt."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref as MR
+from pcrcg_amd import indoor_config, synthetic
+from pcrcg_amd.architectures import KPFCNN
+from pcrcg_amd.config import Config
+from pcrcg_amd.correspondences import get_correspondences
+from pcrcg_amd.loss import MetricLoss
+from pcrcg_amd.pyramid import collate_fn_descriptor
+from pcrcg_amd.train_forward import forward_train
+from pcrcg_amd.trainer import Trainer
+
+pytestmark = pytest.mark.gpu
+LOSS_CFG = Config(pos_margin=0.1, neg_margin=1.4, pos_radius=0.0375, safe_radius=0.1, matchability_radius=0.05,
+                  max_points=256)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def _to(batch, dev):
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, list):
+            out[k] = [t.to(dev) if isinstance(t, torch.Tensor) else t for t in v]
+        elif isinstance(v, torch.Tensor):
+            out[k] = v.to(dev)
+        else:
+            out[k] = v
+    return out
+
+
+def test_full_model_gradients_match_oracle_autograd(cuda, golden_dir):
+    """d(scalar)/d(every parameter) through encoder, GNN, saliency head and decoder."""
+    gold = torch.load(os.path.join(golden_dir, "model_mini.pt"))
+    col = torch.load(os.path.join(golden_dir, "collate_mini.pt"))
+    cfg = indoor_config(**{k: v for k, v in gold["config"].items() if k in ("first_feats_dim", "gnn_feats_dim")})
+    net = KPFCNN(cfg)
+    net.load_state_dict(gold["state_dict"])
+    net = net.to(cuda).train()
+    batch = _to(col["batch"], cuda)
+    n = batch["points"][0].shape[0]
+    g = torch.Generator().manual_seed(1)
+    r1, r2, r3 = torch.randn(n, 32, generator=g), torch.randn(n, generator=g), torch.randn(n, generator=g)
+
+    def scalar(out, dev):
+        return (out["feats_f"] * r1.to(dev)).sum() + (out["scores_overlap"] * r2.to(dev)).sum() \
+            + (out["scores_saliency"] * r3.to(dev)).sum()
+
+    out = forward_train(net, batch)
+    for k in gold["outputs"]:                                     # the forward values still match the reference
+        assert rel(out[k], gold["outputs"][k]) < 1e-4, k
+    scalar(out, cuda).backward()
+
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in gold["state_dict"].items()}
+    out0 = MR.kpfcnn_forward_with_grad(sd, dict(gold["config"]), col["batch"])
+    scalar(out0, "cpu").backward()
+    worst = {}
+    names = [n for n, p in net.named_parameters() if p.requires_grad]   # kernel points are fixed (ref:blocks.py:196-198)
+    # biases in front of an InstanceNorm / inside the softmax have an exactly zero gradient: both sides return
+    # rounding noise there, so errors are measured against max(|reference grad|, 1e-4 * largest gradient)
+    floor = 1e-4 * max(float(sd[n].grad.abs().max()) for n in names)
+    params = dict(net.named_parameters())
+    for name in names:
+        p, want = params[name], sd[name].grad
+        assert p.grad is not None and want is not None, name
+        worst[name] = float((p.grad.double().cpu() - want.double()).abs().max() / max(float(want.abs().max()), floor))
+    bad = {k: v for k, v in worst.items() if v > 1e-3}
+    assert not bad, bad
+    assert np.median(list(worst.values())) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+
+
+def _lomatch_inputs(cfg, dev, seed=2):
+    src, tgt, rot, trans = synthetic.lomatch_pair("mini", seed, overlap=0.3)
+    tsfm = np.eye(4)
+    tsfm[:3, :3], tsfm[:3, 3] = rot, trans.flatten()
+    corr = get_correspondences(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), tsfm, 0.0375)
+    item = dict(src_pcd=src, tgt_pcd=tgt, src_feats=np.ones((len(src), 1), np.float32),
+                tgt_feats=np.ones((len(tgt), 1), np.float32), rot=rot, trans=trans, correspondences=corr.cpu(), sample=0)
+    return collate_fn_descriptor([item], cfg, [20, 26, 30, 32], device=dev)
+
+
+def test_train_step_reduces_the_loss_and_updates_every_parameter(cuda):
+    cfg = indoor_config(first_feats_dim=32, gnn_feats_dim=64)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = KPFCNN(cfg).to(cuda)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    trainer = Trainer(net, MetricLoss(LOSS_CFG), lr=0.005, momentum=0.98)
+    inputs = _lomatch_inputs(cfg, cuda)
+    losses = []
+    for _ in range(12):
+        np.random.seed(3)                      # same max_points subset every step: the loss is comparable
+        stats = trainer.train_step(inputs)
+        assert stats["gradient_valid"] == 1.0
+        for k in ("circle_loss", "overlap_loss", "saliency_loss", "recall", "total_loss"):
+            assert np.isfinite(stats[k]), k
+        losses.append(stats["total_loss"])
+    assert losses[-1] < losses[0], losses
+    changed = [k for k, v in net.state_dict().items() if v.is_floating_point() and not torch.equal(v, before[k])]
+    # (the scalar temperature parameter `epsilon` = -5 moves by less than one fp32 ulp per step at lr 0.005)
+    trainable = [k for k, p in net.named_parameters() if p.requires_grad and k != "epsilon"]
+    assert set(trainable) <= set(changed), set(trainable) - set(changed)
+    # evaluation goes through the inference runner and agrees with the training forward
+    np.random.seed(3)
+    val = trainer.inference_one_batch(inputs, "val")
+    assert "total_loss" not in val and np.isfinite(val["recall"])
+    trainer.end_epoch()
+    assert abs(trainer.optimizer.param_groups[0]["lr"] - 0.005 * 0.95) < 1e-12
+
+
+def test_non_finite_gradients_skip_the_step(cuda):
+    cfg = indoor_config(first_feats_dim=32, gnn_feats_dim=64)
+    torch.manual_seed(0)
+    net = KPFCNN(cfg).to(cuda)
+    trainer = Trainer(net, MetricLoss(LOSS_CFG))
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    trainer.flat_grad[5] = float("nan")
+    assert trainer.optimizer_step() is False and trainer.skipped_steps == 1
+    assert all(torch.equal(v, before[k]) for k, v in net.state_dict().items())
+    assert float(trainer.flat_grad.abs().sum()) == 0.0          # bucket cleared for the next pair
