@@ -20,21 +20,43 @@ from .train_forward import forward_train
 LOSS_KEYS = ("circle_loss", "overlap_loss", "saliency_loss", "node_overlap_loss", "pose_loss")   # ref:lib/trainer.py:255
 
 
+class GradientBucket:
+    """One flat fp32 buffer holding every parameter's gradient (p.grad are views into it): the whole
+    data-parallel exchange of a step is a single all-reduce, and the NaN/Inf check reads one tensor."""
+
+    def __init__(self, params, process_group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def all_reduce_mean(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(self.group)
+            if world > 1:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat.div_(world)
+
+    def finite(self):
+        return bool(torch.isfinite(self.flat).all().item())
+
+    def zero(self):
+        self.flat.zero_()                        # optimizer.zero_grad() would drop the views
+
+
 class Trainer:
     def __init__(self, model, desc_loss, lr=0.005, momentum=0.98, weight_decay=1e-6, scheduler_gamma=0.95,
                  iter_size=1, process_group=None):
         self.model, self.desc_loss = model, desc_loss
         self.iter_size = iter_size
-        self.group = process_group
-        self.params = [p for p in model.parameters() if p.requires_grad]
-        # one flat gradient bucket; p.grad are views into it
-        total = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        self.bucket = GradientBucket(model.parameters(), process_group)
+        self.params = self.bucket.params
+        self.flat_grad = self.bucket.flat
         self.optimizer = torch.optim.SGD(self.params, lr=lr, momentum=momentum, weight_decay=weight_decay)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=scheduler_gamma)
         self.skipped_steps = 0
@@ -66,26 +88,18 @@ class Trainer:
         return {k: float(v.detach()) if isinstance(v, torch.Tensor) else float(v) for k, v in res.items()}
 
     # ---- optimisation block -------------------------------------------------------------------------
-    def all_reduce_gradients(self):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size(self.group)
-            if world > 1:
-                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-                self.flat_grad.div_(world)
-
     def gradient_valid(self):
         """validate_gradient (ref:lib/utils.py:100-111) on the reduced bucket: same answer on every rank."""
-        return bool(torch.isfinite(self.flat_grad).all().item())
+        return self.bucket.finite()
 
     def optimizer_step(self):
-        self.all_reduce_gradients()
+        self.bucket.all_reduce_mean()
         ok = self.gradient_valid()
         if ok:
             self.optimizer.step()
         else:
             self.skipped_steps += 1
-        self.flat_grad.zero_()                   # optimizer.zero_grad() would detach the views
+        self.bucket.zero()
         return ok
 
     def train_step(self, inputs):

@@ -58,3 +58,61 @@ def test_two_rank_sharding_protocol():
     for rank, seeds, checks, _, _ in res:                           # ranks worked on their own pairs only
         exp = [float(np.sum(synthetic.pair("mini", s)[0]) + np.sum(synthetic.pair("mini", s)[1])) for s in seeds]
         assert np.allclose(checks, exp)
+
+
+def _train_worker(rank, world, port, q):
+    """Data-parallel optimisation block of pcrcg_amd.trainer.Trainer on a stand-in model (the kernels need a
+    GPU; the bucket / all-reduce / skip protocol does not)."""
+    from pcrcg_amd.trainer import Trainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)                                   # identical replicas
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+    trainer = Trainer(model, desc_loss=None, lr=0.1, momentum=0.9, weight_decay=0.0)
+    g = torch.Generator().manual_seed(100 + rank)          # each rank has its own pair
+    x, y = torch.randn(16, 6, generator=g), torch.randn(16, 2, generator=g)
+    out = []
+    for step in range(3):
+        loss = ((model(x) - y) ** 2).mean()
+        loss.backward()                                    # lands in the flat bucket through the .grad views
+        if step == 1 and rank == 1:
+            trainer.flat_grad[3] = float("inf")            # one rank overflows: BOTH must skip this step
+        ok = trainer.optimizer_step()
+        out.append((ok, [p.detach().clone() for p in model.parameters()]))
+    q.put((rank, [(ok, [t.numpy() for t in ps]) for ok, ps in out], trainer.skipped_steps))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce_and_global_skip():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, steps0, skipped0), (_, steps1, skipped1) = res
+    assert skipped0 == skipped1 == 1
+    assert [ok for ok, _ in steps0] == [ok for ok, _ in steps1] == [True, False, True]
+    for (_, p0), (_, p1) in zip(steps0, steps1):            # replicas stay bit-identical
+        for a, b in zip(p0, p1):
+            assert np.array_equal(a, b)
+    # step 0 equals single-process SGD on the MEAN of the two ranks' gradients
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+    loss = 0
+    for rank in range(world):
+        g = torch.Generator().manual_seed(100 + rank)
+        x, y = torch.randn(16, 6, generator=g), torch.randn(16, 2, generator=g)
+        loss = loss + ((ref(x) - y) ** 2).mean() / world
+    loss.backward()
+    with torch.no_grad():
+        for p, got in zip(ref.parameters(), steps0[0][1]):
+            assert np.allclose((p - 0.1 * p.grad).numpy(), got, atol=1e-6)
+    for a, b in zip(steps0[0][1], steps0[1][1]):            # the skipped step changed nothing
+        assert np.array_equal(a, b)
