@@ -15,8 +15,9 @@ extern "C" {
  *   arg[i] = argmax_j <a_i, b_j>  over the rows of b [m,c]
  * i.e. `torch.matmul(a, b.T).max(1)` without materialising the n x m score matrix (n, m = points in the
  * overlap region, up to tens of thousands).  First index wins ties.  best (optional) receives the maximum. */
+size_t pcrcg_feature_argmax_ws_bytes(int n);
 int pcrcg_feature_argmax(const float* a, int lda, int n, const float* b, int ldb, int m, int c, int64_t* arg,
-                         float* best, void* stream);
+                         float* best, void* ws, size_t ws_bytes, void* stream);
 
 /* pcrcg_gemm_f32 with an optionally transposed A:  C = (Aop * Bop) * row_scale[m] + bias[n],
  * Aop = A ([M,K] row-major, lda >= K) or A^T (A stored [K,M] row-major, lda >= M) when trans_a.

@@ -78,8 +78,9 @@ SIGNATURES = {
     "pcrcg_edgeconv_backward_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_edgeconv_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_feature_argmax_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_feature_argmax": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
-                                     c_void_p]),
+                                     c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

@@ -8,11 +8,20 @@ namespace {
 
 // ---- feature arg-max (ref:lib/loss.py:209-213) ---------------------------------------------------
 // One thread owns a row of A (C floats in registers); rows of B stream through LDS in tiles of TB rows
-// and are read back as wave-uniform (broadcast) float4s, so the inner loop is pure FMA.
+// and are read back as wave-uniform (broadcast) float4s, so the inner loop is pure FMA.  The overlap region
+// has only a few thousand rows, i.e. a few dozen 256-row blocks, so the columns are split over grid.y and
+// the partial winners are merged with a 64-bit atomicMax on (orderable score bits, ~column): the larger
+// score wins, equal scores keep the smaller column.
+__device__ inline unsigned long long pack_best(float v, int j) {
+    const unsigned int b = __float_as_uint(v);
+    const unsigned int key = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)j);
+}
+
 template <int C>
 __global__ void __launch_bounds__(256) k_feature_argmax(const float* __restrict__ a, int lda, int n,
-                                                         const float* __restrict__ b, int ldb, int m,
-                                                         long long* __restrict__ arg, float* __restrict__ best) {
+                                                         const float* __restrict__ b, int ldb, int m, int cols_per,
+                                                         unsigned long long* __restrict__ packed) {
     constexpr int TB = 128;
     __shared__ __attribute__((aligned(16))) float bs[TB * C];
     const int row = blockIdx.x * 256 + threadIdx.x;
@@ -22,8 +31,9 @@ __global__ void __launch_bounds__(256) k_feature_argmax(const float* __restrict_
     for (int k = 0; k < C; ++k) av[k] = a[(long)r * lda + k];
     float bv = -INFINITY;
     int bj = 0;
-    for (int j0 = 0; j0 < m; j0 += TB) {
-        const int tj = min(TB, m - j0);
+    const int jbeg = blockIdx.y * cols_per, jend = min(m, jbeg + cols_per);
+    for (int j0 = jbeg; j0 < jend; j0 += TB) {
+        const int tj = min(TB, jend - j0);
         __syncthreads();
         for (int e = threadIdx.x; e < tj * C; e += 256) bs[e] = b[(long)(j0 + e / C) * ldb + e % C];
         __syncthreads();
@@ -40,29 +50,37 @@ __global__ void __launch_bounds__(256) k_feature_argmax(const float* __restrict_
             if (s > bv) { bv = s; bj = j0 + j; }
         }
     }
-    if (row < n) {
-        arg[row] = bj;
-        if (best) best[row] = bv;
-    }
+    if (row < n && jbeg < jend) atomicMax(&packed[row], pack_best(bv, bj));
 }
 
 // any width: A rows are re-read from memory (L1/L2 resident), one thread per row
 __global__ void __launch_bounds__(256) k_feature_argmax_any(const float* __restrict__ a, int lda, int n,
                                                              const float* __restrict__ b, int ldb, int m, int c,
-                                                             long long* __restrict__ arg, float* __restrict__ best) {
+                                                             int cols_per, unsigned long long* __restrict__ packed) {
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= n) return;
     float bv = -INFINITY;
     int bj = 0;
-    for (int j = 0; j < m; ++j) {
+    const int jbeg = blockIdx.y * cols_per, jend = min(m, jbeg + cols_per);
+    for (int j = jbeg; j < jend; ++j) {
         float s = 0.f;
         for (int k = 0; k < c; ++k) s = fmaf(a[(long)row * lda + k], b[(long)j * ldb + k], s);
         if (s > bv) { bv = s; bj = j; }
     }
-    arg[row] = bj;
-    if (best) best[row] = bv;
+    if (jbeg < jend) atomicMax(&packed[row], pack_best(bv, bj));
 }
 
+__global__ void __launch_bounds__(256) k_feature_argmax_unpack(const unsigned long long* __restrict__ packed, int n,
+                                                                long long* __restrict__ arg, float* __restrict__ best) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    const unsigned long long p = packed[row];
+    arg[row] = (long long)(0xFFFFFFFFu - (unsigned int)(p & 0xFFFFFFFFull));
+    if (best) {
+        const unsigned int key = (unsigned int)(p >> 32);
+        best[row] = __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
+    }
+}
 
 // ---- KPConv backward w.r.t. the input features ---------------------------------------------------
 //   dx[idx[q,h], c] += sum_k w[q,h,k] * d_wf[q,k,c],   w as in kpconv.hip (rigid kernel, linear influence)
@@ -314,17 +332,30 @@ __global__ void __launch_bounds__(256) k_edge_bwd_apply(const float* __restrict_
 
 using namespace pcrcg;
 
+extern "C" size_t pcrcg_feature_argmax_ws_bytes(int n) { return carve_bytes((size_t)(n > 0 ? n : 1), 8); }
+
 extern "C" int pcrcg_feature_argmax(const float* a, int lda, int n, const float* b, int ldb, int m, int c,
-                                    int64_t* arg, float* best, void* stream) {
+                                    int64_t* arg, float* best, void* ws, size_t ws_bytes, void* stream) {
     PCRCG_CHECK_ARG(n >= 0 && m >= 1 && c >= 1 && lda >= c && ldb >= c);
     if (n == 0) return PCRCG_OK;
-    PCRCG_CHECK_ARG(a && b && arg);
+    PCRCG_CHECK_ARG(a && b && arg && ws);
+    Carver cv(ws, ws_bytes);
+    unsigned long long* packed = cv.take<unsigned long long>((size_t)n);
+    PCRCG_CHECK_WS(cv);
     hipStream_t st = as_stream(stream);
-    long long* out = reinterpret_cast<long long*>(arg);
-    const dim3 grid((n + 255) / 256);
-    if (c == 32) hipLaunchKernelGGL(k_feature_argmax<32>, grid, dim3(256), 0, st, a, lda, n, b, ldb, m, out, best);
-    else if (c == 64) hipLaunchKernelGGL(k_feature_argmax<64>, grid, dim3(256), 0, st, a, lda, n, b, ldb, m, out, best);
-    else hipLaunchKernelGGL(k_feature_argmax_any, grid, dim3(256), 0, st, a, lda, n, b, ldb, m, c, out, best);
+    PCRCG_CHECK_HIP(hipMemsetAsync(packed, 0, (size_t)n * 8, st));
+    const int gx = (n + 255) / 256;
+    int splits = (2048 + gx - 1) / gx;                      // ~2k blocks in flight
+    const int max_splits = (m + 127) / 128;                 // at least one LDS tile of columns per block
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const int cols_per = ((m + splits - 1) / splits + 127) / 128 * 128;
+    const dim3 grid(gx, (m + cols_per - 1) / cols_per);
+    if (c == 32) hipLaunchKernelGGL(k_feature_argmax<32>, grid, dim3(256), 0, st, a, lda, n, b, ldb, m, cols_per, packed);
+    else if (c == 64) hipLaunchKernelGGL(k_feature_argmax<64>, grid, dim3(256), 0, st, a, lda, n, b, ldb, m, cols_per, packed);
+    else hipLaunchKernelGGL(k_feature_argmax_any, grid, dim3(256), 0, st, a, lda, n, b, ldb, m, c, cols_per, packed);
+    hipLaunchKernelGGL(k_feature_argmax_unpack, dim3(gx), dim3(256), 0, st, packed, n, reinterpret_cast<long long*>(arg),
+                       best);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

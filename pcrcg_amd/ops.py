@@ -370,6 +370,8 @@ def feature_argmax(a, b, want_best=False):
         raise RuntimeError("pcrcg_amd.feature_argmax: `b` has no rows")
     arg = torch.empty(n, dtype=_I64, device=a.device)
     best = torch.empty(n, dtype=_F32, device=a.device) if want_best else None
+    nbytes = L.pcrcg_feature_argmax_ws_bytes(n)
+    ws = _ws.get("feature_argmax", nbytes, a.device)
     _lib.check(L.pcrcg_feature_argmax(a.data_ptr(), lda, n, b.data_ptr(), ldb, m, c, arg.data_ptr(), _ptr(best),
-                                      _stream()), "pcrcg_feature_argmax")
+                                      ws.data_ptr(), nbytes, _stream()), "pcrcg_feature_argmax")
     return (arg, best) if want_best else arg

@@ -158,7 +158,7 @@ def collate_fn_descriptor(list_data, config, neighborhood_limits, device=None):
     # node-overlap labels of the coarsest level (:309-322): training labels, plain dense torch math
     nodes = out["points"][-1]
     n_src = out["stack_lengths_host"][-1][0]
-    corr_t = torch.as_tensor(np.asarray(corr)).to(device).long()
+    corr_t = (corr if isinstance(corr, torch.Tensor) else torch.as_tensor(np.asarray(corr))).to(device).long()
     src_vis, src_p2n = _node_visibility(nodes[:n_src], src, corr_t[:, 0])
     tgt_vis, tgt_p2n = _node_visibility(nodes[n_src:], tgt, corr_t[:, 1])
     out["node_overlap_gt"] = torch.cat([src_vis, tgt_vis])
