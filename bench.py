@@ -33,13 +33,26 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-from pcrcg_amd import indoor_config, ops, synthetic  # noqa: E402
+from pcrcg_amd import indoor_config, kitti_config, ops, synthetic  # noqa: E402
 from pcrcg_amd.architectures import KPFCNN  # noqa: E402
 from pcrcg_amd.pipeline import PairPipeline  # noqa: E402
 from pcrcg_amd.sharding import pair_seeds_for_rank  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-RECIPE = "S30k"
+RECIPE = "S30k"       # the workload BASELINE.json's metric is quoted on (configs[1]); --workload picks a secondary one
+WORKLOADS = {
+    "S30k": "S30k: 2x30000-pt shell pairs (3DMatch-shaped), indoor hyper-parameters",
+    "U30k": "U30k (secondary): 2x30000 uniform-random points in a 1.07 m cube, indoor hyper-parameters",
+    "K120k": "K120k (secondary, configs[4]): 2x120000-pt KITTI-shaped slabs, KITTI hyper-parameters",
+}
+
+
+def make_pair(recipe, seed):
+    if recipe == "U30k":
+        return synthetic.uniform_pair(30000, 1.07, seed)
+    if recipe == "K120k":
+        return synthetic.slab_pair(120000, seed)
+    return synthetic.pair(recipe, seed)
 
 
 def kpconv_algorithmic_bytes(nq, h, cin, cout, e=4):
@@ -51,7 +64,7 @@ def cpu_baseline(cfg, state_dict, limits):
     """CPU oracle on one S30k pair: front end single-threaded C, model torch-CPU on all cores."""
     from oracle import frontend as OF
     from oracle import model_ref as MR
-    src, tgt = synthetic.pair(RECIPE, 12345)
+    src, tgt = make_pair(RECIPE, 12345)
     pts = np.concatenate([src, tgt])
     lens = np.array([len(src), len(tgt)], np.int32)
     t0 = time.perf_counter()
@@ -86,7 +99,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="S30k")
     args = ap.parse_args()
+    global RECIPE
+    RECIPE = args.workload
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,7 +118,7 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    cfg = indoor_config()
+    cfg = kitti_config() if RECIPE == "K120k" else indoor_config()
     limits = synthetic.LIMITS[RECIPE]
     torch.manual_seed(0)
     np.random.seed(0)
@@ -115,7 +131,7 @@ def main():
     seeds = pair_seeds_for_rank(total, rank, world)
     pool = {}
     for s in sorted(set(seeds)):
-        src, tgt = synthetic.pair(RECIPE, s % 16)     # 16 distinct pairs per rank, cycled
+        src, tgt = make_pair(RECIPE, s % 16)          # 16 distinct pairs per rank, cycled
         if s % 16 not in pool:
             pool[s % 16] = (torch.from_numpy(np.concatenate([src, tgt])).to(dev),
                             torch.tensor([len(src), len(tgt)], dtype=torch.int32, device=dev))
@@ -210,7 +226,8 @@ def main():
         if os.path.exists(pmc_path):        # HBM bytes per launch from the committed rocprofv3 PMC passes
             traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
         line = {
-            "metric": "fragment-pairs/s KPFCNN+GCN fwd, 30k-pt pairs",
+            "metric": "fragment-pairs/s KPFCNN+GCN fwd, 30k-pt pairs" if RECIPE == "S30k"
+                      else f"fragment-pairs/s KPFCNN+GCN fwd, {RECIPE} pairs (secondary workload)",
             "value": round(args.steps * world / elapsed, 3),
             "unit": "fragment-pairs/s",
             "n_gpus": world,
@@ -223,8 +240,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "S30k: 2x30000-pt shell pairs (3DMatch-shaped), pyramid build + KPFCNN+GCN "
-                                   "forward, indoor hyper-parameters, random-init full-width weights, 1 pair/GPU/step; "
+            "config": {"workload": WORKLOADS[RECIPE] + ", pyramid build + KPFCNN+GCN "
+                                   "forward, random-init full-width weights, 1 pair/GPU/step; "
                                    "pyramids are built by a front-end thread on its own HIP stream, forwards are enqueued by "
                                    "one worker thread per model stream (3 streams); the timed region starts and ends with "
                                    "an empty pipeline",

@@ -19,6 +19,7 @@ LIMITS = {
     "C1": [24, 37, 45, 48],
     "S30k": [43, 42, 47, 43],
     "K120k": [62, 58, 60, 60],
+    "U30k": [29, 65, 75, 63],      # scripts/calib_u30k.py (pcrcg_amd.pyramid.calibrate_neighbors on the GPU)
 }
 
 
@@ -46,6 +47,13 @@ def pair(recipe="S30k", seed=0):
     src = shell(rng, n, side, jitter)
     tgt = shell(rng, n, side, jitter)
     return src, tgt
+
+
+def uniform_pair(n=30000, side=1.07, seed=0):
+    """U30k: uniform-random points in a cube (the north_star's wording; SURVEY.md 8d "uniform-volume
+    alternative"): denser neighbourhoods than a surface scan and an 8x decay per level."""
+    rng = np.random.RandomState(seed)
+    return (rng.rand(n, 3) * side).astype(np.float32), (rng.rand(n, 3) * side).astype(np.float32)
 
 
 def slab_pair(n=120000, seed=0, extent=104.0, height=0.6):
