@@ -37,6 +37,20 @@ int pcrcg_gemm_f32_ex(const float* a, int lda, int trans_a, const float* b, int 
 int pcrcg_kpconv_backward_dx(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h,
                              int ld_idx, const float* d_wf, int cin, const float* kp, float extent, float* dx,
                              void* stream);
+/* Whole-op KPConv for a C caller (KPConv.forward and its autograd, ref:models/blocks.py:229-374):
+ *   forward : out [nq,cout] = ((aggregate of x) @ weights [15*cin, cout]) / n_q; `ws` (pcrcg_kpconv_forward_ws_bytes)
+ *             keeps the aggregated features and 1/n_q and must be handed unchanged to the backward call;
+ *   backward: dweights [15*cin, cout] (overwritten) and dx [ns,cin] (ACCUMULATED into, zero it first); either may be
+ *             NULL; `ws` = pcrcg_kpconv_backward_ws_bytes scratch. */
+size_t pcrcg_kpconv_forward_ws_bytes(int nq, int ns, int cin);
+int pcrcg_kpconv_forward(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h, int ld_idx,
+                         const float* x, int cin, const float* kp, float extent, const float* weights, int cout,
+                         float* out, int ld_out, void* ws, size_t ws_bytes, void* stream);
+size_t pcrcg_kpconv_backward_ws_bytes(int nq, int cin, int cout);
+int pcrcg_kpconv_backward(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h, int ld_idx,
+                          int cin, const float* kp, float extent, const float* weights, int cout, const float* dy,
+                          int ld_dy, const void* fwd_ws, size_t fwd_ws_bytes, float* dx, float* dweights, void* ws,
+                          size_t ws_bytes, void* stream);
 /* max_pool (ref:models/blocks.py:86-102): dx[idx[q,h*], c] += dy[q,c], h* = first neighbour attaining y[q,c]. */
 int pcrcg_gather_max_backward(const float* x, int ns, int c, const int64_t* idx, int nq, int h, int ld_idx,
                               const float* y, const float* dy, float* dx, void* stream);

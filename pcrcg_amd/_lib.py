@@ -67,6 +67,13 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p]),
     "pcrcg_kpconv_backward_dx": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                          c_void_p, c_float, c_void_p, c_void_p]),
+    "pcrcg_kpconv_forward_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pcrcg_kpconv_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                     c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_kpconv_backward_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pcrcg_kpconv_backward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_float,
+                                      c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
     "pcrcg_gather_max_backward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                           c_void_p, c_void_p]),
     "pcrcg_gather_first_backward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -459,3 +459,85 @@ extern "C" int pcrcg_edgeconv_backward(const float* ctr, const float* nbr, const
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
+
+// ---- whole-op entry points (the exports SURVEY.md 8b recommends for a C caller) ---------------------
+extern "C" size_t pcrcg_kpconv_forward_ws_bytes(int nq, int ns, int cin) {
+    return pcrcg_kpconv_ws_bytes(ns) + carve_bytes((size_t)(nq > 0 ? nq : 1) * PCRCG_KPOINTS * (size_t)cin, 4) +
+           carve_bytes((size_t)(nq > 0 ? nq : 1), 4);
+}
+
+// Layout of `ws` (kept by the caller until the backward call): [ aggregate scratch | wf [nq,15*cin] | inv_n [nq] ]
+static void kpconv_ws_layout(void* ws, size_t ws_bytes, int nq, int ns, int cin, Carver* cv, void** agg, size_t* agg_bytes,
+                             float** wf, float** inv_n) {
+    *agg_bytes = pcrcg_kpconv_ws_bytes(ns);
+    *agg = cv->take<char>(*agg_bytes);
+    *wf = cv->take<float>((size_t)(nq > 0 ? nq : 1) * PCRCG_KPOINTS * (size_t)cin);
+    *inv_n = cv->take<float>((size_t)(nq > 0 ? nq : 1));
+}
+
+extern "C" int pcrcg_kpconv_forward(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h,
+                                    int ld_idx, const float* x, int cin, const float* kp, float extent,
+                                    const float* weights, int cout, float* out, int ld_out, void* ws, size_t ws_bytes,
+                                    void* stream) {
+    PCRCG_CHECK_ARG(nq >= 0 && cin >= 1 && cout >= 1 && ld_out >= cout && ws);
+    if (nq == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(weights && out);
+    Carver cv(ws, ws_bytes);
+    void* agg; size_t agg_bytes; float *wf, *inv_n;
+    kpconv_ws_layout(ws, ws_bytes, nq, ns, cin, &cv, &agg, &agg_bytes, &wf, &inv_n);
+    PCRCG_CHECK_WS(cv);
+    PCRCG_PROPAGATE(pcrcg_kpconv_aggregate(q_pts, nq, s_pts, ns, idx, h, ld_idx, x, cin, kp, extent, wf, inv_n, agg,
+                                           agg_bytes, stream));
+    return pcrcg_gemm_f32(wf, PCRCG_KPOINTS * cin, weights, cout, 0, out, ld_out, nq, cout, PCRCG_KPOINTS * cin, inv_n,
+                          nullptr, stream);
+}
+
+extern "C" size_t pcrcg_kpconv_backward_ws_bytes(int nq, int cin, int cout) {
+    return carve_bytes((size_t)(nq > 0 ? nq : 1) * PCRCG_KPOINTS * (size_t)cin, 4) +
+           carve_bytes((size_t)(nq > 0 ? nq : 1) * (size_t)cout, 4);
+}
+
+namespace pcrcg {
+namespace {
+__global__ void __launch_bounds__(256) k_scale_rows(const float* __restrict__ src, int ld_src, const float* __restrict__ s,
+                                                     float* __restrict__ dst, long total, int cols) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const long r = t / cols;
+    dst[t] = src[r * ld_src + (t - r * cols)] * s[r];
+}
+}  // namespace
+}  // namespace pcrcg
+
+extern "C" int pcrcg_kpconv_backward(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h,
+                                     int ld_idx, int cin, const float* kp, float extent, const float* weights, int cout,
+                                     const float* dy, int ld_dy, const void* fwd_ws, size_t fwd_ws_bytes, float* dx,
+                                     float* dweights, void* ws, size_t ws_bytes, void* stream) {
+    PCRCG_CHECK_ARG(nq >= 0 && ns >= 1 && cin >= 1 && cout >= 1 && ld_dy >= cout && fwd_ws && ws);
+    PCRCG_CHECK_ARG(weights && dy);
+    hipStream_t st = as_stream(stream);
+    const int kc = PCRCG_KPOINTS * cin;
+    if (nq == 0) {
+        if (dweights) PCRCG_CHECK_HIP(hipMemsetAsync(dweights, 0, (size_t)kc * cout * 4, st));
+        return PCRCG_OK;
+    }
+    Carver fcv(const_cast<void*>(fwd_ws), fwd_ws_bytes);
+    void* agg; size_t agg_bytes; float *wf, *inv_n;
+    kpconv_ws_layout(const_cast<void*>(fwd_ws), fwd_ws_bytes, nq, ns, cin, &fcv, &agg, &agg_bytes, &wf, &inv_n);
+    PCRCG_CHECK_WS(fcv);
+    Carver cv(ws, ws_bytes);
+    float* d_wf = cv.take<float>((size_t)nq * kc);
+    float* dys = cv.take<float>((size_t)nq * cout);
+    PCRCG_CHECK_WS(cv);
+    if (dweights) {                               // dW = wf^T @ (dy / n)
+        const long total = (long)nq * cout;
+        hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, ld_dy, inv_n, dys,
+                           total, cout);
+        PCRCG_PROPAGATE(pcrcg_gemm_f32_ex(wf, kc, 1, dys, cout, 0, dweights, cout, kc, cout, nq, nullptr, nullptr, stream));
+    }
+    if (dx) {                                     // d wf = (dy / n) @ W^T, then scatter through the influence weights
+        PCRCG_PROPAGATE(pcrcg_gemm_f32(dy, ld_dy, weights, cout, 1, d_wf, kc, nq, kc, cout, inv_n, nullptr, stream));
+        PCRCG_PROPAGATE(pcrcg_kpconv_backward_dx(q_pts, nq, s_pts, ns, idx, h, ld_idx, d_wf, cin, kp, extent, dx, stream));
+    }
+    return PCRCG_OK;
+}

@@ -141,3 +141,45 @@ def test_edge_conv_grads(cuda, n, c, k):
     y0.backward(dy.double())
     assert rel(y, y0) < TOL
     assert rel(c1.grad, c0.grad) < TOL and rel(n1.grad, n0.grad) < TOL
+
+
+def test_kpconv_whole_op_c_abi_matches_autograd_path(cuda, mini):
+    """pcrcg_kpconv_forward / pcrcg_kpconv_backward called the way a C host would (raw pointers, caller
+    workspaces) give the same output and gradients as the autograd wrappers."""
+    import ctypes
+    from pcrcg_amd import _lib
+    from pcrcg_amd.kernel_points import load_kernels
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    cin, cout, level = 64, 48, 1
+    s_pts = mini["points"][level].to(cuda)
+    q_pts = mini["points"][level + 1].to(cuda)
+    idx = mini["pools"][level].to(cuda).contiguous()
+    kp = torch.tensor(load_kernels(0.125, 15, dimension=3, fixed="center"), dtype=torch.float32, device=cuda)
+    x = torch.randn(s_pts.shape[0], cin, generator=g).to(cuda)
+    w = (torch.randn(15, cin, cout, generator=g) * 0.2).to(cuda)
+    dy = torch.randn(q_pts.shape[0], cout, generator=g).to(cuda)
+    nq, h, ns = idx.shape[0], idx.shape[1], s_pts.shape[0]
+    stream = torch.cuda.current_stream().cuda_stream
+    fwd_bytes = L.pcrcg_kpconv_forward_ws_bytes(nq, ns, cin)
+    fwd_ws = torch.empty(fwd_bytes, dtype=torch.uint8, device=cuda)
+    out = torch.empty(nq, cout, device=cuda)
+    rc = L.pcrcg_kpconv_forward(q_pts.data_ptr(), nq, s_pts.data_ptr(), ns, idx.data_ptr(), h, h, x.data_ptr(), cin,
+                                kp.data_ptr(), 0.1, w.data_ptr(), cout, out.data_ptr(), cout, fwd_ws.data_ptr(), fwd_bytes,
+                                stream)
+    assert rc == 0, L.pcrcg_last_error()
+    bwd_bytes = L.pcrcg_kpconv_backward_ws_bytes(nq, cin, cout)
+    bwd_ws = torch.empty(bwd_bytes, dtype=torch.uint8, device=cuda)
+    dx, dw = torch.zeros(ns, cin, device=cuda), torch.empty(15 * cin, cout, device=cuda)
+    rc = L.pcrcg_kpconv_backward(q_pts.data_ptr(), nq, s_pts.data_ptr(), ns, idx.data_ptr(), h, h, cin, kp.data_ptr(), 0.1,
+                                 w.data_ptr(), cout, dy.data_ptr(), cout, fwd_ws.data_ptr(), fwd_bytes, dx.data_ptr(),
+                                 dw.data_ptr(), bwd_ws.data_ptr(), bwd_bytes, stream)
+    assert rc == 0, L.pcrcg_last_error()
+    x1, w1 = _leaf(x), _leaf(w)
+    y = AG.kpconv(x1, w1, q_pts, s_pts, idx, kp, 0.1)
+    y.backward(dy)
+    assert rel(out, y) < 1e-6 and rel(dw.reshape(15, cin, cout), w1.grad) < 1e-5 and rel(dx, x1.grad) < 1e-5
+    # too small a workspace is refused before any launch
+    assert L.pcrcg_kpconv_forward(q_pts.data_ptr(), nq, s_pts.data_ptr(), ns, idx.data_ptr(), h, h, x.data_ptr(), cin,
+                                  kp.data_ptr(), 0.1, w.data_ptr(), cout, out.data_ptr(), cout, fwd_ws.data_ptr(), 1024,
+                                  stream) == -2
