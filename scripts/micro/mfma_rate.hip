@@ -6,6 +6,8 @@
 //   mode 4: as 3, B operand read as 4 x ds_read_b32 with row stride 68 floats (the [K,N] weight image)
 //   mode 5: as 3, plus 4 x ds_write_b128 per thread and step (register -> LDS staging of the next tile)
 //   mode 6: as 5, plus 4 x global_load_dwordx4 per thread and step from a 230 MB array (the A / B stream)
+//   mode 7: as 3, plus 4 x global_load_lds_dwordx4 per thread and step (LDS-DMA: same bytes as mode 6, no
+//           VGPR round trip and no ds_write)
 // Build: hipcc --offload-arch=gfx950 -O3 -o mfma_rate mfma_rate.hip ; run: ./mfma_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -26,12 +28,21 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, const float4* __
     float4 stage[4] = {make_float4(a, b, a, b), make_float4(a, b, a, b), make_float4(a, b, a, b), make_float4(a, b, a, b)};
     long gpos = ((long)blockIdx.x * 977 + tid) % (nsrc - 4 * 256 * 2);
     for (int it = 0; it < iters; ++it) {
-        if (MODE >= 5) {
+        if (MODE == 7) {
+            float* dst = &lds[4 * 64 * 36 + (it & 1) * 4608];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + gpos + u * 256),
+                                                 (__attribute__((address_space(3))) void*)(dst + ((tid >> 6) * 4 + u) * 256), 16, 0, 0);
+            gpos += 1024 * 64;
+            if (gpos >= nsrc - 2048) gpos -= nsrc - 4096;
+        }
+        if (MODE == 5 || MODE == 6) {
             float* dst = &lds[4 * 64 * 36 + (it & 1) * 4608];
 #pragma unroll
             for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(&dst[(tid + u * 256) * 4 % 4604]) = stage[u];
         }
-        if (MODE >= 6) {
+        if (MODE == 6) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) stage[u] = src[gpos + u * 256];
             gpos += 1024 * 64;
@@ -100,6 +111,7 @@ int main() {
         run<4>(bpc, 2000);
         run<5>(bpc, 2000);
         run<6>(bpc, 2000);
+        run<7>(bpc, 2000);
     }
     return 0;
 }
