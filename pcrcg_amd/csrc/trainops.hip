@@ -198,7 +198,23 @@ __global__ void __launch_bounds__(256) k_in_bwd_partial(const float* __restrict_
     double a = 0.0, b = 0.0;
     if (ch < c) {
         const float mean = stats[2 * ch], rstd = stats[2 * ch + 1];
-        for (long r = r0 + rl; r < r1; r += 4) {
+        long r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {   // four independent row pairs in flight per thread
+            float xv[4], gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xv[u] = x[(r + 4 * u) * ldx + ch];
+                gv[u] = dy[(r + 4 * u) * ld_dy + ch];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float xh = (xv[u] - mean) * rstd;
+                const float g = gv[u] * (xh > 0.f ? 1.0f : slope);
+                a += (double)g;
+                b += (double)g * (double)xh;
+            }
+        }
+        for (; r < r1; r += 4) {
             const float xh = (x[r * ldx + ch] - mean) * rstd;
             const float g = dy[r * ld_dy + ch] * (xh > 0.f ? 1.0f : slope);
             a += (double)g;
@@ -247,6 +263,29 @@ __global__ void __launch_bounds__(256) k_in_bwd_apply(const float* __restrict__ 
     const float xh = (x[r * ldx + ch] - stats[2 * ch]) * rstd;
     const float g = dy[r * ld_dy + ch] * (xh > 0.f ? 1.0f : slope);
     dx[r * ld_dx + ch] = rstd * (g - means[2 * ch] - xh * means[2 * ch + 1]);
+}
+
+// float4 variant: c, ldx, ld_dy, ld_dx multiples of 4 and 16-byte aligned bases
+__global__ void __launch_bounds__(256) k_in_bwd_apply4(const float* __restrict__ x, long total4, int c4, int ldx,
+                                                        const float* __restrict__ stats, const float* __restrict__ dy,
+                                                        int ld_dy, float slope, const float* __restrict__ means,
+                                                        float* __restrict__ dx, int ld_dx) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total4) return;
+    const long r = t / c4;
+    const int q = (int)(t - r * c4);
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + 4 * q);
+    const float4 gv = *reinterpret_cast<const float4*>(dy + r * ld_dy + 4 * q);
+    const float4 s0 = *reinterpret_cast<const float4*>(stats + 8 * q), s1 = *reinterpret_cast<const float4*>(stats + 8 * q + 4);
+    const float4 m0 = *reinterpret_cast<const float4*>(means + 8 * q), m1 = *reinterpret_cast<const float4*>(means + 8 * q + 4);
+    auto one = [&](float xe, float ge, float mean, float rstd, float mg, float mgx) {
+        const float xh = (xe - mean) * rstd;
+        const float g = ge * (xh > 0.f ? 1.0f : slope);
+        return rstd * (g - mg - xh * mgx);
+    };
+    const float4 o = make_float4(one(xv.x, gv.x, s0.x, s0.y, m0.x, m0.y), one(xv.y, gv.y, s0.z, s0.w, m0.z, m0.w),
+                                 one(xv.z, gv.z, s1.x, s1.y, m1.x, m1.y), one(xv.w, gv.w, s1.z, s1.w, m1.z, m1.w));
+    *reinterpret_cast<float4*>(dx + r * ld_dx + 4 * q) = o;
 }
 
 // ---- softmax backward: ds = scale * p * (dp - sum_j p*dp), one wavefront per row -----------------
@@ -420,8 +459,15 @@ extern "C" int pcrcg_instnorm_backward(const float* x, int n, int c, int ldx, co
                        slope, partial);
     hipLaunchKernelGGL(k_in_bwd_final, dim3((c + 3) / 4), dim3(256), 0, st, partial, chunks, c, (double)n, means);
     const long total = (long)n * c;
-    hipLaunchKernelGGL(k_in_bwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, total, c, ldx, stats,
-                       dy, ld_dy, slope, means, dx, ld_dx);
+    const bool vec = (c % 4 == 0) && (ldx % 4 == 0) && (ld_dy % 4 == 0) && (ld_dx % 4 == 0) &&
+                     (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) |
+                        reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(k_in_bwd_apply4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, x, total / 4,
+                           c / 4, ldx, stats, dy, ld_dy, slope, means, dx, ld_dx);
+    else
+        hipLaunchKernelGGL(k_in_bwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, total, c, ldx,
+                           stats, dy, ld_dy, slope, means, dx, ld_dx);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
