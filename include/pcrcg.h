@@ -237,6 +237,11 @@ typedef struct pcrcg_block {
     const float* kp;     /* [15,3]  ...KPConv.kernel_points */
     const float* kp_w;   /* [15*cin, cout]  ...KPConv.weights */
     const float* kp_wt;  /* [cout, 15*cin]  K-contiguous copy for pcrcg_kpconv_fused, or NULL */
+    const float* kp_w_pad; /* [15*cin_pad, cout]: kp_w with the input channels zero-padded to cin_pad (a multiple of
+                              4), or NULL.  Set when cin % 4 != 0 (PCR-CG's 129-channel first layer,
+                              ref:models/architectures.py:195-514): the runner pads the features likewise, so the
+                              MFMA gather kernel applies instead of the scalar fallback. */
+    int cin_pad;
     const float* unary1; /* [mid, in] or NULL (nn.Identity) */
     const float* unary2; /* [out, mid] */
     const float* shortcut; /* [out, in] or NULL (nn.Identity) */

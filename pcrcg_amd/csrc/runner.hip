@@ -129,14 +129,31 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
         return;
     }
     const size_t m = c.mark();
-    Mat wf = c.mat(nq, PCRCG_KPOINTS * x.cols);
+    // channel counts that are not a multiple of 4 (the 129-channel PCR-CG input): zero-padded copy of the
+    // features + zero-padded weights, so that the MFMA gather kernel applies (zeros change neither the sums nor
+    // the neighbour count of the normaliser)
+    const float* xp = x.p;
+    const float* w = blk.kp_w;
+    int cin = x.cols;
+    if (blk.kp_w_pad && blk.cin_pad > x.cols) {
+        cin = blk.cin_pad;
+        Mat pad = c.mat(x.rows, cin);
+        if (c.live()) {
+            c.check(hipMemsetAsync(pad.p, 0, sizeof(float) * (size_t)x.rows * cin, c.st) == hipSuccess ? PCRCG_OK
+                                                                                                       : PCRCG_ELAUNCH);
+            c.check(pcrcg_copy2d(x.p, x.ld, pad.p, cin, x.rows, x.cols, c.st));
+        }
+        xp = pad.p;
+        w = blk.kp_w_pad;
+    }
+    Mat wf = c.mat(nq, PCRCG_KPOINTS * cin);
     float* inv_n = static_cast<float*>(c.raw(sizeof(float) * (nq > 0 ? nq : 1)));
     const size_t wsb = pcrcg_kpconv_ws_bytes(ns);
     void* ws = c.raw(wsb);
     if (c.live()) {
-        c.check(pcrcg_kpconv_aggregate(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, x.p, x.cols, blk.kp, blk.extent,
+        c.check(pcrcg_kpconv_aggregate(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, xp, cin, blk.kp, blk.extent,
                                        wf.p, inv_n, ws, wsb, c.st));
-        c.check(pcrcg_gemm_f32_colstats(wf.p, wf.ld, blk.kp_w, y.cols, 0, y.p, y.ld, nq, y.cols, wf.cols, inv_n, nullptr,
+        c.check(pcrcg_gemm_f32_colstats(wf.p, wf.ld, w, y.cols, 0, y.p, y.ld, nq, y.cols, wf.cols, inv_n, nullptr,
                                         st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr,
                                         c.st));
     }

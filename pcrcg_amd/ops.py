@@ -218,6 +218,13 @@ def kpconv(q_pts, s_pts, idx, x, kernel_points, weights, extent):
     kdim = kp.shape[0]
     if kdim != 15:
         raise RuntimeError("pcrcg_amd.kpconv: only 15 kernel points are supported")
+    if cin % 4 != 0 and cin > 4:
+        # e.g. PCR-CG's 129-channel first layer: zero-pad the channels so that the MFMA gather kernel applies
+        # (zeros change neither the sums nor the neighbour count of the normaliser)
+        pad = (-cin) % 4
+        x = torch.nn.functional.pad(x, (0, pad))
+        weights = torch.nn.functional.pad(weights, (0, 0, 0, pad))
+        cin += pad
     wf = torch.empty((nq, kdim * cin), dtype=_F32, device=x.device)
     inv_n = torch.empty(nq, dtype=_F32, device=x.device)
     nbytes = L.pcrcg_kpconv_ws_bytes(ns)

@@ -25,7 +25,8 @@ _fp = ctypes.c_void_p
 class Block(ctypes.Structure):
     _fields_ = [("type", ctypes.c_int), ("layer", ctypes.c_int), ("strided", ctypes.c_int),
                 ("in_dim", ctypes.c_int), ("out_dim", ctypes.c_int), ("mid_dim", ctypes.c_int),
-                ("extent", ctypes.c_float), ("kp", _fp), ("kp_w", _fp), ("kp_wt", _fp), ("unary1", _fp), ("unary2", _fp),
+                ("extent", ctypes.c_float), ("kp", _fp), ("kp_w", _fp), ("kp_wt", _fp), ("kp_w_pad", _fp),
+                ("cin_pad", ctypes.c_int), ("unary1", _fp), ("unary2", _fp),
                 ("shortcut", _fp), ("mlp", _fp), ("mlp_ld", ctypes.c_int)]
 
 
@@ -101,6 +102,17 @@ class Runner:
             return None
         return self._w(kp.weights.data.reshape(-1, kp.out_channels).t())
 
+    def _kp_w_pad(self, blk, kp):
+        """Weights with the input channels zero-padded to a multiple of 4 (see pcrcg_block.kp_w_pad)."""
+        cin = kp.in_channels
+        if cin % 4 == 0 or cin < 4:
+            blk.kp_w_pad, blk.cin_pad = None, 0
+            return
+        cp = (cin + 3) // 4 * 4
+        w = torch.zeros((kp.weights.shape[0], cp, kp.out_channels), dtype=torch.float32, device=kp.weights.device)
+        w[:, :cin].copy_(kp.weights.data)
+        blk.kp_w_pad, blk.cin_pad = self._w(w), cp
+
     def _fill_block(self, blk, mod):
         if isinstance(mod, SimpleBlock):
             blk.type, blk.layer, blk.strided = BLK_SIMPLE, mod.layer_ind, int("strided" in mod.block_name)
@@ -109,6 +121,7 @@ class Runner:
             blk.extent = float(kp.KP_extent)
             blk.kp, blk.kp_w = self._w(kp.kernel_points.data), self._w(kp.weights.data)
             blk.kp_wt = self._kp_wt(kp)
+            self._kp_w_pad(blk, kp)
         elif isinstance(mod, ResnetBottleneckBlock):
             blk.type, blk.layer, blk.strided = BLK_RESNETB, mod.layer_ind, int("strided" in mod.block_name)
             kp = mod.KPConv
@@ -116,6 +129,7 @@ class Runner:
             blk.extent = float(kp.KP_extent)
             blk.kp, blk.kp_w = self._w(kp.kernel_points.data), self._w(kp.weights.data)
             blk.kp_wt = self._kp_wt(kp)
+            self._kp_w_pad(blk, kp)
             blk.unary1 = self._w(mod.unary1.mlp.weight.data) if isinstance(mod.unary1, UnaryBlock) else None
             blk.unary2 = self._w(mod.unary2.mlp.weight.data)
             blk.shortcut = (self._w(mod.unary_shortcut.mlp.weight.data)

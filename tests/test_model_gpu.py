@@ -410,3 +410,27 @@ def test_kitti_shaped_k120k_forward_properties(cuda):
     assert (out["feats_f"].norm(dim=1) - 1).abs().max() < 1e-4
     for k in ("scores_overlap", "scores_saliency"):
         assert out[k].min() >= 0 and out[k].max() <= 1
+
+
+def test_image_feature_width_129_input(cuda, mini):
+    """PCR-CG's image-feature injection only changes the first KPConv's Cin from 1 to 129
+    (ref:models/architectures.py:195-514).  With the [N,129] feature matrix supplied by the caller the whole
+    forward matches the oracle (runner and op-by-op path; channels are zero-padded to 132 internally)."""
+    cfg = indoor_config(first_feats_dim=32, gnn_feats_dim=64, in_feats_dim=129)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = KPFCNN(cfg).eval()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(cuda)
+    batch_cpu, _ = mini
+    g = torch.Generator().manual_seed(1)
+    batch_cpu = dict(batch_cpu)
+    batch_cpu["features"] = torch.rand(batch_cpu["points"][0].shape[0], 129, generator=g)
+    ref = MR.kpfcnn_forward(sd, dict(cfg), batch_cpu)
+    batch = _to(batch_cpu, cuda)
+    with torch.no_grad():
+        out_runner = net(batch)
+        out_ops = net.forward_ops(batch)
+    for k in ref:
+        assert rel(out_runner[k], ref[k]) < TOL, k
+        assert rel(out_ops[k], ref[k]) < TOL, k
