@@ -68,6 +68,8 @@ __global__ void __launch_bounds__(256) k_row_positive(const float* __restrict__ 
     if (lane == 0) pos[row] = s > 0.0f ? 1 : 0;
 }
 
+struct __attribute__((packed, aligned(4))) P3 { float x, y, z; };
+
 template <int NB>  // 64-channel blocks handled per wavefront (one float4 per lane and block)
 __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
     const float* __restrict__ q_pts, int nq, const float* __restrict__ s_pts, int ns,
@@ -100,7 +102,8 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
             const long long iv = idx[(long)q * ld_idx + (h < H ? h : H - 1)];   // branch-free, clamped
             const int i = (h < H && iv >= 0 && iv < ns) ? (int)iv : -1;
             const long ic = i >= 0 ? i : 0;
-            const float px = s_pts[3 * ic] - qx, py = s_pts[3 * ic + 1] - qy, pz = s_pts[3 * ic + 2] - qz;
+            const P3 sp = *reinterpret_cast<const P3*>(s_pts + 3 * ic);   // one global_load_dwordx3
+            const float px = sp.x - qx, py = sp.y - qy, pz = sp.z - qz;
             if (chunk == 0) npos += __popcll(__ballot(i >= 0 && pos[ic] != 0));
             const int hn = H - hc < 64 ? H - hc : 64;
             // STEPS groups of 4 neighbours at a time: all their row reads are issued before the first
@@ -166,7 +169,6 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
 // loads, then all gathers, in flight together; the 15 partial sums are combined with two butterfly
 // shuffles.  Kernel points live in SGPRs, loads are branch-free (clamped addresses + select).
 constexpr int C1_PARTS = 4, C1_BATCH = 6;
-struct __attribute__((packed, aligned(4))) P3 { float x, y, z; };
 __global__ void __launch_bounds__(256) k_kpconv_c1(
     const float* __restrict__ q_pts, int nq, const float* __restrict__ s_pts, int ns,
     const long long* __restrict__ idx, int H, int ld_idx, const float* __restrict__ x, const float* __restrict__ kp,
