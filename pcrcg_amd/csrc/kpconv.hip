@@ -76,10 +76,15 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
     const long long* __restrict__ idx, int H, int ld_idx, const float* __restrict__ x, int cin,
     const float* __restrict__ kp, float extent, const unsigned char* __restrict__ pos, float* __restrict__ wf,
     float* __restrict__ inv_n, int nchunk) {
-    constexpr int STEPS = NB >= 4 ? 4 : 8;   // groups of 4 neighbours whose row reads are in flight together
+    // groups of 4 neighbours whose row reads are in flight together.  The kernel is bound by its dependent load
+    // chain, so occupancy beats deeper batches: 4 groups (76 VGPRs, 6 wavefronts/SIMD) measured best for NB = 1
+    // (8 groups: 96 VGPRs / 5 waves, -9 %; 12 groups: 136 / 3 waves, -40 %; 2 groups: 68 / 7 waves, -4 %)
+    constexpr int STEPS = NB >= 4 ? 2 : 4;
     const int lane = threadIdx.x & 63;
     const int hsub = lane >> 4, j = lane & 15;
-    const long gw = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    // the wavefront index is uniform: telling the compiler so moves the item's query, its coordinates and the row
+    // base addresses into SGPRs (fewer VGPRs -> more wavefronts per SIMD, which is what this kernel is short of)
+    const long gw = (long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long nw = (long)gridDim.x * kWavesPerBlock;
     const long items = (long)nq * nchunk;
     const bool jvalid = j < K;

@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_gather_max(const float*
                                                                      const long long* __restrict__ idx, int nq, int h,
                                                                      int ld_idx, float* __restrict__ out, int nchunk) {
     const int lane = threadIdx.x & 63;
-    const long item = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long item = (long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (item >= (long)nq * nchunk) return;
     const int q = (int)(item / nchunk), chunk = (int)(item - (long)q * nchunk);
     const long long* row = idx + (long)q * ld_idx;
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) k_gather_first(const float* __restrict__ 
                                                        const long long* __restrict__ idx, int nq, int ld_idx,
                                                        float* __restrict__ out, int ld_out) {
     const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int q = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (q >= nq) return;
     const long long i = idx[(long)q * ld_idx];
     const bool real = i >= 0 && i < ns;

@@ -164,7 +164,9 @@ __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
     __shared__ u64 s_list[kQueryWaves][CAP];
     __shared__ int s_excl[kQueryWaves][32];
     __shared__ int s_start[kQueryWaves][32];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wavefront index is uniform: readfirstlane lets the compiler keep the query, its cell and every
+    // per-query address in SGPRs)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int gw = blockIdx.x * kQueryWaves + wave, nw = gridDim.x * kQueryWaves;
     const int ns = g.hdr->ns;
     const double inv_cell = g.hdr->inv_cell;

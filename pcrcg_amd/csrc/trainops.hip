@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) k_kpconv_bwd_dx(const float* __restrict__
                                                         float* __restrict__ dx, int nchunk) {
     const int lane = threadIdx.x & 63;
     const int hsub = lane >> 4, j = lane & 15;
-    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long item = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (item >= (long)nq * nchunk) return;
     const int q = (int)(item / nchunk), chunk = (int)(item - (long)q * nchunk);
     const int cc = chunk * 64 + lane;
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) k_gather_max_bwd(const float* __restrict_
                                                          const float* __restrict__ y, const float* __restrict__ dy,
                                                          float* __restrict__ dx, int nchunk) {
     const int lane = threadIdx.x & 63;
-    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long item = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (item >= (long)nq * nchunk) return;
     const int q = (int)(item / nchunk), chunk = (int)(item - (long)q * nchunk);
     const int cc = chunk * 64 + lane;
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) k_gather_first_bwd(const float* __restric
                                                            const long long* __restrict__ idx, int nq, int ld_idx, int ns,
                                                            float* __restrict__ dx) {
     const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int q = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (q >= nq) return;
     const long long i = idx[(long)q * ld_idx];
     if (i < 0 || i >= ns) return;
