@@ -55,9 +55,13 @@ constexpr int K = PCRCG_KPOINTS;
 constexpr int kWavesPerBlock = 4;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// pos[s] = (sum_c x[s,c] > 0); one wavefront per support row.
+// pos[s] = (sum_c x[s,c] > 0); one wavefront per support row.  Also writes the packed record
+// pk[s] = (x, y, z, pos ? 1 : 0): the gather kernels fetch a neighbour's coordinates and flag with ONE 16-byte
+// gather (one cache line) instead of a 12-byte and a 1-byte gather (two lines) -- random line fetches, not
+// feature bytes, are what loads L2 in this kernel.
 __global__ void __launch_bounds__(256) k_row_positive(const float* __restrict__ x, int ns, int cin,
-                                                       unsigned char* __restrict__ pos) {
+                                                       const float* __restrict__ s_pts, unsigned char* __restrict__ pos,
+                                                       float4* __restrict__ pk) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= ns) return;
@@ -65,7 +69,17 @@ __global__ void __launch_bounds__(256) k_row_positive(const float* __restrict__ 
     for (int c = lane; c < cin; c += 64) s += x[(long)row * cin + c];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-    if (lane == 0) pos[row] = s > 0.0f ? 1 : 0;
+    if (lane == 0) {
+        pos[row] = s > 0.0f ? 1 : 0;
+        pk[row] = make_float4(s_pts[3 * (long)row], s_pts[3 * (long)row + 1], s_pts[3 * (long)row + 2], s > 0.0f ? 1.f : 0.f);
+    }
+}
+
+// Cin == 1: pk[s] = (x, y, z, feature)
+__global__ void __launch_bounds__(256) k_pack_c1(const float* __restrict__ x, int ns, const float* __restrict__ s_pts,
+                                                  float4* __restrict__ pk) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row < ns) pk[row] = make_float4(s_pts[3 * (long)row], s_pts[3 * (long)row + 1], s_pts[3 * (long)row + 2], x[row]);
 }
 
 struct __attribute__((packed, aligned(4))) P3 { float x, y, z; };
@@ -74,7 +88,7 @@ template <int NB>  // 64-channel blocks handled per wavefront (one float4 per la
 __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
     const float* __restrict__ q_pts, int nq, const float* __restrict__ s_pts, int ns,
     const long long* __restrict__ idx, int H, int ld_idx, const float* __restrict__ x, int cin,
-    const float* __restrict__ kp, float extent, const unsigned char* __restrict__ pos, float* __restrict__ wf,
+    const float* __restrict__ kp, float extent, const float4* __restrict__ pk, float* __restrict__ wf,
     float* __restrict__ inv_n, int nchunk) {
     // groups of 4 neighbours whose row reads are in flight together.  The kernel is bound by its dependent load
     // chain, so occupancy beats deeper batches: 4 groups (76 VGPRs, 6 wavefronts/SIMD) measured best for NB = 1
@@ -107,9 +121,9 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
             const long long iv = idx[(long)q * ld_idx + (h < H ? h : H - 1)];   // branch-free, clamped
             const int i = (h < H && iv >= 0 && iv < ns) ? (int)iv : -1;
             const long ic = i >= 0 ? i : 0;
-            const P3 sp = *reinterpret_cast<const P3*>(s_pts + 3 * ic);   // one global_load_dwordx3
+            const float4 sp = pk[ic];                                      // coordinates + row-positive flag
             const float px = sp.x - qx, py = sp.y - qy, pz = sp.z - qz;
-            if (chunk == 0) npos += __popcll(__ballot(i >= 0 && pos[ic] != 0));
+            if (chunk == 0) npos += __popcll(__ballot(i >= 0 && sp.w != 0.f));
             const int hn = H - hc < 64 ? H - hc : 64;
             // STEPS groups of 4 neighbours at a time: all their row reads are issued before the first
             // MFMA needs one (STEPS x NB KiB in flight per wavefront)
@@ -176,7 +190,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
 constexpr int C1_PARTS = 4, C1_BATCH = 6;
 __global__ void __launch_bounds__(256) k_kpconv_c1(
     const float* __restrict__ q_pts, int nq, const float* __restrict__ s_pts, int ns,
-    const long long* __restrict__ idx, int H, int ld_idx, const float* __restrict__ x, const float* __restrict__ kp,
+    const long long* __restrict__ idx, int H, int ld_idx, const float4* __restrict__ pk, const float* __restrict__ kp,
     float extent, float* __restrict__ wf, float* __restrict__ inv_n) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int part = t & (C1_PARTS - 1);
@@ -205,11 +219,11 @@ __global__ void __launch_bounds__(256) k_kpconv_c1(
             const int h = h0 + b * C1_PARTS + part;
             const bool real = h < H && iv[b] >= 0 && iv[b] < ns;
             const long ic = real ? iv[b] : 0;
-            const P3 p = *reinterpret_cast<const P3*>(s_pts + 3 * ic);   // one global_load_dwordx3
+            const float4 p = pk[ic];                                     // one 16-byte gather: coordinates + feature
             nx[b] = p.x - qx;
             ny[b] = p.y - qy;
             nz[b] = p.z - qz;
-            const float v = x[ic];
+            const float v = p.w;
             xv[b] = real ? v : 0.f;
         }
 #pragma unroll
@@ -321,7 +335,10 @@ int pcrcg_profile_kpconv_read(float* ms, int* nq, int* h, int* cin, int* cout, i
     return n;
 }
 
-size_t pcrcg_kpconv_ws_bytes(int ns) { return carve_bytes((size_t)(ns > 0 ? ns : 0) + 1, 1); }
+size_t pcrcg_kpconv_ws_bytes(int ns) {
+    const size_t n = (size_t)(ns > 0 ? ns : 0) + 1;
+    return carve_bytes(n, 1) + carve_bytes(n, sizeof(float4));     // row-positive flags + packed (x, y, z, flag) records
+}
 
 int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx,
                            int h, int ld_idx, const float* x, int cin, const float* kp, float extent,
@@ -333,6 +350,7 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
     PCRCG_CHECK_ARG(ns >= 1);
     Carver cv(ws, ws_bytes);
     unsigned char* pos = cv.take<unsigned char>((size_t)ns + 1);
+    float4* pk = cv.take<float4>((size_t)ns + 1);
     PCRCG_CHECK_WS(cv);
     hipStream_t st = as_stream(stream);
     const long long* idx_ll = reinterpret_cast<const long long*>(idx);
@@ -342,13 +360,14 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
         return (int)(b > max_blocks ? max_blocks : b);
     };
     if (cin == 1) {
+        hipLaunchKernelGGL(k_pack_c1, dim3((ns + 255) / 256), dim3(256), 0, st, x, ns, s_pts, pk);
         KpProfScope prof_scope(st, nq, h, cin, 0, 0);
         hipLaunchKernelGGL(k_kpconv_c1, dim3((int)(((long)nq * C1_PARTS + 255) / 256)), dim3(256), 0, st, q_pts, nq, s_pts, ns, idx_ll, h,
-                           ld_idx, x, kp, extent, wf, inv_n);
+                           ld_idx, pk, kp, extent, wf, inv_n);
         PCRCG_CHECK_LAUNCH();
         return PCRCG_OK;
     }
-    if (ns > 0) hipLaunchKernelGGL(k_row_positive, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, pos);
+    if (ns > 0) hipLaunchKernelGGL(k_row_positive, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, s_pts, pos, pk);
     KpProfScope prof_scope(st, nq, h, cin, 0, 0);   // brackets the gather/aggregate kernel only
     const bool aligned = (cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(wf) & 15) == 0);
@@ -366,7 +385,7 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
     const int blocks = blocks_for((long)nq * nchunk);
 #define LAUNCH(NBV)                                                                                             \
     hipLaunchKernelGGL(k_kpconv_mfma<NBV>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, st, q_pts, nq, s_pts, ns, \
-                       idx_ll, h, ld_idx, x, cin, kp, extent, pos, wf, inv_n, nchunk)
+                       idx_ll, h, ld_idx, x, cin, kp, extent, pk, wf, inv_n, nchunk)
     if (nb == 4) LAUNCH(4);
     else if (nb == 2) LAUNCH(2);
     else LAUNCH(1);
