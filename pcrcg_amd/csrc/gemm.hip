@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float* __restrict__ A, i
     static_assert(A_ITERS >= 1 && B_ITERS >= 1, "tile too small");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     // XCD-aware tile order: workgroups are dispatched round-robin over the 8 XCDs (private L2s), so the
     // linear id is remapped such that each XCD walks a CONTIGUOUS range of tiles (n fastest): the n-tiles
