@@ -10,7 +10,7 @@ collective: weak scaling, one pair per rank per step.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of the
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP start/stop events of every launch of the
 dominant kernel (the KPConv neighbour-gather/aggregate kernel) inside the timed region; `cpu_baseline`
 times the CPU oracle (oracle/: C front end + torch-CPU model, a restatement pinned against the
 reference) on a bounded sample on rank 0 at N=1.
@@ -258,8 +258,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "avg_launch_us": round(k_ms * 1e3 / max(len(events), 1), 2),
                          "algorithmic_bytes_per_pair": int(k_bytes / max(args.steps, 1)),
-                         "note": "achieved/frac are measured inside the timed region, where four HIP streams share "
-                                 "the GPU; `isolated` is the same 11 launches run alone right after it",
+                         "note": "durations are the kernels' own start/stop events (hipExtLaunchKernel); achieved/frac "
+                                 "are measured inside the timed region, where four HIP streams share the GPU; `isolated` is the same 11 launches run alone right after it",
                          "isolated": {"achieved": round(iso_gbs, 1), "frac": round(iso_gbs / HBM_PEAK_GBS, 4),
                                       "avg_launch_us": round(iso_ms * 1e3 / max(len(iso), 1), 2),
                                       "per_launch": iso_rows},

@@ -126,9 +126,10 @@ int pcrcg_kpconv_fused(const float* q_pts, int nq, const float* s_pts, int ns, c
 
 /* Measurement aid for bench.py: when enabled, the gather/aggregate kernel of every
  * pcrcg_kpconv_aggregate call (kind 0) and the fused kernel of every pcrcg_kpconv_fused call (kind 1)
- * are bracketed by HIP events recorded on their own stream; _read waits for them and returns up to
- * `cap` records (milliseconds, nq / h / cin of the launch, cout for kind 1).  Not thread-safe; off by
- * default. */
+ * are launched with HIP start / stop events (hipExtLaunchKernel) on their own stream, i.e. the kernel's own
+ * execution time as rocprofv3 reports it, excluding the time its dispatch waited behind other streams; _read
+ * waits for them and returns up to `cap` records (milliseconds, nq / h / cin of the launch, cout for kind 1).
+ * Safe to call from several host threads; off by default. */
 void pcrcg_profile_kpconv(int enable);
 int pcrcg_profile_kpconv_read(float* ms, int* nq, int* h, int* cin, int* cout, int* kind, int cap);
 

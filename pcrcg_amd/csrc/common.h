@@ -38,8 +38,10 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
 
 constexpr int kWave = 64;
 
-// Optional HIP-event bracket around a KPConv kernel launch (bench.py roofline); see
-// pcrcg_profile_kpconv in include/pcrcg.h.  kind 0 = gather/aggregate kernel, 1 = fused kernel.
+// Optional start / stop events of a KPConv kernel (bench.py roofline); see pcrcg_profile_kpconv in
+// include/pcrcg.h.  The events are handed to hipExtLaunchKernelGGL, so they stamp the kernel's own begin and
+// end (what rocprofv3 reports), not the time its dispatch waited behind other streams.  a/b are NULL when
+// profiling is off (a plain launch).  kind 0 = gather/aggregate kernel, 1 = fused kernel.
 struct KpProfScope {
     hipStream_t st;
     hipEvent_t a, b;

@@ -25,6 +25,8 @@
 #include <mutex>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace pcrcg {
@@ -36,15 +38,13 @@ static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;   // forwards may be enqueued from several host threads
 
 KpProfScope::KpProfScope(hipStream_t s, int nq_, int h_, int cin_, int cout_, int kind_)
-    : st(s), nq(nq_), h(h_), cin(cin_), cout(cout_), kind(kind_), on(g_prof_on) {
+    : st(s), a(nullptr), b(nullptr), nq(nq_), h(h_), cin(cin_), cout(cout_), kind(kind_), on(g_prof_on) {
     if (!on) return;
-    hipEventCreate(&a);
-    hipEventCreate(&b);
-    hipEventRecord(a, st);
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
 }
 KpProfScope::~KpProfScope() {
     if (!on) return;
-    hipEventRecord(b, st);
     std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof.push_back({a, b, nq, h, cin, cout, kind});
 }
@@ -362,13 +362,14 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
     if (cin == 1) {
         hipLaunchKernelGGL(k_pack_c1, dim3((ns + 255) / 256), dim3(256), 0, st, x, ns, s_pts, pk);
         KpProfScope prof_scope(st, nq, h, cin, 0, 0);
-        hipLaunchKernelGGL(k_kpconv_c1, dim3((int)(((long)nq * C1_PARTS + 255) / 256)), dim3(256), 0, st, q_pts, nq, s_pts, ns, idx_ll, h,
-                           ld_idx, pk, kp, extent, wf, inv_n);
+        hipExtLaunchKernelGGL(k_kpconv_c1, dim3((int)(((long)nq * C1_PARTS + 255) / 256)), dim3(256), 0, st, prof_scope.a,
+                              prof_scope.b, 0, q_pts, nq, s_pts, ns, idx_ll, h, ld_idx, (const float4*)pk, kp, extent, wf,
+                              inv_n);
         PCRCG_CHECK_LAUNCH();
         return PCRCG_OK;
     }
     if (ns > 0) hipLaunchKernelGGL(k_row_positive, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, s_pts, pos, pk);
-    KpProfScope prof_scope(st, nq, h, cin, 0, 0);   // brackets the gather/aggregate kernel only
+    KpProfScope prof_scope(st, nq, h, cin, 0, 0);   // start / stop events of the gather/aggregate kernel itself
     const bool aligned = (cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(wf) & 15) == 0);
     if (!aligned) {
@@ -384,8 +385,9 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
     const int nchunk = (nblk + nb - 1) / nb;
     const int blocks = blocks_for((long)nq * nchunk);
 #define LAUNCH(NBV)                                                                                             \
-    hipLaunchKernelGGL(k_kpconv_mfma<NBV>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, st, q_pts, nq, s_pts, ns, \
-                       idx_ll, h, ld_idx, x, cin, kp, extent, pk, wf, inv_n, nchunk)
+    hipExtLaunchKernelGGL(k_kpconv_mfma<NBV>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, st, prof_scope.a,     \
+                          prof_scope.b, 0, q_pts, nq, s_pts, ns, idx_ll, h, ld_idx, x, cin, kp, extent,         \
+                          (const float4*)pk, wf, inv_n, nchunk)
     if (nb == 4) LAUNCH(4);
     else if (nb == 2) LAUNCH(2);
     else LAUNCH(1);

@@ -12,6 +12,8 @@
 //            weights are read straight from L2 as float4s along K from a K-contiguous copy
 //            Wt [Cout, 15*Cin] (no LDS staging: every element is used once per workgroup).
 // Output rows are scaled by 1/n_q (neighbour count with positive feature sum, :369-372).
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace pcrcg {
@@ -179,7 +181,7 @@ int pcrcg_kpconv_fused(const float* q_pts, int nq, const float* s_pts, int ns, c
     PCRCG_CHECK_WS(cv);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(k_row_positive2, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, pos);
-    KpProfScope prof_scope(st, nq, h, cin, cout, 1);   // brackets the fused kernel only
+    KpProfScope prof_scope(st, nq, h, cin, cout, 1);   // start / stop events of the fused kernel itself
     const size_t lds = sizeof(float) * (TQ * ROW + TQ);
     const int blocks = (nq + TQ - 1) / TQ;
     const long long* idx_ll = reinterpret_cast<const long long*>(idx);
@@ -192,8 +194,8 @@ int pcrcg_kpconv_fused(const float* q_pts, int nq, const float* s_pts, int ns, c
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
             configured = true;                                                                              \
         }                                                                                                   \
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, q_pts, nq, s_pts, ns, idx_ll, h, ld_idx, x, cin, \
-                           kp, extent, pos, wt, out, ld_out);                                               \
+        hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, prof_scope.a, prof_scope.b, 0, q_pts, nq, s_pts, \
+                              ns, idx_ll, h, ld_idx, x, cin, kp, extent, (const unsigned char*)pos, wt, out, ld_out); \
     } while (0)
     if (cout == 64) LAUNCH(1);
     else if (cout == 128) LAUNCH(2);
