@@ -183,3 +183,27 @@ def test_kpconv_whole_op_c_abi_matches_autograd_path(cuda, mini):
     assert L.pcrcg_kpconv_forward(q_pts.data_ptr(), nq, s_pts.data_ptr(), ns, idx.data_ptr(), h, h, x.data_ptr(), cin,
                                   kp.data_ptr(), 0.1, w.data_ptr(), cout, out.data_ptr(), cout, fwd_ws.data_ptr(), 1024,
                                   stream) == -2
+
+
+def test_kpconv_more_than_64_neighbours(cuda):
+    """Tables wider than one wavefront (H > 64: the kernels loop over 64-neighbour chunks) -- forward and both
+    gradients against the oracle, on a dense cloud where most rows really have > 64 neighbours."""
+    from pcrcg_amd import ops
+    from pcrcg_amd.kernel_points import load_kernels
+    g = torch.Generator().manual_seed(4)
+    pts = torch.rand(1500, 3, generator=g) * 0.2
+    lens = torch.tensor([900, 600], dtype=torch.int32)
+    grid = ops.CellGrid(pts.to(cuda), lens.to(cuda), 0.0625)
+    idx, meta = grid.query(pts.to(cuda), lens.to(cuda), 90)
+    assert int(meta[0]) > 64 and int((idx[:, 64] < 1500).sum()) > 200          # column 64 is really populated
+    kp = torch.tensor(load_kernels(0.0625, 15, dimension=3, fixed="center"), dtype=torch.float32)
+    for cin, cout in ((1, 8), (64, 16), (20, 12)):
+        x, w = torch.randn(1500, cin, generator=g), torch.randn(15, cin, cout, generator=g) * 0.2
+        dy = torch.randn(1500, cout, generator=g)
+        x1, w1 = _leaf(x, cuda), _leaf(w, cuda)
+        y = AG.kpconv(x1, w1, pts.to(cuda), pts.to(cuda), idx, kp.to(cuda), 0.05)
+        y.backward(dy.to(cuda))
+        x0, w0 = _leaf(x, dtype=torch.float64), _leaf(w, dtype=torch.float64)
+        y0 = MR.kpconv(pts.double(), pts.double(), idx.cpu(), x0, kp.double(), w0, 0.05)
+        y0.backward(dy.double())
+        assert rel(y, y0) < TOL and rel(w1.grad, w0.grad) < TOL and rel(x1.grad, x0.grad) < TOL, (cin, cout)
