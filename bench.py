@@ -44,8 +44,6 @@ WORKLOADS = {
     "S30k": "S30k: 2x30000-pt shell pairs (3DMatch-shaped), indoor hyper-parameters",
     "U30k": "U30k (secondary): 2x30000 uniform-random points in a 1.07 m cube, indoor hyper-parameters",
     "K120k": "K120k (secondary, configs[4]): 2x120000-pt KITTI-shaped slabs, KITTI hyper-parameters",
-    "REAL": "REAL (secondary): the reference's two real 3DMatch demo fragments (25337 + 14602 points, "
-            "tests/golden/real_pair.npz), indoor hyper-parameters, limits [41,38,36,35]",
 }
 
 
@@ -54,10 +52,6 @@ def make_pair(recipe, seed):
         return synthetic.uniform_pair(30000, 1.07, seed)
     if recipe == "K120k":
         return synthetic.slab_pair(120000, seed)
-    if recipe == "REAL":        # one real pair; `seed` only jitters it by < 1 um so that steps are not byte-identical
-        g = np.load(os.path.join(REPO, "tests", "golden", "real_pair.npz"))
-        eps = np.float32(1e-7 * (seed % 16))
-        return g["src"] + eps, g["tgt"] + eps
     return synthetic.pair(recipe, seed)
 
 
@@ -125,7 +119,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     cfg = kitti_config() if RECIPE == "K120k" else indoor_config()
-    limits = [41, 38, 36, 35] if RECIPE == "REAL" else synthetic.LIMITS[RECIPE]
+    limits = synthetic.LIMITS[RECIPE]
     torch.manual_seed(0)
     np.random.seed(0)
     net = KPFCNN(cfg).eval()

@@ -1,0 +1,144 @@
+"""Tie-order fixtures: how the path behaves when point distances are EXACTLY equal.  Runs only in the build
+container.
+
+Real scans are full of equal distances (on the reference's two demo fragments, ref:assets/cloud_bin_{21,34}.pth,
+17 734 of the 39 939 level-0 rows hold a tie).  The reference cuts its neighbour tables at `[:, :limit]`
+(ref:datasets/dataloader.py:65-69); when the cut falls inside a group of equal distance, which members survive
+is decided by nanoflann's traversal order + an unstable std::sort -- reference-internal and arbitrary.  Those
+assets are reference DATA and are not shipped; the committed fixtures use the synthetic recipe `T8k` instead
+(pcrcg_amd.synthetic: shell pair snapped to a 1/128 m lattice -- 13 705 of 16 000 level-0 rows hold a tie, 517
+duplicate points), which is harsher than the real pair:
+
+  tests/golden/frontend_digests.json["T8k"]  pyramid of the UNMODIFIED reference C++ front end (same digest scheme
+                                    as the other recipes, scripts/make_golden_frontend.py)
+  tests/golden/model_ties.pt        outputs of the UNMODIFIED reference KPFCNN (reduced-width weights of
+                                    model_mini.pt) on the reference's own collate of that pair, limits from the
+                                    reference's calibration formula on the pair itself; every 13th row, twice:
+                                      rows            the reference's tables as they are;
+                                      rows_canonical  the same tables with every tie group re-ordered by index
+                                                      before the cut.
+The HIP path defines the order inside a tie group (index ascending) and is held to `rows_canonical`; `rows`
+documents how far the reference-internal arbitrariness moves the outputs.
+
+`--real` additionally prints the same statistics for the reference's demo fragments (read in place, nothing
+written)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+from make_golden_frontend import sha  # noqa: E402
+
+REPO = ref_import.REPO
+OUT = os.path.join(REPO, "tests", "golden")
+STRIDE = 13
+
+
+def ref_pyramid(F, canonicalise_table, src, tgt):
+    """Untruncated reference tables + digests; limits by ref:datasets/dataloader.py:402-434 on this pair."""
+    pts, lens = np.concatenate([src, tgt]), np.array([len(src), len(tgt)], np.int32)
+    r, dl, d, tabs, limits = 0.0625, 0.05, {}, [], []
+    for l in range(4):
+        d[f"points{l}"] = {"shape": list(pts.shape), "sha256": sha(pts)}
+        d[f"lens{l}"] = {"shape": list(lens.shape), "sha256": sha(lens)}
+        t = F.ref_batch_query(pts, pts, lens, lens, r)
+        counts = (t < len(pts)).sum(1)
+        hist = np.bincount(counts, minlength=906)[:905]
+        limits.append(int(np.sum(np.cumsum(hist) < 0.8 * hist.sum())))
+        level = {"conv": (t, pts, pts)}
+        if l < 3:
+            sp, sl = F.ref_subsample_batch(pts, lens, dl)
+            level["pool"] = (F.ref_batch_query(sp, pts, sl, lens, r), sp, pts)
+            level["up"] = (F.ref_batch_query(pts, sp, lens, sl, 2 * r), pts, sp)
+        for name, (tab, q, s) in level.items():
+            canon, ties = canonicalise_table(tab, q, s)
+            d[f"{name}{l}"] = {"shape": list(tab.shape), "sha256_canonical": sha(canon), "tie_rows": int(ties)}
+        tabs.append(level)
+        if l < 3:
+            pts, lens, r, dl = sp, sl, r * 2, dl * 2
+    return d, tabs, limits
+
+
+def model_rows(F, canonicalise_table, src, tgt, tabs, limits):
+    from datasets.dataloader import collate_fn_descriptor
+    from models.architectures import KPFCNN
+    gold = torch.load(os.path.join(OUT, "model_mini.pt"))
+    cfg = ref_import.indoor_config(first_feats_dim=gold["config"]["first_feats_dim"],
+                                   gnn_feats_dim=gold["config"]["gnn_feats_dim"])
+    item = dict(rot=np.eye(3, dtype=np.float32), trans=np.zeros((3, 1), np.float32),
+                correspondences=torch.stack([torch.arange(0, 50), torch.arange(0, 50)], 1), sample=0, src_pcd=src,
+                tgt_pcd=tgt, src_feats=np.ones((len(src), 1), np.float32), tgt_feats=np.ones((len(tgt), 1), np.float32))
+    batch = collate_fn_descriptor([item], cfg, limits)
+    model = KPFCNN(cfg).eval()
+    model.load_state_dict(gold["state_dict"])
+    with torch.no_grad():
+        out = model(batch)
+    canon = {k: (list(v) if isinstance(v, list) else v) for k, v in batch.items()}
+    straddle = {}
+    for l, level in enumerate(tabs):
+        for name, key in (("conv", "neighbors"), ("pool", "pools"), ("up", "upsamples")):
+            if name not in level:
+                continue
+            t, q, s = level[name]
+            c, _ = canonicalise_table(t, q, s)
+            straddle[f"{name}{l}"] = int((np.sort(c[:, :limits[l]], 1) != np.sort(t[:, :limits[l]], 1)).any(1).sum())
+            canon[key][l] = torch.from_numpy(c[:, :limits[l]].astype(np.int64))
+    with torch.no_grad():
+        out_c = model(canon)
+    return batch, out, out_c, straddle
+
+
+def main():
+    F = ref_import.setup()
+    F.build(ref=True)
+    from oracle import model_ref as MR
+    from pcrcg_amd import synthetic as S
+    from tests.tieutil import canonicalise_table
+    src, tgt = S.pair("T8k", 0)
+    d, tabs, limits = ref_pyramid(F, canonicalise_table, src, tgt)
+    path = os.path.join(OUT, "frontend_digests.json")
+    digests = json.load(open(path))
+    digests.pop("REAL", None)
+    digests["T8k"] = d
+    json.dump(digests, open(path, "w"), indent=1, sort_keys=True)
+    batch, out, out_c, straddle = model_rows(F, canonicalise_table, src, tgt, tabs, limits)
+    torch.save({"limits": limits, "stride": STRIDE, "levels": [int(p.shape[0]) for p in batch["points"]],
+                "rows": {k: v[::STRIDE].clone() for k, v in out.items()},
+                "rows_canonical": {k: v[::STRIDE].clone() for k, v in out_c.items()},
+                "means": {k: float(v.double().mean()) for k, v in out.items()},
+                "rows_with_different_kept_set": straddle}, os.path.join(OUT, "model_ties.pt"))
+    print("T8k limits", limits, "levels", [int(p.shape[0]) for p in batch["points"]])
+    print("T8k tie rows", {k: v["tie_rows"] for k, v in d.items() if "tie_rows" in v})
+    print("T8k rows whose kept set depends on the tie order", straddle, "=", sum(straddle.values()))
+    print("T8k reference order vs canonical order:", {k: round(MR.rel_err(out_c[k], out[k]), 4) for k in out})
+    if "--real" in sys.argv:
+        rs = np.asarray(torch.load("/root/reference/assets/cloud_bin_21.pth", weights_only=False)).astype(np.float32)
+        rt = np.asarray(torch.load("/root/reference/assets/cloud_bin_34.pth", weights_only=False)).astype(np.float32)
+        d, tabs, limits = ref_pyramid(F, canonicalise_table, rs, rt)
+        batch, out, out_c, straddle = model_rows(F, canonicalise_table, rs, rt, tabs, limits)
+        print("REAL limits", limits, "levels", [int(p.shape[0]) for p in batch["points"]])
+        print("REAL tie rows", {k: v["tie_rows"] for k, v in d.items() if "tie_rows" in v})
+        print("REAL rows whose kept set depends on the tie order", straddle, "=", sum(straddle.values()))
+        print("REAL reference order vs canonical order:", {k: round(MR.rel_err(out_c[k], out[k]), 4) for k in out})
+        # the oracle C front end on the real pair: digests must equal the reference's
+        from oracle import frontend as OF
+        pts, lens = np.concatenate([rs, rt]), np.array([len(rs), len(rt)], np.int32)
+        r, dl, ok = 0.0625, 0.05, True
+        for l in range(4):
+            t = OF.oracle_batch_query(pts, pts, lens, lens, r)
+            ok &= sha(canonicalise_table(t, pts, pts)[0]) == d[f"conv{l}"]["sha256_canonical"]
+            if l == 3:
+                break
+            sp, sl = OF.oracle_subsample_batch(pts, lens, dl)
+            ok &= sha(sp) == d[f"points{l + 1}"]["sha256"]
+            pts, lens, r, dl = sp, sl, r * 2, dl * 2
+        print("REAL oracle C front end == reference C++ (points bit-exact, conv tables modulo ties):", bool(ok))
+
+
+if __name__ == "__main__":
+    main()

@@ -27,11 +27,7 @@ def _bits(a):
 
 
 def _stack(recipe, seed=0):
-    if recipe == "REAL":    # the reference's demo assets: two real 3DMatch fragments (scripts/make_golden_real.py)
-        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_pair.npz"))
-        src, tgt = g["src"], g["tgt"]
-    else:
-        src, tgt = synthetic.pair(recipe, seed)
+    src, tgt = synthetic.pair(recipe, seed)     # T8k: lattice-snapped, full of exactly equal distances + duplicates
     return np.concatenate([src, tgt]), np.array([len(src), len(tgt)], np.int32)
 
 
@@ -67,7 +63,7 @@ def test_subsample_golden_mini(cuda, golden_dir):
         pts, lens, dl = sp, sl, dl * 2
 
 
-@pytest.mark.parametrize("recipe", ["C1", "S30k", "REAL"])
+@pytest.mark.parametrize("recipe", ["C1", "S30k", "T8k"])
 def test_subsample_digests_and_oracle(cuda, golden_dir, recipe):
     dig = json.load(open(os.path.join(golden_dir, "frontend_digests.json")))[recipe]
     pts, lens = _stack(recipe)
@@ -136,7 +132,7 @@ def test_batch_query_golden_mini(cuda, golden_dir):
         assert_tables_equal_mod_ties(got, g[name], q, s)
 
 
-@pytest.mark.parametrize("recipe", ["C1", "S30k", "REAL"])
+@pytest.mark.parametrize("recipe", ["C1", "S30k", "T8k"])
 def test_batch_query_digests_and_oracle(cuda, golden_dir, recipe):
     dig = json.load(open(os.path.join(golden_dir, "frontend_digests.json")))[recipe]
     pts, lens = _stack(recipe)

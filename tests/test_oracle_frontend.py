@@ -22,11 +22,7 @@ def _bits(a):
 
 
 def _stack(recipe, seed=0):
-    if recipe == "REAL":    # the reference's demo assets: two real 3DMatch fragments (scripts/make_golden_real.py)
-        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_pair.npz"))
-        src, tgt = g["src"], g["tgt"]
-    else:
-        src, tgt = synthetic.pair(recipe, seed)
+    src, tgt = synthetic.pair(recipe, seed)     # T8k: lattice-snapped, full of exactly equal distances + duplicates
     return np.concatenate([src, tgt]), np.array([len(src), len(tgt)], np.int32)
 
 
@@ -52,7 +48,7 @@ def test_mini_pyramid_full_vectors(golden_dir):
         pts, lens, r, dl = sp, sl, r * 2, dl * 2
 
 
-@pytest.mark.parametrize("recipe", ["C1", "S30k", "REAL"])
+@pytest.mark.parametrize("recipe", ["C1", "S30k", "T8k"])
 def test_digests(golden_dir, recipe):
     dig = json.load(open(os.path.join(golden_dir, "frontend_digests.json")))[recipe]
     pts, lens = _stack(recipe)
