@@ -4,8 +4,9 @@ Trainer.inference_one_batch / the optimisation block of inference_one_epoch (ref
 
   forward (train_forward, HIP kernels)  ->  MetricLoss  ->  total = unweighted sum of the loss keys
   (ref:lib/trainer.py:255-260)  ->  backward (HIP backward kernels through torch.autograd's graph)
-  ->  ONE all-reduce(sum) of a flat fp32 gradient bucket over the ranks (RCCL; every parameter's .grad is
-  a view into the bucket, so there is no pack / unpack copy), scaled by 1/world  ->  the reference's
+  ->  all-reduce(sum) of a flat fp32 gradient bucket over the ranks (RCCL; every parameter's .grad is a view
+  into the bucket, so there is no pack / unpack copy), issued as a few large contiguous slices that start as
+  soon as backward has produced them (the exchange overlaps the rest of backward), scaled by 1/world  ->  the reference's
   NaN/Inf gradient check (ref:lib/utils.py:100-111) evaluated on the REDUCED bucket, which makes the
   skip decision identical on every rank without a second collective  ->  SGD step.
 
@@ -34,13 +35,71 @@ class GradientBucket:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
 
-    def all_reduce_mean(self):
+        self._chunks = None       # overlap mode: [(start, end, n_params)] slices of the flat buffer
+        self._armed = False
+
+    # ---- overlap of the exchange with backward -----------------------------------------------------
+    def enable_overlap(self, n_chunks=4):
+        """Split the bucket into `n_chunks` contiguous slices (parameters are laid out in forward order, so
+        backward completes the LAST slice first) and all-reduce each slice asynchronously as soon as every
+        parameter in it has received its gradient, while backward is still running on the earlier layers.
+        xGMI is point-to-point and a ring all-reduce is per-link bound (~1.4 ms for the whole
+        bucket), so a few large slices, not many small ones."""
+        sizes = [p.numel() for p in self.params]
+        total, target = sum(sizes), sum(sizes) / float(n_chunks)
+        self._chunks, self._chunk_of = [], {}
+        start = acc = count = 0
+        for i, n in enumerate(sizes):
+            self._chunk_of[id(self.params[i])] = len(self._chunks)
+            acc += n
+            count += 1
+            if acc >= target * (len(self._chunks) + 1) - 1e-9 or i == len(sizes) - 1:
+                self._chunks.append((start, acc, count))
+                start, count = acc, 0
+        assert self._chunks[-1][1] == total
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def arm(self, on=True):
+        """Call before the backward pass whose gradients complete the optimiser step (the last of iter_size)."""
+        self._armed = bool(on) and self._chunks is not None and self._world() > 1
+        self._seen = [0] * len(self._chunks or [])
+        self._handles = {}
+
+    def _world(self):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size(self.group)
-            if world > 1:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-                self.flat.div_(world)
+            return dist.get_world_size(self.group)
+        return 1
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        import torch.distributed as dist
+        k = self._chunk_of[id(p)]
+        self._seen[k] += 1
+        a, b, n = self._chunks[k]
+        if self._seen[k] == n and k not in self._handles:
+            self._handles[k] = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def all_reduce_mean(self):
+        """Finish the exchange: wait for the slices already in flight, reduce the rest (slices holding a
+        parameter that received no gradient never complete on their own), divide by the world size."""
+        import torch.distributed as dist
+        world = self._world()
+        if world <= 1:
+            self._armed = False
+            return
+        if self._armed:
+            for k, (a, b, _) in enumerate(self._chunks):
+                h = self._handles.get(k)
+                if h is None:
+                    h = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                h.wait()
+            self._armed = False
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.div_(world)
 
     def finite(self):
         return bool(torch.isfinite(self.flat).all().item())
@@ -51,10 +110,12 @@ class GradientBucket:
 
 class Trainer:
     def __init__(self, model, desc_loss, lr=0.005, momentum=0.98, weight_decay=1e-6, scheduler_gamma=0.95,
-                 iter_size=1, process_group=None):
+                 iter_size=1, process_group=None, overlap_chunks=4):
         self.model, self.desc_loss = model, desc_loss
         self.iter_size = iter_size
         self.bucket = GradientBucket(model.parameters(), process_group)
+        if overlap_chunks and overlap_chunks > 1:
+            self.bucket.enable_overlap(overlap_chunks)
         self.params = self.bucket.params
         self.flat_grad = self.bucket.flat
         self.optimizer = torch.optim.SGD(self.params, lr=lr, momentum=momentum, weight_decay=weight_decay)
@@ -83,6 +144,7 @@ class Trainer:
             res = self.desc_loss(loss_input)
             if train:
                 c_loss = sum(res[k] for k in res if k in LOSS_KEYS)
+                self.bucket.arm((self._iter + 1) % self.iter_size == 0)   # exchange overlaps the step's last backward
                 c_loss.backward()               # accumulates into the flat bucket (iter_size > 1 sums pairs)
                 res["total_loss"] = c_loss
         return {k: float(v.detach()) if isinstance(v, torch.Tensor) else float(v) for k, v in res.items()}

@@ -10,19 +10,20 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pcrcg_amd import indoor_config, synthetic  # noqa: E402
+from pcrcg_amd import indoor_config, kitti_config, synthetic  # noqa: E402
 from pcrcg_amd.architectures import KPFCNN  # noqa: E402
 from pcrcg_amd.pipeline import PairPipeline  # noqa: E402
 
 K = int(os.environ.get("K", 40))
 dev = torch.device("cuda:0")
-cfg = indoor_config()
-limits = synthetic.LIMITS["S30k"]
+RECIPE = os.environ.get("RECIPE", "S30k")          # S30k | K120k
+cfg = kitti_config() if RECIPE == "K120k" else indoor_config()
+limits = synthetic.LIMITS[RECIPE]
 torch.manual_seed(0)
 net = KPFCNN(cfg).to(dev).eval()
 pairs = []
 for s in range(4):
-    a, b = synthetic.pair("S30k", 100 + s)
+    a, b = synthetic.slab_pair(120000, 100 + s) if RECIPE == "K120k" else synthetic.pair("S30k", 100 + s)
     pts = torch.from_numpy(__import__("numpy").concatenate([a, b])).to(dev)
     lens = torch.tensor([len(a), len(b)], dtype=torch.int32, device=dev)
     pairs.append((pts, lens))

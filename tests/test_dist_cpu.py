@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -60,7 +61,7 @@ def test_two_rank_sharding_protocol():
         assert np.allclose(checks, exp)
 
 
-def _train_worker(rank, world, port, q):
+def _train_worker(rank, world, port, q, overlap=0):
     """Data-parallel optimisation block of pcrcg_amd.trainer.Trainer on a stand-in model (the kernels need a
     GPU; the bucket / all-reduce / skip protocol does not)."""
     from pcrcg_amd.trainer import Trainer
@@ -69,27 +70,31 @@ def _train_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)                                   # identical replicas
     model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
-    trainer = Trainer(model, desc_loss=None, lr=0.1, momentum=0.9, weight_decay=0.0)
+    trainer = Trainer(model, desc_loss=None, lr=0.1, momentum=0.9, weight_decay=0.0, overlap_chunks=overlap)
     g = torch.Generator().manual_seed(100 + rank)          # each rank has its own pair
     x, y = torch.randn(16, 6, generator=g), torch.randn(16, 2, generator=g)
     out = []
     for step in range(3):
         loss = ((model(x) - y) ** 2).mean()
-        loss.backward()                                    # lands in the flat bucket through the .grad views
         if step == 1 and rank == 1:
-            trainer.flat_grad[3] = float("inf")            # one rank overflows: BOTH must skip this step
+            loss = loss * float("inf")                     # one rank overflows: BOTH must skip this step
+        trainer.bucket.arm(True)                           # overlap mode: slices are all-reduced from inside backward
+        loss.backward()                                    # lands in the flat bucket through the .grad views
         ok = trainer.optimizer_step()
         out.append((ok, [p.detach().clone() for p in model.parameters()]))
     q.put((rank, [(ok, [t.numpy() for t in ps]) for ok, ps in out], trainer.skipped_steps))
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_all_reduce_and_global_skip():
+@pytest.mark.parametrize("overlap", [0, 3])
+def test_two_rank_gradient_all_reduce_and_global_skip(overlap):
+    """overlap = 3: the bucket is exchanged as three slices launched from inside backward (asynchronously) --
+    same replicas, same updates, same skip decision as the single all-reduce."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))
