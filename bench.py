@@ -196,6 +196,7 @@ def main():
         # of a launch is looked up by its input width, which is unique per KPConv in this architecture)
         couts = [blk.KPConv.out_channels for blk in net.encoder_blocks]
         cout_of = {blk.KPConv.in_channels: blk.KPConv.out_channels for blk in net.encoder_blocks}
+        assert all(cout_of[blk.KPConv.in_channels] == blk.KPConv.out_channels for blk in net.encoder_blocks)
         gather = {"ms": 0.0, "bytes": 0, "n": 0}
         fused = {"ms": 0.0, "bytes": 0, "flops": 0, "n": 0}
         per_pair = len(couts)
