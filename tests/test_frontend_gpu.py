@@ -218,3 +218,20 @@ def test_k120k_properties(cuda):
     assert sp.shape[0] == int(sl.sum()) and torch.equal(sp, sp2) and torch.equal(sl, sl2)
     op, ol = OF.oracle_subsample_batch(pts, lens, 0.6)
     assert (sl.cpu().numpy() == ol).all() and (_bits(sp.cpu().numpy()) == _bits(op)).all()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_lattice_clouds_vs_oracle(cuda, seed):
+    """Tiny clouds on coarse lattices (duplicates, exact ties, points on cell boundaries, one-point clouds,
+    negative coordinates): HIP front end == oracle, exactly."""
+    rng = np.random.RandomState(1000 + seed)
+    n0, n1 = int(rng.randint(1, 300)), int(rng.randint(1, 200))
+    lattice, dl = int(rng.randint(2, 10)), float(rng.choice([0.25, 0.5, 1.0, 1.7]))
+    pts = (rng.randint(-lattice, lattice + 1, size=(n0 + n1, 3)) / np.float32(4)).astype(np.float32)
+    lens = np.array([n0, n1], np.int32)
+    sp, sl = grid_subsampling.subsample_batch(pts, lens, sampleDl=dl)
+    op, ol = OF.oracle_subsample_batch(pts, lens, dl)
+    assert (sl == ol).all() and sp.shape == op.shape and (_bits(sp) == _bits(op)).all()
+    for q, s_, ql, sl_, r in ((pts, pts, lens, lens, 1.2 * dl), (op, pts, ol, lens, 1.2 * dl), (pts, op, lens, ol, 2.4 * dl)):
+        got = radius_neighbors.batch_query(q, s_, ql, sl_, radius=r)
+        assert (got == OF.oracle_batch_query(q, s_, ql, sl_, r)).all()

@@ -100,3 +100,25 @@ def test_against_reference_library():
     rp, rl = OF.ref_subsample_batch(pts, lens, 0.11, max_p=50)
     op, ol = OF.oracle_subsample_batch(pts, lens, 0.11, max_p=50)
     assert (rl == ol).all() and (_bits(rp) == _bits(op)).all()
+
+
+@pytest.mark.skipif(not OF.have_ref(), reason="oracle/_ref (reference checker library) not built")
+def test_random_lattice_clouds_against_reference_library():
+    """Property test (hypothesis): tiny clouds on coarse lattices -- duplicates, exact distance ties, points on
+    cell boundaries, one-point clouds, negative coordinates -- oracle C front end vs the reference C++."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None, derandomize=True)
+    @given(st.integers(1, 120), st.integers(1, 90), st.integers(2, 9), st.sampled_from([0.25, 0.5, 1.0, 1.7]),
+           st.integers(0, 2 ** 31 - 1))
+    def check(n0, n1, lattice, dl, seed):
+        rng = np.random.RandomState(seed)
+        pts = (rng.randint(-lattice, lattice + 1, size=(n0 + n1, 3)) / np.float32(4)).astype(np.float32)
+        lens = np.array([n0, n1], np.int32)
+        rp, rl = OF.ref_subsample_batch(pts, lens, dl)
+        op, ol = OF.oracle_subsample_batch(pts, lens, dl)
+        assert (rl == ol).all() and (_bits(rp) == _bits(op)).all()
+        for q, s_, ql, sl, r in ((pts, pts, lens, lens, 1.2 * dl), (rp, pts, rl, lens, 1.2 * dl), (pts, rp, lens, rl, 2.4 * dl)):
+            assert_tables_equal_mod_ties(OF.oracle_batch_query(q, s_, ql, sl, r), OF.ref_batch_query(q, s_, ql, sl, r), q, s_)
+
+    check()
