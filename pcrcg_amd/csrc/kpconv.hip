@@ -172,9 +172,13 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = 4 * hsub + r;
-                if (k < K)
-                    *reinterpret_cast<float4*>(o + (long)k * cin + c) =
-                        make_float4(acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]);
+                if (k < K) {
+                    // streamed once (the contraction GEMM reads it back): non-temporal, so that 230 MB of wf do not
+                    // push the feature rows the gathers re-read out of L2
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f val = {acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]};
+                    __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + (long)k * cin + c));
+                }
             }
         }
         if (chunk == 0 && lane == 0) inv_n[q] = 1.0f / (float)(npos > 1 ? npos : 1);
