@@ -234,9 +234,9 @@ __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
             const u64 mine = list[e];
             int rank = 0;
             for (int j = 0; j < nl; ++j) rank += list[j] < mine ? 1 : 0;
-            if (rank < cols) row[rank] = (long long)(unsigned)(mine & 0xFFFFFFFFull);
+            if (rank < cols) __builtin_nontemporal_store((long long)(unsigned)(mine & 0xFFFFFFFFull), &row[rank]);
         }
-        for (int j = nl + lane; j < cols; j += 64) row[j] = (long long)ns;   // shadow index  (:324)
+        for (int j = nl + lane; j < cols; j += 64) __builtin_nontemporal_store((long long)ns, &row[j]);   // shadow index  (:324)
         if (lane == 0) {
             if (out_count) out_count[qi] = nhit;
             if ((nhit > CAP || !inrange) && status) *status = 1;
