@@ -29,7 +29,15 @@
  *                                defined as {s : d2(q,s) < r*r} in fp32 and the ORDER as ascending
  *                                (d2, index).  Inside groups of exactly equal d2 the reference's
  *                                order is an artefact of KD-tree traversal + introsort (SURVEY.md
- *                                8a-2); this oracle and the HIP path both use ascending index there.
+ *                                8a-2); this function uses ascending index there.
+ *   oracle_radius_neighbors_batch_reforder  the same tables in the REFERENCE's order, tie groups
+ *                                included: nanoflann 1.3.0's tree build and traversal and libstdc++'s
+ *                                std::sort restated step by step (see the comment above the kd_*
+ *                                functions below).  Equal to the reference entry for entry
+ *                                (tests/test_oracle_frontend.py::test_reference_tie_order_*).
+ *                                Outside the contract: an EMPTY query cloud followed by a non-empty
+ *                                one -- the reference advances one cloud per query (`if`, :270), so
+ *                                it searches the wrong cloud there; collate never produces that.
  *
  * Build: gcc -std=c11 -O2 -ffp-contract=off (no FMA contraction: the reference is built by
  * distutils with -O2 and no -march, so every fp32 product and sum is rounded separately).
@@ -381,3 +389,346 @@ int* oracle_radius_neighbors_batch(const float* q, int nq, const float* s, int n
 }
 
 void oracle_free(void* p) { free(p); }
+
+/* ------------------------------------------------------------------------------------------- */
+/* Reference ORDER inside groups of exactly equal distance.
+ *
+ * oracle_radius_neighbors_batch above defines that order as ascending index.  The reference's order is an
+ * artefact of two third-party pieces, restated here so that the oracle can reproduce the reference tables
+ * entry for entry (used to count how many rows a `[:, :limit]` cut makes ambiguous, tests/ and DESIGN.md):
+ *
+ *   - nanoflann 1.3.0 (vendored, zip:cpp_utils/nanoflann/nanoflann.hpp): KDTreeSingleIndexAdaptor with leaf
+ *     size 10 (ref:.../neighbors.cpp:245): buildIndex :1190-1203 (vind = iota, root bbox :1318-1338),
+ *     divideTree :857-905, middleSplit_ :909-957, planeSplit :967-1003, computeMinMax :836-848;
+ *     findNeighbors :1221-1243, computeInitialDistances :1005-1022, searchLevel :1348-1410 (hits are appended
+ *     in traversal order, RadiusResultSet::addPoint :246-250);
+ *   - libstdc++ std::sort (GCC 11 bits/stl_algo.h: __sort, __introsort_loop, __unguarded_partition_pivot,
+ *     __move_median_to_first, __unguarded_partition, __final_insertion_sort, heap fallback __partial_sort) with
+ *     IndexDist_Sorter (:208-214: compares the distance only) -- unstable, so the order of equal distances
+ *     depends on the traversal order above.
+ * All arithmetic is fp32 exactly as written there (this file is built with -ffp-contract=off). */
+typedef struct { float low, high; } kd_iv;
+typedef struct kd_node {
+    int leaf, left, right;       /* leaf: vind range [left, right) */
+    int divfeat;
+    float divlow, divhigh;
+    int child1, child2;          /* node indices */
+} kd_node;
+typedef struct {
+    const float* pts;            /* this cloud's supports [n,3] */
+    int n;
+    int* vind;
+    kd_node* nodes;
+    int nnodes, cap;
+    kd_iv root[3];
+} kd_tree;
+
+static float kd_get(const kd_tree* t, int idx, int d) { return t->pts[3 * (size_t)idx + d]; }
+
+static void kd_minmax(const kd_tree* t, const int* ind, int count, int d, float* mn, float* mx) {
+    *mn = *mx = kd_get(t, ind[0], d);
+    for (int i = 1; i < count; ++i) {
+        float v = kd_get(t, ind[i], d);
+        if (v < *mn) *mn = v;
+        if (v > *mx) *mx = v;
+    }
+}
+
+static void kd_plane_split(const kd_tree* t, int* ind, int count, int cutfeat, float cutval, int* lim1, int* lim2) {
+    /* IndexType is size_t in the reference: `right` never goes below 0 thanks to the `right &&` tests */
+    size_t left = 0, right = (size_t)count - 1;
+    for (;;) {
+        while (left <= right && kd_get(t, ind[left], cutfeat) < cutval) ++left;
+        while (right && left <= right && kd_get(t, ind[right], cutfeat) >= cutval) --right;
+        if (left > right || !right) break;
+        int tmp = ind[left]; ind[left] = ind[right]; ind[right] = tmp;
+        ++left; --right;
+    }
+    *lim1 = (int)left;
+    right = (size_t)count - 1;
+    for (;;) {
+        while (left <= right && kd_get(t, ind[left], cutfeat) <= cutval) ++left;
+        while (right && left <= right && kd_get(t, ind[right], cutfeat) > cutval) --right;
+        if (left > right || !right) break;
+        int tmp = ind[left]; ind[left] = ind[right]; ind[right] = tmp;
+        ++left; --right;
+    }
+    *lim2 = (int)left;
+}
+
+static int kd_divide(kd_tree* t, int left, int right, kd_iv* bbox) {
+    if (t->nnodes == t->cap) {
+        t->cap = t->cap ? 2 * t->cap : 1024;
+        t->nodes = (kd_node*)realloc(t->nodes, sizeof(kd_node) * (size_t)t->cap);
+    }
+    const int me = t->nnodes++;
+    if (right - left <= 10) {                                  /* leaf_max_size (neighbors.cpp:245) */
+        kd_node nd = {1, left, right, 0, 0.f, 0.f, -1, -1};
+        for (int d = 0; d < 3; ++d) bbox[d].low = bbox[d].high = kd_get(t, t->vind[left], d);
+        for (int k = left + 1; k < right; ++k)
+            for (int d = 0; d < 3; ++d) {
+                float v = kd_get(t, t->vind[k], d);
+                if (bbox[d].low > v) bbox[d].low = v;
+                if (bbox[d].high < v) bbox[d].high = v;
+            }
+        t->nodes[me] = nd;
+        return me;
+    }
+    int* ind = t->vind + left;
+    const int count = right - left;
+    /* middleSplit_ */
+    const float EPS = 0.00001f;
+    float max_span = bbox[0].high - bbox[0].low;
+    for (int d = 1; d < 3; ++d) {
+        float span = bbox[d].high - bbox[d].low;
+        if (span > max_span) max_span = span;
+    }
+    float max_spread = -1.f;
+    int cutfeat = 0;
+    for (int d = 0; d < 3; ++d) {
+        float span = bbox[d].high - bbox[d].low;
+        if (span > (1 - EPS) * max_span) {
+            float mn, mx;
+            kd_minmax(t, ind, count, d, &mn, &mx);
+            float spread = mx - mn;
+            if (spread > max_spread) { cutfeat = d; max_spread = spread; }
+        }
+    }
+    float split_val = (bbox[cutfeat].low + bbox[cutfeat].high) / 2;
+    float mn, mx, cutval;
+    kd_minmax(t, ind, count, cutfeat, &mn, &mx);
+    if (split_val < mn) cutval = mn;
+    else if (split_val > mx) cutval = mx;
+    else cutval = split_val;
+    int lim1, lim2, idx;
+    kd_plane_split(t, ind, count, cutfeat, cutval, &lim1, &lim2);
+    if (lim1 > count / 2) idx = lim1;
+    else if (lim2 < count / 2) idx = lim2;
+    else idx = count / 2;
+
+    kd_iv lb[3], rb[3];
+    memcpy(lb, bbox, sizeof(lb));
+    memcpy(rb, bbox, sizeof(rb));
+    lb[cutfeat].high = cutval;
+    const int c1 = kd_divide(t, left, left + idx, lb);
+    rb[cutfeat].low = cutval;
+    const int c2 = kd_divide(t, left + idx, right, rb);
+    kd_node nd = {0, 0, 0, cutfeat, lb[cutfeat].high, rb[cutfeat].low, c1, c2};
+    t->nodes[me] = nd;
+    for (int d = 0; d < 3; ++d) {
+        bbox[d].low = lb[d].low < rb[d].low ? lb[d].low : rb[d].low;
+        bbox[d].high = lb[d].high > rb[d].high ? lb[d].high : rb[d].high;
+    }
+    return me;
+}
+
+typedef struct { size_t first; float second; } kd_pair;
+typedef struct { kd_pair* v; size_t n, cap; } kd_vec;
+
+static void kd_push(kd_vec* r, size_t idx, float d) {
+    if (r->n == r->cap) {
+        r->cap = r->cap ? 2 * r->cap : 64;
+        r->v = (kd_pair*)realloc(r->v, sizeof(kd_pair) * r->cap);
+    }
+    r->v[r->n].first = idx;
+    r->v[r->n].second = d;
+    r->n++;
+}
+
+static void kd_search(const kd_tree* t, int node, const float* vec, float mindistsq, float* dists, float radius,
+                      kd_vec* res) {
+    const kd_node* nd = &t->nodes[node];
+    if (nd->leaf) {
+        for (int i = nd->left; i < nd->right; ++i) {
+            const int index = t->vind[i];
+            float result = 0.0f;                                   /* L2_Simple_Adaptor::evalMetric */
+            for (int d = 0; d < 3; ++d) {
+                const float diff = vec[d] - kd_get(t, index, d);
+                result += diff * diff;
+            }
+            if (result < radius) {                                  /* worstDist() == radius; addPoint tests again */
+                if (result < radius) kd_push(res, (size_t)index, result);
+            }
+        }
+        return;
+    }
+    const int idx = nd->divfeat;
+    const float val = vec[idx];
+    const float diff1 = val - nd->divlow, diff2 = val - nd->divhigh;
+    int best, other;
+    float cut_dist;
+    if ((diff1 + diff2) < 0) { best = nd->child1; other = nd->child2; cut_dist = (val - nd->divhigh) * (val - nd->divhigh); }
+    else { best = nd->child2; other = nd->child1; cut_dist = (val - nd->divlow) * (val - nd->divlow); }
+    kd_search(t, best, vec, mindistsq, dists, radius, res);
+    const float dst = dists[idx];
+    mindistsq = mindistsq + cut_dist - dst;
+    dists[idx] = cut_dist;
+    if (mindistsq * 1.0f <= radius) kd_search(t, other, vec, mindistsq, dists, radius, res);   /* epsError = 1 + 0 */
+    dists[idx] = dst;
+}
+
+/* ---- libstdc++ std::sort with comp(a, b) = a.second < b.second ---- */
+#define KD_LT(a, b) ((a).second < (b).second)
+static void kd_swap(kd_pair* a, kd_pair* b) { kd_pair t = *a; *a = *b; *b = t; }
+
+static void kd_adjust_heap(kd_pair* first, long hole, long len, kd_pair value) {
+    const long top = hole;
+    long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (KD_LT(first[child], first[child - 1])) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    long parent = (hole - 1) / 2;                                   /* __push_heap */
+    while (hole > top && KD_LT(first[parent], value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+
+static void kd_heapsort(kd_pair* first, kd_pair* last) {           /* __partial_sort(first, last, last) */
+    const long len = last - first;
+    if (len >= 2) {                                                 /* __make_heap */
+        long parent = (len - 2) / 2;
+        for (;;) {
+            kd_pair v = first[parent];
+            kd_adjust_heap(first, parent, len, v);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    /* __heap_select has no elements beyond `middle == last`; __sort_heap: */
+    while (last - first > 1) {
+        --last;
+        kd_pair v = *last;                                          /* __pop_heap(first, last, last) */
+        *last = *first;
+        kd_adjust_heap(first, 0, last - first, v);
+    }
+}
+
+static void kd_unguarded_linear_insert(kd_pair* last) {
+    kd_pair val = *last;
+    kd_pair* next = last - 1;
+    while (KD_LT(val, *next)) { *last = *next; last = next; --next; }
+    *last = val;
+}
+
+static void kd_insertion_sort(kd_pair* first, kd_pair* last) {
+    if (first == last) return;
+    for (kd_pair* i = first + 1; i != last; ++i) {
+        if (KD_LT(*i, *first)) {
+            kd_pair val = *i;
+            memmove(first + 1, first, sizeof(kd_pair) * (size_t)(i - first));
+            *first = val;
+        } else {
+            kd_unguarded_linear_insert(i);
+        }
+    }
+}
+
+static void kd_introsort_loop(kd_pair* first, kd_pair* last, long depth_limit) {
+    while (last - first > 16) {
+        if (depth_limit == 0) { kd_heapsort(first, last); return; }
+        --depth_limit;
+        kd_pair* mid = first + (last - first) / 2;                  /* __unguarded_partition_pivot */
+        kd_pair *a = first + 1, *b = mid, *c = last - 1;            /* __move_median_to_first(first, a, b, c) */
+        if (KD_LT(*a, *b)) {
+            if (KD_LT(*b, *c)) kd_swap(first, b);
+            else if (KD_LT(*a, *c)) kd_swap(first, c);
+            else kd_swap(first, a);
+        } else if (KD_LT(*a, *c)) kd_swap(first, a);
+        else if (KD_LT(*b, *c)) kd_swap(first, c);
+        else kd_swap(first, b);
+        kd_pair *lo = first + 1, *hi = last;                         /* __unguarded_partition(first+1, last, first) */
+        for (;;) {
+            while (KD_LT(*lo, *first)) ++lo;
+            --hi;
+            while (KD_LT(*first, *hi)) --hi;
+            if (!(lo < hi)) break;
+            kd_swap(lo, hi);
+            ++lo;
+        }
+        kd_introsort_loop(lo, last, depth_limit);
+        last = lo;
+    }
+}
+
+static void kd_std_sort(kd_pair* first, kd_pair* last) {
+    if (first == last) return;
+    long n = last - first, lg = 0;
+    while ((n >> (lg + 1)) > 0) ++lg;                               /* std::__lg */
+    kd_introsort_loop(first, last, 2 * lg);
+    if (last - first > 16) {                                         /* __final_insertion_sort */
+        kd_insertion_sort(first, first + 16);
+        for (kd_pair* i = first + 16; i != last; ++i) kd_unguarded_linear_insert(i);
+    } else {
+        kd_insertion_sort(first, last);
+    }
+}
+
+/* Same contract as oracle_radius_neighbors_batch, rows in the REFERENCE's order (ties included). */
+int* oracle_radius_neighbors_batch_reforder(const float* q, int nq, const float* s, int ns, const int* qlen,
+                                            const int* slen, int nb, float radius, int* cols) {
+    *cols = 0;
+    if (nq <= 0) return NULL;
+    const float r2 = radius * radius;
+    kd_vec* rows = (kd_vec*)calloc((size_t)nq, sizeof(kd_vec));
+    int qoff = 0, soff = 0;
+    size_t max_count = 0;
+    for (int b = 0; b < nb; ++b) {
+        kd_tree t;
+        memset(&t, 0, sizeof(t));
+        t.pts = s + 3 * (size_t)soff;
+        t.n = slen[b];
+        if (t.n > 0) {
+            t.vind = (int*)malloc(sizeof(int) * (size_t)t.n);
+            for (int i = 0; i < t.n; ++i) t.vind[i] = i;
+            for (int d = 0; d < 3; ++d) t.root[d].low = t.root[d].high = kd_get(&t, 0, d);
+            for (int k = 1; k < t.n; ++k)
+                for (int d = 0; d < 3; ++d) {
+                    float v = kd_get(&t, k, d);
+                    if (v < t.root[d].low) t.root[d].low = v;
+                    if (v > t.root[d].high) t.root[d].high = v;
+                }
+            kd_divide(&t, 0, t.n, t.root);                           /* updates root bbox in place, as the reference */
+        }
+        for (int i = 0; i < qlen[b]; ++i) {
+            kd_vec* r = &rows[qoff + i];
+            if (t.n > 0) {
+                const float* vec = q + 3 * (size_t)(qoff + i);
+                float dists[3] = {0.f, 0.f, 0.f}, distsq = 0.f;     /* computeInitialDistances */
+                for (int d = 0; d < 3; ++d) {
+                    if (vec[d] < t.root[d].low) { dists[d] = (vec[d] - t.root[d].low) * (vec[d] - t.root[d].low); distsq += dists[d]; }
+                    if (vec[d] > t.root[d].high) { dists[d] = (vec[d] - t.root[d].high) * (vec[d] - t.root[d].high); distsq += dists[d]; }
+                }
+                kd_search(&t, 0, vec, distsq, dists, r2, r);
+                kd_std_sort(r->v, r->v + r->n);
+                for (size_t j = 0; j < r->n; ++j) r->v[j].first += (size_t)soff;
+            }
+            if (r->n > max_count) max_count = r->n;
+        }
+        free(t.vind);
+        free(t.nodes);
+        qoff += qlen[b];
+        soff += slen[b];
+    }
+    int* out = NULL;
+    if (max_count > 0) {
+        out = (int*)malloc(sizeof(int) * (size_t)nq * max_count);
+        for (int i = 0; i < nq; ++i)
+            for (size_t j = 0; j < max_count; ++j)
+                out[(size_t)i * max_count + j] = j < rows[i].n ? (int)rows[i].v[j].first : ns;
+    }
+    for (int i = 0; i < nq; ++i) free(rows[i].v);
+    free(rows);
+    *cols = (int)max_count;
+    return out;
+}

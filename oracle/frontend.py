@@ -57,6 +57,8 @@ def oracle_lib():
         lib.oracle_radius_neighbors_batch.argtypes = [_f32p, ctypes.c_int, _f32p, ctypes.c_int, _i32p,
                                                       _i32p, ctypes.c_int, ctypes.c_float, _i32p]
         lib.oracle_radius_neighbors_batch.restype = ctypes.c_void_p
+        lib.oracle_radius_neighbors_batch_reforder.argtypes = lib.oracle_radius_neighbors_batch.argtypes
+        lib.oracle_radius_neighbors_batch_reforder.restype = ctypes.c_void_p
         lib.oracle_free.argtypes = [ctypes.c_void_p]
         _oracle = lib
     return _oracle
@@ -114,10 +116,12 @@ def _query(fn, free, queries, supports, q_batches, s_batches, radius):
     return out
 
 
-def oracle_batch_query(queries, supports, q_batches, s_batches, radius=0.1):
+def oracle_batch_query(queries, supports, q_batches, s_batches, radius=0.1, tie_order="index"):
+    """tie_order "index": equal distances in ascending index order (the order the HIP path defines);
+    "reference": the reference's own order (nanoflann 1.3.0 traversal + libstdc++ std::sort restated)."""
     lib = oracle_lib()
-    return _query(lib.oracle_radius_neighbors_batch, lib.oracle_free, queries, supports, q_batches,
-                  s_batches, radius)
+    fn = {"index": lib.oracle_radius_neighbors_batch, "reference": lib.oracle_radius_neighbors_batch_reforder}[tie_order]
+    return _query(fn, lib.oracle_free, queries, supports, q_batches, s_batches, radius)
 
 
 def ref_batch_query(queries, supports, q_batches, s_batches, radius=0.1):

@@ -53,7 +53,8 @@ def main():
     mini = pyramid("mini", 0)
     np.savez_compressed(os.path.join(OUT, "frontend_mini.npz"),
                         **{k: v for k, v in mini.items() if not k.startswith("points0")})
-    digests = {}
+    path = os.path.join(OUT, "frontend_digests.json")
+    digests = json.load(open(path)) if os.path.exists(path) else {}      # keeps T8k (scripts/make_golden_ties.py)
     for recipe in ("C1", "S30k"):
         p = pyramid(recipe, 0)
         d = {}
@@ -69,9 +70,11 @@ def main():
                 else:
                     q, s = p[f"points{l}"], p[f"points{l + 1}"]
                 canon, tie_rows = canonicalise_table(v, q, s)
-                d[k] = {"shape": list(v.shape), "sha256_canonical": sha(canon), "tie_rows": int(tie_rows)}
+                # sha256: the table exactly as the reference returns it (its own order inside tie groups)
+                d[k] = {"shape": list(v.shape), "sha256": sha(v), "sha256_canonical": sha(canon),
+                        "tie_rows": int(tie_rows)}
         digests[recipe] = d
-    with open(os.path.join(OUT, "frontend_digests.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(digests, f, indent=1, sort_keys=True)
     # libstdc++ unordered_map iteration orders for a few key sets (pins oracle_umap_order and the HIP path)
     rng = np.random.RandomState(7)

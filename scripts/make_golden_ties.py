@@ -57,7 +57,8 @@ def ref_pyramid(F, canonicalise_table, src, tgt):
             level["up"] = (F.ref_batch_query(pts, sp, lens, sl, 2 * r), pts, sp)
         for name, (tab, q, s) in level.items():
             canon, ties = canonicalise_table(tab, q, s)
-            d[f"{name}{l}"] = {"shape": list(tab.shape), "sha256_canonical": sha(canon), "tie_rows": int(ties)}
+            d[f"{name}{l}"] = {"shape": list(tab.shape), "sha256": sha(tab), "sha256_canonical": sha(canon),
+                               "tie_rows": int(ties)}
         tabs.append(level)
         if l < 3:
             pts, lens, r, dl = sp, sl, r * 2, dl * 2

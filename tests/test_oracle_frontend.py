@@ -122,3 +122,63 @@ def test_random_lattice_clouds_against_reference_library():
             assert_tables_equal_mod_ties(OF.oracle_batch_query(q, s_, ql, sl, r), OF.ref_batch_query(q, s_, ql, sl, r), q, s_)
 
     check()
+
+
+# ---- the reference's own order inside tie groups (nanoflann traversal + libstdc++ std::sort restated) ----------
+def _ref_order_pyramid(recipe):
+    pts, lens = _stack(recipe)
+    r, dl = 0.0625, 0.05
+    for l in range(4):
+        yield f"conv{l}", OF.oracle_batch_query(pts, pts, lens, lens, r, tie_order="reference")
+        if l == 3:
+            break
+        sp, sl = OF.oracle_subsample_batch(pts, lens, dl)
+        yield f"pool{l}", OF.oracle_batch_query(sp, pts, sl, lens, r, tie_order="reference")
+        yield f"up{l}", OF.oracle_batch_query(pts, sp, lens, sl, 2 * r, tie_order="reference")
+        pts, lens, r, dl = sp, sl, r * 2, dl * 2
+
+
+def test_reference_tie_order_mini_full_tables(golden_dir):
+    g = np.load(os.path.join(golden_dir, "frontend_mini.npz"))
+    for name, t in _ref_order_pyramid("mini"):
+        assert t.shape == g[name].shape and (t == g[name]).all(), name
+
+
+@pytest.mark.parametrize("recipe", ["C1", "S30k", "T8k"])
+def test_reference_tie_order_digests(golden_dir, recipe):
+    """Entry-for-entry equality with the tables the reference returns (T8k: 13 705 of 16 000 level-0 rows hold a tie)."""
+    dig = json.load(open(os.path.join(golden_dir, "frontend_digests.json")))[recipe]
+    for name, t in _ref_order_pyramid(recipe):
+        assert list(t.shape) == dig[name]["shape"] and _sha(t) == dig[name]["sha256"], name
+
+
+@pytest.mark.skipif(not OF.have_ref(), reason="oracle/_ref (reference checker library) not built")
+def test_reference_tie_order_against_reference_library():
+    """Coarse lattices (deep groups of equal distance, duplicates), 1-3 clouds, empty support clouds; plus two
+    cases whose rows are long enough for the introsort partition loop and hold thousands of equal keys."""
+    rng = np.random.default_rng(2)
+    for _ in range(150):
+        nb = int(rng.integers(1, 4))
+        sl = rng.integers(0, 400, nb).astype(np.int32)
+        ql = rng.integers(1, 200, nb).astype(np.int32)     # an EMPTY query cloud before a non-empty one is outside the
+        if sl.sum() == 0:                                  # contract: the reference advances one cloud per query (:270)
+            continue
+        step = float(rng.choice([1 / 4, 1 / 8, 1 / 16, 1 / 64, 1 / 1024]))
+        s = (np.round(rng.random((sl.sum(), 3)) / step) * step).astype(np.float32)
+        q = (np.round(rng.random((ql.sum(), 3)) / step) * step).astype(np.float32)
+        r = float(rng.choice([0.2, 0.35, 0.5, 1.0]))
+        try:
+            want = OF.ref_batch_query(q, s, ql, sl, r)
+        except RuntimeError:
+            with pytest.raises(RuntimeError):
+                OF.oracle_batch_query(q, s, ql, sl, r, tie_order="reference")
+            continue
+        got = OF.oracle_batch_query(q, s, ql, sl, r, tie_order="reference")
+        assert got.shape == want.shape and (got == want).all()
+    s = np.zeros((5000, 3), np.float32)
+    s[:2500, 0] = 0.25
+    q = np.zeros((7, 3), np.float32)
+    assert (OF.oracle_batch_query(q, s, [7], [5000], 1.0, tie_order="reference") == OF.ref_batch_query(q, s, [7], [5000], 1.0)).all()
+    s = (rng.integers(0, 6, (20000, 3)) / 8).astype(np.float32)
+    assert (OF.oracle_batch_query(s[:100], s, [100], [20000], 0.4, tie_order="reference")
+            == OF.ref_batch_query(s[:100], s, [100], [20000], 0.4)).all()
