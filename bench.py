@@ -141,7 +141,10 @@ def main():
     # enqueues the forwards.  The timed region starts from an EMPTY pipeline and ends with it empty again:
     # all K pyramid builds and all K forwards are submitted, executed and finished inside it.
     DEPTH = int(os.environ.get("PCRCG_PIPE_DEPTH", "4"))
-    pipe = PairPipeline(net, cfg, limits, dev, model_streams=int(os.environ.get("PCRCG_MODEL_STREAMS", "3")))
+    if os.environ.get("PCRCG_SWITCH_US"):
+        sys.setswitchinterval(float(os.environ["PCRCG_SWITCH_US"]) * 1e-6)
+    pipe = PairPipeline(net, cfg, limits, dev, model_streams=int(os.environ.get("PCRCG_MODEL_STREAMS", "3")),
+                        front_streams=int(os.environ.get("PCRCG_FRONT_STREAMS", "1")))
 
     def run_pairs(first, count):
         """Push pairs first..first+count-1 through the pipeline, at most DEPTH in flight."""

@@ -89,12 +89,64 @@ int pcrcg_cellgrid_build(const float* sup, int ns, const int* slen, int nb, floa
 int pcrcg_radius_query(const float* q, int nq, const int* qlen, int ns, const int* slen, int nb,
                        float radius, const void* grid, int cols, int64_t* out_idx, int* out_count,
                        int* out_max_count, int* status, void* stream);
+/* pcrcg_radius_query that also reports the rows whose REFERENCE order is not the (d2, index) order: rows that hold
+ * two neighbours of EXACTLY equal d2, the first of them inside the kept `cols` columns.
+ *   out_tie_rows [nq] i32: the row numbers (unordered), out_tie_count [1] i32: how many -- accumulated with
+ *   atomicAdd, zero it before the call.  Both NULL = pcrcg_radius_query. */
+int pcrcg_radius_query_ex(const float* q, int nq, const int* qlen, int ns, const int* slen, int nb,
+                          float radius, const void* grid, int cols, int64_t* out_idx, int* out_count,
+                          int* out_max_count, int* status, int* out_tie_rows, int* out_tie_count, void* stream);
 /* Convenience: zero out_max_count/status, build the grid in `ws`, run one query. */
 size_t pcrcg_radius_neighbors_ws_bytes(int ns, int nb);
 int pcrcg_radius_neighbors_batch(const float* q, int nq, const float* sup, int ns, const int* qlen,
                                  const int* slen, int nb, float radius, int cols, int64_t* out_idx,
                                  int* out_count, int* out_max_count, int* status, void* ws,
                                  size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Front end: the reference's order inside groups of exactly equal distance
+ * batch_nanoflann_neighbors sorts its hits by distance only (IndexDist_Sorter, zip:cpp_utils/nanoflann/
+ * nanoflann.hpp:208-214) with an unstable std::sort over nanoflann's traversal order, and
+ * batch_neighbors_kpconv then cuts the rows at `[:, :limit]` (ref:datasets/dataloader.py:65-69): which members of
+ * a tie group survive, and which of two equidistant coarse points lands in column 0 of an upsample table, is
+ * decided by that order.  These calls reproduce it entry for entry (pcrcg_amd/csrc/tieorder.hip):
+ *
+ *   pcrcg_kdforest_build   nanoflann 1.3.0's KD-tree (leaf size 10, ref:.../neighbors.cpp:245) for each of the
+ *                          nb clouds of `sup` -- the clouds of ALL pyramid levels can be stacked into one forest.
+ *                          forest = workspace of pcrcg_kdforest_ws_bytes(ns, nb) bytes.  max_cloud: an upper
+ *                          bound of the largest slen[] if the host knows one (fewer launches), 0 otherwise; a
+ *                          bound that is too small is reported as status 1 by the reorder calls.
+ *   pcrcg_radius_reorder   rewrites rows of a table produced by pcrcg_radius_query(_ex): the query clouds
+ *                          0..nbq-1 search the forest's clouds cloud0..cloud0+nbq-1; indices are written relative
+ *                          to the first of them and rows are padded with their total size (the table's shadow
+ *                          index).  rows [nrows] i32 = the rows to redo (out_tie_rows; NULL = all nq rows);
+ *                          count [nq] i32 (may be NULL) = out_count of the query, cross-checked;
+ *                          max_count = staging width (>= the longest list among `rows`, <= 1024);
+ *                          idx [nq, cols] i64.
+ *   pcrcg_radius_reorder_jobs  the same for up to PCRCG_MAX_REORDER_JOBS tables over one forest in ONE launch
+ *                          (all tables of a pair).
+ *                          status [1] i32 (may be NULL): 1 tree deeper than supported, 2 traversal stack
+ *                          overflow (more than 128 pending branches), 3 hit count differs from `count`,
+ *                          4 list longer than max_count.
+ * ---------------------------------------------------------------------------------------------- */
+#define PCRCG_MAX_REORDER_JOBS 12
+typedef struct pcrcg_reorder_job {
+    const float* q;       /* [nq,3] queries of the table */
+    const int* qlen;      /* [nbq] */
+    const int* rows;      /* [nrows] rows to redo, NULL = all */
+    const int* count;     /* [nq] or NULL */
+    int64_t* idx;         /* [nq, cols] table, rewritten in place */
+    int nq, nbq, cloud0, nrows, max_count, cols;
+    float radius;
+} pcrcg_reorder_job;
+size_t pcrcg_kdforest_ws_bytes(int ns, int nb);
+int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, int max_cloud, void* forest,
+                         size_t forest_bytes, void* stream);
+int pcrcg_radius_reorder(const float* q, int nq, const int* qlen, int nbq, const float* sup, int ns, int nb,
+                         const void* forest, int cloud0, float radius, const int* rows, int nrows, const int* count,
+                         int max_count, int cols, int64_t* idx, int* status, void* stream);
+int pcrcg_radius_reorder_jobs(const pcrcg_reorder_job* jobs, int njobs, const float* sup, int ns, int nb,
+                              const void* forest, int* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * KPConv (rigid, linear influence, sum aggregation) -- replaces KPConv.forward

@@ -25,6 +25,13 @@ SIGNATURES = {
     "pcrcg_cellgrid_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "pcrcg_radius_query": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcrcg_radius_query_ex": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcrcg_kdforest_ws_bytes": (c_size_t, [c_int, c_int]),
+    "pcrcg_kdforest_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_radius_reorder": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                     c_float, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pcrcg_radius_reorder_jobs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pcrcg_radius_neighbors_ws_bytes": (c_size_t, [c_int, c_int]),
     "pcrcg_radius_neighbors_batch": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float,
                                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

@@ -160,8 +160,10 @@ __global__ void __launch_bounds__(256) k_grid_scatter(const float* __restrict__ 
 template <int CAP, bool REDO>
 __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
     const float* __restrict__ q, int nq, const int* __restrict__ qlen, int nb, float r2, GridView g, int cols,
-    long long* __restrict__ out_idx, int* __restrict__ out_count, int* __restrict__ out_max, int* __restrict__ status) {
+    long long* __restrict__ out_idx, int* __restrict__ out_count, int* __restrict__ out_max, int* __restrict__ status,
+    int* __restrict__ tie_rows, int* __restrict__ tie_count) {
     __shared__ u64 s_list[kQueryWaves][CAP];
+    __shared__ u64 s_sorted[kQueryWaves][CAP];
     __shared__ int s_excl[kQueryWaves][32];
     __shared__ int s_start[kQueryWaves][32];
     // (the wavefront index is uniform: readfirstlane lets the compiler keep the query, its cell and every
@@ -171,6 +173,7 @@ __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
     const int ns = g.hdr->ns;
     const double inv_cell = g.hdr->inv_cell;
     u64* list = s_list[wave];
+    u64* sorted = s_sorted[wave];
     int wave_max = 0;
     if (REDO && blockIdx.x == 0 && threadIdx.x == 0 && g.hdr->overflow && status) *status = 2;
     for (int qi = gw; qi < nq; qi += nw) {
@@ -234,9 +237,23 @@ __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
             const u64 mine = list[e];
             int rank = 0;
             for (int j = 0; j < nl; ++j) rank += list[j] < mine ? 1 : 0;
-            if (rank < cols) __builtin_nontemporal_store((long long)(unsigned)(mine & 0xFFFFFFFFull), &row[rank]);
+            sorted[rank] = mine;
         }
-        for (int j = nl + lane; j < cols; j += 64) __builtin_nontemporal_store((long long)ns, &row[j]);   // shadow index  (:324)
+        __builtin_amdgcn_wave_barrier();
+        // the row in ascending (d2, index) order, padded with the shadow index (:324); a pair of neighbours with
+        // EXACTLY equal d2 whose first member lies inside the kept columns makes the row's reference order
+        // depend on the reference's traversal (tieorder.hip): report the row
+        bool tie = false;
+        for (int e = lane; e < cols; e += 64) {
+            long long vout = (long long)ns;
+            if (e < nl) {
+                const u64 mine = sorted[e];
+                vout = (long long)(unsigned)(mine & 0xFFFFFFFFull);
+                tie |= e + 1 < nl && (unsigned)(sorted[e + 1] >> 32) == (unsigned)(mine >> 32);
+            }
+            __builtin_nontemporal_store(vout, &row[e]);
+        }
+        if (tie_rows && __ballot(tie) != 0ull && lane == 0) tie_rows[atomicAdd(tie_count, 1)] = qi;
         if (lane == 0) {
             if (out_count) out_count[qi] = nhit;
             if ((nhit > CAP || !inrange) && status) *status = 1;
@@ -291,7 +308,15 @@ int pcrcg_cellgrid_build(const float* sup, int ns, const int* slen, int nb, floa
 int pcrcg_radius_query(const float* q, int nq, const int* qlen, int ns, const int* slen, int nb,
                        float radius, const void* grid, int cols, int64_t* out_idx, int* out_count,
                        int* out_max_count, int* status, void* stream) {
+    return pcrcg_radius_query_ex(q, nq, qlen, ns, slen, nb, radius, grid, cols, out_idx, out_count, out_max_count,
+                                 status, nullptr, nullptr, stream);
+}
+
+int pcrcg_radius_query_ex(const float* q, int nq, const int* qlen, int ns, const int* slen, int nb,
+                          float radius, const void* grid, int cols, int64_t* out_idx, int* out_count,
+                          int* out_max_count, int* status, int* out_tie_rows, int* out_tie_count, void* stream) {
     PCRCG_CHECK_ARG(nq >= 0 && ns >= 0 && nb >= 1 && cols >= 1);
+    PCRCG_CHECK_ARG((out_tie_rows == nullptr) == (out_tie_count == nullptr));
     PCRCG_CHECK_ARG(qlen && slen && grid && out_idx && out_max_count);
     PCRCG_CHECK_ARG(nq == 0 || q);
     (void)slen;
@@ -304,10 +329,12 @@ int pcrcg_radius_query(const float* q, int nq, const int* qlen, int ns, const in
     const int max_blocks = 256 * 16;   // 256 CUs x a few workgroups each; waves loop over queries
     if (blocks > max_blocks) blocks = max_blocks;
     hipLaunchKernelGGL((k_radius_query<kListCapFast, false>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, q, nq, qlen,
-                       nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status);
+                       nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status,
+                       out_tie_rows, out_tie_count);
     const int redo_blocks = blocks < 512 ? blocks : 512;
     hipLaunchKernelGGL((k_radius_query<kListCapFull, true>), dim3(redo_blocks), dim3(kQueryWaves * 64), 0, st, q, nq,
-                       qlen, nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status);
+                       qlen, nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status,
+                       out_tie_rows, out_tie_count);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

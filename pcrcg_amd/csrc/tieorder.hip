@@ -1,0 +1,910 @@
+// tieorder.hip -- the reference's neighbour ORDER inside groups of exactly equal distance, on gfx950.
+//
+// pcrcg_radius_query (radius.hip) returns every row in ascending (d2, index) order.  The reference
+// (ref:cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:211-333) sorts by d2 only, with an unstable
+// std::sort over the hits in the order nanoflann's KD-tree traversal found them -- so inside a group of
+// EXACTLY equal d2 its order is decided by
+//   * nanoflann 1.3.0 (zip:cpp_utils/nanoflann/nanoflann.hpp): the tree build (buildIndex :1190-1203,
+//     computeBoundingBox :1318-1338, divideTree :857-905, middleSplit_ :909-957, planeSplit :967-1003,
+//     leaf size 10 from neighbors.cpp:245) and the traversal (findNeighbors :1221-1243,
+//     computeInitialDistances :1005-1022, searchLevel :1348-1410, RadiusResultSet::addPoint :246-250), and
+//   * libstdc++'s std::sort (introsort: median-of-3 pivot, unguarded Hoare partition, threshold 16, heap sort
+//     after 2*lg(n) levels, final insertion sort) with IndexDist_Sorter (:208-214, compares d2 only).
+// With the `[:, :limit]` cut of ref:datasets/dataloader.py:65-69 that order decides WHICH members of a tie group
+// survive, and column 0 of an upsample table decides which feature closest_pool copies, so it is part of the
+// reference's result.  Rows without a tie have one possible order; rows with a tie (reported by
+// pcrcg_radius_query_ex) are redone here:
+//
+//   forest build   one tree per cloud, all clouds of all pyramid levels in ONE forest (a handful of launches for
+//                  the whole pair).  A node's split (dimension, value, index) and the Hoare partition of its
+//                  index range are reproduced exactly; the partition is the sequential part of the reference, and
+//                  is parallelised through the identity  "pass k swaps the k-th misplaced element from the left
+//                  with the k-th misplaced element from the right":
+//                    nodes > 1024 points  one workgroup per node and level (block prefix sums); levels
+//                                         are separate launches over a device-side queue.  A workgroup keeps a
+//                                         child that holds more than 3/4 of its node, so a queued node is at most
+//                                         3/4 of its parent and 2.41*log2(n/1024) launches always suffice, however
+//                                         skewed the splits are;
+//                    nodes <= 1024 points the whole subtree inside one workgroup with its points in LDS, one
+//                                         wavefront per node of a level (ballot / popcount prefix sums).
+//   reorder        one wavefront per row, all tables of a pair in one launch: the reference's traversal with an
+//                  explicit stack in LDS (leaf points tested 64 at a time, appended in order with ballot /
+//                  popcount), then lane 0 replays std::sort step by step on the LDS list and the wavefront writes
+//                  the row.
+//
+// The oracle's CPU restatement (oracle/front_end.c: oracle_radius_neighbors_batch_reforder) is checked against the
+// unmodified reference entry for entry; this file is checked against both (tests/test_tieorder_gpu.py).
+// Compiled with -ffp-contract=off (every fp32 product and sum rounds separately, like the reference build).
+#include <cfloat>
+
+#include "block_scan.h"
+#include "common.h"
+
+namespace pcrcg {
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr int kLeafMax = 10;          // KDTreeSingleIndexAdaptorParams(10), neighbors.cpp:245
+constexpr int kSubMax = 1024;         // nodes up to this size are finished inside one workgroup (LDS)
+constexpr int kSubLevelNodes = 96;    // disjoint ranges of >= 11 points inside 1024 points
+constexpr int kSubThreads = 512;
+constexpr int kLaneNodeMax = 32;      // nodes up to this size: one LANE per node, the reference's loops as written
+constexpr int kBigThreads = 256;      // workgroup of the big-node kernel; each scan step covers kBigThreads * kBigVec positions
+constexpr int kBigVec = 4;
+constexpr int kMaxBigLevels = 96;     // launches over nodes > kSubMax points (2.41 * log2(n / 1024) + 2 are needed)
+constexpr int kTravStack = 128;       // pending far children per query (<= tree depth)
+constexpr int kReorderWaves = 4;      // rows per workgroup of the reorder kernel
+constexpr int kMaxRow = 1024;         // longest row the reorder kernel stages (= the cell-grid search's own bound)
+
+constexpr int kStUnfinished = 1;      // more than kMaxBigLevels levels of big nodes
+constexpr int kStStack = 2;           // traversal stack overflow
+constexpr int kStCount = 3;           // tree search and cell-grid search disagree on a row's hit count
+constexpr int kStWidth = 4;           // a row holds more hits than the staging width
+
+struct KdNode {   // 64 bytes
+    int left, right;        // range in vind
+    int divfeat;            // -1: leaf
+    float divlow, divhigh;
+    int child1, child2;
+    int is_root;
+    float lo[3], hi[3];     // box handed down by the parent (root: the cloud's tight box, read by the search)
+    int pad[2];
+};
+
+struct KdCtl {
+    int node_count, sub_count, status, pad;
+    int big_count[kMaxBigLevels + 2];
+};
+
+struct KdView {
+    KdCtl* ctl;
+    int* soff;       // [nb+1]
+    KdNode* nodes;   // [2*ns + nb + 2]
+    int* vind;       // [ns] global support index
+    int* scratch;    // [ns]
+    int* bigq[2];    // [bigcap]
+    int* subq;       // [subcap]
+    int bigcap, subcap;
+};
+
+inline size_t forest_bytes(int ns, int nb) {
+    const size_t N = (size_t)(ns > 0 ? ns : 0);
+    return carve_bytes(1, sizeof(KdCtl)) + carve_bytes((size_t)nb + 1, sizeof(int)) +
+           carve_bytes(2 * N + nb + 2, sizeof(KdNode)) + 2 * carve_bytes(N + 1, sizeof(int)) +
+           2 * carve_bytes(N / (kSubMax + 1) + nb + 1, sizeof(int)) + carve_bytes(N / (kLeafMax + 1) + nb + 1, sizeof(int));
+}
+
+inline KdView forest_view(void* ws, size_t bytes, int ns, int nb, bool* ok) {
+    const size_t N = (size_t)(ns > 0 ? ns : 0);
+    Carver cv(ws, bytes);
+    KdView v;
+    v.ctl = reinterpret_cast<KdCtl*>(cv.take<char>(sizeof(KdCtl)));
+    v.soff = cv.take<int>((size_t)nb + 1);
+    v.nodes = cv.take<KdNode>(2 * N + nb + 2);
+    v.vind = cv.take<int>(N + 1);
+    v.scratch = cv.take<int>(N + 1);
+    v.bigcap = (int)(N / (kSubMax + 1) + nb + 1);
+    v.subcap = (int)(N / (kLeafMax + 1) + nb + 1);
+    v.bigq[0] = cv.take<int>((size_t)v.bigcap);
+    v.bigq[1] = cv.take<int>((size_t)v.bigcap);
+    v.subq = cv.take<int>((size_t)v.subcap);
+    *ok = cv.ok();
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forest build
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_kd_init(const int* __restrict__ slen, int ns, int nb, KdView v) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        KdCtl* c = v.ctl;
+        c->node_count = nb;
+        c->sub_count = 0;
+        c->status = 0;
+        for (int l = 0; l < kMaxBigLevels + 2; ++l) c->big_count[l] = 0;
+        int s = 0;
+        for (int b = 0; b < nb; ++b) {
+            const int n = slen[b];
+            KdNode nd;
+            nd.left = s;
+            nd.right = s + n;
+            nd.divfeat = -1;
+            nd.divlow = nd.divhigh = 0.f;
+            nd.child1 = nd.child2 = -1;
+            nd.is_root = 1;
+            for (int d = 0; d < 3; ++d) { nd.lo[d] = 0.f; nd.hi[d] = 0.f; }
+            nd.pad[0] = nd.pad[1] = 0;
+            v.nodes[b] = nd;
+            if (n > kSubMax) v.bigq[0][c->big_count[0]++] = b;
+            else if (n > 0) v.subq[c->sub_count++] = b;      // small roots still need their box
+            v.soff[b] = s;
+            s += n;
+        }
+        v.soff[nb] = s;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) v.vind[i] = i;
+}
+
+// children of a split node: allocate, classify (leaf / wavefront subtree / big node of the next level)
+__device__ __forceinline__ void kd_emit_children(const KdView& v, int id, int left, int right, int idx, int cutfeat,
+                                                 float cutval, float divlow, float divhigh, const float* lo,
+                                                 const float* hi, int next_level, int keep_side, int* c1_out,
+                                                 int* c2_out, int prealloc = -1) {
+    const int c1 = prealloc >= 0 ? prealloc : atomicAdd(&v.ctl->node_count, 2), c2 = c1 + 1;
+    for (int side = 0; side < 2; ++side) {
+        KdNode ch;
+        ch.left = side == 0 ? left : left + idx;
+        ch.right = side == 0 ? left + idx : right;
+        ch.divfeat = -1;
+        ch.divlow = ch.divhigh = 0.f;
+        ch.child1 = ch.child2 = -1;
+        ch.is_root = 0;
+        for (int d = 0; d < 3; ++d) { ch.lo[d] = lo[d]; ch.hi[d] = hi[d]; }
+        if (side == 0) ch.hi[cutfeat] = cutval; else ch.lo[cutfeat] = cutval;    // divideTree :891-898
+        ch.pad[0] = ch.pad[1] = 0;
+        v.nodes[c1 + side] = ch;
+        const int n = ch.right - ch.left;
+        if (next_level >= 0 && side != keep_side) {
+            if (n > kSubMax) v.bigq[next_level & 1][atomicAdd(&v.ctl->big_count[next_level], 1)] = c1 + side;
+            else if (n > kLeafMax) v.subq[atomicAdd(&v.ctl->sub_count, 1)] = c1 + side;
+        }
+    }
+    KdNode* nd = &v.nodes[id];
+    nd->divfeat = cutfeat;
+    nd->divlow = divlow;
+    nd->divhigh = divhigh;
+    nd->child1 = c1;
+    nd->child2 = c2;
+    *c1_out = c1;
+    *c2_out = c2;
+}
+
+// middleSplit_ :909-944: split dimension and value from the handed-down box and the node's actual min / max
+__device__ __forceinline__ void kd_choose_split(const float* lo, const float* hi, const float* mn, const float* mx,
+                                                int* cutfeat, float* cutval) {
+    const float EPS = 0.00001f;
+    float max_span = hi[0] - lo[0];
+    for (int d = 1; d < 3; ++d) {
+        const float span = hi[d] - lo[d];
+        if (span > max_span) max_span = span;
+    }
+    float max_spread = -1.f;
+    int cf = 0;
+    for (int d = 0; d < 3; ++d) {
+        const float span = hi[d] - lo[d];
+        if (span > (1 - EPS) * max_span) {
+            const float spread = mx[d] - mn[d];
+            if (spread > max_spread) { cf = d; max_spread = spread; }
+        }
+    }
+    const float split_val = (lo[cf] + hi[cf]) / 2;
+    *cutfeat = cf;
+    *cutval = split_val < mn[cf] ? mn[cf] : (split_val > mx[cf] ? mx[cf] : split_val);
+}
+
+// One pass of planeSplit :967-1003 over positions [lo, hi) of the node, by a whole workgroup.  The sequential loop
+// swaps the k-th element from the left that belongs right with the k-th element from the right that belongs
+// left, until the two scans cross -- i.e. exactly the misplaced elements on either side of the final boundary
+// B = lo + #small, paired in that order.
+template <bool STRICT>
+__device__ void kd_hoare_block(const float* __restrict__ sup, int* vind, int* scratch, int lo, int hi, int nsmall,
+                               int feat, float cut, int* smem) {
+    const int B = lo + nsmall;
+    int m = 0;
+    for (int start = lo; start < B; start += kBigThreads * kBigVec) {
+        const int p0 = start + (int)threadIdx.x * kBigVec;
+        bool flag[kBigVec];
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < kBigVec; ++u) {
+            flag[u] = false;
+            if (p0 + u < B) {
+                const float val = sup[3 * (long)vind[p0 + u] + feat];
+                flag[u] = !(STRICT ? val < cut : val <= cut);
+            }
+            c += flag[u] ? 1 : 0;
+        }
+        int tot;
+        int r = block_excl_scan_i32<kBigThreads>(c, &tot, smem);
+#pragma unroll
+        for (int u = 0; u < kBigVec; ++u)
+            if (flag[u]) scratch[lo + m + r++] = p0 + u;
+        m += tot;
+    }
+    int m2 = 0;
+    for (int start = B; start < hi; start += kBigThreads * kBigVec) {
+        const int p0 = start + (int)threadIdx.x * kBigVec;
+        bool flag[kBigVec];
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < kBigVec; ++u) {
+            flag[u] = false;
+            if (p0 + u < hi) {
+                const float val = sup[3 * (long)vind[p0 + u] + feat];
+                flag[u] = STRICT ? val < cut : val <= cut;
+            }
+            c += flag[u] ? 1 : 0;
+        }
+        int tot;
+        int r = block_excl_scan_i32<kBigThreads>(c, &tot, smem);
+#pragma unroll
+        for (int u = 0; u < kBigVec; ++u)
+            if (flag[u]) scratch[B + m2 + r++] = p0 + u;
+        m2 += tot;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < m; k += kBigThreads) {
+        const int a = scratch[lo + k], b = scratch[B + (m - 1 - k)];
+        const int t = vind[a];
+        vind[a] = vind[b];
+        vind[b] = t;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float wave_min_f(float x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x = fminf(x, __shfl_xor(x, d, 64));
+    return x;
+}
+__device__ __forceinline__ float wave_max_f(float x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x = fmaxf(x, __shfl_xor(x, d, 64));
+    return x;
+}
+__device__ __forceinline__ int wave_sum_i(int x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+
+// nodes > kSubMax points: one workgroup per node of this level
+__global__ void __launch_bounds__(kBigThreads) k_kd_big(const float* __restrict__ sup, KdView v, int level, int final_check) {
+    __shared__ float s_red[kBigThreads / 64][8];
+    __shared__ int s_redi[kBigThreads / 64][2];
+    __shared__ int s_scan[kBigThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cnt = v.ctl->big_count[level];
+    const int* q = v.bigq[level & 1];
+    if (final_check) {   // big nodes still queued after the last level that was launched
+        if (cnt > 0 && blockIdx.x == 0 && threadIdx.x == 0) v.ctl->status = kStUnfinished;
+        return;
+    }
+    __shared__ int s_next[2];
+    for (int w = blockIdx.x; w < cnt; w += gridDim.x) {
+        int id = q[w];
+        int left, right, is_root;
+        float lo[3], hi[3];
+        {
+            const KdNode nd = v.nodes[id];
+            left = nd.left;
+            right = nd.right;
+            is_root = nd.is_root;
+            for (int d = 0; d < 3; ++d) { lo[d] = nd.lo[d]; hi[d] = nd.hi[d]; }
+        }
+        for (;;) {   // this node, then -- while one child keeps more than 3/4 of the points -- that child
+            const int n = right - left;
+            int* ind = v.vind + left;
+            int* scr = v.scratch + left;
+            // actual min / max of the node (computeMinMax :836-848; for a root also the tree's box :1318-1338)
+            float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            for (int p = threadIdx.x; p < n; p += kBigThreads) {
+                const float* c = sup + 3 * (long)ind[p];
+                for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], c[d]); mx[d] = fmaxf(mx[d], c[d]); }
+            }
+            for (int d = 0; d < 3; ++d) { mn[d] = wave_min_f(mn[d]); mx[d] = wave_max_f(mx[d]); }
+            if (lane == 0) for (int d = 0; d < 3; ++d) { s_red[wave][d] = mn[d]; s_red[wave][3 + d] = mx[d]; }
+            __syncthreads();
+            for (int d = 0; d < 3; ++d) {
+                mn[d] = s_red[0][d];
+                mx[d] = s_red[0][3 + d];
+                for (int ww = 1; ww < kBigThreads / 64; ++ww) { mn[d] = fminf(mn[d], s_red[ww][d]); mx[d] = fmaxf(mx[d], s_red[ww][3 + d]); }
+            }
+            __syncthreads();
+            if (is_root) for (int d = 0; d < 3; ++d) { lo[d] = mn[d]; hi[d] = mx[d]; }
+            int cutfeat;
+            float cutval;
+            kd_choose_split(lo, hi, mn, mx, &cutfeat, &cutval);
+            // class counts; largest value below / smallest value above the cut (the children's tight boxes on cutfeat)
+            int nless = 0, neq = 0;
+            float max_less = -FLT_MAX, min_greater = FLT_MAX;
+            for (int p = threadIdx.x; p < n; p += kBigThreads) {
+                const float val = sup[3 * (long)ind[p] + cutfeat];
+                if (val < cutval) { ++nless; max_less = fmaxf(max_less, val); }
+                else if (val == cutval) ++neq;
+                else min_greater = fminf(min_greater, val);
+            }
+            nless = wave_sum_i(nless);
+            neq = wave_sum_i(neq);
+            max_less = wave_max_f(max_less);
+            min_greater = wave_min_f(min_greater);
+            if (lane == 0) { s_redi[wave][0] = nless; s_redi[wave][1] = neq; s_red[wave][6] = max_less; s_red[wave][7] = min_greater; }
+            __syncthreads();
+            nless = neq = 0;
+            max_less = -FLT_MAX;
+            min_greater = FLT_MAX;
+            for (int ww = 0; ww < kBigThreads / 64; ++ww) {
+                nless += s_redi[ww][0];
+                neq += s_redi[ww][1];
+                max_less = fmaxf(max_less, s_red[ww][6]);
+                min_greater = fminf(min_greater, s_red[ww][7]);
+            }
+            __syncthreads();
+            kd_hoare_block<true>(sup, ind, scr, 0, n, nless, cutfeat, cutval, s_scan);          // -> lim1 = nless
+            kd_hoare_block<false>(sup, ind, scr, nless, n, neq, cutfeat, cutval, s_scan);       // -> lim2 = nless + neq
+            const int lim1 = nless, lim2 = nless + neq, half = n / 2;
+            const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);                    // middleSplit_ :951-956
+            const float divlow = idx > lim1 ? cutval : max_less;
+            const float divhigh = idx < lim2 ? cutval : min_greater;
+            const int big_side = idx >= n - idx ? 0 : 1, big_n = big_side == 0 ? idx : n - idx;
+            const int keep = (big_n > kSubMax && 4l * big_n > 3l * n) ? big_side : -1;
+            if (threadIdx.x == 0) {
+                if (is_root) for (int d = 0; d < 3; ++d) { v.nodes[id].lo[d] = lo[d]; v.nodes[id].hi[d] = hi[d]; }
+                int c1, c2;
+                kd_emit_children(v, id, left, right, idx, cutfeat, cutval, divlow, divhigh, lo, hi, level + 1, keep, &c1, &c2);
+                s_next[0] = keep == 0 ? c1 : c2;
+            }
+            __syncthreads();
+            if (keep < 0) break;
+            id = s_next[0];
+            if (keep == 0) { right = left + idx; hi[cutfeat] = cutval; } else { left = left + idx; lo[cutfeat] = cutval; }
+            is_root = 0;
+            __syncthreads();
+        }
+    }
+}
+
+// One pass of planeSplit over positions [lo, hi) of a node whose points sit in LDS, by one wavefront: the same
+// pairing as kd_hoare_block with ballot / popcount prefix sums.  cv = the node's coordinate on the cut dimension
+// by LDS slot, ord = slot by position, list = scratch by position.
+template <bool STRICT>
+__device__ __forceinline__ void kd_hoare_wave(const float* cv, int* ord, int* list, int lo, int hi, int nsmall,
+                                              float cut, int lane) {
+    const int B = lo + nsmall;
+    const u64 below = (1ull << lane) - 1ull;
+    int m = 0;
+    for (int start = lo; start < B; start += 64) {
+        const int p = start + lane;
+        bool flag = false;
+        if (p < B) {
+            const float val = cv[ord[p]];
+            flag = !(STRICT ? val < cut : val <= cut);
+        }
+        const u64 mask = __ballot(flag);
+        if (flag) list[lo + m + __popcll(mask & below)] = p;
+        m += __popcll(mask);
+    }
+    int m2 = 0;
+    for (int start = B; start < hi; start += 64) {
+        const int p = start + lane;
+        bool flag = false;
+        if (p < hi) {
+            const float val = cv[ord[p]];
+            flag = STRICT ? val < cut : val <= cut;
+        }
+        const u64 mask = __ballot(flag);
+        if (flag) list[B + m2 + __popcll(mask & below)] = p;
+        m2 += __popcll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < m; k += 64) {
+        const int a = list[lo + k], b = list[B + (m - 1 - k)];
+        const int t = ord[a];
+        ord[a] = ord[b];
+        ord[b] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// record a split node of an LDS subtree and queue its children that are not leaves
+__device__ __forceinline__ void kd_sub_emit(const KdView& v, int nid, int left, int l, int r, int idx, int cutfeat,
+                                            float cutval, float divlow, float divhigh, const float* lo, const float* hi,
+                                            int child_ids, int* nq_id, int* nq_l, int* nq_r, float (*nq_box)[6], int* nq_cnt) {
+    int c1, c2;
+    kd_emit_children(v, nid, left + l, left + r, idx, cutfeat, cutval, divlow, divhigh, lo, hi, -1, -1, &c1, &c2, child_ids);
+    for (int side = 0; side < 2; ++side) {
+        const int cl = side == 0 ? l : l + idx, cr = side == 0 ? l + idx : r;
+        if (cr - cl > kLeafMax) {
+            const int slot = atomicAdd(nq_cnt, 1);
+            nq_id[slot] = side == 0 ? c1 : c2;
+            nq_l[slot] = cl;
+            nq_r[slot] = cr;
+            for (int d = 0; d < 3; ++d) { nq_box[slot][d] = lo[d]; nq_box[slot][3 + d] = hi[d]; }
+            if (side == 0) nq_box[slot][3 + cutfeat] = cutval; else nq_box[slot][cutfeat] = cutval;
+        }
+    }
+}
+
+// nodes <= kSubMax points: one workgroup builds the whole subtree with its points in LDS; of the nodes of a level,
+// those above kLaneNodeMax points are dealt to the workgroup's wavefronts (ballot / popcount partition), the small
+// ones to single lanes that run the reference's sequential loops as they are written.
+__global__ void __launch_bounds__(kSubThreads) k_kd_sub(const float* __restrict__ sup, KdView v) {
+    __shared__ int s_gi[kSubMax];
+    __shared__ float s_c[3][kSubMax];
+    __shared__ int s_ord[kSubMax];
+    __shared__ int s_list[kSubMax];
+    __shared__ int q_id[2][kSubLevelNodes], q_l[2][kSubLevelNodes], q_r[2][kSubLevelNodes];
+    __shared__ float q_box[2][kSubLevelNodes][6];
+    __shared__ int q_cnt[2];
+    __shared__ int s_base;
+    constexpr int kWaves = kSubThreads / 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int total = v.ctl->sub_count;
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        const int id = v.subq[w];
+        const KdNode nd = v.nodes[id];
+        const int left = nd.left, n = nd.right - nd.left;
+        for (int p = threadIdx.x; p < n; p += kSubThreads) {
+            const int g = v.vind[left + p];
+            s_gi[p] = g;
+            s_ord[p] = p;
+            for (int d = 0; d < 3; ++d) s_c[d][p] = sup[3 * (long)g + d];
+        }
+        if (threadIdx.x == 0) {
+            q_cnt[0] = 0;
+            q_cnt[1] = 0;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            if (nd.is_root) {      // a small cloud: its tight box is the tree's box (:1318-1338)
+                for (int p = lane; p < n; p += 64)
+                    for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], s_c[d][p]); mx[d] = fmaxf(mx[d], s_c[d][p]); }
+                for (int d = 0; d < 3; ++d) { mn[d] = wave_min_f(mn[d]); mx[d] = wave_max_f(mx[d]); }
+                if (lane == 0) for (int d = 0; d < 3; ++d) { v.nodes[id].lo[d] = mn[d]; v.nodes[id].hi[d] = mx[d]; }
+            }
+            if (n > kLeafMax && lane == 0) {
+                q_id[0][0] = id;
+                q_l[0][0] = 0;
+                q_r[0][0] = n;
+                for (int d = 0; d < 3; ++d) {
+                    q_box[0][0][d] = nd.is_root ? mn[d] : nd.lo[d];
+                    q_box[0][0][3 + d] = nd.is_root ? mx[d] : nd.hi[d];
+                }
+                q_cnt[0] = 1;
+            }
+        }
+        __syncthreads();
+        int cur = 0;
+        while (q_cnt[cur] > 0) {
+            const int cnt = q_cnt[cur];
+            if (threadIdx.x == 0) s_base = atomicAdd(&v.ctl->node_count, 2 * cnt);   // ids of this level's children
+            __syncthreads();
+            const int base = s_base;
+            for (int i = wave; i < cnt; i += kWaves) {      // larger nodes: one wavefront each
+                const int nid = q_id[cur][i], l = q_l[cur][i], r = q_r[cur][i], count = r - l;
+                if (count <= kLaneNodeMax) continue;
+                float lo[3], hi[3], nmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, nmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+                for (int d = 0; d < 3; ++d) { lo[d] = q_box[cur][i][d]; hi[d] = q_box[cur][i][3 + d]; }
+                for (int p = l + lane; p < r; p += 64) {
+                    const int o = s_ord[p];
+                    for (int d = 0; d < 3; ++d) { nmn[d] = fminf(nmn[d], s_c[d][o]); nmx[d] = fmaxf(nmx[d], s_c[d][o]); }
+                }
+                for (int d = 0; d < 3; ++d) { nmn[d] = wave_min_f(nmn[d]); nmx[d] = wave_max_f(nmx[d]); }
+                int cutfeat;
+                float cutval;
+                kd_choose_split(lo, hi, nmn, nmx, &cutfeat, &cutval);
+                const float* cv = s_c[cutfeat];
+                int nless = 0, neq = 0;
+                float max_less = -FLT_MAX, min_greater = FLT_MAX;
+                for (int p = l + lane; p < r; p += 64) {
+                    const float val = cv[s_ord[p]];
+                    if (val < cutval) { ++nless; max_less = fmaxf(max_less, val); }
+                    else if (val == cutval) ++neq;
+                    else min_greater = fminf(min_greater, val);
+                }
+                nless = wave_sum_i(nless);
+                neq = wave_sum_i(neq);
+                max_less = wave_max_f(max_less);
+                min_greater = wave_min_f(min_greater);
+                kd_hoare_wave<true>(cv, s_ord, s_list, l, r, nless, cutval, lane);
+                kd_hoare_wave<false>(cv, s_ord, s_list, l + nless, r, neq, cutval, lane);
+                const int lim1 = nless, lim2 = nless + neq, half = count / 2;
+                const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
+                const float divlow = idx > lim1 ? cutval : max_less;
+                const float divhigh = idx < lim2 ? cutval : min_greater;
+                if (lane == 0)
+                    kd_sub_emit(v, nid, left, l, r, idx, cutfeat, cutval, divlow, divhigh, lo, hi, base + 2 * i, q_id[cur ^ 1],
+                                q_l[cur ^ 1], q_r[cur ^ 1], q_box[cur ^ 1], &q_cnt[cur ^ 1]);
+            }
+            for (int i = threadIdx.x; i < cnt; i += kSubThreads) {      // small nodes: one lane each, literally
+                const int nid = q_id[cur][i], l = q_l[cur][i], r = q_r[cur][i], count = r - l;
+                if (count > kLaneNodeMax) continue;
+                float lo[3], hi[3], nmn[3], nmx[3];
+                for (int d = 0; d < 3; ++d) { lo[d] = q_box[cur][i][d]; hi[d] = q_box[cur][i][3 + d]; }
+                for (int d = 0; d < 3; ++d) {
+                    nmn[d] = nmx[d] = s_c[d][s_ord[l]];
+                    for (int p = l + 1; p < r; ++p) {
+                        const float val = s_c[d][s_ord[p]];
+                        if (val < nmn[d]) nmn[d] = val;
+                        if (val > nmx[d]) nmx[d] = val;
+                    }
+                }
+                int cutfeat;
+                float cutval;
+                kd_choose_split(lo, hi, nmn, nmx, &cutfeat, &cutval);
+                const float* cv = s_c[cutfeat];
+                int* ind = s_ord + l;
+                // planeSplit :967-1003 (IndexType is unsigned there: `right` stops at 0 through the `right &&` tests)
+                unsigned lft = 0, rgt = (unsigned)count - 1;
+                for (;;) {
+                    while (lft <= rgt && cv[ind[lft]] < cutval) ++lft;
+                    while (rgt && lft <= rgt && cv[ind[rgt]] >= cutval) --rgt;
+                    if (lft > rgt || !rgt) break;
+                    const int t = ind[lft]; ind[lft] = ind[rgt]; ind[rgt] = t;
+                    ++lft; --rgt;
+                }
+                const int lim1 = (int)lft;
+                rgt = (unsigned)count - 1;
+                for (;;) {
+                    while (lft <= rgt && cv[ind[lft]] <= cutval) ++lft;
+                    while (rgt && lft <= rgt && cv[ind[rgt]] > cutval) --rgt;
+                    if (lft > rgt || !rgt) break;
+                    const int t = ind[lft]; ind[lft] = ind[rgt]; ind[rgt] = t;
+                    ++lft; --rgt;
+                }
+                const int lim2 = (int)lft, half = count / 2;
+                const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
+                float divlow = cv[ind[0]], divhigh = cv[ind[idx]];       // tight boxes of the two children on cutfeat
+                for (int p = 1; p < idx; ++p) divlow = fmaxf(divlow, cv[ind[p]]);
+                for (int p = idx + 1; p < count; ++p) divhigh = fminf(divhigh, cv[ind[p]]);
+                kd_sub_emit(v, nid, left, l, r, idx, cutfeat, cutval, divlow, divhigh, lo, hi, base + 2 * i, q_id[cur ^ 1],
+                            q_l[cur ^ 1], q_r[cur ^ 1], q_box[cur ^ 1], &q_cnt[cur ^ 1]);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) q_cnt[cur] = 0;
+            cur ^= 1;
+            __syncthreads();
+        }
+        for (int p = threadIdx.x; p < n; p += kSubThreads) v.vind[left + p] = s_gi[s_ord[p]];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// libstdc++ std::sort(first, last, comp) with comp(a, b) = a.d2 < b.d2, replayed on packed (d2 bits << 32 | index)
+// entries.  d2 >= +0, so the unsigned order of the upper word is the float order.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool lt(u64 a, u64 b) { return (unsigned)(a >> 32) < (unsigned)(b >> 32); }
+
+__device__ __forceinline__ void adjust_heap(u64* first, int hole, int len, u64 value) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (lt(first[child], first[child - 1])) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;                       // __push_heap
+    while (hole > top && lt(first[parent], value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+
+__device__ __forceinline__ void heap_sort(u64* first, int len) {      // __partial_sort(first, last, last)
+    if (len >= 2) {
+        for (int parent = (len - 2) / 2;; --parent) {  // __make_heap
+            adjust_heap(first, parent, len, first[parent]);
+            if (parent == 0) break;
+        }
+    }
+    for (int last = len; last > 1;) {                  // __sort_heap
+        --last;
+        const u64 value = first[last];
+        first[last] = first[0];
+        adjust_heap(first, 0, last, value);
+    }
+}
+
+__device__ __forceinline__ void unguarded_linear_insert(u64* a, int last) {
+    const u64 val = a[last];
+    int next = last - 1;
+    while (lt(val, a[next])) { a[last] = a[next]; last = next; --next; }
+    a[last] = val;
+}
+
+__device__ __forceinline__ void insertion_sort(u64* a, int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        if (lt(a[i], a[first])) {
+            const u64 val = a[i];
+            for (int j = i; j > first; --j) a[j] = a[j - 1];    // move_backward
+            a[first] = val;
+        } else {
+            unguarded_linear_insert(a, i);
+        }
+    }
+}
+
+__device__ __forceinline__ void std_sort(u64* a, int n) {
+    if (n == 0) return;
+    int lg = 0;
+    while ((n >> (lg + 1)) > 0) ++lg;
+    // __introsort_loop: the recursion on [cut, last) and the loop on [first, cut) touch disjoint ranges, so an
+    // explicit stack in any order gives the same array
+    int st_first[64], st_last[64], st_depth[64], sp = 0;
+    st_first[0] = 0; st_last[0] = n; st_depth[0] = 2 * lg; sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = st_first[sp], last = st_last[sp], depth = st_depth[sp];
+        while (last - first > 16) {
+            if (depth == 0) { heap_sort(a + first, last - first); break; }
+            --depth;
+            const int mid = first + (last - first) / 2;
+            const int ia = first + 1, ib = mid, ic = last - 1;          // __move_median_to_first(first, a, b, c)
+            int med;
+            if (lt(a[ia], a[ib])) med = lt(a[ib], a[ic]) ? ib : (lt(a[ia], a[ic]) ? ic : ia);
+            else med = lt(a[ia], a[ic]) ? ia : (lt(a[ib], a[ic]) ? ic : ib);
+            { const u64 t = a[first]; a[first] = a[med]; a[med] = t; }
+            int lo = first + 1, hi = last;                                 // __unguarded_partition(first + 1, last, first)
+            for (;;) {
+                while (lt(a[lo], a[first])) ++lo;
+                --hi;
+                while (lt(a[first], a[hi])) --hi;
+                if (!(lo < hi)) break;
+                const u64 t = a[lo]; a[lo] = a[hi]; a[hi] = t;
+                ++lo;
+            }
+            if (sp < 64) { st_first[sp] = lo; st_last[sp] = last; st_depth[sp] = depth; ++sp; }
+            last = lo;
+        }
+    }
+    if (n > 16) {                                                          // __final_insertion_sort
+        insertion_sort(a, 0, 16);
+        for (int i = 16; i != n; ++i) unguarded_linear_insert(a, i);
+    } else {
+        insertion_sort(a, 0, n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reorder: one wavefront per row, the tables of a pair in one launch
+// ------------------------------------------------------------------------------------------------
+struct ReorderJobs {
+    pcrcg_reorder_job job[PCRCG_MAX_REORDER_JOBS];
+    int row_begin[PCRCG_MAX_REORDER_JOBS + 1];
+    int njobs;
+};
+
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ float unif(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+
+__global__ void __launch_bounds__(kReorderWaves * 64) k_reorder(ReorderJobs jobs, const float* __restrict__ sup, KdView v,
+                                                                 int W, int* __restrict__ status) {
+    extern __shared__ u64 s_dyn[];
+    // per wavefront: W staged hits, then the traversal stack (node, mindistsq, dists[3] per entry)
+    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
+    const size_t per_wave = (size_t)W + (size_t)kTravStack * 5 / 2 + 1;
+    u64* mine = s_dyn + per_wave * wave;
+    int* st_node = reinterpret_cast<int*>(mine + W);
+    float* st_min = reinterpret_cast<float*>(st_node + kTravStack);
+    float* st_d = st_min + kTravStack;      // [kTravStack][3]
+    const int t = blockIdx.x * kReorderWaves + wave;
+    if (t == 0 && lane == 0 && v.ctl->status && status) *status = v.ctl->status;
+    if (t >= jobs.row_begin[jobs.njobs]) return;
+    int ji = 0;
+    while (ji + 1 < jobs.njobs && t >= jobs.row_begin[ji + 1]) ++ji;
+    const pcrcg_reorder_job& jb = jobs.job[ji];
+    const int local = t - jobs.row_begin[ji];
+    const int qi = jb.rows ? uni(jb.rows[local]) : local;
+    const float* q = jb.q;
+    int b = 0, qacc = 0;
+    while (b < jb.nbq - 1 && qi >= qacc + jb.qlen[b]) { qacc += jb.qlen[b]; ++b; }
+    const int root = jb.cloud0 + b;
+    const int seg = v.soff[jb.cloud0], pad = v.soff[jb.cloud0 + jb.nbq] - seg;
+    const float r2 = jb.radius * jb.radius;      // neighbors.cpp:226
+    const float vx = q[3 * (long)qi], vy = q[3 * (long)qi + 1], vz = q[3 * (long)qi + 2];
+    const u64 below = (1ull << lane) - 1ull;
+    int n = 0, err = 0;
+    const KdNode* rt = &v.nodes[root];
+    if (rt->right > rt->left) {
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, distsq = 0.f;                  // computeInitialDistances :1005-1022
+        if (vx < rt->lo[0]) { d0 = (vx - rt->lo[0]) * (vx - rt->lo[0]); distsq += d0; }
+        if (vx > rt->hi[0]) { d0 = (vx - rt->hi[0]) * (vx - rt->hi[0]); distsq += d0; }
+        if (vy < rt->lo[1]) { d1 = (vy - rt->lo[1]) * (vy - rt->lo[1]); distsq += d1; }
+        if (vy > rt->hi[1]) { d1 = (vy - rt->hi[1]) * (vy - rt->hi[1]); distsq += d1; }
+        if (vz < rt->lo[2]) { d2 = (vz - rt->lo[2]) * (vz - rt->lo[2]); distsq += d2; }
+        if (vz > rt->hi[2]) { d2 = (vz - rt->hi[2]) * (vz - rt->hi[2]); distsq += d2; }
+        int sp = 1;
+        st_node[0] = root;
+        st_min[0] = distsq;
+        st_d[0] = d0; st_d[1] = d1; st_d[2] = d2;
+        while (sp > 0) {
+            --sp;
+            __builtin_amdgcn_wave_barrier();
+            int node = uni(st_node[sp]);
+            const float mind = unif(st_min[sp]);
+            d0 = unif(st_d[3 * sp]); d1 = unif(st_d[3 * sp + 1]); d2 = unif(st_d[3 * sp + 2]);
+            for (;;) {                                                     // searchLevel :1348-1410
+                const KdNode* nd = &v.nodes[node];
+                const int feat = uni(nd->divfeat);
+                if (feat < 0) {
+                    const int l = uni(nd->left), r = uni(nd->right);
+                    for (int base = l; base < r; base += 64) {             // the leaf's points in vind order
+                        const int i = base + lane;
+                        bool hit = false;
+                        float result = 0.0f;
+                        int g = 0;
+                        if (i < r) {
+                            g = v.vind[i];
+                            const float e0 = vx - sup[3 * (long)g], e1 = vy - sup[3 * (long)g + 1], e2 = vz - sup[3 * (long)g + 2];
+                            result += e0 * e0;
+                            result += e1 * e1;
+                            result += e2 * e2;
+                            hit = result < r2;
+                        }
+                        const u64 mask = __ballot(hit);
+                        const int pos = n + __popcll(mask & below);
+                        if (hit && pos < W) mine[pos] = ((u64)__float_as_uint(result) << 32) | (unsigned)g;
+                        n += __popcll(mask);
+                    }
+                    break;
+                }
+                const float val = feat == 0 ? vx : (feat == 1 ? vy : vz);
+                const float divlow = unif(nd->divlow), divhigh = unif(nd->divhigh);
+                const int child1 = uni(nd->child1), child2 = uni(nd->child2);
+                const float diff1 = val - divlow, diff2 = val - divhigh;
+                int best, other;
+                float cut_dist;
+                if ((diff1 + diff2) < 0) { best = child1; other = child2; cut_dist = (val - divhigh) * (val - divhigh); }
+                else { best = child2; other = child1; cut_dist = (val - divlow) * (val - divlow); }
+                // the far child is visited after the near subtree, with the same mindistsq / dists as here
+                const float dcur = feat == 0 ? d0 : (feat == 1 ? d1 : d2);
+                const float mind2 = mind + cut_dist - dcur;
+                if (mind2 * 1.0f <= r2) {
+                    if (sp < kTravStack) {
+                        st_node[sp] = other;        // every lane stores the same value
+                        st_min[sp] = mind2;
+                        st_d[3 * sp] = feat == 0 ? cut_dist : d0;
+                        st_d[3 * sp + 1] = feat == 1 ? cut_dist : d1;
+                        st_d[3 * sp + 2] = feat == 2 ? cut_dist : d2;
+                        ++sp;
+                    } else {
+                        err = kStStack;
+                    }
+                }
+                node = best;
+            }
+        }
+    }
+    if (n > W && !err) err = kStWidth;
+    if (jb.count && n != jb.count[qi] && !err) err = kStCount;
+    if (err) {
+        if (status && lane == 0) *status = err;
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) std_sort(mine, n);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    long long* row = reinterpret_cast<long long*>(jb.idx) + (long)qi * jb.cols;
+    for (int j = lane; j < jb.cols; j += 64)
+        row[j] = j < n ? (long long)((int)(unsigned)(mine[j] & 0xFFFFFFFFull) - seg) : (long long)pad;
+}
+
+}  // namespace
+}  // namespace pcrcg
+
+using namespace pcrcg;
+
+extern "C" {
+
+size_t pcrcg_kdforest_ws_bytes(int ns, int nb) { return forest_bytes(ns, nb < 1 ? 1 : nb); }
+
+int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, int max_cloud, void* forest,
+                         size_t forest_bytes_, void* stream) {
+    PCRCG_CHECK_ARG(ns >= 0 && nb >= 1 && slen && forest && max_cloud >= 0);
+    PCRCG_CHECK_ARG(ns == 0 || sup);
+    hipStream_t st = as_stream(stream);
+    bool ok;
+    KdView v = forest_view(forest, forest_bytes_, ns, nb, &ok);
+    if (!ok) {
+        set_error("pcrcg_kdforest_build: workspace too small (%zu needed, %zu given)", forest_bytes(ns, nb), forest_bytes_);
+        return PCRCG_EWORKSPACE;
+    }
+    int init_blocks = (ns + 255) / 256;
+    init_blocks = init_blocks < 1 ? 1 : (init_blocks > 1024 ? 1024 : init_blocks);
+    hipLaunchKernelGGL(k_kd_init, dim3(init_blocks), dim3(256), 0, st, slen, ns, nb, v);
+    if (ns > 0) {
+        // launches over the big nodes: a queued node holds at most 3/4 of its parent's points (k_kd_big keeps the
+        // heavier child otherwise), so log_{4/3}(n / 1024) = 2.41 * log2(n / 1024) levels empty the queue
+        int levels = 2;
+        for (double n = (double)(max_cloud > 0 && max_cloud < ns ? max_cloud : ns); n > (double)kSubMax; n *= 0.75) ++levels;
+        if (levels > kMaxBigLevels) levels = kMaxBigLevels;
+        if (levels > 2) {
+            const int big_blocks = v.bigcap < 256 ? v.bigcap : 256;
+            for (int l = 0; l < levels; ++l)
+                hipLaunchKernelGGL(k_kd_big, dim3(big_blocks), dim3(kBigThreads), 0, st, sup, v, l, 0);
+            hipLaunchKernelGGL(k_kd_big, dim3(1), dim3(kBigThreads), 0, st, sup, v, levels, 1);   // flags leftovers
+        }
+        const int sub_blocks = v.subcap < 2048 ? v.subcap : 2048;
+        hipLaunchKernelGGL(k_kd_sub, dim3(sub_blocks), dim3(kSubThreads), 0, st, sup, v);
+    }
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+int pcrcg_radius_reorder_jobs(const pcrcg_reorder_job* jobs, int njobs, const float* sup, int ns, int nb,
+                              const void* forest, int* status, void* stream) {
+    PCRCG_CHECK_ARG(njobs >= 0 && njobs <= PCRCG_MAX_REORDER_JOBS && (njobs == 0 || jobs) && forest && nb >= 1 && ns >= 0);
+    ReorderJobs pack;
+    int total = 0, width = 1;
+    pack.njobs = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const pcrcg_reorder_job& j = jobs[i];
+        PCRCG_CHECK_ARG(j.nq >= 0 && j.nbq >= 1 && j.cloud0 >= 0 && j.cloud0 + j.nbq <= nb && j.qlen && j.idx);
+        PCRCG_CHECK_ARG(j.cols >= 1 && j.max_count >= 0 && j.max_count <= kMaxRow && j.radius > 0.0f);
+        const int nrows = j.rows ? j.nrows : j.nq;
+        PCRCG_CHECK_ARG(nrows >= 0 && nrows <= j.nq && (j.nq == 0 || (j.q && sup)));
+        if (nrows == 0) continue;
+        pack.job[pack.njobs] = j;
+        pack.row_begin[pack.njobs] = total;
+        ++pack.njobs;
+        total += nrows;
+        if (j.max_count > width) width = j.max_count;
+    }
+    pack.row_begin[pack.njobs] = total;
+    if (total == 0) return PCRCG_OK;
+    hipStream_t st = as_stream(stream);
+    bool ok;
+    KdView v = forest_view(const_cast<void*>(forest), forest_bytes(ns, nb), ns, nb, &ok);
+    const size_t per_wave = (size_t)width + (size_t)kTravStack * 5 / 2 + 1;
+    const size_t lds = per_wave * kReorderWaves * sizeof(u64);
+    hipLaunchKernelGGL(k_reorder, dim3((total + kReorderWaves - 1) / kReorderWaves), dim3(kReorderWaves * 64), lds, st, pack,
+                       sup, v, width, status);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+int pcrcg_radius_reorder(const float* q, int nq, const int* qlen, int nbq, const float* sup, int ns, int nb,
+                         const void* forest, int cloud0, float radius, const int* rows, int nrows, const int* count,
+                         int max_count, int cols, int64_t* idx, int* status, void* stream) {
+    pcrcg_reorder_job j;
+    j.q = q;
+    j.qlen = qlen;
+    j.rows = rows;
+    j.count = count;
+    j.idx = idx;
+    j.nq = nq;
+    j.nbq = nbq;
+    j.cloud0 = cloud0;
+    j.nrows = nrows;
+    j.max_count = max_count;
+    j.cols = cols;
+    j.radius = radius;
+    return pcrcg_radius_reorder_jobs(&j, 1, sup, ns, nb, forest, status, stream);
+}
+}

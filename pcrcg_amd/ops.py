@@ -1,6 +1,8 @@
 """Tensor-level wrappers over the C ABI (include/pcrcg.h).  PyTorch is used only for device memory
 and streams; every computation below runs in the hand-written HIP kernels of libpcrcg_hip.so.
 All tensors must live on a HIP device -- there is no CPU path."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -124,8 +126,10 @@ class CellGrid:
                                           self.radius, self.grid.data_ptr(), self.nbytes, _stream()),
                    "pcrcg_cellgrid_build")
 
-    def query(self, queries, q_lengths, cols, want_counts=False):
-        """-> (idx [Nq, cols] i64, max_count [1] i32 device, status [1] i32 device[, counts [Nq] i32])."""
+    def query(self, queries, q_lengths, cols, want_counts=False, want_ties=False):
+        """-> (idx [Nq, cols] i64, meta [3] i32 device = (max_count, status, tie_rows)[, counts [Nq] i32]
+        [, tie_rows [Nq] i32: the first meta[2] entries are the rows holding a group of exactly equal distances
+        inside the kept columns, whose reference order KdForest.reorder restores])."""
         L = _lib.lib()
         queries = _dev(queries, _F32, "queries").contiguous()
         q_lengths = _dev(q_lengths, _I32, "q_batches").contiguous()
@@ -133,15 +137,84 @@ class CellGrid:
             raise RuntimeError("Wrong number of batch elements: different for queries and supports ")
         nq = queries.shape[0]
         idx = torch.empty((nq, int(cols)), dtype=_I64, device=queries.device)
-        meta = torch.zeros(2, dtype=_I32, device=queries.device)  # [max_count, status]
-        counts = torch.empty(nq, dtype=_I32, device=queries.device) if want_counts else None
-        _lib.check(L.pcrcg_radius_query(queries.data_ptr(), nq, q_lengths.data_ptr(), self.ns,
-                                        self.lengths.data_ptr(), self.nb, self.radius, self.grid.data_ptr(),
-                                        int(cols), idx.data_ptr(), _ptr(counts), meta[0:1].data_ptr(),
-                                        meta[1:2].data_ptr(), _stream()), "pcrcg_radius_query")
-        if want_counts:
-            return idx, meta, counts
-        return idx, meta
+        meta = torch.zeros(3, dtype=_I32, device=queries.device)  # [max_count, status, tie_rows]
+        counts = torch.empty(nq, dtype=_I32, device=queries.device) if (want_counts or want_ties) else None
+        ties = torch.empty(max(nq, 1), dtype=_I32, device=queries.device) if want_ties else None
+        _lib.check(L.pcrcg_radius_query_ex(queries.data_ptr(), nq, q_lengths.data_ptr(), self.ns,
+                                           self.lengths.data_ptr(), self.nb, self.radius, self.grid.data_ptr(),
+                                           int(cols), idx.data_ptr(), _ptr(counts), meta[0:1].data_ptr(),
+                                           meta[1:2].data_ptr(), _ptr(ties), meta[2:3].data_ptr() if want_ties else None,
+                                           _stream()), "pcrcg_radius_query_ex")
+        out = (idx, meta)
+        if want_counts or want_ties:
+            out += (counts,)
+        if want_ties:
+            out += (ties,)
+        return out
+
+
+MAX_REORDER_JOBS = 12     # PCRCG_MAX_REORDER_JOBS
+
+
+class ReorderJob(ctypes.Structure):
+    """pcrcg_reorder_job (include/pcrcg.h)."""
+    _fields_ = [("q", ctypes.c_void_p), ("qlen", ctypes.c_void_p), ("rows", ctypes.c_void_p), ("count", ctypes.c_void_p),
+                ("idx", ctypes.c_void_p), ("nq", ctypes.c_int), ("nbq", ctypes.c_int), ("cloud0", ctypes.c_int),
+                ("nrows", ctypes.c_int), ("max_count", ctypes.c_int), ("cols", ctypes.c_int), ("radius", ctypes.c_float)]
+
+
+class KdForest:
+    """nanoflann-1.3.0-identical KD-trees (leaf size 10) over stacked clouds -- the clouds of every pyramid level in
+    one forest -- used to give rows with exactly equal distances the reference's own order (csrc/tieorder.hip)."""
+
+    def __init__(self, supports, lengths, max_cloud=0):
+        """max_cloud: the largest cloud's size if the host knows it (fewer launches), 0 = unknown."""
+        L = _lib.lib()
+        self.supports = _dev(supports, _F32, "supports").contiguous()
+        self.lengths = _dev(lengths, _I32, "s_batches").contiguous()
+        self.ns, self.nb = self.supports.shape[0], self.lengths.shape[0]
+        self.nbytes = L.pcrcg_kdforest_ws_bytes(self.ns, self.nb)
+        self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=self.supports.device)
+        _lib.check(L.pcrcg_kdforest_build(self.supports.data_ptr(), self.ns, self.lengths.data_ptr(), self.nb,
+                                          int(max_cloud), self.ws.data_ptr(), self.nbytes, _stream()),
+                   "pcrcg_kdforest_build")
+
+    def reorder(self, idx, queries, q_lengths, cloud0, radius, max_count, rows=None, nrows=None, counts=None,
+                status=None):
+        """Rewrite rows of `idx` [Nq, cols] (in place) in the reference's order.  The query clouds search the
+        forest's clouds cloud0 .. cloud0 + len(q_lengths) - 1.  rows [>= nrows] i32 = rows to redo (None: all)."""
+        return self.reorder_tables([dict(idx=idx, q=queries, qlen=q_lengths, cloud0=cloud0, radius=radius,
+                                         max_count=max_count, rows=rows, nrows=nrows, counts=counts)], status)
+
+    def reorder_tables(self, tables, status=None):
+        """The same for several tables (dicts with the arguments of `reorder`) in one launch."""
+        L = _lib.lib()
+        if len(tables) > MAX_REORDER_JOBS:
+            for i in range(0, len(tables), MAX_REORDER_JOBS):
+                status = self.reorder_tables(tables[i:i + MAX_REORDER_JOBS], status)
+            return status
+        jobs = (ReorderJob * max(len(tables), 1))()
+        keep = []
+        for j, t in zip(jobs, tables):
+            idx = _dev(t["idx"], _I64, "idx")
+            if not idx.is_contiguous():
+                raise RuntimeError("pcrcg_amd.KdForest.reorder: idx must be contiguous")
+            q = _dev(t["q"], _F32, "queries").contiguous()
+            qlen = _dev(t["qlen"], _I32, "q_batches").contiguous()
+            keep += [q, qlen]
+            rows, counts = t.get("rows"), t.get("counts")
+            j.q, j.qlen, j.rows, j.count, j.idx = q.data_ptr(), qlen.data_ptr(), _ptr(rows), _ptr(counts), idx.data_ptr()
+            j.nq, j.nbq, j.cloud0 = idx.shape[0], qlen.shape[0], int(t["cloud0"])
+            j.nrows = idx.shape[0] if rows is None else int(t["nrows"])
+            j.max_count, j.cols, j.radius = int(t["max_count"]), idx.shape[1], float(t["radius"])
+            if status is None:
+                status = torch.zeros(1, dtype=_I32, device=idx.device)
+        if status is None:
+            return None
+        _lib.check(L.pcrcg_radius_reorder_jobs(ctypes.cast(jobs, ctypes.c_void_p), len(tables), self.supports.data_ptr(),
+                                               self.ns, self.nb, self.ws.data_ptr(), status.data_ptr(), _stream()),
+                   "pcrcg_radius_reorder_jobs")
+        return status
 
 
 # ------------------------------------------------------------------------------------------------

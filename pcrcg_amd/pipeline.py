@@ -4,8 +4,9 @@ The front end of a pair (grid subsampling + radius searches) is made of many sma
 kernels and needs host round trips (each subsampled level's row count sizes the next level's tensors);
 the model forward is a few hundred kernels enqueued by one call.  Three things overlap here:
 
-  * a front-end worker thread builds pyramids on its own HIP stream (its host round trips wait with the
-    GIL released, so they do not stall the thread that enqueues forwards);
+  * front-end worker threads build pyramids, each on its own HIP stream (their host round trips wait with the
+    GIL released, so they do not stall the threads that enqueue forwards); with two of them the pyramid of
+    pair k+1 is being built while pair k still waits for its last round trip;
   * forwards of consecutive pairs alternate between two model streams, so the coarse levels of one pair
     (a few hundred points, few workgroups) overlap with the fine levels of the next;
   * one event per pair hands the finished batch dict from the front-end stream to a model stream.
@@ -28,7 +29,7 @@ import threading
 
 import torch
 
-from .pyramid import build_pyramid
+from .pyramid import build_pyramid, check_tie_status
 
 
 def _tensors(batch):
@@ -41,59 +42,125 @@ def _tensors(batch):
                     yield t
 
 
+class _Mailbox:
+    """Items keyed by sequence number; get(k) blocks until item k has been put (front-end workers finish out of
+    order, a forward worker consumes its pairs in order)."""
+
+    def __init__(self):
+        self._items, self._cv = {}, threading.Condition()
+
+    def put(self, key, item):
+        with self._cv:
+            self._items[key] = item
+            self._cv.notify_all()
+
+    def get(self, key):
+        with self._cv:
+            while key not in self._items and None not in self._items:
+                self._cv.wait()
+            return self._items.pop(key) if key in self._items else None
+
+
 class PairPipeline:
-    def __init__(self, net, config, neighborhood_limits, device=None, model_streams=2, threaded=True):
+    def __init__(self, net, config, neighborhood_limits, device=None, model_streams=2, threaded=True, front_streams=1):
         self.net, self.config, self.limits = net, config, neighborhood_limits
         self.device = torch.device(device if device is not None else "cuda")
-        self.front = torch.cuda.Stream(device=self.device)
+        import os
+        prio = int(os.environ.get("PCRCG_FRONT_PRIORITY", "0"))
+        self.fronts = [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(max(1, front_streams))]
+        self.front = self.fronts[0]
+        # restores the reference's tie order (csrc/tieorder.hip)
+        self.tie = torch.cuda.Stream(device=self.device, priority=prio) if os.environ.get("PCRCG_TIE_STREAM", "0") == "1" else None
         self.models = [torch.cuda.Stream(device=self.device) for _ in range(max(1, model_streams))]
         self._turn = 0
-        self._requests = queue.Queue()
+        self._requests = [queue.Queue() for _ in self.fronts]
         self._ready = queue.Queue()
         self._outstanding = 0
         self._worker = None
+        self._front_workers = []
         self._threaded = threaded
-        # submit()/result() mode: per-worker queues of prepared pairs and of finished forwards
-        self._fwd_in = [queue.Queue() for _ in self.models]
+        # submit()/result() mode: per-forward-worker mailbox of prepared pairs and queue of finished forwards
+        self._fwd_in = [_Mailbox() for _ in self.models]
         self._fwd_out = [queue.Queue() for _ in self.models]
         self._fwd_workers = []
         self._submitted = 0
         self._returned = 0
+        # tie-order status words of pairs in flight: (pinned host copy, event) -- read once the event has passed
+        self._tie_pending = []
+        self._tie_lock = threading.Lock()
         if threaded:
-            self._worker = threading.Thread(target=self._serve, name="pcrcg-front-end", daemon=True)
-            self._worker.start()
+            for f in range(len(self.fronts)):
+                t = threading.Thread(target=self._serve, args=(f,), name=f"pcrcg-front-end-{f}", daemon=True)
+                t.start()
+                self._front_workers.append(t)
+            self._worker = self._front_workers[0]
             for w in range(len(self.models)):
                 t = threading.Thread(target=self._serve_forward, args=(w,), name=f"pcrcg-forward-{w}", daemon=True)
                 t.start()
                 self._fwd_workers.append(t)
 
     # ---- front end -----------------------------------------------------------------------------
-    def prepare(self, points, lengths):
-        """Build the pyramid of one pair on the front-end stream (blocking variant)."""
-        with torch.cuda.stream(self.front):
-            batch = build_pyramid(points, lengths, self.config, self.limits)
+    def prepare(self, points, lengths, f=0):
+        """Build the pyramid of one pair on front-end stream f (blocking variant)."""
+        with torch.cuda.stream(self.fronts[f]):
+            batch = build_pyramid(points, lengths, self.config, self.limits, defer_tie_check=True, tie_stream=self.tie)
+            status = batch.pop("tie_status", None)
+            tie_event = batch.pop("tie_event", None)
             done = torch.cuda.Event()
-            done.record(self.front)
-        return batch, done
+            done.record(self.fronts[f])
+        host = None
+        if status is not None:               # asynchronous copy: no host sync for a word that is 0 on sane clouds
+            with torch.cuda.stream(self.tie if self.tie is not None else self.fronts[f]):
+                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                host.copy_(status, non_blocking=True)
+                tie_event = torch.cuda.Event()
+                tie_event.record(self.tie if self.tie is not None else self.fronts[f])
+        self._check_tie_status(wait=False)
+        if host is not None:
+            with self._tie_lock:
+                self._tie_pending.append((host, tie_event))
+        return batch, (done, tie_event)
 
-    def _serve(self):
+    def _check_tie_status(self, wait):
+        """Raise if restoring the reference's tie order failed for an earlier pair (pyramid.check_tie_status)."""
+        with self._tie_lock:
+            pending, self._tie_pending = self._tie_pending, []
+        bad, keep = 0, []
+        for host, ev in pending:
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                bad = bad or int(host[0])
+            else:
+                keep.append((host, ev))
+        with self._tie_lock:
+            self._tie_pending = keep + self._tie_pending
+        check_tie_status(bad)
+
+    def _serve(self, f):
         torch.cuda.set_device(self.device)
         while True:
-            item = self._requests.get()
+            item = self._requests[f].get()
             if item is None:
                 return
-            dest = self._ready
-            if len(item) == 3:              # submit(): hand the pair to its forward worker
-                dest, item = self._fwd_in[item[2]], item[:2]
-            try:
-                dest.put(self.prepare(*item))
-            except BaseException as e:      # surfaced by next_prepared() / result()
-                dest.put(e)
+            if len(item) == 4:              # submit(): hand the pair to its forward worker
+                points, lengths, w, seq = item
+                try:
+                    self._fwd_in[w].put(seq, self.prepare(points, lengths, f))
+                except BaseException as e:  # surfaced by result()
+                    self._fwd_in[w].put(seq, e)
+            else:
+                try:
+                    self._ready.put(self.prepare(*item, f))
+                except BaseException as e:  # surfaced by next_prepared()
+                    self._ready.put(e)
 
     def _serve_forward(self, w):
         torch.cuda.set_device(self.device)
+        seq = w
         while True:
-            item = self._fwd_in[w].get()
+            item = self._fwd_in[w].get(seq)
+            seq += len(self.models)
             if item is None:
                 return
             try:
@@ -109,7 +176,7 @@ class PairPipeline:
         if self._worker is None:
             self._ready.put(self.prepare(points, lengths))
         else:
-            self._requests.put((points, lengths))
+            self._requests[0].put((points, lengths))      # served in order: one front-end worker
 
     def next_prepared(self):
         item = self._ready.get()
@@ -124,7 +191,9 @@ class PairPipeline:
         for t in _tensors(batch):          # allocated on the front-end stream, consumed on `stream`
             if t.is_cuda:
                 t.record_stream(stream)
-        stream.wait_event(done)
+        for ev in (done if isinstance(done, tuple) else (done,)):
+            if ev is not None:
+                stream.wait_event(ev)
         with torch.cuda.stream(stream), torch.no_grad():
             out = self.net(batch)
         return out
@@ -138,10 +207,11 @@ class PairPipeline:
     # ---- submit / result: front end and forward both off the caller's thread -------------------
     def submit(self, points, lengths):
         """Queue one pair for pyramid build + forward; results are returned by result() in this order."""
-        w = self._submitted % len(self.models)
+        seq = self._submitted
+        w = seq % len(self.models)
         self._submitted += 1
         if self._threaded:
-            self._requests.put((points, lengths, w))
+            self._requests[seq % len(self.fronts)].put((points, lengths, w, seq))
         else:
             self._fwd_out[w].put(self._forward(self.prepare(points, lengths), self.models[w]))
 
@@ -166,16 +236,18 @@ class PairPipeline:
         self.synchronize()
 
     def synchronize(self):
-        self.front.synchronize()
+        for s in self.fronts + ([self.tie] if self.tie is not None else []):
+            s.synchronize()
         for s in self.models:
             s.synchronize()
+        self._check_tie_status(wait=True)
 
     def close(self):
-        if self._worker is not None:
-            self._requests.put(None)
-            self._worker.join(timeout=10)
-            self._worker = None
+        for f, t in enumerate(self._front_workers):
+            self._requests[f].put(None)
+            t.join(timeout=10)
+        self._front_workers, self._worker = [], None
         for w, t in enumerate(self._fwd_workers):
-            self._fwd_in[w].put(None)
+            self._fwd_in[w].put(None, None)
             t.join(timeout=10)
         self._fwd_workers = []

@@ -6,6 +6,8 @@ The reference runs this on the CPU inside DataLoader workers and ships ten index
 here the stacked cloud is uploaded once and every table is produced in HBM.  Per level the supports
 are binned once and the conv / pool / upsample searches reuse that grid (all three use the level's
 radius, :273,:298,:301)."""
+import os
+
 import numpy as np
 import torch
 
@@ -39,35 +41,72 @@ def _layer_plan(config):
     return levels
 
 
-def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=False):
+TIE_ORDERS = ("auto", "reference", "index")
+
+
+TIE_STATUS_TEXT = {1: "KD-tree deeper than supported", 2: "traversal stack overflow",
+                   3: "KD-tree and cell-grid searches disagree", 4: "row longer than the staging width"}
+
+
+def check_tie_status(code):
+    if code != 0:
+        raise RuntimeError("pcrcg_amd.build_pyramid: restoring the reference's tie order failed (status %d: %s)" % (
+            code, TIE_STATUS_TEXT.get(code, "?")))
+
+
+def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=False, tie_order=None,
+                  defer_tie_check=False, tie_stream=None):
     """points [N0,3] f32 and lengths [B] i32 on the device -> the reference's batch dict
     (ref:datasets/dataloader.py:363-380) restricted to the keys KPFCNN.forward reads, all on the
     device: points, neighbors, pools, upsamples (int64, shadow = support count), stack_lengths,
     features (ones).  Extra keys: 'stack_lengths_host' (list of python int lists) and, if
-    want_counts, 'neighbor_counts' (untruncated list lengths of the conv tables, for calibration)."""
+    want_counts, 'neighbor_counts' (untruncated list lengths of the conv tables, for calibration).
+
+    tie_order: order of neighbours at EXACTLY equal distance, which decides what `[:, :limit]` keeps and what
+    column 0 of an upsample table holds (csrc/tieorder.hip):
+      "auto"       the reference's order (nanoflann traversal + std::sort replayed); the KD-forest is built only
+                   when some row holds such a tie, and only those rows are redone  [default];
+      "reference"  the same through the KD-forest for every row (a cross-check of "auto");
+      "index"      ascending index -- a defined order, NOT the reference's; no forest.
+    None = the environment variable PCRCG_TIE_ORDER if set, else "auto".
+    defer_tie_check: the restore step reports "cannot happen on sane clouds" conditions (a KD-tree with more than
+    128 pending branches on one query's path, ...) through a device status word.  By default it is read back here
+    (one more host sync); with defer_tie_check=True it is returned as out["tie_status"] ([1] i32 device tensor or
+    None) and the CALLER must pass its value to check_tie_status() once the stream has finished (PairPipeline
+    does)."""
     config = as_config(config)
+    if tie_order is None:
+        tie_order = os.environ.get("PCRCG_TIE_ORDER", "auto")
+    if tie_order not in TIE_ORDERS:
+        raise ValueError(f"pcrcg_amd.build_pyramid: tie_order must be one of {TIE_ORDERS}")
     if not points.is_cuda:
         raise RuntimeError("pcrcg_amd.build_pyramid: points must be on a HIP device (no CPU path)")
     pts = points.to(torch.float32).contiguous()
     lens = lengths.to(_I32).contiguous()
     plan = _layer_plan(config)
+    want_ties = tie_order != "index"
     in_points, in_neighbors, in_pools, in_ups, in_lens = [], [], [], [], []
     metas, tables, counts_out = [], [], []
     empty_idx = torch.zeros((0, 1), dtype=torch.int64, device=pts.device)
     carried = None   # grid over the current level's points built for the previous level's upsample search
+
+    def search(grid, key, layer, q_pts, q_lens, sup_level, limit, keep_counts=False):
+        res = grid.query(q_pts, q_lens, limit, want_counts=keep_counts, want_ties=want_ties)
+        idx, meta = res[0], res[1]
+        metas.append(meta)
+        tables.append(dict(key=key, layer=layer, q=q_pts, qlen=q_lens, sup_level=sup_level, radius=grid.radius,
+                           counts=res[2] if len(res) > 2 else None, ties=res[3] if want_ties else None))
+        if keep_counts:
+            counts_out.append(res[2])
+        return idx
+
     for layer, lv in enumerate(plan):
         limit = int(neighborhood_limits[layer])
         grid = None
         if lv["has_conv"]:
             grid = carried if carried is not None and carried.radius == float(lv["r_conv"]) else \
                 ops.CellGrid(pts, lens, lv["r_conv"])
-            if want_counts:
-                conv_i, meta, cnt = grid.query(pts, lens, limit, want_counts=True)
-                counts_out.append(cnt)
-            else:
-                conv_i, meta = grid.query(pts, lens, limit)
-            metas.append(meta)
-            tables.append(("neighbors", layer))
+            conv_i = search(grid, "neighbors", layer, pts, lens, layer, limit, keep_counts=want_counts)
         else:
             conv_i = empty_idx
         if lv["pooled"]:
@@ -75,13 +114,9 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
             if grid is None or grid.radius != float(lv["r_pool"]):
                 grid = carried if carried is not None and carried.radius == float(lv["r_pool"]) else \
                     ops.CellGrid(pts, lens, lv["r_pool"])
-            pool_i, meta = grid.query(pool_p, pool_b, limit)
-            metas.append(meta)
-            tables.append(("pools", layer))
+            pool_i = search(grid, "pools", layer, pool_p, pool_b, layer, limit)
             up_grid = ops.CellGrid(pool_p, pool_b, 2 * lv["r_pool"])
-            up_i, meta = up_grid.query(pts, lens, limit)
-            metas.append(meta)
-            tables.append(("upsamples", layer))
+            up_i = search(up_grid, "upsamples", layer, pts, lens, layer + 1, limit)
             # the next level's conv and pool searches use these supports with this radius: hand it on
             carried = up_grid
         else:
@@ -97,21 +132,66 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
         pts, lens = pool_p, pool_b
     out = {"points": in_points, "neighbors": in_neighbors, "pools": in_pools, "upsamples": in_ups,
            "stack_lengths": in_lens}
-    # one host round trip for all tables: column counts (neighbors[:, :limit] keeps FEWER columns
-    # when the longest list is shorter than the limit, ref:datasets/dataloader.py:65-67) and status
-    meta_h = torch.stack(metas).cpu().tolist() if metas else []
-    for (key, layer), (max_count, status) in zip(tables, meta_h):
+    # one host round trip for all tables and levels: column counts (neighbors[:, :limit] keeps FEWER columns
+    # when the longest list is shorter than the limit, ref:datasets/dataloader.py:65-67), status, the
+    # number of rows holding a tie, and the per-level cloud lengths
+    nb = in_lens[0].shape[0]
+    host = torch.cat([m for m in metas] + [l.to(_I32) for l in in_lens]).cpu().tolist()
+    meta_h = [host[3 * i:3 * i + 3] for i in range(len(metas))]
+    lens_h = [host[3 * len(metas) + nb * i:3 * len(metas) + nb * (i + 1)] for i in range(len(in_lens))]
+    redo = []
+    for tab, (max_count, status, tie_rows) in zip(tables, meta_h):
         if status != 0:
-            raise RuntimeError(f"pcrcg_amd.build_pyramid: radius search capacity exceeded ({key}[{layer}])")
-        t = out[key][layer]
-        if max_count < t.shape[1]:
-            out[key][layer] = t[:, :max(max_count, 0)]
+            raise RuntimeError(f"pcrcg_amd.build_pyramid: radius search capacity exceeded ({tab['key']}[{tab['layer']}])")
+        tab["max_count"] = max_count
+        if max_count > 0 and (tie_order == "reference" or (tie_order == "auto" and tie_rows > 0)):
+            redo.append((tab, tie_rows))
+    out["tie_status"] = out["tie_event"] = None
+    if redo:
+        if tie_stream is not None:
+            if not defer_tie_check:
+                raise ValueError("pcrcg_amd.build_pyramid: tie_stream requires defer_tie_check=True")
+            tie_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(tie_stream):
+                status = _restore_reference_order(out, redo, in_points, in_lens, max(max(l) for l in lens_h),
+                                                  all_rows=tie_order == "reference")
+                out["tie_event"] = torch.cuda.Event()
+                out["tie_event"].record(tie_stream)
+            for tab, _ in redo:        # allocated on the current stream, read / written on tie_stream
+                for t in (out[tab["key"]][tab["layer"]], tab["q"], tab["qlen"], tab["ties"], tab["counts"]):
+                    if t is not None:
+                        t.record_stream(tie_stream)
+            for t in in_points + in_lens:
+                t.record_stream(tie_stream)
+        else:
+            status = _restore_reference_order(out, redo, in_points, in_lens, max(max(l) for l in lens_h),
+                                              all_rows=tie_order == "reference")
+        if defer_tie_check:
+            out["tie_status"] = status
+        else:
+            check_tie_status(int(status.item()))
+    for tab in tables:
+        t = out[tab["key"]][tab["layer"]]
+        if tab["max_count"] < t.shape[1]:
+            out[tab["key"]][tab["layer"]] = t[:, :max(tab["max_count"], 0)]
     out["features"] = torch.ones((in_points[0].shape[0], 1), dtype=torch.float32, device=points.device)
-    lens_h = torch.stack([l.to(_I32) for l in in_lens]).cpu().tolist()
     out["stack_lengths_host"] = lens_h
     if want_counts:
         out["neighbor_counts"] = counts_out
     return out
+
+
+def _restore_reference_order(out, redo, level_points, level_lens, max_cloud, all_rows):
+    """Rows with exactly equal distances -> the reference's order (ops.KdForest): one forest over the clouds of
+    all levels, then one launch for all tables that reported such rows.  -> status [1] i32 (device)."""
+    nb = level_lens[0].shape[0]
+    forest = ops.KdForest(torch.cat(level_points, 0), torch.cat([l.to(_I32) for l in level_lens], 0), max_cloud)
+    status = torch.zeros(1, dtype=_I32, device=level_points[0].device)
+    forest.reorder_tables([dict(idx=out[tab["key"]][tab["layer"]], q=tab["q"], qlen=tab["qlen"], cloud0=nb * tab["sup_level"],
+                                radius=tab["radius"], max_count=tab["max_count"], counts=tab["counts"],
+                                rows=None if all_rows else tab["ties"], nrows=None if all_rows else tie_rows)
+                           for tab, tie_rows in redo], status)
+    return status
 
 
 def _point2node(nodes, points):

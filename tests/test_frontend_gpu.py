@@ -129,7 +129,8 @@ def test_batch_query_golden_mini(cuda, golden_dir):
     for name, q, s, ql, sl, r in _pyramid_tables(pts, lens):
         got = radius_neighbors.batch_query(q, s, ql, sl, radius=r)
         assert got.dtype == np.int32
-        assert_tables_equal_mod_ties(got, g[name], q, s)
+        assert got.shape == g[name].shape and (got == g[name]).all(), name     # ties in the reference's own order
+        assert_tables_equal_mod_ties(radius_neighbors.batch_query(q, s, ql, sl, radius=r, tie_order="index"), g[name], q, s)
 
 
 @pytest.mark.parametrize("recipe", ["C1", "S30k", "T8k"])
@@ -139,11 +140,13 @@ def test_batch_query_digests_and_oracle(cuda, golden_dir, recipe):
     for name, q, s, ql, sl, r in _pyramid_tables(pts, lens):
         got = radius_neighbors.batch_query(q, s, ql, sl, radius=r)
         assert list(got.shape) == dig[name]["shape"]
+        assert _sha(got) == dig[name]["sha256"], name            # the reference's table, entry for entry
+        got = radius_neighbors.batch_query(q, s, ql, sl, radius=r, tie_order="index")
         canon, _ = canonicalise_table(got, q, s)
-        assert (canon == got).all(), "HIP rows must already be in canonical (d2, index) order"
+        assert (canon == got).all(), "tie_order='index' rows are in canonical (d2, index) order"
         assert _sha(canon) == dig[name]["sha256_canonical"], name
         exp = OF.oracle_batch_query(q, s, ql, sl, r)
-        assert (got == exp).all(), name  # oracle uses the same canonical order: exact equality
+        assert (got == exp).all(), name  # oracle's index order: exact equality
 
 
 def test_batch_query_edge_cases(cuda):
@@ -155,13 +158,18 @@ def test_batch_query_edge_cases(cuda):
     ql = np.array([40, 3, 77], np.int32)
     for r in (0.05, 0.2, 0.9):
         got = radius_neighbors.batch_query(q, s, ql, sl, radius=r)
-        exp = OF.oracle_batch_query(q, s, ql, sl, r)
+        exp = OF.oracle_batch_query(q, s, ql, sl, r, tie_order="reference")
         assert got.shape == exp.shape and (got == exp).all()
         assert ((got == len(s)) | (got < len(s))).all()
-    # exact ties: supports mirrored about the query must come out in ascending index order
+        got = radius_neighbors.batch_query(q, s, ql, sl, radius=r, tie_order="index")
+        assert (got == OF.oracle_batch_query(q, s, ql, sl, r)).all()
+    # exact ties: supports mirrored about the query come out in the reference's order by default (here: what its
+    # insertion sort leaves of the KD-tree leaf order), in ascending index order with tie_order="index"
     q1 = np.zeros((1, 3), np.float32)
     s1 = np.array([[0.1, 0, 0], [-0.1, 0, 0], [0, 0.1, 0], [0, -0.1, 0], [0.05, 0, 0]], np.float32)
     got = radius_neighbors.batch_query(q1, s1, [1], [5], radius=0.5)
+    assert got.tolist() == OF.oracle_batch_query(q1, s1, [1], [5], 0.5, tie_order="reference").tolist()
+    got = radius_neighbors.batch_query(q1, s1, [1], [5], radius=0.5, tie_order="index")
     assert got.tolist() == [[4, 0, 1, 2, 3]]
     # strict inequality d2 < r2 (nanoflann.hpp:249-253): a support at exactly r is excluded
     s2 = np.array([[0.5, 0, 0], [0.25, 0, 0]], np.float32)
@@ -175,7 +183,7 @@ def test_batch_query_edge_cases(cuda):
     # more neighbours than the first-guess width (128) of the shim
     dense = (rng.rand(400, 3) * 0.1).astype(np.float32)
     got = radius_neighbors.batch_query(dense, dense, [400], [400], radius=1.0)
-    exp = OF.oracle_batch_query(dense, dense, [400], [400], 1.0)
+    exp = OF.oracle_batch_query(dense, dense, [400], [400], 1.0, tie_order="reference")
     assert got.shape == (400, 400) and (got == exp).all()
 
 
@@ -185,7 +193,7 @@ def test_truncation_and_counts(cuda):
     grid = ops.CellGrid(tp, tl, 0.0625)
     idx, meta, cnt = grid.query(tp, tl, 24, want_counts=True)
     full = OF.oracle_batch_query(pts, pts, lens, lens, 0.0625)
-    assert meta.tolist() == [full.shape[1], 0]
+    assert meta.tolist()[:2] == [full.shape[1], 0]
     assert idx.dtype == torch.int64 and idx.shape == (len(pts), 24)
     assert (idx.cpu().numpy() == full[:, :24]).all()
     assert (cnt.cpu().numpy() == (full < len(pts)).sum(1)).all()
@@ -234,4 +242,6 @@ def test_random_lattice_clouds_vs_oracle(cuda, seed):
     assert (sl == ol).all() and sp.shape == op.shape and (_bits(sp) == _bits(op)).all()
     for q, s_, ql, sl_, r in ((pts, pts, lens, lens, 1.2 * dl), (op, pts, ol, lens, 1.2 * dl), (pts, op, lens, ol, 2.4 * dl)):
         got = radius_neighbors.batch_query(q, s_, ql, sl_, radius=r)
+        assert (got == OF.oracle_batch_query(q, s_, ql, sl_, r, tie_order="reference")).all()
+        got = radius_neighbors.batch_query(q, s_, ql, sl_, radius=r, tie_order="index")
         assert (got == OF.oracle_batch_query(q, s_, ql, sl_, r)).all()
