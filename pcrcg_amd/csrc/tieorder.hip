@@ -36,6 +36,7 @@
 // unmodified reference entry for entry; this file is checked against both (tests/test_tieorder_gpu.py).
 // Compiled with -ffp-contract=off (every fp32 product and sum rounds separately, like the reference build).
 #include <cfloat>
+#include <cstdlib>
 
 #include "block_scan.h"
 #include "common.h"
@@ -48,16 +49,17 @@ typedef unsigned long long u64;
 constexpr int kLeafMax = 10;          // KDTreeSingleIndexAdaptorParams(10), neighbors.cpp:245
 constexpr int kSubMax = 1024;         // nodes up to this size are finished inside one workgroup (LDS)
 constexpr int kSubLevelNodes = 96;    // disjoint ranges of >= 11 points inside 1024 points
-constexpr int kSubThreads = 512;
+constexpr int kSubThreads = 512;       // = kBigThreads: big nodes and LDS subtrees are tasks of ONE kernel
 constexpr int kLaneNodeMax = 32;      // nodes up to this size: one LANE per node, the reference's loops as written
-constexpr int kBigThreads = 256;      // workgroup of the big-node kernel; each scan step covers kBigThreads * kBigVec positions
-constexpr int kBigVec = 4;
-constexpr int kMaxBigLevels = 96;     // launches over nodes > kSubMax points (2.41 * log2(n / 1024) + 2 are needed)
+constexpr int kBigThreads = 512;      // each scan step of a big node covers kBigThreads * kBigVec positions
+constexpr int kBigVec = 2;
+constexpr int kForestBlocks = 96;     // workgroups of the forest kernel (they pull tasks from a device-side queue)
+constexpr int kSpinLimitDefault = 1 << 20;   // polls of an empty queue before a workgroup gives up (status 1)
 constexpr int kTravStack = 128;       // pending far children per query (<= tree depth)
 constexpr int kReorderWaves = 4;      // rows per workgroup of the reorder kernel
 constexpr int kMaxRow = 1024;         // longest row the reorder kernel stages (= the cell-grid search's own bound)
 
-constexpr int kStUnfinished = 1;      // more than kMaxBigLevels levels of big nodes
+constexpr int kStUnfinished = 1;      // the forest kernel gave up waiting for work (never seen)
 constexpr int kStStack = 2;           // traversal stack overflow
 constexpr int kStCount = 3;           // tree search and cell-grid search disagree on a row's hit count
 constexpr int kStWidth = 4;           // a row holds more hits than the staging width
@@ -73,8 +75,10 @@ struct KdNode {   // 64 bytes
 };
 
 struct KdCtl {
-    int node_count, sub_count, status, pad;
-    int big_count[kMaxBigLevels + 2];
+    int node_count, status;
+    int q_head, q_tail;     // task queue: slots [q_head, q_tail) are waiting
+    int pending;            // tasks queued or running; 0 = forest finished
+    int pad[3];
 };
 
 struct KdView {
@@ -83,16 +87,15 @@ struct KdView {
     KdNode* nodes;   // [2*ns + nb + 2]
     int* vind;       // [ns] global support index
     int* scratch;    // [ns]
-    int* bigq[2];    // [bigcap]
-    int* subq;       // [subcap]
-    int bigcap, subcap;
+    int* taskq;      // [2*ns + nb + 2] node ids, -1 = slot not written yet
+    int qcap;
 };
 
 inline size_t forest_bytes(int ns, int nb) {
     const size_t N = (size_t)(ns > 0 ? ns : 0);
     return carve_bytes(1, sizeof(KdCtl)) + carve_bytes((size_t)nb + 1, sizeof(int)) +
            carve_bytes(2 * N + nb + 2, sizeof(KdNode)) + 2 * carve_bytes(N + 1, sizeof(int)) +
-           2 * carve_bytes(N / (kSubMax + 1) + nb + 1, sizeof(int)) + carve_bytes(N / (kLeafMax + 1) + nb + 1, sizeof(int));
+           carve_bytes(2 * N + nb + 2, sizeof(int));
 }
 
 inline KdView forest_view(void* ws, size_t bytes, int ns, int nb, bool* ok) {
@@ -104,11 +107,8 @@ inline KdView forest_view(void* ws, size_t bytes, int ns, int nb, bool* ok) {
     v.nodes = cv.take<KdNode>(2 * N + nb + 2);
     v.vind = cv.take<int>(N + 1);
     v.scratch = cv.take<int>(N + 1);
-    v.bigcap = (int)(N / (kSubMax + 1) + nb + 1);
-    v.subcap = (int)(N / (kLeafMax + 1) + nb + 1);
-    v.bigq[0] = cv.take<int>((size_t)v.bigcap);
-    v.bigq[1] = cv.take<int>((size_t)v.bigcap);
-    v.subq = cv.take<int>((size_t)v.subcap);
+    v.qcap = (int)(2 * N + nb + 2);
+    v.taskq = cv.take<int>((size_t)v.qcap);
     *ok = cv.ok();
     return v;
 }
@@ -120,10 +120,9 @@ __global__ void __launch_bounds__(256) k_kd_init(const int* __restrict__ slen, i
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         KdCtl* c = v.ctl;
         c->node_count = nb;
-        c->sub_count = 0;
         c->status = 0;
-        for (int l = 0; l < kMaxBigLevels + 2; ++l) c->big_count[l] = 0;
-        int s = 0;
+        c->q_head = 0;
+        int s = 0, tasks = 0;
         for (int b = 0; b < nb; ++b) {
             const int n = slen[b];
             KdNode nd;
@@ -136,38 +135,66 @@ __global__ void __launch_bounds__(256) k_kd_init(const int* __restrict__ slen, i
             for (int d = 0; d < 3; ++d) { nd.lo[d] = 0.f; nd.hi[d] = 0.f; }
             nd.pad[0] = nd.pad[1] = 0;
             v.nodes[b] = nd;
-            if (n > kSubMax) v.bigq[0][c->big_count[0]++] = b;
-            else if (n > 0) v.subq[c->sub_count++] = b;      // small roots still need their box
+            if (n > 0) v.taskq[tasks++] = b;          // every non-empty cloud is a task (small roots need their box)
             v.soff[b] = s;
             s += n;
         }
         v.soff[nb] = s;
+        for (int i = tasks; i < nb; ++i) v.taskq[i] = -1;
+        c->q_tail = tasks;
+        c->pending = tasks;
     }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) v.vind[i] = i;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.qcap; i += gridDim.x * blockDim.x) {
+        if (i < ns) v.vind[i] = i;
+        if (i >= nb) v.taskq[i] = -1;                  // slots 0..nb-1 belong to the roots (thread 0 above)
+    }
 }
 
-// children of a split node: allocate, classify (leaf / wavefront subtree / big node of the next level)
+// ---- device-side task queue of the forest kernel (one thread of a workgroup calls these) ----
+__device__ __forceinline__ int ald(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void kd_push_task(const KdView& v, int id) {
+    // the node record and its vind range were written before the caller's release fence
+    atomicAdd(&v.ctl->pending, 1);
+    const int slot = atomicAdd(&v.ctl->q_tail, 1);
+    __hip_atomic_store(&v.taskq[slot], id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// -> node id, or -1 when the forest is finished (or the wait was abandoned)
+__device__ __noinline__ int kd_pop_task(KdCtl* ctl, const int* taskq, int spin_limit) {
+    for (int spins = 0;;) {
+        const int h = ald(&ctl->q_head), t = ald(&ctl->q_tail);
+        if (h < t) {
+            if (atomicCAS(&ctl->q_head, h, h + 1) != h) continue;
+            int id;
+            while ((id = __hip_atomic_load(&taskq[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > spin_limit) { ctl->status = kStUnfinished; return -1; }
+            }
+            return id;
+        }
+        if (ald(&ctl->pending) == 0) return -1;
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > spin_limit) { ctl->status = kStUnfinished; return -1; }
+    }
+}
+
+// children of a split node: allocate and write their records (queueing is the caller's business)
 __device__ __forceinline__ void kd_emit_children(const KdView& v, int id, int left, int right, int idx, int cutfeat,
                                                  float cutval, float divlow, float divhigh, const float* lo,
-                                                 const float* hi, int next_level, int keep_side, int* c1_out,
-                                                 int* c2_out, int prealloc = -1) {
+                                                 const float* hi, int* c1_out, int* c2_out, int prealloc = -1) {
     const int c1 = prealloc >= 0 ? prealloc : atomicAdd(&v.ctl->node_count, 2), c2 = c1 + 1;
     for (int side = 0; side < 2; ++side) {
-        KdNode ch;
-        ch.left = side == 0 ? left : left + idx;
-        ch.right = side == 0 ? left + idx : right;
-        ch.divfeat = -1;
-        ch.divlow = ch.divhigh = 0.f;
-        ch.child1 = ch.child2 = -1;
-        ch.is_root = 0;
-        for (int d = 0; d < 3; ++d) { ch.lo[d] = lo[d]; ch.hi[d] = hi[d]; }
-        if (side == 0) ch.hi[cutfeat] = cutval; else ch.lo[cutfeat] = cutval;    // divideTree :891-898
-        ch.pad[0] = ch.pad[1] = 0;
-        v.nodes[c1 + side] = ch;
-        const int n = ch.right - ch.left;
-        if (next_level >= 0 && side != keep_side) {
-            if (n > kSubMax) v.bigq[next_level & 1][atomicAdd(&v.ctl->big_count[next_level], 1)] = c1 + side;
-            else if (n > kLeafMax) v.subq[atomicAdd(&v.ctl->sub_count, 1)] = c1 + side;
+        KdNode* ch = &v.nodes[c1 + side];
+        ch->left = side == 0 ? left : left + idx;
+        ch->right = side == 0 ? left + idx : right;
+        ch->divfeat = -1;
+        ch->divlow = ch->divhigh = 0.f;
+        ch->child1 = ch->child2 = -1;
+        ch->is_root = 0;
+        for (int d = 0; d < 3; ++d) {                                            // divideTree :891-898
+            ch->lo[d] = (side == 1 && d == cutfeat) ? cutval : lo[d];
+            ch->hi[d] = (side == 0 && d == cutfeat) ? cutval : hi[d];
         }
     }
     KdNode* nd = &v.nodes[id];
@@ -179,6 +206,8 @@ __device__ __forceinline__ void kd_emit_children(const KdView& v, int id, int le
     *c1_out = c1;
     *c2_out = c2;
 }
+
+__device__ __forceinline__ float sel3(const float* a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
 
 // middleSplit_ :909-944: split dimension and value from the handed-down box and the node's actual min / max
 __device__ __forceinline__ void kd_choose_split(const float* lo, const float* hi, const float* mn, const float* mx,
@@ -198,9 +227,10 @@ __device__ __forceinline__ void kd_choose_split(const float* lo, const float* hi
             if (spread > max_spread) { cf = d; max_spread = spread; }
         }
     }
-    const float split_val = (lo[cf] + hi[cf]) / 2;
+    const float split_val = (sel3(lo, cf) + sel3(hi, cf)) / 2;
+    const float mnc = sel3(mn, cf), mxc = sel3(mx, cf);
     *cutfeat = cf;
-    *cutval = split_val < mn[cf] ? mn[cf] : (split_val > mx[cf] ? mx[cf] : split_val);
+    *cutval = split_val < mnc ? mnc : (split_val > mxc ? mxc : split_val);
 }
 
 // One pass of planeSplit :967-1003 over positions [lo, hi) of the node, by a whole workgroup.  The sequential loop
@@ -280,20 +310,15 @@ __device__ __forceinline__ int wave_sum_i(int x) {
 }
 
 // nodes > kSubMax points: one workgroup per node of this level
-__global__ void __launch_bounds__(kBigThreads) k_kd_big(const float* __restrict__ sup, KdView v, int level, int final_check) {
+// a node > kSubMax points: the whole workgroup partitions it, queues its children, and -- while one child keeps more
+// than 3/4 of the points -- goes on with that child itself
+__device__ void kd_big_task(const float* __restrict__ sup, const KdView& v, int id) {
     __shared__ float s_red[kBigThreads / 64][8];
     __shared__ int s_redi[kBigThreads / 64][2];
     __shared__ int s_scan[kBigThreads / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cnt = v.ctl->big_count[level];
-    const int* q = v.bigq[level & 1];
-    if (final_check) {   // big nodes still queued after the last level that was launched
-        if (cnt > 0 && blockIdx.x == 0 && threadIdx.x == 0) v.ctl->status = kStUnfinished;
-        return;
-    }
     __shared__ int s_next[2];
-    for (int w = blockIdx.x; w < cnt; w += gridDim.x) {
-        int id = q[w];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
         int left, right, is_root;
         float lo[3], hi[3];
         {
@@ -359,16 +384,25 @@ __global__ void __launch_bounds__(kBigThreads) k_kd_big(const float* __restrict_
             const float divhigh = idx < lim2 ? cutval : min_greater;
             const int big_side = idx >= n - idx ? 0 : 1, big_n = big_side == 0 ? idx : n - idx;
             const int keep = (big_n > kSubMax && 4l * big_n > 3l * n) ? big_side : -1;
+            __threadfence();             // the partition of vind is visible before a child is queued
+            __syncthreads();
             if (threadIdx.x == 0) {
                 if (is_root) for (int d = 0; d < 3; ++d) { v.nodes[id].lo[d] = lo[d]; v.nodes[id].hi[d] = hi[d]; }
                 int c1, c2;
-                kd_emit_children(v, id, left, right, idx, cutfeat, cutval, divlow, divhigh, lo, hi, level + 1, keep, &c1, &c2);
+                kd_emit_children(v, id, left, right, idx, cutfeat, cutval, divlow, divhigh, lo, hi, &c1, &c2);
+                __threadfence();
+                if (keep != 0 && idx > kLeafMax) kd_push_task(v, c1);
+                if (keep != 1 && n - idx > kLeafMax) kd_push_task(v, c2);
                 s_next[0] = keep == 0 ? c1 : c2;
             }
             __syncthreads();
             if (keep < 0) break;
             id = s_next[0];
-            if (keep == 0) { right = left + idx; hi[cutfeat] = cutval; } else { left = left + idx; lo[cutfeat] = cutval; }
+            if (keep == 0) right = left + idx; else left = left + idx;
+            for (int d = 0; d < 3; ++d) {
+                if (keep == 0 && d == cutfeat) hi[d] = cutval;
+                if (keep == 1 && d == cutfeat) lo[d] = cutval;
+            }
             is_root = 0;
             __syncthreads();
         }
@@ -424,7 +458,7 @@ __device__ __forceinline__ void kd_sub_emit(const KdView& v, int nid, int left, 
                                             float cutval, float divlow, float divhigh, const float* lo, const float* hi,
                                             int child_ids, int* nq_id, int* nq_l, int* nq_r, float (*nq_box)[6], int* nq_cnt) {
     int c1, c2;
-    kd_emit_children(v, nid, left + l, left + r, idx, cutfeat, cutval, divlow, divhigh, lo, hi, -1, -1, &c1, &c2, child_ids);
+    kd_emit_children(v, nid, left + l, left + r, idx, cutfeat, cutval, divlow, divhigh, lo, hi, &c1, &c2, child_ids);
     for (int side = 0; side < 2; ++side) {
         const int cl = side == 0 ? l : l + idx, cr = side == 0 ? l + idx : r;
         if (cr - cl > kLeafMax) {
@@ -441,7 +475,7 @@ __device__ __forceinline__ void kd_sub_emit(const KdView& v, int nid, int left, 
 // nodes <= kSubMax points: one workgroup builds the whole subtree with its points in LDS; of the nodes of a level,
 // those above kLaneNodeMax points are dealt to the workgroup's wavefronts (ballot / popcount partition), the small
 // ones to single lanes that run the reference's sequential loops as they are written.
-__global__ void __launch_bounds__(kSubThreads) k_kd_sub(const float* __restrict__ sup, KdView v) {
+__device__ void kd_sub_task(const float* __restrict__ sup, const KdView& v, int id) {
     __shared__ int s_gi[kSubMax];
     __shared__ float s_c[3][kSubMax];
     __shared__ int s_ord[kSubMax];
@@ -452,9 +486,7 @@ __global__ void __launch_bounds__(kSubThreads) k_kd_sub(const float* __restrict_
     __shared__ int s_base;
     constexpr int kWaves = kSubThreads / 64;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int total = v.ctl->sub_count;
-    for (int w = blockIdx.x; w < total; w += gridDim.x) {
-        const int id = v.subq[w];
+    {
         const KdNode nd = v.nodes[id];
         const int left = nd.left, n = nd.right - nd.left;
         for (int p = threadIdx.x; p < n; p += kSubThreads) {
@@ -581,6 +613,30 @@ __global__ void __launch_bounds__(kSubThreads) k_kd_sub(const float* __restrict_
         }
         for (int p = threadIdx.x; p < n; p += kSubThreads) v.vind[left + p] = s_gi[s_ord[p]];
         __syncthreads();
+    }
+}
+
+// The forest in one launch: workgroups pull nodes from the device-side queue until no task is queued or running.
+// A node's record and index range are written by the workgroup that split its parent, possibly on another CU:
+// release fence before the push, acquire fence (L1 invalidate) after the pop.
+__global__ void __launch_bounds__(kBigThreads) k_kd_forest(const float* __restrict__ sup, KdView v, int spin_limit) {
+    __shared__ int s_task;
+    static_assert(kBigThreads == kSubThreads, "one workgroup shape for both task kinds");
+    bool more = true;
+    while (more) {
+        if (threadIdx.x == 0) s_task = kd_pop_task(v.ctl, v.taskq, spin_limit);
+        __syncthreads();
+        const int id = s_task;
+        more = id >= 0;
+        if (more) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int n = v.nodes[id].right - v.nodes[id].left;
+            if (n > kSubMax) kd_big_task(sup, v, id);
+            else kd_sub_task(sup, v, id);
+            __threadfence();
+        }
+        __syncthreads();
+        if (more && threadIdx.x == 0) atomicSub(&v.ctl->pending, 1);
     }
 }
 
@@ -835,24 +891,17 @@ int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, int 
         set_error("pcrcg_kdforest_build: workspace too small (%zu needed, %zu given)", forest_bytes(ns, nb), forest_bytes_);
         return PCRCG_EWORKSPACE;
     }
-    int init_blocks = (ns + 255) / 256;
+    int init_blocks = (v.qcap + 255) / 256;
     init_blocks = init_blocks < 1 ? 1 : (init_blocks > 1024 ? 1024 : init_blocks);
     hipLaunchKernelGGL(k_kd_init, dim3(init_blocks), dim3(256), 0, st, slen, ns, nb, v);
     if (ns > 0) {
-        // launches over the big nodes: a queued node holds at most 3/4 of its parent's points (k_kd_big keeps the
-        // heavier child otherwise), so log_{4/3}(n / 1024) = 2.41 * log2(n / 1024) levels empty the queue
-        int levels = 2;
-        for (double n = (double)(max_cloud > 0 && max_cloud < ns ? max_cloud : ns); n > (double)kSubMax; n *= 0.75) ++levels;
-        if (levels > kMaxBigLevels) levels = kMaxBigLevels;
-        if (levels > 2) {
-            const int big_blocks = v.bigcap < 256 ? v.bigcap : 256;
-            for (int l = 0; l < levels; ++l)
-                hipLaunchKernelGGL(k_kd_big, dim3(big_blocks), dim3(kBigThreads), 0, st, sup, v, l, 0);
-            hipLaunchKernelGGL(k_kd_big, dim3(1), dim3(kBigThreads), 0, st, sup, v, levels, 1);   // flags leftovers
-        }
-        const int sub_blocks = v.subcap < 2048 ? v.subcap : 2048;
-        hipLaunchKernelGGL(k_kd_sub, dim3(sub_blocks), dim3(kSubThreads), 0, st, sup, v);
+        // one workgroup per ~1024 points can be busy at the deepest level of big nodes / the LDS subtrees
+        int blocks = ns / kSubMax + nb;
+        if (blocks > kForestBlocks) blocks = kForestBlocks;
+        const char* env = getenv("PCRCG_KD_SPIN_LIMIT");      // debugging aid
+        hipLaunchKernelGGL(k_kd_forest, dim3(blocks), dim3(kBigThreads), 0, st, sup, v, env ? atoi(env) : kSpinLimitDefault);
     }
+    (void)max_cloud;
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
