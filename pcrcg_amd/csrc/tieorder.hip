@@ -50,10 +50,10 @@ constexpr int kLeafMax = 10;          // KDTreeSingleIndexAdaptorParams(10), nei
 constexpr int kSubMax = 1024;         // nodes up to this size are finished inside one workgroup (LDS)
 constexpr int kSubLevelNodes = 96;    // disjoint ranges of >= 11 points inside 1024 points
 constexpr int kSubThreads = 512;       // = kBigThreads: big nodes and LDS subtrees are tasks of ONE kernel
-constexpr int kLaneNodeMax = 32;      // nodes up to this size: one LANE per node, the reference's loops as written
+constexpr int kLaneNodeMax = 0;       // nodes up to this size: one LANE per node, the reference's loops as written
 constexpr int kBigThreads = 512;      // each scan step of a big node covers kBigThreads * kBigVec positions
-constexpr int kBigVec = 2;
-constexpr int kForestBlocks = 96;     // workgroups of the forest kernel (they pull tasks from a device-side queue)
+constexpr int kBigVec = 4;
+constexpr int kForestBlocks = 160;    // workgroups of the forest kernel (they pull tasks from a device-side queue)
 constexpr int kSpinLimitDefault = 1 << 20;   // polls of an empty queue before a workgroup gives up (status 1)
 constexpr int kTravStack = 128;       // pending far children per query (<= tree depth)
 constexpr int kReorderWaves = 4;      // rows per workgroup of the reorder kernel
@@ -174,7 +174,7 @@ __device__ __noinline__ int kd_pop_task(KdCtl* ctl, const int* taskq, int spin_l
             return id;
         }
         if (ald(&ctl->pending) == 0) return -1;
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(32);
         if (++spins > spin_limit) { ctl->status = kStUnfinished; return -1; }
     }
 }
@@ -384,7 +384,8 @@ __device__ void kd_big_task(const float* __restrict__ sup, const KdView& v, int 
             const float divhigh = idx < lim2 ? cutval : min_greater;
             const int big_side = idx >= n - idx ? 0 : 1, big_n = big_side == 0 ? idx : n - idx;
             const int keep = (big_n > kSubMax && 4l * big_n > 3l * n) ? big_side : -1;
-            __threadfence();             // the partition of vind is visible before a child is queued
+            // every wavefront's stores have left the CU at the barrier (workgroup release); ONE agent-scope release
+            // by thread 0 below then writes this XCD's L2 back before a child is queued (other XCDs have their own L2)
             __syncthreads();
             if (threadIdx.x == 0) {
                 if (is_root) for (int d = 0; d < 3; ++d) { v.nodes[id].lo[d] = lo[d]; v.nodes[id].hi[d] = hi[d]; }
@@ -632,8 +633,7 @@ __global__ void __launch_bounds__(kBigThreads) k_kd_forest(const float* __restri
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const int n = v.nodes[id].right - v.nodes[id].left;
             if (n > kSubMax) kd_big_task(sup, v, id);
-            else kd_sub_task(sup, v, id);
-            __threadfence();
+            else kd_sub_task(sup, v, id);      // a subtree's results are read by the next kernel only
         }
         __syncthreads();
         if (more && threadIdx.x == 0) atomicSub(&v.ctl->pending, 1);
