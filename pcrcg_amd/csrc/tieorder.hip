@@ -53,6 +53,7 @@ constexpr int kSubThreads = 512;       // = kBigThreads: big nodes and LDS subtr
 constexpr int kLaneNodeMax = 0;       // nodes up to this size: one LANE per node, the reference's loops as written
 constexpr int kBigThreads = 512;      // each scan step of a big node covers kBigThreads * kBigVec positions
 constexpr int kBigVec = 4;
+constexpr int kOwnMax = 4096;          // a workgroup that splits a node up to this size also splits its big descendants itself
 constexpr int kForestBlocks = 160;    // workgroups of the forest kernel (they pull tasks from a device-side queue)
 constexpr int kSpinLimitDefault = 1 << 20;   // polls of an empty queue before a workgroup gives up (status 1)
 constexpr int kTravStack = 128;       // pending far children per query (<= tree depth)
@@ -157,7 +158,7 @@ __device__ __forceinline__ void kd_push_task(const KdView& v, int id) {
     // the node record and its vind range were written before the caller's release fence
     atomicAdd(&v.ctl->pending, 1);
     const int slot = atomicAdd(&v.ctl->q_tail, 1);
-    __hip_atomic_store(&v.taskq[slot], id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&v.taskq[slot], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // caller fenced already
 }
 
 // -> node id, or -1 when the forest is finished (or the wait was abandoned)
@@ -167,7 +168,7 @@ __device__ __noinline__ int kd_pop_task(KdCtl* ctl, const int* taskq, int spin_l
         if (h < t) {
             if (atomicCAS(&ctl->q_head, h, h + 1) != h) continue;
             int id;
-            while ((id = __hip_atomic_load(&taskq[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+            while ((id = __hip_atomic_load(&taskq[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {   // acquire fence: caller
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > spin_limit) { ctl->status = kStUnfinished; return -1; }
             }
@@ -317,8 +318,11 @@ __device__ void kd_big_task(const float* __restrict__ sup, const KdView& v, int 
     __shared__ int s_redi[kBigThreads / 64][2];
     __shared__ int s_scan[kBigThreads / 64];
     __shared__ int s_next[2];
+    __shared__ int s_stack[64], s_sp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {
+    if (threadIdx.x == 0) s_sp = 0;
+    __syncthreads();
+    for (;;) {      // this node; then the big descendants this workgroup kept for itself (s_stack)
         int left, right, is_root;
         float lo[3], hi[3];
         {
@@ -334,9 +338,17 @@ __device__ void kd_big_task(const float* __restrict__ sup, const KdView& v, int 
             int* scr = v.scratch + left;
             // actual min / max of the node (computeMinMax :836-848; for a root also the tree's box :1318-1338)
             float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-            for (int p = threadIdx.x; p < n; p += kBigThreads) {
-                const float* c = sup + 3 * (long)ind[p];
-                for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], c[d]); mx[d] = fmaxf(mx[d], c[d]); }
+            for (int p = threadIdx.x; p < n; p += 4 * kBigThreads) {      // 4 independent gathers in flight per thread
+                int g[4];
+                float c[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = p + u * kBigThreads < n ? ind[p + u * kBigThreads] : ind[p];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    for (int d = 0; d < 3; ++d) c[u][d] = sup[3 * (long)g[u] + d];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], c[u][d]); mx[d] = fmaxf(mx[d], c[u][d]); }
             }
             for (int d = 0; d < 3; ++d) { mn[d] = wave_min_f(mn[d]); mx[d] = wave_max_f(mx[d]); }
             if (lane == 0) for (int d = 0; d < 3; ++d) { s_red[wave][d] = mn[d]; s_red[wave][3 + d] = mx[d]; }
@@ -354,11 +366,20 @@ __device__ void kd_big_task(const float* __restrict__ sup, const KdView& v, int 
             // class counts; largest value below / smallest value above the cut (the children's tight boxes on cutfeat)
             int nless = 0, neq = 0;
             float max_less = -FLT_MAX, min_greater = FLT_MAX;
-            for (int p = threadIdx.x; p < n; p += kBigThreads) {
-                const float val = sup[3 * (long)ind[p] + cutfeat];
-                if (val < cutval) { ++nless; max_less = fmaxf(max_less, val); }
-                else if (val == cutval) ++neq;
-                else min_greater = fminf(min_greater, val);
+            for (int p = threadIdx.x; p < n; p += 4 * kBigThreads) {
+                int g[4];
+                float val[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = p + u * kBigThreads < n ? ind[p + u * kBigThreads] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) val[u] = g[u] >= 0 ? sup[3 * (long)g[u] + cutfeat] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (g[u] < 0) continue;
+                    if (val[u] < cutval) { ++nless; max_less = fmaxf(max_less, val[u]); }
+                    else if (val[u] == cutval) ++neq;
+                    else min_greater = fminf(min_greater, val[u]);
+                }
             }
             nless = wave_sum_i(nless);
             neq = wave_sum_i(neq);
@@ -377,7 +398,7 @@ __device__ void kd_big_task(const float* __restrict__ sup, const KdView& v, int 
             }
             __syncthreads();
             kd_hoare_block<true>(sup, ind, scr, 0, n, nless, cutfeat, cutval, s_scan);          // -> lim1 = nless
-            kd_hoare_block<false>(sup, ind, scr, nless, n, neq, cutfeat, cutval, s_scan);       // -> lim2 = nless + neq
+            if (neq > 0) kd_hoare_block<false>(sup, ind, scr, nless, n, neq, cutfeat, cutval, s_scan);   // -> lim2 = nless + neq
             const int lim1 = nless, lim2 = nless + neq, half = n / 2;
             const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);                    // middleSplit_ :951-956
             const float divlow = idx > lim1 ? cutval : max_less;
@@ -391,9 +412,16 @@ __device__ void kd_big_task(const float* __restrict__ sup, const KdView& v, int 
                 if (is_root) for (int d = 0; d < 3; ++d) { v.nodes[id].lo[d] = lo[d]; v.nodes[id].hi[d] = hi[d]; }
                 int c1, c2;
                 kd_emit_children(v, id, left, right, idx, cutfeat, cutval, divlow, divhigh, lo, hi, &c1, &c2);
-                __threadfence();
-                if (keep != 0 && idx > kLeafMax) kd_push_task(v, c1);
-                if (keep != 1 && n - idx > kLeafMax) kd_push_task(v, c2);
+                // hand-offs cost more than the split of a few thousand points: below kOwnMax only the LDS subtrees
+                // go to other workgroups, big children stay here (s_stack)
+                bool fenced = false;
+                for (int side = 0; side < 2; ++side) {
+                    const int cn = side == 0 ? idx : n - idx, cid = side == 0 ? c1 : c2;
+                    if (side == keep || cn <= kLeafMax) continue;
+                    if (cn > kSubMax && n <= kOwnMax && s_sp < 64) { s_stack[s_sp++] = cid; continue; }
+                    if (!fenced) { __threadfence(); fenced = true; }     // the agent-scope release of this hand-off
+                    kd_push_task(v, cid);
+                }
                 s_next[0] = keep == 0 ? c1 : c2;
             }
             __syncthreads();
@@ -407,6 +435,11 @@ __device__ void kd_big_task(const float* __restrict__ sup, const KdView& v, int 
             is_root = 0;
             __syncthreads();
         }
+        if (s_sp == 0) break;                      // uniform: written before the barrier that ended the loop above
+        __syncthreads();
+        if (threadIdx.x == 0) s_next[1] = s_stack[--s_sp];
+        __syncthreads();
+        id = s_next[1];
     }
 }
 
@@ -554,7 +587,7 @@ __device__ void kd_sub_task(const float* __restrict__ sup, const KdView& v, int 
                 max_less = wave_max_f(max_less);
                 min_greater = wave_min_f(min_greater);
                 kd_hoare_wave<true>(cv, s_ord, s_list, l, r, nless, cutval, lane);
-                kd_hoare_wave<false>(cv, s_ord, s_list, l + nless, r, neq, cutval, lane);
+                if (neq > 0) kd_hoare_wave<false>(cv, s_ord, s_list, l + nless, r, neq, cutval, lane);
                 const int lim1 = nless, lim2 = nless + neq, half = count / 2;
                 const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
                 const float divlow = idx > lim1 ? cutval : max_less;
