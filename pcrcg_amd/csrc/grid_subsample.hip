@@ -233,14 +233,24 @@ struct UmapWs {
 
 constexpr int kUmapThreads = 1024;
 
-__device__ void umap_order_block(const u64* __restrict__ key, int m, UmapWs w, int* __restrict__ smem) {
+constexpr int kUmapLds = 1109;   // growth stages up to this bucket count (13 ... 1109: seven stages) run out of LDS
+
+// `wg` = global scratch (any size); the first growth stages are a few hundred elements each and pure latency, so
+// their scratch lives in LDS (`s_lds`, 11 * kUmapLds ints) -- same code, the pointers are generic.
+__device__ void umap_order_block(const u64* __restrict__ key, int m, UmapWs wg, int* __restrict__ smem, int* s_lds) {
     const int tid = threadIdx.x;
+    UmapWs wl;
+    wl.ord_a = s_lds + 0 * kUmapLds; wl.ord_b = s_lds + 1 * kUmapLds; wl.bkt = s_lds + 2 * kUmapLds;
+    wl.frank = s_lds + 3 * kUmapLds; wl.cbr = s_lds + 4 * kUmapLds; wl.start = s_lds + 5 * kUmapLds;
+    wl.member = s_lds + 6 * kUmapLds; wl.first = s_lds + 7 * kUmapLds; wl.cnt = s_lds + 8 * kUmapLds;
+    wl.fill = s_lds + 9 * kUmapLds; wl.brank = s_lds + 10 * kUmapLds;
     int cur = 0;
-    int* ord = w.ord_a;
-    int* nord = w.ord_b;
+    int* ord = wl.ord_a;
     for (int s = 1; cur < m && s < kNGrow; ++s) {
         const u64 B = kGrow[s];
         const int cur2 = (u64)m < B ? m : (int)B;
+        const UmapWs w = B <= (u64)kUmapLds ? wl : wg;
+        int* nord = ord == w.ord_a ? w.ord_b : w.ord_a;
         for (u64 b = tid; b < B; b += kUmapThreads) { w.first[b] = kInfIdx; w.cnt[b] = 0; w.fill[b] = 0; }
         __syncthreads();
         for (int t = tid; t < cur2; t += kUmapThreads) {
@@ -305,12 +315,12 @@ __device__ void umap_order_block(const u64* __restrict__ key, int m, UmapWs w, i
             }
         }
         __syncthreads();
-        int* tmp = ord; ord = nord; nord = tmp;
+        ord = nord;
         cur = cur2;
     }
-    // leave the final order in ord_a
-    if (ord != w.ord_a)
-        for (int t = tid; t < m; t += kUmapThreads) w.ord_a[t] = ord[t];
+    // leave the final order in the global ord_a
+    if (ord != wg.ord_a)
+        for (int t = tid; t < m; t += kUmapThreads) wg.ord_a[t] = ord[t];
     __syncthreads();
 }
 
@@ -339,6 +349,7 @@ __global__ void __launch_bounds__(kUmapThreads) k_order_emit(int n, int nb, cons
                                                               float* __restrict__ out_pts, int* __restrict__ out_len,
                                                               int* __restrict__ out_m) {
     __shared__ int smem[kUmapThreads / 64];
+    __shared__ int s_lds[11 * kUmapLds];
     const int b = blockIdx.x;
     const int mt = *mtot;
     // cells of clouds < b precede this cloud's cells (first-occurrence order is input order)
@@ -351,7 +362,7 @@ __global__ void __launch_bounds__(kUmapThreads) k_order_emit(int n, int nb, cons
     }
     const int m = cell_hi - cell_lo;
     UmapWs w = umap_carve(ebase, bbase, estride, bstride, cell_lo, 3l * cell_lo + 16l * b);
-    umap_order_block(ckey + cell_lo, m, w, smem);
+    umap_order_block(ckey + cell_lo, m, w, smem, s_lds);
     const int keep = min(m, max_p);                                         // :185-205
     for (int j = threadIdx.x; j < keep; j += kUmapThreads) {
         const long c = cell_lo + w.ord_a[j];
@@ -369,8 +380,9 @@ __global__ void __launch_bounds__(kUmapThreads) k_umap_only(const u64* __restric
                                                              int* __restrict__ bbase, long estride, long bstride,
                                                              int* __restrict__ order) {
     __shared__ int smem[kUmapThreads / 64];
+    __shared__ int s_lds[11 * kUmapLds];
     UmapWs w = umap_carve(ebase, bbase, estride, bstride, 0, 0);
-    umap_order_block(key, m, w, smem);
+    umap_order_block(key, m, w, smem, s_lds);
     for (int j = threadIdx.x; j < m; j += kUmapThreads) order[j] = w.ord_a[j];
 }
 
