@@ -248,7 +248,9 @@ def main():
                                    "forward, random-init full-width weights, 1 pair/GPU/step; "
                                    "pyramids are built by a front-end thread on its own HIP stream, forwards are enqueued by "
                                    "one worker thread per model stream (3 streams); the timed region starts and ends with "
-                                   "an empty pipeline",
+                                   "an empty pipeline; neighbour tables in the reference's own order inside groups "
+                                   "of exactly equal distance (tie_order=%s)" % os.environ.get("PCRCG_TIE_ORDER", "auto"),
+                       "tie_order": os.environ.get("PCRCG_TIE_ORDER", "auto"),
                        "limits": limits, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "KPConv neighbour-gather kernels (k_kpconv_mfma / k_kpconv_c1 / "
                                                      "k_kpconv_fused), %d launches/pair" % per_pair,
