@@ -1,5 +1,7 @@
 /* c_host_frontend.c -- a plain C host driving libpcrcg_hip.so through include/pcrcg.h (no Python, no torch):
- * two synthetic clouds -> grid subsampling -> radius neighbours of the subsampled level.  Prints the numbers
+ * two synthetic clouds -> grid subsampling -> radius neighbours of the subsampled level; then the same clouds snapped
+ * to a 1/32 lattice (exactly equal distances everywhere) -> radius neighbours in the REFERENCE's order inside tie
+ * groups (pcrcg_radius_query_ex + pcrcg_kdforest_build + pcrcg_radius_reorder).  Prints the numbers
  * tests/test_c_host_gpu.py compares with the Python binding on the same input.
  *
  * Build:  gcc -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_host_frontend.c -o c_host_frontend \
@@ -72,6 +74,48 @@ int main(void) {
     for (int i = 0; i < 3 * m; ++i) coord_sum += (double)h_sub[i];
     printf("abi=%d m=%d len0=%d len1=%d max_count=%d status=%d idx_sum=%llu shadow=%llu coord_sum=%.6f\n",
            pcrcg_abi_version(), m, sub_len[0], sub_len[1], max_count, status, idx_sum, shadow, coord_sum);
+
+    /* 3. lattice-snapped clouds: the table in the reference's own order inside groups of equal distance */
+    {
+        const int tn = 1500 * nb, tcols = 48;
+        const float tr = 0.11f;
+        int t_len[2] = {1500, 1500};
+        float* h_t = (float*)malloc(sizeof(float) * 3 * tn);
+        for (int i = 0; i < 3 * tn; ++i) h_t[i] = (float)(int)(h_pts[i] * 32.0f) * (1.0f / 32.0f);
+        float* d_t;
+        int *d_tlen, *d_tcount, *d_ties, *d_meta;     /* meta: max_count, status, tie_count, reorder status */
+        int64_t* d_tidx;
+        CHECK_HIP(hipMalloc((void**)&d_t, sizeof(float) * 3 * tn));
+        CHECK_HIP(hipMalloc((void**)&d_tlen, sizeof(int) * nb));
+        CHECK_HIP(hipMalloc((void**)&d_tcount, sizeof(int) * tn));
+        CHECK_HIP(hipMalloc((void**)&d_ties, sizeof(int) * tn));
+        CHECK_HIP(hipMalloc((void**)&d_meta, sizeof(int) * 4));
+        CHECK_HIP(hipMalloc((void**)&d_tidx, sizeof(int64_t) * (size_t)tn * tcols));
+        CHECK_HIP(hipMemcpy(d_t, h_t, sizeof(float) * 3 * tn, hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(d_tlen, t_len, sizeof(int) * nb, hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemset(d_meta, 0, sizeof(int) * 4));
+        size_t gbytes = pcrcg_cellgrid_ws_bytes(tn, nb), fbytes = pcrcg_kdforest_ws_bytes(tn, nb);
+        void *grid, *forest;
+        CHECK_HIP(hipMalloc(&grid, gbytes));
+        CHECK_HIP(hipMalloc(&forest, fbytes));
+        CHECK_PCRCG(pcrcg_cellgrid_build(d_t, tn, d_tlen, nb, tr, grid, gbytes, NULL));
+        CHECK_PCRCG(pcrcg_radius_query_ex(d_t, tn, d_tlen, tn, d_tlen, nb, tr, grid, tcols, d_tidx, d_tcount, d_meta,
+                                          d_meta + 1, d_ties, d_meta + 2, NULL));
+        int meta[4];
+        CHECK_HIP(hipMemcpy(meta, d_meta, sizeof(int) * 4, hipMemcpyDeviceToHost));
+        CHECK_PCRCG(pcrcg_kdforest_build(d_t, tn, d_tlen, nb, 1500, forest, fbytes, NULL));
+        CHECK_PCRCG(pcrcg_radius_reorder(d_t, tn, d_tlen, nb, d_t, tn, nb, forest, 0, tr, d_ties, meta[2], d_tcount,
+                                         meta[0], tcols, d_tidx, d_meta + 3, NULL));
+        int64_t* h_tidx = (int64_t*)malloc(sizeof(int64_t) * (size_t)tn * tcols);
+        CHECK_HIP(hipMemcpy(h_tidx, d_tidx, sizeof(int64_t) * (size_t)tn * tcols, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(meta, d_meta, sizeof(int) * 4, hipMemcpyDeviceToHost));
+        unsigned long long order_sum = 0;          /* order-sensitive checksum of the kept columns */
+        const int keep = meta[0] < tcols ? meta[0] : tcols;
+        for (int i = 0; i < tn; ++i)
+            for (int j = 0; j < keep; ++j) order_sum += (unsigned long long)(j + 1) * (unsigned long long)h_tidx[(size_t)i * tcols + j];
+        printf("tie_max_count=%d tie_status=%d tie_rows=%d reorder_status=%d order_sum=%llu\n", meta[0], meta[1], meta[2],
+               meta[3], order_sum);
+    }
 
     /* argument validation happens before any launch */
     if (pcrcg_grid_subsample_batch(NULL, n, d_len, nb, dl, 0, d_sub, d_sub_len, d_m, ws, ws_bytes, NULL) != PCRCG_EBADARG) return 4;

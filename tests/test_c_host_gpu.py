@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from pcrcg_amd import ops
+from pcrcg_amd.cpp_wrappers.cpp_neighbors import radius_neighbors
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -48,3 +49,16 @@ def test_c_host_program_matches_python_binding(cuda, tmp_path):
     assert int(got["max_count"]) == int(meta[0]) and int(got["status"]) == 0
     assert int(got["idx_sum"]) == int(idx.sum()) and int(got["shadow"]) == int((idx == m).sum())
     assert abs(float(got["coord_sum"]) - float(sub.double().sum())) < 1e-3
+
+    # part 3 of the program: lattice-snapped clouds, the reference's order inside tie groups -- against the Python
+    # mirror of batch_query (same ABI calls) and, through it, the oracle-pinned order
+    raw = _lcg_points(3 * 8000)[:3 * 3000]
+    snapped = (np.floor(raw * np.float32(32.0)).astype(np.int32).astype(np.float32) * np.float32(1.0 / 32.0)).reshape(-1, 3)
+    want = radius_neighbors.batch_query(snapped, snapped, [1500, 1500], [1500, 1500], radius=0.11)
+    by_index = radius_neighbors.batch_query(snapped, snapped, [1500, 1500], [1500, 1500], radius=0.11, tie_order="index")
+    keep = min(want.shape[1], 48)
+    w = np.arange(1, keep + 1, dtype=np.uint64)[None, :]
+    assert int(got["tie_status"]) == 0 and int(got["reorder_status"]) == 0 and int(got["tie_rows"]) > 1000
+    assert int(got["tie_max_count"]) == want.shape[1]
+    assert int(got["order_sum"]) == int((want[:, :keep].astype(np.uint64) * w).sum())
+    assert int(got["order_sum"]) != int((by_index[:, :keep].astype(np.uint64) * w).sum())
