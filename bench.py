@@ -144,7 +144,8 @@ def main():
     if os.environ.get("PCRCG_SWITCH_US"):
         sys.setswitchinterval(float(os.environ["PCRCG_SWITCH_US"]) * 1e-6)
     pipe = PairPipeline(net, cfg, limits, dev, model_streams=int(os.environ.get("PCRCG_MODEL_STREAMS", "3")),
-                        front_streams=int(os.environ.get("PCRCG_FRONT_STREAMS", "1")))
+                        front_streams=int(os.environ.get("PCRCG_FRONT_STREAMS", "1")),
+                        interleave=int(os.environ.get("PCRCG_FRONT_INTERLEAVE", "2")))
 
     def run_pairs(first, count):
         """Push pairs first..first+count-1 through the pipeline, at most DEPTH in flight."""
@@ -165,11 +166,19 @@ def main():
     out = run_pairs(0, args.warmup)
     fence()
     ops.kpconv_profile_start()        # HIP events around every KPConv gather/aggregate launch from here on
+    for k in getattr(pipe, "front_stats", {}):
+        pipe.front_stats[k] = 0
     t0 = time.perf_counter()
     out = run_pairs(args.warmup, args.steps)
     submit = time.perf_counter() - t0      # host time until the last forward was enqueued (GPU may still be busy)
     fence()
     elapsed = time.perf_counter() - t0
+    front_stats = dict(getattr(pipe, "front_stats", {}))
+    if os.environ.get("PCRCG_PIPE_STATS"):
+        from pcrcg_amd import pyramid as _pyr
+        print("restore step host time per call (ms):", {k: round(1e3 * v / max(_pyr.HOST_TIMES["calls"], 1), 3)
+                                                          for k, v in _pyr.HOST_TIMES.items() if k != "calls"},
+              "calls", _pyr.HOST_TIMES["calls"], file=sys.stderr, flush=True)
     events = ops.kpconv_profile_stop()
     assert out["feats_f"].shape[1] == cfg.final_feats_dim
 
@@ -184,6 +193,13 @@ def main():
                 net(batch_iso)
         torch.cuda.synchronize()
         iso = ops.kpconv_profile_stop()
+    if os.environ.get("PCRCG_PIPE_STATS") and rank == 0:
+        st = front_stats
+        n = max(st.get("pairs", 1), 1)
+        print("front-end worker per pair: advance (python + launches) %.3f ms, waiting for round trips %.3f ms, idle (no "
+              "request) %.3f ms; %d of %d resumes found their value already there" % (
+                  1e3 * st.get("advance_s", 0) / n, 1e3 * st.get("wait_s", 0) / n, 1e3 * st.get("idle_s", 0) / n,
+                  st.get("resumed_ready", 0), st.get("resumes", 0)), file=sys.stderr, flush=True)
     pipe.close()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

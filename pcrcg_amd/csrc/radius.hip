@@ -157,27 +157,26 @@ __global__ void __launch_bounds__(256) k_grid_scatter(const float* __restrict__ 
 
 // One wavefront per query.  Pass 1 (REDO = false) handles every query with a small LDS list; a query
 // whose list does not fit marks its row, and pass 2 (REDO = true, large list) redoes only marked rows.
-template <int CAP, bool REDO>
-__global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
+template <int CAP, bool REDO, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_radius_query(
     const float* __restrict__ q, int nq, const int* __restrict__ qlen, int nb, float r2, GridView g, int cols,
     long long* __restrict__ out_idx, int* __restrict__ out_count, int* __restrict__ out_max, int* __restrict__ status,
     int* __restrict__ tie_rows, int* __restrict__ tie_count) {
-    __shared__ u64 s_list[kQueryWaves][CAP];
-    __shared__ u64 s_sorted[kQueryWaves][CAP];
-    __shared__ int s_excl[kQueryWaves][32];
-    __shared__ int s_start[kQueryWaves][32];
+    __shared__ u64 s_list[WAVES][CAP];
+    __shared__ u64 s_sorted[WAVES][CAP];
+    __shared__ int s_excl[WAVES][32];
+    __shared__ int s_start[WAVES][32];
     // (the wavefront index is uniform: readfirstlane lets the compiler keep the query, its cell and every
     // per-query address in SGPRs)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int gw = blockIdx.x * kQueryWaves + wave, nw = gridDim.x * kQueryWaves;
+    const int gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
     const int ns = g.hdr->ns;
     const double inv_cell = g.hdr->inv_cell;
     u64* list = s_list[wave];
     u64* sorted = s_sorted[wave];
     int wave_max = 0;
     if (REDO && blockIdx.x == 0 && threadIdx.x == 0 && g.hdr->overflow && status) *status = 2;
-    for (int qi = gw; qi < nq; qi += nw) {
-        if (REDO && out_idx[(long)qi * cols] != kRedoMark) continue;   // wave-uniform
+    auto one_query = [&](const int qi) {
         // cloud of this query: walk the (few) query lengths
         int b = 0, qacc = 0;
         while (b < nb - 1 && qi >= qacc + qlen[b]) { qacc += qlen[b]; ++b; }
@@ -231,7 +230,7 @@ __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
         if (!REDO && nhit > CAP) {   // leave the row to pass 2
             if (lane == 0) row[0] = kRedoMark;
             wave_max = nhit > wave_max ? nhit : wave_max;
-            continue;
+            return;
         }
         for (int e = lane; e < nl; e += 64) {
             const u64 mine = list[e];
@@ -260,6 +259,21 @@ __global__ void __launch_bounds__(kQueryWaves * 64) k_radius_query(
         }
         wave_max = nhit > wave_max ? nhit : wave_max;
         __builtin_amdgcn_wave_barrier();
+    };
+    if (!REDO) {
+        for (int qi = gw; qi < nq; qi += nw) one_query(qi);
+    } else {
+        // rare second pass (a row held more hits than the first pass stages): a small grid; each lane looks at one
+        // row's marker, the wavefront then redoes the marked rows one by one
+        for (int base = gw * 64; base < nq; base += nw * 64) {
+            const int r = base + lane;
+            u64 todo = __ballot(r < nq && out_idx[(long)r * cols] == kRedoMark);
+            while (todo) {
+                const int bit = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                one_query(base + bit);
+            }
+        }
     }
     // one contended word: only the few waves that actually raise the maximum issue an atomic
     if (lane == 0 && wave_max > aload(out_max)) atomicMax(out_max, wave_max);
@@ -328,13 +342,15 @@ int pcrcg_radius_query_ex(const float* q, int nq, const int* qlen, int ns, const
     int blocks = (nq + kQueryWaves - 1) / kQueryWaves;
     const int max_blocks = 256 * 16;   // 256 CUs x a few workgroups each; waves loop over queries
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL((k_radius_query<kListCapFast, false>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, q, nq, qlen,
+    hipLaunchKernelGGL((k_radius_query<kListCapFast, false, kQueryWaves>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, q, nq, qlen,
                        nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status,
                        out_tie_rows, out_tie_count);
-    const int redo_blocks = blocks < 512 ? blocks : 512;
-    hipLaunchKernelGGL((k_radius_query<kListCapFull, true>), dim3(redo_blocks), dim3(kQueryWaves * 64), 0, st, q, nq,
-                       qlen, nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status,
-                       out_tie_rows, out_tie_count);
+    // second pass: one wavefront per workgroup, 16 KB of LDS -- it finds a free slot at once on a busy GPU and
+    // normally has nothing to do
+    const int redo_blocks = blocks < 64 ? blocks : 64;
+    hipLaunchKernelGGL((k_radius_query<kListCapFull, true, 1>), dim3(redo_blocks), dim3(64), 0, st, q, nq, qlen, nb, r2, g,
+                       cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status, out_tie_rows,
+                       out_tie_count);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

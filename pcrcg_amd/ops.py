@@ -79,9 +79,9 @@ def kpconv_profile_stop(cap=1 << 16):
 # ------------------------------------------------------------------------------------------------
 # front end
 # ------------------------------------------------------------------------------------------------
-def grid_subsample(points, lengths, dl, max_p=0):
-    """batch_grid_subsampling on device.  points [N,3] f32, lengths [B] i32 ->
-    (sub_points [M,3] f32, sub_lengths [B] i32).  One host sync (to learn M)."""
+def grid_subsample_launch(points, lengths, dl, max_p=0):
+    """batch_grid_subsampling on device WITHOUT the host round trip: -> (rows [max(N,1),3] f32 of which the first M
+    are valid, sub_lengths [B] i32, M [1] i32 on the device)."""
     L = _lib.lib()
     points = _dev(points, _F32, "points").contiguous()
     lengths = _dev(lengths, _I32, "lengths").contiguous()
@@ -94,8 +94,24 @@ def grid_subsample(points, lengths, dl, max_p=0):
     _lib.check(L.pcrcg_grid_subsample_batch(points.data_ptr(), n, lengths.data_ptr(), nb, float(dl), int(max_p),
                                             out.data_ptr(), out_len.data_ptr(), out_m.data_ptr(), ws.data_ptr(),
                                             nbytes, _stream()), "pcrcg_grid_subsample_batch")
-    m = int(out_m.item())
-    return out[:m], out_len
+    return out, out_len, out_m
+
+
+def grid_subsample(points, lengths, dl, max_p=0):
+    """batch_grid_subsampling on device.  points [N,3] f32, lengths [B] i32 ->
+    (sub_points [M,3] f32, sub_lengths [B] i32).  One host sync (to learn M)."""
+    out, out_len, out_m = grid_subsample_launch(points, lengths, dl, max_p)
+    return out[:int(out_m.item())], out_len
+
+
+def host_copy(t):
+    """Asynchronous device -> pinned-host copy of a small int tensor on the current stream:
+    -> (pinned tensor, event recorded after the copy); read the tensor after event.synchronize()."""
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return host, ev
 
 
 def umap_order(keys):

@@ -4,9 +4,13 @@ The front end of a pair (grid subsampling + radius searches) is made of many sma
 kernels and needs host round trips (each subsampled level's row count sizes the next level's tensors);
 the model forward is a few hundred kernels enqueued by one call.  Three things overlap here:
 
-  * front-end worker threads build pyramids, each on its own HIP stream (their host round trips wait with the
-    GIL released, so they do not stall the threads that enqueue forwards); with two of them the pyramid of
-    pair k+1 is being built while pair k still waits for its last round trip;
+  * a front-end worker thread builds pyramids on its own HIP stream (its host round trips wait with the
+    GIL released, so they do not stall the threads that enqueue forwards).  A pyramid needs four host round
+    trips (three subsampled row counts, one for the table widths), during which its stream would sit idle -- a
+    third of the time: the worker therefore INTERLEAVES the pyramids of `interleave` consecutive pairs on that one
+    stream (pyramid.pyramid_steps is a generator that yields at each round trip), so the kernels of pair k+1 run
+    while the host waits for pair k.  More front-end STREAMS (front_streams > 1) were measured and lose: every
+    stream beyond front end + three model streams costs more than it overlaps;
   * forwards of consecutive pairs alternate between two model streams, so the coarse levels of one pair
     (a few hundred points, few workgroups) overlap with the fine levels of the next;
   * one event per pair hands the finished batch dict from the front-end stream to a model stream.
@@ -24,12 +28,14 @@ Two ways to drive it:
 The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); with the front-end
 stream, three model streams and the default stream that is one too few and two streams serialise -- set
 GPU_MAX_HW_QUEUES=8 in the environment before the first HIP call (bench.py does)."""
+import collections
 import queue
 import threading
+import time
 
 import torch
 
-from .pyramid import build_pyramid, check_tie_status
+from .pyramid import check_tie_status, pyramid_steps
 
 
 def _tensors(batch):
@@ -62,15 +68,13 @@ class _Mailbox:
 
 
 class PairPipeline:
-    def __init__(self, net, config, neighborhood_limits, device=None, model_streams=2, threaded=True, front_streams=1):
+    def __init__(self, net, config, neighborhood_limits, device=None, model_streams=2, threaded=True, front_streams=1,
+                 interleave=2):
         self.net, self.config, self.limits = net, config, neighborhood_limits
         self.device = torch.device(device if device is not None else "cuda")
-        import os
-        prio = int(os.environ.get("PCRCG_FRONT_PRIORITY", "0"))
-        self.fronts = [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(max(1, front_streams))]
+        self.fronts = [torch.cuda.Stream(device=self.device) for _ in range(max(1, front_streams))]
         self.front = self.fronts[0]
-        # restores the reference's tie order (csrc/tieorder.hip)
-        self.tie = torch.cuda.Stream(device=self.device, priority=prio) if os.environ.get("PCRCG_TIE_STREAM", "0") == "1" else None
+        self._interleave = max(1, int(interleave))
         self.models = [torch.cuda.Stream(device=self.device) for _ in range(max(1, model_streams))]
         self._turn = 0
         self._requests = [queue.Queue() for _ in self.fronts]
@@ -100,26 +104,101 @@ class PairPipeline:
                 self._fwd_workers.append(t)
 
     # ---- front end -----------------------------------------------------------------------------
-    def prepare(self, points, lengths, f=0):
-        """Build the pyramid of one pair on front-end stream f (blocking variant)."""
-        with torch.cuda.stream(self.fronts[f]):
-            batch = build_pyramid(points, lengths, self.config, self.limits, defer_tie_check=True, tie_stream=self.tie)
-            status = batch.pop("tie_status", None)
-            tie_event = batch.pop("tie_event", None)
-            done = torch.cuda.Event()
-            done.record(self.fronts[f])
+    def _steps(self, points, lengths):
+        return pyramid_steps(points, lengths, self.config, self.limits, defer_tie_check=True)
+
+    def _finish(self, batch, f):
+        """Called under the front-end stream once a pyramid generator has returned its batch."""
+        status = batch.pop("tie_status", None)
         host = None
         if status is not None:               # asynchronous copy: no host sync for a word that is 0 on sane clouds
-            with torch.cuda.stream(self.tie if self.tie is not None else self.fronts[f]):
-                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-                host.copy_(status, non_blocking=True)
-                tie_event = torch.cuda.Event()
-                tie_event.record(self.tie if self.tie is not None else self.fronts[f])
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(status, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(self.fronts[f])
         self._check_tie_status(wait=False)
         if host is not None:
             with self._tie_lock:
-                self._tie_pending.append((host, tie_event))
-        return batch, (done, tie_event)
+                self._tie_pending.append((host, done))
+        return batch, done
+
+    def prepare(self, points, lengths, f=0):
+        """Build the pyramid of one pair on front-end stream f (blocking variant)."""
+        with torch.cuda.stream(self.fronts[f]):
+            steps = self._steps(points, lengths)
+            try:
+                while True:
+                    next(steps).synchronize()
+            except StopIteration as fin:
+                return self._finish(fin.value, f)
+
+    def _serve(self, f):
+        """Front-end worker: up to `interleave` pyramids in flight on stream f, advanced round-robin -- the oldest one
+        is resumed as soon as the value it waits for has arrived, the others' kernels keep the stream busy."""
+        torch.cuda.set_device(self.device)
+        active = collections.deque()          # [generator, event it waits for, request]
+        closing = False
+        stats = self.front_stats = {"wait_s": 0.0, "advance_s": 0.0, "idle_s": 0.0, "pairs": 0, "resumed_ready": 0, "resumes": 0}
+
+        def deliver(item, result):
+            if len(item) == 4:                # submit(): hand the pair to its forward worker (in-order mailbox)
+                self._fwd_in[item[2]].put(item[3], result)
+            else:
+                self._ready.put(result)
+
+        def advance(entry):
+            """Resume a generator; True if it is still running."""
+            try:
+                with torch.cuda.stream(self.fronts[f]):
+                    try:
+                        entry[1] = next(entry[0])
+                        return True
+                    except StopIteration as fin:
+                        deliver(entry[2], self._finish(fin.value, f))
+            except BaseException as e:        # surfaced by result() / next_prepared()
+                deliver(entry[2], e)
+            return False
+
+        while True:
+            # request()/next_prepared() deliver through one queue in completion order: keep those strictly serial
+            while not closing and len(active) < self._interleave and all(len(e[2]) == 4 for e in active):
+                t0 = time.perf_counter()
+                try:
+                    item = self._requests[f].get(block=not active)
+                except queue.Empty:
+                    break
+                finally:
+                    stats["idle_s"] += time.perf_counter() - t0
+                if item is None:
+                    closing = True
+                    break
+                entry = [self._steps(item[0], item[1]), None, item]
+                stats["pairs"] += 1
+                t0 = time.perf_counter()
+                running = advance(entry)
+                stats["advance_s"] += time.perf_counter() - t0
+                if running:
+                    active.append(entry)
+                if len(item) != 4:
+                    break
+            if not active:
+                if closing:
+                    return
+                continue
+            entry = active.popleft()
+            t0 = time.perf_counter()
+            stats["resumes"] += 1
+            stats["resumed_ready"] += 1 if entry[1].query() else 0
+            entry[1].synchronize()
+            t1 = time.perf_counter()
+            running = advance(entry)
+            stats["wait_s"] += t1 - t0
+            stats["advance_s"] += time.perf_counter() - t1
+            if running:
+                if len(entry[2]) == 4:
+                    active.append(entry)
+                else:
+                    active.appendleft(entry)      # serial mode: finish this pair before admitting the next
 
     def _check_tie_status(self, wait):
         """Raise if restoring the reference's tie order failed for an earlier pair (pyramid.check_tie_status)."""
@@ -136,24 +215,6 @@ class PairPipeline:
         with self._tie_lock:
             self._tie_pending = keep + self._tie_pending
         check_tie_status(bad)
-
-    def _serve(self, f):
-        torch.cuda.set_device(self.device)
-        while True:
-            item = self._requests[f].get()
-            if item is None:
-                return
-            if len(item) == 4:              # submit(): hand the pair to its forward worker
-                points, lengths, w, seq = item
-                try:
-                    self._fwd_in[w].put(seq, self.prepare(points, lengths, f))
-                except BaseException as e:  # surfaced by result()
-                    self._fwd_in[w].put(seq, e)
-            else:
-                try:
-                    self._ready.put(self.prepare(*item, f))
-                except BaseException as e:  # surfaced by next_prepared()
-                    self._ready.put(e)
 
     def _serve_forward(self, w):
         torch.cuda.set_device(self.device)
@@ -191,9 +252,7 @@ class PairPipeline:
         for t in _tensors(batch):          # allocated on the front-end stream, consumed on `stream`
             if t.is_cuda:
                 t.record_stream(stream)
-        for ev in (done if isinstance(done, tuple) else (done,)):
-            if ev is not None:
-                stream.wait_event(ev)
+        stream.wait_event(done)
         with torch.cuda.stream(stream), torch.no_grad():
             out = self.net(batch)
         return out
@@ -236,7 +295,7 @@ class PairPipeline:
         self.synchronize()
 
     def synchronize(self):
-        for s in self.fronts + ([self.tie] if self.tie is not None else []):
+        for s in self.fronts:
             s.synchronize()
         for s in self.models:
             s.synchronize()

@@ -55,7 +55,7 @@ def check_tie_status(code):
 
 
 def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=False, tie_order=None,
-                  defer_tie_check=False, tie_stream=None):
+                  defer_tie_check=False):
     """points [N0,3] f32 and lengths [B] i32 on the device -> the reference's batch dict
     (ref:datasets/dataloader.py:363-380) restricted to the keys KPFCNN.forward reads, all on the
     device: points, neighbors, pools, upsamples (int64, shadow = support count), stack_lengths,
@@ -73,7 +73,24 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
     128 pending branches on one query's path, ...) through a device status word.  By default it is read back here
     (one more host sync); with defer_tie_check=True it is returned as out["tie_status"] ([1] i32 device tensor or
     None) and the CALLER must pass its value to check_tie_status() once the stream has finished (PairPipeline
-    does)."""
+    does).
+
+    The build needs four host round trips (three subsampled row counts, one for all table widths); this function
+    waits for each of them.  pyramid_steps() is the same build as a generator that YIELDS at those points, so that a
+    caller can keep the stream busy with another pair's pyramid meanwhile (PairPipeline does)."""
+    steps = pyramid_steps(points, lengths, config, neighborhood_limits, want_counts, tie_order, defer_tie_check)
+    try:
+        while True:
+            next(steps).synchronize()
+    except StopIteration as done:
+        return done.value
+
+
+def pyramid_steps(points, lengths, config, neighborhood_limits, want_counts=False, tie_order=None,
+                  defer_tie_check=False):
+    """Generator form of build_pyramid: enqueues kernels on the current stream, yields a torch.cuda.Event whenever
+    it needs a value from the device (resume it -- under the same current stream -- once the event has passed),
+    and returns the batch dict through StopIteration.value."""
     config = as_config(config)
     if tie_order is None:
         tie_order = os.environ.get("PCRCG_TIE_ORDER", "auto")
@@ -110,7 +127,10 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
         else:
             conv_i = empty_idx
         if lv["pooled"]:
-            pool_p, pool_b = ops.grid_subsample(pts, lens, lv["dl"])      # one host sync (row count)
+            rows, pool_b, m_dev = ops.grid_subsample_launch(pts, lens, lv["dl"])
+            m_host, ev = ops.host_copy(m_dev)
+            yield ev                                                         # host round trip: the row count
+            pool_p = rows[:int(m_host[0])]
             if grid is None or grid.radius != float(lv["r_pool"]):
                 grid = carried if carried is not None and carried.radius == float(lv["r_pool"]) else \
                     ops.CellGrid(pts, lens, lv["r_pool"])
@@ -136,7 +156,9 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
     # when the longest list is shorter than the limit, ref:datasets/dataloader.py:65-67), status, the
     # number of rows holding a tie, and the per-level cloud lengths
     nb = in_lens[0].shape[0]
-    host = torch.cat([m for m in metas] + [l.to(_I32) for l in in_lens]).cpu().tolist()
+    host_t, ev = ops.host_copy(torch.cat([m for m in metas] + [l.to(_I32) for l in in_lens]))
+    yield ev
+    host = host_t.tolist()
     meta_h = [host[3 * i:3 * i + 3] for i in range(len(metas))]
     lens_h = [host[3 * len(metas) + nb * i:3 * len(metas) + nb * (i + 1)] for i in range(len(in_lens))]
     redo = []
@@ -146,30 +168,16 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
         tab["max_count"] = max_count
         if max_count > 0 and (tie_order == "reference" or (tie_order == "auto" and tie_rows > 0)):
             redo.append((tab, tie_rows))
-    out["tie_status"] = out["tie_event"] = None
+    out["tie_status"] = None
     if redo:
-        if tie_stream is not None:
-            if not defer_tie_check:
-                raise ValueError("pcrcg_amd.build_pyramid: tie_stream requires defer_tie_check=True")
-            tie_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(tie_stream):
-                status = _restore_reference_order(out, redo, in_points, in_lens, max(max(l) for l in lens_h),
-                                                  all_rows=tie_order == "reference")
-                out["tie_event"] = torch.cuda.Event()
-                out["tie_event"].record(tie_stream)
-            for tab, _ in redo:        # allocated on the current stream, read / written on tie_stream
-                for t in (out[tab["key"]][tab["layer"]], tab["q"], tab["qlen"], tab["ties"], tab["counts"]):
-                    if t is not None:
-                        t.record_stream(tie_stream)
-            for t in in_points + in_lens:
-                t.record_stream(tie_stream)
-        else:
-            status = _restore_reference_order(out, redo, in_points, in_lens, max(max(l) for l in lens_h),
-                                              all_rows=tie_order == "reference")
+        status = _restore_reference_order(out, redo, in_points, in_lens, max(max(l) for l in lens_h),
+                                          all_rows=tie_order == "reference")
         if defer_tie_check:
             out["tie_status"] = status
         else:
-            check_tie_status(int(status.item()))
+            status_h, ev = ops.host_copy(status)
+            yield ev
+            check_tie_status(int(status_h[0]))
     for tab in tables:
         t = out[tab["key"]][tab["layer"]]
         if tab["max_count"] < t.shape[1]:
@@ -181,16 +189,28 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
     return out
 
 
+HOST_TIMES = {"cat": 0.0, "forest": 0.0, "reorder": 0.0, "calls": 0}     # host seconds spent in the restore step
+
+
 def _restore_reference_order(out, redo, level_points, level_lens, max_cloud, all_rows):
     """Rows with exactly equal distances -> the reference's order (ops.KdForest): one forest over the clouds of
     all levels, then one launch for all tables that reported such rows.  -> status [1] i32 (device)."""
+    import time
+    t0 = time.perf_counter()
     nb = level_lens[0].shape[0]
-    forest = ops.KdForest(torch.cat(level_points, 0), torch.cat([l.to(_I32) for l in level_lens], 0), max_cloud)
+    sup, slen = torch.cat(level_points, 0), torch.cat([l.to(_I32) for l in level_lens], 0)
+    t1 = time.perf_counter()
+    forest = ops.KdForest(sup, slen, max_cloud)
+    t2 = time.perf_counter()
     status = torch.zeros(1, dtype=_I32, device=level_points[0].device)
     forest.reorder_tables([dict(idx=out[tab["key"]][tab["layer"]], q=tab["q"], qlen=tab["qlen"], cloud0=nb * tab["sup_level"],
                                 radius=tab["radius"], max_count=tab["max_count"], counts=tab["counts"],
                                 rows=None if all_rows else tab["ties"], nrows=None if all_rows else tie_rows)
                            for tab, tie_rows in redo], status)
+    HOST_TIMES["cat"] += t1 - t0
+    HOST_TIMES["forest"] += t2 - t1
+    HOST_TIMES["reorder"] += time.perf_counter() - t2
+    HOST_TIMES["calls"] += 1
     return status
 
 
