@@ -174,11 +174,6 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     front_stats = dict(getattr(pipe, "front_stats", {}))
-    if os.environ.get("PCRCG_PIPE_STATS"):
-        from pcrcg_amd import pyramid as _pyr
-        print("restore step host time per call (ms):", {k: round(1e3 * v / max(_pyr.HOST_TIMES["calls"], 1), 3)
-                                                          for k, v in _pyr.HOST_TIMES.items() if k != "calls"},
-              "calls", _pyr.HOST_TIMES["calls"], file=sys.stderr, flush=True)
     events = ops.kpconv_profile_stop()
     assert out["feats_f"].shape[1] == cfg.final_feats_dim
 

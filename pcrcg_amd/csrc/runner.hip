@@ -401,8 +401,6 @@ int validate(const pcrcg_model* m, const pcrcg_batch* b) {
 
 using namespace pcrcg;
 
-namespace { __global__ void k_noop() {} }
-
 extern "C" {
 
 size_t pcrcg_kpfcnn_ws_bytes(const pcrcg_model* model, const pcrcg_batch* batch) {
@@ -422,8 +420,6 @@ int pcrcg_kpfcnn_forward(const pcrcg_model* model, const pcrcg_batch* batch, con
     c.base = static_cast<char*>(ws);
     c.cap = ws_bytes;
     c.st = as_stream(stream);
-    if (const char* env = getenv("PCRCG_DUMMY_LAUNCHES"))       // experiment: is the pipeline bound by the launch rate?
-        for (int i = atoi(env); i > 0; --i) hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, c.st);
     forward(c, *model, *batch, *out);
     return c.rc;
 }

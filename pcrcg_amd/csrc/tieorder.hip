@@ -929,7 +929,7 @@ int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, int 
     hipLaunchKernelGGL(k_kd_init, dim3(init_blocks), dim3(256), 0, st, slen, ns, nb, v);
     if (ns > 0) {
         // one workgroup per ~1024 points can be busy at the deepest level of big nodes / the LDS subtrees
-        int blocks = ns / kSubMax + nb;
+        int blocks = ns / (2 * kSubMax) + nb;
         if (blocks > kForestBlocks) blocks = kForestBlocks;
         const char* env = getenv("PCRCG_KD_SPIN_LIMIT");      // debugging aid
         hipLaunchKernelGGL(k_kd_forest, dim3(blocks), dim3(kBigThreads), 0, st, sup, v, env ? atoi(env) : kSpinLimitDefault);

@@ -189,28 +189,16 @@ def pyramid_steps(points, lengths, config, neighborhood_limits, want_counts=Fals
     return out
 
 
-HOST_TIMES = {"cat": 0.0, "forest": 0.0, "reorder": 0.0, "calls": 0}     # host seconds spent in the restore step
-
-
 def _restore_reference_order(out, redo, level_points, level_lens, max_cloud, all_rows):
     """Rows with exactly equal distances -> the reference's order (ops.KdForest): one forest over the clouds of
     all levels, then one launch for all tables that reported such rows.  -> status [1] i32 (device)."""
-    import time
-    t0 = time.perf_counter()
     nb = level_lens[0].shape[0]
-    sup, slen = torch.cat(level_points, 0), torch.cat([l.to(_I32) for l in level_lens], 0)
-    t1 = time.perf_counter()
-    forest = ops.KdForest(sup, slen, max_cloud)
-    t2 = time.perf_counter()
+    forest = ops.KdForest(torch.cat(level_points, 0), torch.cat([l.to(_I32) for l in level_lens], 0), max_cloud)
     status = torch.zeros(1, dtype=_I32, device=level_points[0].device)
     forest.reorder_tables([dict(idx=out[tab["key"]][tab["layer"]], q=tab["q"], qlen=tab["qlen"], cloud0=nb * tab["sup_level"],
                                 radius=tab["radius"], max_count=tab["max_count"], counts=tab["counts"],
                                 rows=None if all_rows else tab["ties"], nrows=None if all_rows else tie_rows)
                            for tab, tie_rows in redo], status)
-    HOST_TIMES["cat"] += t1 - t0
-    HOST_TIMES["forest"] += t2 - t1
-    HOST_TIMES["reorder"] += time.perf_counter() - t2
-    HOST_TIMES["calls"] += 1
     return status
 
 
