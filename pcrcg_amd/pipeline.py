@@ -105,21 +105,13 @@ class PairPipeline:
 
     # ---- front end -----------------------------------------------------------------------------
     def _steps(self, points, lengths):
-        return pyramid_steps(points, lengths, self.config, self.limits, defer_tie_check=True)
+        return pyramid_steps(points, lengths, self.config, self.limits, defer_tie_check=True, defer_restore=True)
 
     def _finish(self, batch, f):
         """Called under the front-end stream once a pyramid generator has returned its batch."""
-        status = batch.pop("tie_status", None)
-        host = None
-        if status is not None:               # asynchronous copy: no host sync for a word that is 0 on sane clouds
-            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-            host.copy_(status, non_blocking=True)
         done = torch.cuda.Event()
         done.record(self.fronts[f])
         self._check_tie_status(wait=False)
-        if host is not None:
-            with self._tie_lock:
-                self._tie_pending.append((host, done))
         return batch, done
 
     def prepare(self, points, lengths, f=0):
@@ -249,11 +241,22 @@ class PairPipeline:
     # ---- model ---------------------------------------------------------------------------------
     def _forward(self, prepared, stream):
         batch, done = prepared
-        for t in _tensors(batch):          # allocated on the front-end stream, consumed on `stream`
+        restore, touched = batch.pop("restore", (None, ()))
+        for t in list(_tensors(batch)) + list(touched):    # allocated on the front-end stream, consumed on `stream`
             if t.is_cuda:
                 t.record_stream(stream)
         stream.wait_event(done)
         with torch.cuda.stream(stream), torch.no_grad():
+            if restore is not None:
+                # the reference's order inside tie groups (csrc/tieorder.hip), here rather than on the front-end
+                # stream: that stream is the pipeline's bottleneck, the model streams wait for pyramids half of the time
+                status = restore()
+                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                host.copy_(status, non_blocking=True)    # asynchronous: the word is 0 on sane clouds
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                with self._tie_lock:
+                    self._tie_pending.append((host, ev))
             out = self.net(batch)
         return out
 

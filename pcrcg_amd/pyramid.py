@@ -87,10 +87,14 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
 
 
 def pyramid_steps(points, lengths, config, neighborhood_limits, want_counts=False, tie_order=None,
-                  defer_tie_check=False):
+                  defer_tie_check=False, defer_restore=False):
     """Generator form of build_pyramid: enqueues kernels on the current stream, yields a torch.cuda.Event whenever
     it needs a value from the device (resume it -- under the same current stream -- once the event has passed),
-    and returns the batch dict through StopIteration.value."""
+    and returns the batch dict through StopIteration.value.
+    defer_restore: do not launch the tie-order restore step (KD-forest + reorder) here; return it as
+    out["restore"] = (callable -> status tensor or None, [tensors it touches]) for the consumer to run on ITS stream
+    before it reads the tables (PairPipeline runs it on the pair's model stream, which has slack, instead of the
+    front-end stream, which is the pipeline's bottleneck)."""
     config = as_config(config)
     if tie_order is None:
         tie_order = os.environ.get("PCRCG_TIE_ORDER", "auto")
@@ -170,14 +174,22 @@ def pyramid_steps(points, lengths, config, neighborhood_limits, want_counts=Fals
             redo.append((tab, tie_rows))
     out["tie_status"] = None
     if redo:
-        status = _restore_reference_order(out, redo, in_points, in_lens, max(max(l) for l in lens_h),
-                                          all_rows=tie_order == "reference")
-        if defer_tie_check:
-            out["tie_status"] = status
+        for tab, _ in redo:
+            tab["idx"] = out[tab["key"]][tab["layer"]]        # full-width, contiguous (trimmed views are made below)
+        max_cloud, all_rows = max(max(l) for l in lens_h), tie_order == "reference"
+        if defer_restore:
+            touched = list(in_points) + list(in_lens)
+            for tab, _ in redo:
+                touched += [t for t in (tab["idx"], tab["q"], tab["qlen"], tab["ties"], tab["counts"]) if t is not None]
+            out["restore"] = (lambda: _restore_reference_order(redo, in_points, in_lens, max_cloud, all_rows), touched)
         else:
-            status_h, ev = ops.host_copy(status)
-            yield ev
-            check_tie_status(int(status_h[0]))
+            status = _restore_reference_order(redo, in_points, in_lens, max_cloud, all_rows)
+            if defer_tie_check:
+                out["tie_status"] = status
+            else:
+                status_h, ev = ops.host_copy(status)
+                yield ev
+                check_tie_status(int(status_h[0]))
     for tab in tables:
         t = out[tab["key"]][tab["layer"]]
         if tab["max_count"] < t.shape[1]:
@@ -189,13 +201,13 @@ def pyramid_steps(points, lengths, config, neighborhood_limits, want_counts=Fals
     return out
 
 
-def _restore_reference_order(out, redo, level_points, level_lens, max_cloud, all_rows):
+def _restore_reference_order(redo, level_points, level_lens, max_cloud, all_rows):
     """Rows with exactly equal distances -> the reference's order (ops.KdForest): one forest over the clouds of
     all levels, then one launch for all tables that reported such rows.  -> status [1] i32 (device)."""
     nb = level_lens[0].shape[0]
     forest = ops.KdForest(torch.cat(level_points, 0), torch.cat([l.to(_I32) for l in level_lens], 0), max_cloud)
     status = torch.zeros(1, dtype=_I32, device=level_points[0].device)
-    forest.reorder_tables([dict(idx=out[tab["key"]][tab["layer"]], q=tab["q"], qlen=tab["qlen"], cloud0=nb * tab["sup_level"],
+    forest.reorder_tables([dict(idx=tab["idx"], q=tab["q"], qlen=tab["qlen"], cloud0=nb * tab["sup_level"],
                                 radius=tab["radius"], max_count=tab["max_count"], counts=tab["counts"],
                                 rows=None if all_rows else tab["ties"], nrows=None if all_rows else tie_rows)
                            for tab, tie_rows in redo], status)
