@@ -139,6 +139,20 @@ def main():
             ok &= sha(sp) == d[f"points{l + 1}"]["sha256"]
             pts, lens, r, dl = sp, sl, r * 2, dl * 2
         print("REAL oracle C front end == reference C++ (points bit-exact, conv tables modulo ties):", bool(ok))
+        pts, lens = np.concatenate([rs, rt]), np.array([len(rs), len(rt)], np.int32)
+        r, dl, exact, rows = 0.0625, 0.05, True, 0
+        for l in range(4):
+            cases = [(pts, pts, lens, lens, r)]
+            if l < 3:
+                sp, sl = OF.oracle_subsample_batch(pts, lens, dl)
+                cases += [(sp, pts, sl, lens, r), (pts, sp, lens, sl, 2 * r)]
+            for q, s_, ql, sl_, rr in cases:
+                a, b = OF.oracle_batch_query(q, s_, ql, sl_, rr, tie_order="reference"), F.ref_batch_query(q, s_, ql, sl_, rr)
+                exact &= a.shape == b.shape and bool((a == b).all())
+                rows += len(a)
+            if l < 3:
+                pts, lens, r, dl = sp, sl, r * 2, dl * 2
+        print("REAL oracle reference-order tables == reference C++ entry for entry:", bool(exact), "rows", rows)
 
 
 if __name__ == "__main__":
