@@ -103,7 +103,7 @@ int main(void) {
                                           d_meta + 1, d_ties, d_meta + 2, NULL));
         int meta[4];
         CHECK_HIP(hipMemcpy(meta, d_meta, sizeof(int) * 4, hipMemcpyDeviceToHost));
-        CHECK_PCRCG(pcrcg_kdforest_build(d_t, tn, d_tlen, nb, 1500, forest, fbytes, NULL));
+        CHECK_PCRCG(pcrcg_kdforest_build(d_t, tn, d_tlen, nb, forest, fbytes, NULL));
         CHECK_PCRCG(pcrcg_radius_reorder(d_t, tn, d_tlen, nb, d_t, tn, nb, forest, 0, tr, d_ties, meta[2], d_tcount,
                                          meta[0], tcols, d_tidx, d_meta + 3, NULL));
         int64_t* h_tidx = (int64_t*)malloc(sizeof(int64_t) * (size_t)tn * tcols);

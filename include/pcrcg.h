@@ -113,9 +113,7 @@ int pcrcg_radius_neighbors_batch(const float* q, int nq, const float* sup, int n
  *
  *   pcrcg_kdforest_build   nanoflann 1.3.0's KD-tree (leaf size 10, ref:.../neighbors.cpp:245) for each of the
  *                          nb clouds of `sup` -- the clouds of ALL pyramid levels can be stacked into one forest.
- *                          forest = workspace of pcrcg_kdforest_ws_bytes(ns, nb) bytes.  max_cloud: an upper
- *                          bound of the largest slen[] if the host knows one (fewer launches), 0 otherwise; a
- *                          bound that is too small is reported as status 1 by the reorder calls.
+ *                          forest = workspace of pcrcg_kdforest_ws_bytes(ns, nb) bytes; one launch.
  *   pcrcg_radius_reorder   rewrites rows of a table produced by pcrcg_radius_query(_ex): the query clouds
  *                          0..nbq-1 search the forest's clouds cloud0..cloud0+nbq-1; indices are written relative
  *                          to the first of them and rows are padded with their total size (the table's shadow
@@ -125,7 +123,7 @@ int pcrcg_radius_neighbors_batch(const float* q, int nq, const float* sup, int n
  *                          idx [nq, cols] i64.
  *   pcrcg_radius_reorder_jobs  the same for up to PCRCG_MAX_REORDER_JOBS tables over one forest in ONE launch
  *                          (all tables of a pair).
- *                          status [1] i32 (may be NULL): 1 tree deeper than supported, 2 traversal stack
+ *                          status [1] i32 (may be NULL): 1 forest kernel gave up waiting for work, 2 traversal stack
  *                          overflow (more than 128 pending branches), 3 hit count differs from `count`,
  *                          4 list longer than max_count.
  * ---------------------------------------------------------------------------------------------- */
@@ -140,8 +138,8 @@ typedef struct pcrcg_reorder_job {
     float radius;
 } pcrcg_reorder_job;
 size_t pcrcg_kdforest_ws_bytes(int ns, int nb);
-int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, int max_cloud, void* forest,
-                         size_t forest_bytes, void* stream);
+int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, void* forest, size_t forest_bytes,
+                         void* stream);
 int pcrcg_radius_reorder(const float* q, int nq, const int* qlen, int nbq, const float* sup, int ns, int nb,
                          const void* forest, int cloud0, float radius, const int* rows, int nrows, const int* count,
                          int max_count, int cols, int64_t* idx, int* status, void* stream);

@@ -15,18 +15,20 @@
 // reference's result.  Rows without a tie have one possible order; rows with a tie (reported by
 // pcrcg_radius_query_ex) are redone here:
 //
-//   forest build   one tree per cloud, all clouds of all pyramid levels in ONE forest (a handful of launches for
-//                  the whole pair).  A node's split (dimension, value, index) and the Hoare partition of its
-//                  index range are reproduced exactly; the partition is the sequential part of the reference, and
-//                  is parallelised through the identity  "pass k swaps the k-th misplaced element from the left
-//                  with the k-th misplaced element from the right":
-//                    nodes > 1024 points  one workgroup per node and level (block prefix sums); levels
-//                                         are separate launches over a device-side queue.  A workgroup keeps a
-//                                         child that holds more than 3/4 of its node, so a queued node is at most
-//                                         3/4 of its parent and 2.41*log2(n/1024) launches always suffice, however
-//                                         skewed the splits are;
+//   forest build   one tree per cloud, all clouds of all pyramid levels in ONE forest built by ONE launch.  A node's
+//                  split (dimension, value, index) and the Hoare partition of its index range are reproduced
+//                  exactly; the partition is the sequential part of the reference, and is parallelised through the
+//                  identity  "a pass swaps the k-th misplaced element from the left with the k-th misplaced element
+//                  from the right":
+//                    nodes > 1024 points  one 512-thread workgroup per node (block prefix sums, four gathers in
+//                                         flight per thread).  It keeps a child that holds more than 3/4 of the node
+//                                         (skewed trees cannot explode the task count) and, below 4096 points, all
+//                                         its big descendants (a hand-off costs more than such a split);
 //                    nodes <= 1024 points the whole subtree inside one workgroup with its points in LDS, one
 //                                         wavefront per node of a level (ballot / popcount prefix sums).
+//                  Nodes are TASKS of a persistent kernel: workgroups pop node ids from a device-side queue and push
+//                  the children they do not keep (release fence before the push, acquire fence after the pop: the
+//                  eight XCDs have separate L2s), until no task is queued or running.
 //   reorder        one wavefront per row, all tables of a pair in one launch: the reference's traversal with an
 //                  explicit stack in LDS (leaf points tested 64 at a time, appended in order with ballot /
 //                  popcount), then lane 0 replays std::sort step by step on the LDS list and the wavefront writes
@@ -50,7 +52,6 @@ constexpr int kLeafMax = 10;          // KDTreeSingleIndexAdaptorParams(10), nei
 constexpr int kSubMax = 1024;         // nodes up to this size are finished inside one workgroup (LDS)
 constexpr int kSubLevelNodes = 96;    // disjoint ranges of >= 11 points inside 1024 points
 constexpr int kSubThreads = 512;       // = kBigThreads: big nodes and LDS subtrees are tasks of ONE kernel
-constexpr int kLaneNodeMax = 0;       // nodes up to this size: one LANE per node, the reference's loops as written
 constexpr int kBigThreads = 512;      // each scan step of a big node covers kBigThreads * kBigVec positions
 constexpr int kBigVec = 4;
 constexpr int kOwnMax = 4096;          // a workgroup that splits a node up to this size also splits its big descendants itself
@@ -506,9 +507,9 @@ __device__ __forceinline__ void kd_sub_emit(const KdView& v, int nid, int left, 
     }
 }
 
-// nodes <= kSubMax points: one workgroup builds the whole subtree with its points in LDS; of the nodes of a level,
-// those above kLaneNodeMax points are dealt to the workgroup's wavefronts (ballot / popcount partition), the small
-// ones to single lanes that run the reference's sequential loops as they are written.
+// nodes <= kSubMax points: one workgroup builds the whole subtree with its points in LDS; the nodes of a level are
+// dealt to the workgroup's wavefronts (ballot / popcount partition).  (One LANE per small node running the
+// reference's sequential loops literally was measured too: slower, 200 vs 122 us per pyramid.)
 __device__ void kd_sub_task(const float* __restrict__ sup, const KdView& v, int id) {
     __shared__ int s_gi[kSubMax];
     __shared__ float s_c[3][kSubMax];
@@ -560,9 +561,8 @@ __device__ void kd_sub_task(const float* __restrict__ sup, const KdView& v, int 
             if (threadIdx.x == 0) s_base = atomicAdd(&v.ctl->node_count, 2 * cnt);   // ids of this level's children
             __syncthreads();
             const int base = s_base;
-            for (int i = wave; i < cnt; i += kWaves) {      // larger nodes: one wavefront each
+            for (int i = wave; i < cnt; i += kWaves) {
                 const int nid = q_id[cur][i], l = q_l[cur][i], r = q_r[cur][i], count = r - l;
-                if (count <= kLaneNodeMax) continue;
                 float lo[3], hi[3], nmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, nmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
                 for (int d = 0; d < 3; ++d) { lo[d] = q_box[cur][i][d]; hi[d] = q_box[cur][i][3 + d]; }
                 for (int p = l + lane; p < r; p += 64) {
@@ -595,50 +595,6 @@ __device__ void kd_sub_task(const float* __restrict__ sup, const KdView& v, int 
                 if (lane == 0)
                     kd_sub_emit(v, nid, left, l, r, idx, cutfeat, cutval, divlow, divhigh, lo, hi, base + 2 * i, q_id[cur ^ 1],
                                 q_l[cur ^ 1], q_r[cur ^ 1], q_box[cur ^ 1], &q_cnt[cur ^ 1]);
-            }
-            for (int i = threadIdx.x; i < cnt; i += kSubThreads) {      // small nodes: one lane each, literally
-                const int nid = q_id[cur][i], l = q_l[cur][i], r = q_r[cur][i], count = r - l;
-                if (count > kLaneNodeMax) continue;
-                float lo[3], hi[3], nmn[3], nmx[3];
-                for (int d = 0; d < 3; ++d) { lo[d] = q_box[cur][i][d]; hi[d] = q_box[cur][i][3 + d]; }
-                for (int d = 0; d < 3; ++d) {
-                    nmn[d] = nmx[d] = s_c[d][s_ord[l]];
-                    for (int p = l + 1; p < r; ++p) {
-                        const float val = s_c[d][s_ord[p]];
-                        if (val < nmn[d]) nmn[d] = val;
-                        if (val > nmx[d]) nmx[d] = val;
-                    }
-                }
-                int cutfeat;
-                float cutval;
-                kd_choose_split(lo, hi, nmn, nmx, &cutfeat, &cutval);
-                const float* cv = s_c[cutfeat];
-                int* ind = s_ord + l;
-                // planeSplit :967-1003 (IndexType is unsigned there: `right` stops at 0 through the `right &&` tests)
-                unsigned lft = 0, rgt = (unsigned)count - 1;
-                for (;;) {
-                    while (lft <= rgt && cv[ind[lft]] < cutval) ++lft;
-                    while (rgt && lft <= rgt && cv[ind[rgt]] >= cutval) --rgt;
-                    if (lft > rgt || !rgt) break;
-                    const int t = ind[lft]; ind[lft] = ind[rgt]; ind[rgt] = t;
-                    ++lft; --rgt;
-                }
-                const int lim1 = (int)lft;
-                rgt = (unsigned)count - 1;
-                for (;;) {
-                    while (lft <= rgt && cv[ind[lft]] <= cutval) ++lft;
-                    while (rgt && lft <= rgt && cv[ind[rgt]] > cutval) --rgt;
-                    if (lft > rgt || !rgt) break;
-                    const int t = ind[lft]; ind[lft] = ind[rgt]; ind[rgt] = t;
-                    ++lft; --rgt;
-                }
-                const int lim2 = (int)lft, half = count / 2;
-                const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
-                float divlow = cv[ind[0]], divhigh = cv[ind[idx]];       // tight boxes of the two children on cutfeat
-                for (int p = 1; p < idx; ++p) divlow = fmaxf(divlow, cv[ind[p]]);
-                for (int p = idx + 1; p < count; ++p) divhigh = fminf(divhigh, cv[ind[p]]);
-                kd_sub_emit(v, nid, left, l, r, idx, cutfeat, cutval, divlow, divhigh, lo, hi, base + 2 * i, q_id[cur ^ 1],
-                            q_l[cur ^ 1], q_r[cur ^ 1], q_box[cur ^ 1], &q_cnt[cur ^ 1]);
             }
             __syncthreads();
             if (threadIdx.x == 0) q_cnt[cur] = 0;
@@ -913,9 +869,9 @@ extern "C" {
 
 size_t pcrcg_kdforest_ws_bytes(int ns, int nb) { return forest_bytes(ns, nb < 1 ? 1 : nb); }
 
-int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, int max_cloud, void* forest,
-                         size_t forest_bytes_, void* stream) {
-    PCRCG_CHECK_ARG(ns >= 0 && nb >= 1 && slen && forest && max_cloud >= 0);
+int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, void* forest, size_t forest_bytes_,
+                         void* stream) {
+    PCRCG_CHECK_ARG(ns >= 0 && nb >= 1 && slen && forest);
     PCRCG_CHECK_ARG(ns == 0 || sup);
     hipStream_t st = as_stream(stream);
     bool ok;
@@ -934,7 +890,6 @@ int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, int 
         const char* env = getenv("PCRCG_KD_SPIN_LIMIT");      // debugging aid
         hipLaunchKernelGGL(k_kd_forest, dim3(blocks), dim3(kBigThreads), 0, st, sup, v, env ? atoi(env) : kSpinLimitDefault);
     }
-    (void)max_cloud;
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

@@ -183,8 +183,7 @@ class KdForest:
     """nanoflann-1.3.0-identical KD-trees (leaf size 10) over stacked clouds -- the clouds of every pyramid level in
     one forest -- used to give rows with exactly equal distances the reference's own order (csrc/tieorder.hip)."""
 
-    def __init__(self, supports, lengths, max_cloud=0):
-        """max_cloud: the largest cloud's size if the host knows it (fewer launches), 0 = unknown."""
+    def __init__(self, supports, lengths):
         L = _lib.lib()
         self.supports = _dev(supports, _F32, "supports").contiguous()
         self.lengths = _dev(lengths, _I32, "s_batches").contiguous()
@@ -192,8 +191,7 @@ class KdForest:
         self.nbytes = L.pcrcg_kdforest_ws_bytes(self.ns, self.nb)
         self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=self.supports.device)
         _lib.check(L.pcrcg_kdforest_build(self.supports.data_ptr(), self.ns, self.lengths.data_ptr(), self.nb,
-                                          int(max_cloud), self.ws.data_ptr(), self.nbytes, _stream()),
-                   "pcrcg_kdforest_build")
+                                          self.ws.data_ptr(), self.nbytes, _stream()), "pcrcg_kdforest_build")
 
     def reorder(self, idx, queries, q_lengths, cloud0, radius, max_count, rows=None, nrows=None, counts=None,
                 status=None):

@@ -44,7 +44,7 @@ def _layer_plan(config):
 TIE_ORDERS = ("auto", "reference", "index")
 
 
-TIE_STATUS_TEXT = {1: "KD-tree deeper than supported", 2: "traversal stack overflow",
+TIE_STATUS_TEXT = {1: "the KD-forest kernel gave up waiting for work", 2: "traversal stack overflow",
                    3: "KD-tree and cell-grid searches disagree", 4: "row longer than the staging width"}
 
 
@@ -176,14 +176,14 @@ def pyramid_steps(points, lengths, config, neighborhood_limits, want_counts=Fals
     if redo:
         for tab, _ in redo:
             tab["idx"] = out[tab["key"]][tab["layer"]]        # full-width, contiguous (trimmed views are made below)
-        max_cloud, all_rows = max(max(l) for l in lens_h), tie_order == "reference"
+        all_rows = tie_order == "reference"
         if defer_restore:
             touched = list(in_points) + list(in_lens)
             for tab, _ in redo:
                 touched += [t for t in (tab["idx"], tab["q"], tab["qlen"], tab["ties"], tab["counts"]) if t is not None]
-            out["restore"] = (lambda: _restore_reference_order(redo, in_points, in_lens, max_cloud, all_rows), touched)
+            out["restore"] = (lambda: _restore_reference_order(redo, in_points, in_lens, all_rows), touched)
         else:
-            status = _restore_reference_order(redo, in_points, in_lens, max_cloud, all_rows)
+            status = _restore_reference_order(redo, in_points, in_lens, all_rows)
             if defer_tie_check:
                 out["tie_status"] = status
             else:
@@ -201,11 +201,11 @@ def pyramid_steps(points, lengths, config, neighborhood_limits, want_counts=Fals
     return out
 
 
-def _restore_reference_order(redo, level_points, level_lens, max_cloud, all_rows):
+def _restore_reference_order(redo, level_points, level_lens, all_rows):
     """Rows with exactly equal distances -> the reference's order (ops.KdForest): one forest over the clouds of
     all levels, then one launch for all tables that reported such rows.  -> status [1] i32 (device)."""
     nb = level_lens[0].shape[0]
-    forest = ops.KdForest(torch.cat(level_points, 0), torch.cat([l.to(_I32) for l in level_lens], 0), max_cloud)
+    forest = ops.KdForest(torch.cat(level_points, 0), torch.cat([l.to(_I32) for l in level_lens], 0))
     status = torch.zeros(1, dtype=_I32, device=level_points[0].device)
     forest.reorder_tables([dict(idx=tab["idx"], q=tab["q"], qlen=tab["qlen"], cloud0=nb * tab["sup_level"],
                                 radius=tab["radius"], max_count=tab["max_count"], counts=tab["counts"],
