@@ -44,6 +44,8 @@ WORKLOADS = {
     "S30k": "S30k: 2x30000-pt shell pairs (3DMatch-shaped), indoor hyper-parameters",
     "U30k": "U30k (secondary): 2x30000 uniform-random points in a 1.07 m cube, indoor hyper-parameters",
     "K120k": "K120k (secondary, configs[4]): 2x120000-pt KITTI-shaped slabs, KITTI hyper-parameters",
+    "T30k": "T30k (secondary): the S30k pairs snapped to a 1/256 m lattice (voxelised-scan-like: most rows hold exactly "
+            "equal distances), indoor hyper-parameters, limits calibrated on the first pair",
 }
 
 
@@ -119,7 +121,13 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     cfg = kitti_config() if RECIPE == "K120k" else indoor_config()
-    limits = synthetic.LIMITS[RECIPE]
+    limits = synthetic.LIMITS.get(RECIPE)
+    if limits is None:      # the reference's calibration formula on the first pair (ref:datasets/dataloader.py:402-434)
+        from pcrcg_amd.pyramid import calibrate_neighbors
+        a, b = make_pair(RECIPE, 0)
+        limits = [int(v) for v in calibrate_neighbors(
+            [(torch.from_numpy(np.concatenate([a, b])).to(dev), torch.tensor([len(a), len(b)], dtype=torch.int32, device=dev))],
+            cfg, samples_threshold=0)]
     torch.manual_seed(0)
     np.random.seed(0)
     net = KPFCNN(cfg).eval()

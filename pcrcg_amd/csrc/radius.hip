@@ -33,6 +33,7 @@ constexpr int kListCapFull = 1024;    // second pass for the rare longer lists (
                                       // ref:datasets/dataloader.py:407)
 constexpr long long kRedoMark = -2;   // row[0] marker: list did not fit the first pass
 constexpr int kQueryWaves = 4;        // waves (= queries in flight) per workgroup
+constexpr int kTieCap = 256;          // tie rows staged per workgroup before they go to the global list
 
 struct GridHeader {   // first 256 bytes of the grid workspace
     double inv_cell;  // 1 / (radius * (1 + 1e-5)): cells are a hair wider than the radius
@@ -166,6 +167,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
     __shared__ u64 s_sorted[WAVES][CAP];
     __shared__ int s_excl[WAVES][32];
     __shared__ int s_start[WAVES][32];
+    // rows that hold a tie are collected per workgroup and appended to the global list with ONE atomic per workgroup:
+    // on voxelised scans most rows hold one, and one atomic per row on a single word cost 1 ms per 60k-row query
+    __shared__ int s_tie[kTieCap];
+    __shared__ int s_ntie, s_tie_base;
+    if (threadIdx.x == 0) s_ntie = 0;
+    __syncthreads();
     // (the wavefront index is uniform: readfirstlane lets the compiler keep the query, its cell and every
     // per-query address in SGPRs)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -252,7 +259,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
             }
             __builtin_nontemporal_store(vout, &row[e]);
         }
-        if (tie_rows && __ballot(tie) != 0ull && lane == 0) tie_rows[atomicAdd(tie_count, 1)] = qi;
+        if (tie_rows && __ballot(tie) != 0ull && lane == 0) {
+            const int slot = atomicAdd(&s_ntie, 1);
+            if (slot < kTieCap) s_tie[slot] = qi;
+            else tie_rows[atomicAdd(tie_count, 1)] = qi;          // list full: straight to the global list
+        }
         if (lane == 0) {
             if (out_count) out_count[qi] = nhit;
             if ((nhit > CAP || !inrange) && status) *status = 1;
@@ -277,6 +288,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
     }
     // one contended word: only the few waves that actually raise the maximum issue an atomic
     if (lane == 0 && wave_max > aload(out_max)) atomicMax(out_max, wave_max);
+    if (tie_rows) {
+        __syncthreads();
+        const int n = s_ntie < kTieCap ? s_ntie : kTieCap;
+        if (threadIdx.x == 0 && n > 0) s_tie_base = atomicAdd(tie_count, n);
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += WAVES * 64) tie_rows[s_tie_base + j] = s_tie[j];
+    }
 }
 
 __global__ void k_zero2(int* a, int* b) {

@@ -56,7 +56,7 @@ constexpr int kBigThreads = 512;      // each scan step of a big node covers kBi
 constexpr int kBigVec = 4;
 constexpr int kOwnMax = 4096;          // a workgroup that splits a node up to this size also splits its big descendants itself
 constexpr int kForestBlocks = 160;    // workgroups of the forest kernel (they pull tasks from a device-side queue)
-constexpr int kSpinLimitDefault = 1 << 20;   // polls of an empty queue before a workgroup gives up (status 1)
+constexpr int kSpinLimitDefault = 1 << 18;   // polls of an empty queue before a workgroup gives up (status 1)
 constexpr int kTravStack = 128;       // pending far children per query (<= tree depth)
 constexpr int kReorderWaves = 4;      // rows per workgroup of the reorder kernel
 constexpr int kMaxRow = 1024;         // longest row the reorder kernel stages (= the cell-grid search's own bound)

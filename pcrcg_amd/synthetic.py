@@ -12,8 +12,9 @@ RECIPES = {
     "S30k": (30000, 1.3, 0.02),     # BASELINE.json configs[1], "3DMatch-shaped"
     "mini": (1500, 0.45, 0.02),     # small parity case
     "T8k": (8000, 0.9, 0.02),       # tie-rich case: coordinates snapped to a 1/128 m lattice (see pair())
+    "T30k": (30000, 1.3, 0.02),     # S30k snapped to a 1/256 m lattice: the bench's "voxelised scan" workload
 }
-LATTICE = {"T8k": 128.0}
+LATTICE = {"T8k": 128.0, "T30k": 256.0}
 
 # neighbourhood limits measured on the recipes with the reference's calibrate_neighbors formula
 # (ref:datasets/dataloader.py:402-434); see scripts/make_golden_frontend.py

@@ -11,7 +11,7 @@ from pcrcg_amd.config import indoor_config  # noqa: E402
 from pcrcg_amd.pyramid import build_pyramid  # noqa: E402
 
 recipe, mode, iters = sys.argv[1], sys.argv[2], int(sys.argv[3])
-limits = synthetic.LIMITS.get(recipe, [25, 36, 45, 42])
+limits = synthetic.LIMITS.get(recipe, [42, 41, 47, 43] if recipe == "T30k" else [25, 36, 45, 42])
 dev = torch.device("cuda:0")
 src, tgt = synthetic.pair(recipe, 0)
 pts = torch.from_numpy(np.concatenate([src, tgt])).to(dev)
