@@ -358,7 +358,9 @@ int pcrcg_radius_query_ex(const float* q, int nq, const int* qlen, int ns, const
     GridView g = grid_view(const_cast<void*>(grid), grid_bytes(ns, nb), ns, nb, &ok);
     const float r2 = radius * radius;  // neighbors.cpp:226
     int blocks = (nq + kQueryWaves - 1) / kQueryWaves;
-    const int max_blocks = 256 * 16;   // 256 CUs x a few workgroups each; waves loop over queries
+    const int max_blocks = 256 * 4;    // 4 workgroups (16 wavefronts) per CU, wavefronts loop over the queries: inside the pipeline a
+                                       // smaller grid takes less from the model streams, and on voxelised data every workgroup
+                                       // appends its tie rows with one atomic on one word (4096 workgroups: 264 us per 60k-row table)
     if (blocks > max_blocks) blocks = max_blocks;
     hipLaunchKernelGGL((k_radius_query<kListCapFast, false, kQueryWaves>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, q, nq, qlen,
                        nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status,
