@@ -31,8 +31,9 @@
 //                  eight XCDs have separate L2s), until no task is queued or running.
 //   reorder        one wavefront per row, all tables of a pair in one launch: the reference's traversal with an
 //                  explicit stack in LDS (leaf points tested 64 at a time, appended in order with ballot /
-//                  popcount), then lane 0 replays std::sort step by step on the LDS list and the wavefront writes
-//                  the row.
+//                  popcount); then std::sort is replayed on the LDS list: its introsort partition phase step by step
+//                  on lane 0 (nothing up to 16 hits), its final insertion sort -- a STABLE sort of what that phase
+//                  left -- as a rank sort on all lanes; the wavefront writes the row.
 //
 // The oracle's CPU restatement (oracle/front_end.c: oracle_radius_neighbors_batch_reforder) is checked against the
 // unmodified reference entry for entry; this file is checked against both (tests/test_tieorder_gpu.py).
@@ -673,27 +674,7 @@ __device__ __forceinline__ void heap_sort(u64* first, int len) {      // __parti
     }
 }
 
-__device__ __forceinline__ void unguarded_linear_insert(u64* a, int last) {
-    const u64 val = a[last];
-    int next = last - 1;
-    while (lt(val, a[next])) { a[last] = a[next]; last = next; --next; }
-    a[last] = val;
-}
-
-__device__ __forceinline__ void insertion_sort(u64* a, int first, int last) {
-    if (first == last) return;
-    for (int i = first + 1; i != last; ++i) {
-        if (lt(a[i], a[first])) {
-            const u64 val = a[i];
-            for (int j = i; j > first; --j) a[j] = a[j - 1];    // move_backward
-            a[first] = val;
-        } else {
-            unguarded_linear_insert(a, i);
-        }
-    }
-}
-
-__device__ __forceinline__ void std_sort(u64* a, int n) {
+__device__ __forceinline__ void std_sort_partition_phase(u64* a, int n) {
     if (n == 0) return;
     int lg = 0;
     while ((n >> (lg + 1)) > 0) ++lg;
@@ -726,11 +707,22 @@ __device__ __forceinline__ void std_sort(u64* a, int n) {
             last = lo;
         }
     }
-    if (n > 16) {                                                          // __final_insertion_sort
-        insertion_sort(a, 0, 16);
-        for (int i = 16; i != n; ++i) unguarded_linear_insert(a, i);
-    } else {
-        insertion_sort(a, 0, n);
+    // __final_insertion_sort (insertion sort of the first 16, unguarded inserts of the rest) moves an element only
+    // past STRICTLY greater ones: it is the stable sort of what the loop above left, and the caller does that with
+    // all lanes (stable_sort_wave) instead of one.
+}
+
+// the stable sort by d2 of a[0, n) into out[0, n), by the whole wavefront: rank = #smaller + #equal before
+__device__ __forceinline__ void stable_sort_wave(const u64* a, u64* out, int n, int lane) {
+    for (int i = lane; i < n; i += 64) {
+        const u64 mine = a[i];
+        const unsigned key = (unsigned)(mine >> 32);
+        int r = 0;
+        for (int j = 0; j < n; ++j) {
+            const unsigned kj = (unsigned)(a[j] >> 32);
+            r += (kj < key || (kj == key && j < i)) ? 1 : 0;
+        }
+        out[r] = mine;
     }
 }
 
@@ -749,14 +741,17 @@ __device__ __forceinline__ float unif(float x) { return __int_as_float(__builtin
 __global__ void __launch_bounds__(kReorderWaves * 64) k_reorder(ReorderJobs jobs, const float* __restrict__ sup, KdView v,
                                                                  int W, int* __restrict__ status) {
     extern __shared__ u64 s_dyn[];
-    // per wavefront: W staged hits, then the traversal stack (node, mindistsq, dists[3] per entry)
-    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
-    const size_t per_wave = (size_t)W + (size_t)kTravStack * 5 / 2 + 1;
+    // per wavefront: W staged hits, then a region that holds the traversal stack (node, mindistsq, dists[3] per
+    // entry) first and the sorted row afterwards
+    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6)), waves = (int)(blockDim.x >> 6);
+    const size_t second = (size_t)W > (size_t)kTravStack * 5 / 2 ? (size_t)W : (size_t)kTravStack * 5 / 2;
+    const size_t per_wave = (size_t)W + second + 1;
     u64* mine = s_dyn + per_wave * wave;
+    u64* sorted = mine + W;
     int* st_node = reinterpret_cast<int*>(mine + W);
     float* st_min = reinterpret_cast<float*>(st_node + kTravStack);
     float* st_d = st_min + kTravStack;      // [kTravStack][3]
-    const int t = blockIdx.x * kReorderWaves + wave;
+    const int t = blockIdx.x * waves + wave;
     if (t == 0 && lane == 0 && v.ctl->status && status) *status = v.ctl->status;
     if (t >= jobs.row_begin[jobs.njobs]) return;
     int ji = 0;
@@ -852,12 +847,17 @@ __global__ void __launch_bounds__(kReorderWaves * 64) k_reorder(ReorderJobs jobs
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) std_sort(mine, n);
+    // std::sort: the introsort partition phase is sequential (lane 0; nothing to do up to 16 hits), the final
+    // insertion sort is a stable sort and is done by all lanes
+    if (lane == 0 && n > 16) std_sort_partition_phase(mine, n);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    stable_sort_wave(mine, sorted, n, lane);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     long long* row = reinterpret_cast<long long*>(jb.idx) + (long)qi * jb.cols;
     for (int j = lane; j < jb.cols; j += 64)
-        row[j] = j < n ? (long long)((int)(unsigned)(mine[j] & 0xFFFFFFFFull) - seg) : (long long)pad;
+        row[j] = j < n ? (long long)((int)(unsigned)(sorted[j] & 0xFFFFFFFFull) - seg) : (long long)pad;
 }
 
 }  // namespace
@@ -918,10 +918,11 @@ int pcrcg_radius_reorder_jobs(const pcrcg_reorder_job* jobs, int njobs, const fl
     hipStream_t st = as_stream(stream);
     bool ok;
     KdView v = forest_view(const_cast<void*>(forest), forest_bytes(ns, nb), ns, nb, &ok);
-    const size_t per_wave = (size_t)width + (size_t)kTravStack * 5 / 2 + 1;
-    const size_t lds = per_wave * kReorderWaves * sizeof(u64);
-    hipLaunchKernelGGL(k_reorder, dim3((total + kReorderWaves - 1) / kReorderWaves), dim3(kReorderWaves * 64), lds, st, pack,
-                       sup, v, width, status);
+    const size_t second = (size_t)width > (size_t)kTravStack * 5 / 2 ? (size_t)width : (size_t)kTravStack * 5 / 2;
+    const size_t per_wave = (size_t)width + second + 1;
+    const int waves = width > 512 ? 2 : kReorderWaves;           // 64 KB of dynamic LDS per workgroup at most
+    const size_t lds = per_wave * waves * sizeof(u64);
+    hipLaunchKernelGGL(k_reorder, dim3((total + waves - 1) / waves), dim3(waves * 64), lds, st, pack, sup, v, width, status);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
