@@ -67,7 +67,7 @@ constexpr int kStStack = 2;           // traversal stack overflow
 constexpr int kStCount = 3;           // tree search and cell-grid search disagree on a row's hit count
 constexpr int kStWidth = 4;           // a row holds more hits than the staging width
 
-struct KdNode {   // 64 bytes
+struct alignas(64) KdNode {   // 64 bytes, one cache line (aligned: lets the compiler merge the field loads)
     int left, right;        // range in vind
     int divfeat;            // -1: leaf
     float divlow, divhigh;
