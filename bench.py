@@ -63,7 +63,8 @@ def kpconv_algorithmic_bytes(nq, h, cin, cout, e=4):
 
 
 def cpu_baseline(cfg, state_dict, limits):
-    """CPU oracle on one S30k pair: front end single-threaded C, model torch-CPU on all cores."""
+    """CPU oracle on one pair: front end single-threaded C -- the restatement of the reference's own algorithm
+    (nanoflann KD-trees + std::sort: its tables entry for entry) --, model torch-CPU on all cores."""
     from oracle import frontend as OF
     from oracle import model_ref as MR
     src, tgt = make_pair(RECIPE, 12345)
@@ -76,14 +77,14 @@ def cpu_baseline(cfg, state_dict, limits):
     for l in range(cfg.num_layers):
         batch["points"].append(torch.from_numpy(pts))
         batch["stack_lengths"].append(torch.from_numpy(lens))
-        batch["neighbors"].append(torch.from_numpy(OF.oracle_batch_query(pts, pts, lens, lens, r)[:, :limits[l]]).long())
+        batch["neighbors"].append(torch.from_numpy(OF.oracle_batch_query(pts, pts, lens, lens, r, tie_order="reference")[:, :limits[l]]).long())
         if l == cfg.num_layers - 1:
             batch["pools"].append(empty)
             batch["upsamples"].append(empty)
             break
         sp, sl = OF.oracle_subsample_batch(pts, lens, dl)
-        batch["pools"].append(torch.from_numpy(OF.oracle_batch_query(sp, pts, sl, lens, r)[:, :limits[l]]).long())
-        batch["upsamples"].append(torch.from_numpy(OF.oracle_batch_query(pts, sp, lens, sl, 2 * r)[:, :limits[l]]).long())
+        batch["pools"].append(torch.from_numpy(OF.oracle_batch_query(sp, pts, sl, lens, r, tie_order="reference")[:, :limits[l]]).long())
+        batch["upsamples"].append(torch.from_numpy(OF.oracle_batch_query(pts, sp, lens, sl, 2 * r, tie_order="reference")[:, :limits[l]]).long())
         pts, lens, r, dl = sp, sl, r * 2, dl * 2
     batch["features"] = torch.ones((batch["points"][0].shape[0], 1))
     t1 = time.perf_counter()
@@ -91,7 +92,7 @@ def cpu_baseline(cfg, state_dict, limits):
     t2 = time.perf_counter()
     return {"value": round(1.0 / (t2 - t0), 4), "unit": "fragment-pairs/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"1 {RECIPE} pair: oracle C front end {t1 - t0:.2f}s (1 thread) + torch-CPU model "
+            "sample": f"1 {RECIPE} pair: oracle C front end (KD-trees as in the reference) {t1 - t0:.2f}s (1 thread) + torch-CPU model "
                       f"{t2 - t1:.2f}s ({torch.get_num_threads()} threads)"}
 
 
