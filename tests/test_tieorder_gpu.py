@@ -157,3 +157,15 @@ def test_skewed_tree(cuda):
     want = OF.oracle_batch_query(q, s, [len(q)], [len(s)], 0.01, tie_order="reference")
     got, status, n_ties = _reorder_case(cuda, q, s, [len(q)], [len(s)], 0.01, want.shape[1])
     assert status == 0 and n_ties > 0 and (got == want).all()
+
+
+def test_more_tie_rows_than_a_workgroup_stages(cuda):
+    """300 000 queries on 1024 workgroups = 293 rows per workgroup, nearly all of them with a tie: more than the 256
+    a workgroup collects before it appends to the global list (the overflow goes to the list one by one)."""
+    rng = np.random.default_rng(13)
+    pts = (rng.integers(0, 96, (300000, 3)) / np.float32(64)).astype(np.float32)
+    want = OF.oracle_batch_query(pts, pts, [300000], [300000], 0.03, tie_order="reference")
+    cols = min(want.shape[1], 24)
+    got, status, n_ties = _reorder_case(cuda, pts, pts, [300000], [300000], 0.03, cols)
+    assert status == 0 and n_ties > 280000
+    assert (got[:, :cols] == want[:, :cols]).all()
