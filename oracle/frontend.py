@@ -174,3 +174,36 @@ def ref_umap_order(keys):
     order = np.empty(k.shape[0], np.int32)
     lib.ref_umap_order(k.ctypes.data_as(_u64p), k.shape[0], order.ctypes.data_as(_i32p))
     return order
+
+
+def oracle_pyramid(points, lengths, cfg, limits, tie_order="reference", query=None, subsample=None):
+    """The reference's collate_fn_descriptor pyramid (ref:datasets/dataloader.py:230-361) on the CPU
+    checker: per level one conv table, then grid subsampling, one pool and one upsample table; radius
+    and cell size double per level; tables cut at [:, :limit] and cast to int64.  Returns the batch
+    dict the model reads (torch CPU tensors).  ``query`` / ``subsample`` default to this repo's C
+    restatement; pass ref_batch_query / ref_subsample_batch to run the unmodified reference cores."""
+    import torch
+    if query is None:
+        def query(q, s, ql, sl, radius):
+            return oracle_batch_query(q, s, ql, sl, radius, tie_order=tie_order)
+    subsample = subsample or oracle_subsample_batch
+    pts, lens = _f32(points), _i32(lengths)
+    r = cfg["first_subsampling_dl"] * cfg["conv_radius"]
+    dl = 2 * cfg["first_subsampling_dl"]
+    batch = {"points": [], "neighbors": [], "pools": [], "upsamples": [], "stack_lengths": []}
+    empty = torch.zeros((0, 1), dtype=torch.int64)
+    n_layers = cfg["num_layers"]
+    for l in range(n_layers):
+        batch["points"].append(torch.from_numpy(pts))
+        batch["stack_lengths"].append(torch.from_numpy(lens))
+        batch["neighbors"].append(torch.from_numpy(query(pts, pts, lens, lens, r)[:, :limits[l]]).long())
+        if l == n_layers - 1:
+            batch["pools"].append(empty)
+            batch["upsamples"].append(empty)
+            break
+        sp, sl = subsample(pts, lens, dl)
+        batch["pools"].append(torch.from_numpy(query(sp, pts, sl, lens, r)[:, :limits[l]]).long())
+        batch["upsamples"].append(torch.from_numpy(query(pts, sp, lens, sl, 2 * r)[:, :limits[l]]).long())
+        pts, lens, r, dl = sp, sl, r * 2, dl * 2
+    batch["features"] = torch.ones((batch["points"][0].shape[0], 1))
+    return batch

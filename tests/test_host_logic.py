@@ -46,12 +46,24 @@ def test_layer_plan_radii():
     assert abs(k[0]["r_conv"] - 1.275) < 1e-9 and abs(k[0]["dl"] - 0.6) < 1e-9
 
 
-def test_kernel_points():
+def test_kernel_points(golden_dir):
+    """load_kernels reproduces ref:kernels/kernel_points.py:388-470 under the same np.random stream: a seed-0
+    model built here equals the reference's seed-0 model (fixture state_dict) bit for bit -- kernel points and,
+    because the constructors draw from torch's generator in the same order, every weight."""
+    from pcrcg_amd.kernel_points import DISPOSITION_15_CENTER_3D
+    assert DISPOSITION_15_CENTER_3D.shape == (15, 3) and DISPOSITION_15_CENTER_3D.dtype == np.float64
+    assert (DISPOSITION_15_CENTER_3D[0] == 0).all()
     np.random.seed(0)
     kp = load_kernels(0.0625)
     assert kp.shape == (15, 3) and kp.dtype == np.float32
-    r = np.linalg.norm(kp, axis=1)
-    assert r[0] < 0.05 * 0.0625 * 3 and abs(r[1:].mean() / 0.0625 - 0.66) < 0.02
+    mm = torch.load(os.path.join(golden_dir, "model_mini.pt"))
+    torch.manual_seed(0)
+    np.random.seed(0)
+    sd = KPFCNN(indoor_config(first_feats_dim=32, gnn_feats_dim=64)).state_dict()
+    kps = [k for k in mm["state_dict"] if k.endswith("kernel_points")]
+    assert len(kps) == 11
+    for k, v in mm["state_dict"].items():
+        assert torch.equal(sd[k], v), k
 
 
 def test_no_cpu_fallback_and_no_oracle_in_product():
