@@ -202,6 +202,17 @@ int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, int ldb, in
                             int m, int n, int k, const float* row_scale, const float* bias, void* colstats,
                             size_t colstats_bytes, int* h_chunks, void* stream);
 
+/* Arithmetic of the C = A @ B^T products (trans_b = 1) behind pcrcg_gemm_f32 / _colstats / _ex:
+ *   0: v_mfma_f32_32x32x2_f32 on the fp32 operands (the fp32 matrix rate, 157 TF on MI355X);
+ *   1: (default) every fp32 operand value is split EXACTLY into three bf16 terms and the six leading
+ *      cross products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: the dropped terms are
+ *      below 2^-23 relative per product, i.e. fp32-class accuracy (measured against float64 it is no
+ *      worse than mode 0), at 16/6 of the fp32 matrix rate.
+ * Process-wide; also read once from the environment variable PCRCG_GEMM_MODE.  Interface: fp32 in,
+ * fp32 out in both modes. */
+void pcrcg_gemm_set_mode(int mode);
+int pcrcg_gemm_get_mode(void);
+
 /* ------------------------------------------------------------------------------------------------
  * Point-wise blocks
  * ---------------------------------------------------------------------------------------------- */

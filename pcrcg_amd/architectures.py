@@ -3,6 +3,7 @@
 signature and result dict, same state_dict keys and shapes; the forward pass runs in the HIP kernels
 behind pcrcg_amd.ops."""
 import os
+import threading
 
 import numpy as np
 import torch
@@ -13,6 +14,8 @@ from . import ops
 from .blocks import NearestUpsampleBlock, block_decider
 from .config import as_config
 from .gcn import GCN
+
+_RUNNER_LOCK = threading.Lock()   # module-level: a lock attribute would make the nn.Module uncopyable
 
 
 class KPFCNN(nn.Module):
@@ -103,11 +106,18 @@ class KPFCNN(nn.Module):
             return forward_train(self, batch)
         if self.use_runner:
             # the whole forward below, enqueued by one call into the C++ runner (csrc/runner.hip)
-            if self._runner is None:
-                from .runner import Runner
-                self._runner = Runner(self)
-            return self._runner.forward(batch)
+            return self.runner().forward(batch)
         return self.forward_ops(batch)
+
+    def runner(self):
+        """The (lazily created) descriptor cache of the C++ runner; creation is serialised because forwards may
+        be enqueued from several host threads (pcrcg_amd/pipeline.py)."""
+        if self._runner is None:
+            with _RUNNER_LOCK:
+                if self._runner is None:
+                    from .runner import Runner
+                    self._runner = Runner(self)
+        return self._runner
 
     def forward_ops(self, batch):
         """Op-by-op forward through pcrcg_amd.ops (one FFI call per kernel); same kernels, same results

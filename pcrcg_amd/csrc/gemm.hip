@@ -333,7 +333,27 @@ int launch(bool trans_b, dim3 grid, hipStream_t st, const float* a, int lda, con
 }  // namespace
 }  // namespace pcrcg
 
+namespace pcrcg {
+int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
+                     const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
+                     hipStream_t st);   // gemm_x6.hip
+}
+
 using namespace pcrcg;
+
+// Arithmetic of the C = A * B^T products: 0 = v_mfma_f32_32x32x2_f32 (fp32 operands), 1 = six
+// v_mfma_f32_32x32x16_bf16 on the exact three-term bf16 split of the fp32 operands (gemm_x6.hip; fp32-class
+// accuracy at 2.7x the matrix rate).  Default 1; PCRCG_GEMM_MODE / pcrcg_gemm_set_mode override.
+static int g_gemm_mode = -1;
+static int gemm_mode() {
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("PCRCG_GEMM_MODE");
+        g_gemm_mode = e ? (atoi(e) != 0) : 1;
+    }
+    return g_gemm_mode;
+}
+extern "C" void pcrcg_gemm_set_mode(int mode) { g_gemm_mode = mode != 0; }
+extern "C" int pcrcg_gemm_get_mode(void) { return gemm_mode(); }
 
 static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc,
                          int m, int n, int k, const float* row_scale, const float* bias, void* colstats,
@@ -374,6 +394,8 @@ static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, i
     PCRCG_CHECK_ARG((trans_a ? lda >= m : lda >= k) && ldc >= n);
     PCRCG_CHECK_ARG(trans_b ? ldb >= k : ldb >= n);
     hipStream_t st = as_stream(stream);
+    if (!trans_a && trans_b && gemm_mode() == 1)
+        return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks, st);
     const int vec_a = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     const int vec_b = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
     // Tile / split selection (sweep in scripts/gemm_tune.py on the path's shapes): these GEMMs are skinny

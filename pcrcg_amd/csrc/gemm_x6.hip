@@ -1,0 +1,382 @@
+// gemm_x6.hip -- fp32-accurate GEMM on the gfx950 bf16 matrix cores:  C = (A * B^T) * row_scale[m] + bias[n]
+// with A [M,K] and B [N,K] both row-major fp32 (k-contiguous: nn.Linear / 1x1 conv weights, K-contiguous
+// copies of the KPConv weights).  Same contract and epilogue as k_gemm_f32 (gemm.hip); replaces the same
+// reference lines (ref:models/blocks.py:361-372, :487; ref:models/architectures.py:528,538-539;
+// ref:models/gcn.py:123-132,165-173).
+//
+// Arithmetic.  v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (157 TF), 1/16 of the bf16 matrix rate.
+// Every fp32 value is EXACTLY the sum of three bf16 values (24 significand bits = 3 x 8):
+//     x = x1 + x2 + x3,   x1 = trunc_bf16(x), x2 = trunc_bf16(x - x1), x3 = x - x1 - x2   (all exact)
+// so  a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1) + [a2b3 + a3b2 + a3b3],  and the bracket is below
+// 2^-23 |ab| -- the size of ONE fp32 rounding.  bf16 x bf16 products are exact in the matrix core and are
+// accumulated in fp32, so six v_mfma_f32_32x32x16_bf16 per 16-deep k-chunk give an fp32-class result
+// (measured on the CPU restatement, scripts/exp_splitbf16.py: the full-width model's outputs are as close to
+// a float64 run as the plain fp32 model's are, 9e-7 vs 1.3e-6) at 16/6 = 2.7x the fp32 matrix rate.
+// The three-term split is the point: the two-term variant (3 MFMAs) leaves 2^-16 per product and moved
+// intermediate activations by 1.7e-4 in the same experiment -- outside this path's 1e-4 bar.
+//
+// Structure: 256 threads = 4 wavefronts (2 x 2), block tile BM x BN x 32.  Operand tiles are loaded as
+// float4 pairs (8 consecutive k of one row per thread and pass), split on the VALU and written to LDS as
+// three bf16 planes with 80-byte rows (64 B of data + 16 B pad: the ds_read_b128 of 8 consecutive k for the
+// 32 rows of an MFMA operand is bank-conflict free, 20*r mod 64 enumerates the sixteen 4-bank slots).  One
+// LDS stage; the next tile's global loads are in flight while the current one is multiplied (register
+// prefetch), and two or more co-resident blocks per CU overlap one block's split/write phase with the
+// others' MFMA phase.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "pcrcg_train.h"
+
+namespace pcrcg {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+
+// Register loads hidden from hipcc's s_waitcnt bookkeeping (guide 5.7, form ii).  hipcc merges the vmcnt state of
+// the two register sets of the k-loop conservatively and waits for BOTH at the top of every step (ISA checked),
+// i.e. it turns prefetch distance 2 into 1; with the loads in asm the waits below are counted by hand instead:
+// vm_wait<N>() leaves the N newest loads in flight, pin() makes every later use of a destination register
+// depend on a statement that follows the wait.
+__device__ __forceinline__ void gload16(f32x4& dst, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pin(f32x4& r) { asm volatile("" : "+v"(r)); }
+
+constexpr int ROWB = 80;   // bytes per LDS row of one plane: 32 bf16 + 16 B pad
+
+// two fp32 -> their three bf16 terms, packed pairwise (low half = first element)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    const float h0 = __uint_as_float(u0 & 0xffff0000u), h1 = __uint_as_float(u1 & 0xffff0000u);
+    const float r0 = x0 - h0, r1 = x1 - h1;                                   // exact
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    const float m0 = __uint_as_float(v0 & 0xffff0000u), m1 = __uint_as_float(v1 & 0xffff0000u);
+    const float l0 = r0 - m0, l1 = r1 - m1;                                   // exact, <= 8 significant bits
+    p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                          // {hi16(x1), hi16(x0)}
+    p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    p3 = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+}
+
+template <int BM, int BN>
+constexpr int lds_bytes() { return 3 * (BM + BN) * ROWB; }
+
+template <int BM, int BN, int MINB>
+__global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                        int ldb, float* __restrict__ C, int ldc, int M, int N, int Kdim,
+                                                        const float* __restrict__ row_scale,
+                                                        const float* __restrict__ bias, int k_per_split, int vec_a,
+                                                        int vec_b, int atomic_out, double* __restrict__ colp,
+                                                        int colp_chunks) {
+    constexpr int WAVES_M = 2, WAVES_N = 2;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_ITERS = BM * 4 / 256;    // (row, 8-k group) items per thread
+    constexpr int B_ITERS = BN * 4 / 256;
+    constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;
+    static_assert(A_ITERS >= 1 && B_ITERS >= 1, "tile too small");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const As = smem;
+    unsigned char* const Bs = smem + 3 * A_PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    // XCD-aware tile order (as k_gemm_f32): each XCD walks a contiguous range of tiles, n fastest
+    const int gx = gridDim.x, ntile = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gx * blockIdx.y;
+    const int xq = ntile >> 3, xr = ntile & 7, xcd = lin & 7, slot = lin >> 3;
+    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+    const int tile_x = tile % gx, tile_y = tile / gx;
+    const int m0 = tile_y * BM, n0 = tile_x * BN;
+    const int k_begin = blockIdx.z * k_per_split;
+    const int k_end = min(Kdim, k_begin + k_per_split);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // two register sets: tile s is consumed from set s&1 while tiles s+1 (other set) and s+2 (this set, re-issued
+    // right after its split) are in flight -- these GEMMs stream A from HBM, so bytes in flight are the currency
+    f32x4 ra[2][A_ITERS][2], rb[2][B_ITERS][2];
+    constexpr int TILE_LOADS = 2 * (A_ITERS + B_ITERS);     // global_load_dwordx4 per thread and tile
+
+    // unguarded 16-byte loads of a full 32-deep k-slab; rows past the matrix are CLAMPED to its last row: they only
+    // feed output rows / columns the epilogue masks, so no zero fill is needed along M or N (only along K, below)
+    auto load_fast = [&](const float* __restrict__ P, int ld, int row0, int rows, int k0, int it, f32x4* dst) {
+        const int e = tid + it * 256;
+        const float* p = P + (long)min(row0 + (e >> 2), rows - 1) * ld + k0 + (e & 3) * 8;
+        gload16(dst[0], p);
+        gload16(dst[1], p + 4);
+    };
+    auto load_edge = [&](const float* __restrict__ P, int ld, int row0, int rows, int k0, int it, f32x4* dst) {
+        const int e = tid + it * 256;
+        const int gr = row0 + (e >> 2), gk = k0 + (e & 3) * 8, ke = k_end - 1;
+        const float* p = P + (long)min(gr, rows - 1) * ld;      // always a valid address
+        const bool rok = gr < rows;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[min(gk + j, ke)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (rok && gk + j < k_end) ? v[j] : 0.f;
+        dst[0] = f32x4{v[0], v[1], v[2], v[3]};
+        dst[1] = f32x4{v[4], v[5], v[6], v[7]};
+    };
+    // FAST: both operands 16-byte aligned and the slab k0..k0+31 inside [k_begin, k_end).  The choice is made
+    // OUTSIDE the k-loop: a branch between load flavours inside it makes hipcc merge their vmcnt bookkeeping and
+    // wait for (nearly) everything in flight at the top of every step, which turns prefetch distance 2 into 1.
+    auto load_tiles = [&](auto fast, int k0, f32x4 (*qa)[2], f32x4 (*qb)[2]) {
+        if constexpr (decltype(fast)::value) {
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) load_fast(A, lda, m0, M, k0, it, qa[it]);
+#pragma unroll
+            for (int it = 0; it < B_ITERS; ++it) load_fast(B, ldb, n0, N, k0, it, qb[it]);
+        } else {
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) load_edge(A, lda, m0, M, k0, it, qa[it]);
+#pragma unroll
+            for (int it = 0; it < B_ITERS; ++it) load_edge(B, ldb, n0, N, k0, it, qb[it]);
+        }
+    };
+    auto store_one = [&](unsigned char* base, int plane_bytes, int it, const f32x4* src) {
+        const int e = tid + it * 256;
+        unsigned q1[4], q2[4], q3[4];
+        split2(src[0].x, src[0].y, q1[0], q2[0], q3[0]);
+        split2(src[0].z, src[0].w, q1[1], q2[1], q3[1]);
+        split2(src[1].x, src[1].y, q1[2], q2[2], q3[2]);
+        split2(src[1].z, src[1].w, q1[3], q2[3], q3[3]);
+        const u32x4 p1 = {q1[0], q1[1], q1[2], q1[3]}, p2 = {q2[0], q2[1], q2[2], q2[3]},
+                    p3 = {q3[0], q3[1], q3[2], q3[3]};
+        unsigned char* d = base + (e >> 2) * ROWB + (e & 3) * 16;
+        *reinterpret_cast<u32x4*>(d) = p1;
+        *reinterpret_cast<u32x4*>(d + plane_bytes) = p2;
+        *reinterpret_cast<u32x4*>(d + 2 * plane_bytes) = p3;
+    };
+    auto store_tiles = [&](f32x4 (*qa)[2], f32x4 (*qb)[2]) {
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) store_one(As, A_PLANE, it, qa[it]);
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it) store_one(Bs, B_PLANE, it, qb[it]);
+    };
+
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nsteps = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
+    auto multiply = [&]() {
+#pragma unroll
+        for (int c = 0; c < BK / 16; ++c) {
+            bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    a[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                        As + p * A_PLANE + (wm * WM + i * 32 + l31) * ROWB + (c * 2 + half) * 16));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    b[j][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                        Bs + p * B_PLANE + (wn * WN + j * 32 + l31) * ROWB + (c * 2 + half) * 16));
+            // smallest terms first: a3b1 a2b2 a1b3 | a2b1 a1b2 | a1b1
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int pa = (t == 0 ? 2 : t == 1 ? 1 : t == 2 ? 0 : t == 3 ? 1 : 0);
+                const int pb = (t == 0 ? 0 : t == 1 ? 1 : t == 2 ? 2 : t == 3 ? 0 : t == 4 ? 1 : 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    // steps [0, nfast) use the fast loads; a k tail (K not a multiple of 32) or unaligned operands use guarded ones
+    const int nfast = (vec_a && vec_b) ? (k_end - k_begin) / BK : 0;
+    // Wait until only the other set's loads are in flight, then split this set into LDS.  `live` = 0 zeroes the tile
+    // (the phantom second half of an odd tile count).
+    auto consume = [&](f32x4 (*qa)[2], f32x4 (*qb)[2], bool live) {
+        vm_wait<TILE_LOADS>();
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) { pin(qa[it][0]); pin(qa[it][1]); }
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it) { pin(qb[it][0]); pin(qb[it][1]); }
+        if (!live) {
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) { qa[it][0] = f32x4{0.f, 0.f, 0.f, 0.f}; qa[it][1] = qa[it][0]; }
+        }
+        __syncthreads();                                                  // previous tile fully read
+        store_tiles(qa, qb);                                              // registers -> LDS (split)
+    };
+    if (nfast > 0) {
+        // ONE region without control-flow joins between a load and its wait: every join makes hipcc copy the
+        // (still in flight) destination registers of the asm loads, which is exactly the garbage the guide warns of
+        // (seen in the ISA of an earlier version with peeled tail steps: v_mov of a set before its s_waitcnt).
+        // So all loads are unconditional -- past the last tile they re-read it (an L1/L2 hit) and are never used --,
+        // an odd tile count is rounded up with a zeroed phantom tile, and nothing is peeled.
+        std::true_type fast;
+        const int k_last = k_begin + (nfast - 1) * BK;
+        load_tiles(fast, k_begin, ra[0], rb[0]);
+        load_tiles(fast, min(k_begin + BK, k_last), ra[1], rb[1]);
+        for (int s = 0; s < nfast; s += 2) {
+            consume(ra[0], rb[0], true);
+            load_tiles(fast, min(k_begin + (s + 2) * BK, k_last), ra[0], rb[0]);   // tile s+2 into the freed set
+            __syncthreads();
+            multiply();
+            consume(ra[1], rb[1], s + 1 < nfast);
+            load_tiles(fast, min(k_begin + (s + 3) * BK, k_last), ra[1], rb[1]);
+            __syncthreads();
+            multiply();
+        }
+        vm_wait<0>();                                                     // the two unused trailing prefetches
+    }
+    for (int s = nfast; s < nsteps; ++s) {       // k tail / unaligned operands: guarded loads hipcc counts itself
+        std::false_type slow;
+        load_tiles(slow, k_begin + s * BK, ra[0], rb[0]);
+        __syncthreads();
+        store_tiles(ra[0], rb[0]);
+        __syncthreads();
+        multiply();
+    }
+
+    // epilogue (as k_gemm_f32): C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool first_split = blockIdx.z == 0;
+    float rs[TM][16], bv[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            rs[i][r] = row_scale ? row_scale[min(gm, M - 1)] : 1.0f;
+        }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int gn = n0 + wn * WN + j * 32 + l31;
+        bv[j] = (bias && first_split) ? bias[min(gn, N - 1)] : 0.0f;
+    }
+    float cs[TN], cq[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = n0 + wn * WN + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float v = acc[i][j][r] * rs[i][r] + bv[j];
+                if (gm < M && gn < N) {
+                    float* dst = C + (long)gm * ldc + gn;
+                    if (atomic_out) atomicAdd(dst, v);
+                    else *dst = v;
+                    cs[j] += v;
+                    cq[j] += v * v;
+                }
+            }
+        }
+    if (colp) {
+        const int chunk = tile_y * WAVES_M + wm;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float s = cs[j] + __shfl_xor(cs[j], 32, 64), q2 = cq[j] + __shfl_xor(cq[j], 32, 64);
+            const int gn = n0 + wn * WN + j * 32 + l31;
+            if (half == 0 && gn < N) {
+                colp[(long)gn * colp_chunks + chunk] = (double)s;
+                colp[((long)N + gn) * colp_chunks + chunk] = (double)q2;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int MINB>
+int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n,
+              int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b, int atomic_out,
+              double* colp, int colp_chunks) {
+    constexpr size_t lds = lds_bytes<BM, BN>();
+    auto kern = k_gemm_x6<BM, BN, MINB>;
+    static bool configured = false;
+    if (!configured) {
+        PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split,
+                       vec_a, vec_b, atomic_out, colp, colp_chunks);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+}  // namespace
+
+// Called by gemm_dispatch (gemm.hip) for C = A * B^T products when the split-bf16 mode is on.
+int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
+                     const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
+                     hipStream_t st) {
+    const int vec_a = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+    const int vec_b = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+    struct Tile { int bm, bn; };
+    static const Tile tiles[4] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    // Tile / split choice from the sweep of scripts/gemm_x6_bench.py over the path's shapes: the 64x64 tile wins or
+    // ties everywhere (the kernel is bound by per-block latency, so many small blocks beat few large ones) except
+    // for very tall N <= 64 products, where 128x64 halves the re-reads of B.  K is split (fp32 atomics into a
+    // zeroed C) only when the tiles alone leave most CUs idle, or when K is so long that one block's k-loop
+    // dominates; each split costs a memset and atomic traffic, so never below 256 k per split.
+    int pick = -1;
+    if (const char* e = getenv("PCRCG_X6_TILE")) pick = atoi(e);          // tuning aid
+    if (pick < 0 || pick > 3) pick = (n <= 64 && m >= 32768) ? 1 : 3;
+    const int BM = tiles[pick].bm, BN = tiles[pick].bn;
+    const int gx = (n + BN - 1) / BN, gy = (m + BM - 1) / BM;
+    int splits = 1;
+    const int ktiles = (k + BK - 1) / BK;
+    while ((long)gx * gy * splits < 200 && k / (2 * splits) >= 256 && splits < 32) splits *= 2;
+    while ((long)gx * gy * splits < 1024 && k / splits > 1024 && splits < 32) splits *= 2;
+    if (const char* e = getenv("PCRCG_X6_SPLITK")) splits = atoi(e) > 0 ? atoi(e) : splits;   // tuning aid
+    int k_per_split = ((ktiles + splits - 1) / splits) * BK;
+    if (k_per_split < BK) k_per_split = BK;
+    splits = k > 0 ? (k + k_per_split - 1) / k_per_split : 1;
+    if (splits < 1) splits = 1;
+    const int atomic_out = splits > 1;
+    if (atomic_out) {
+        if (ldc == n) PCRCG_CHECK_HIP(hipMemsetAsync(c, 0, (size_t)m * n * sizeof(float), st));
+        else PCRCG_CHECK_HIP(hipMemset2DAsync(c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), m, st));
+    }
+    dim3 grid(gx, gy, splits);
+    static const bool log_shapes = getenv("PCRCG_GEMM_LOG") != nullptr;   // tuning aid
+    if (log_shapes)
+        fprintf(stderr, "pcrcg_gemm_x6 m=%d n=%d k=%d lda=%d ldb=%d ldc=%d tile=%dx%d grid=%dx%dx%d rs=%d bias=%d stats=%d\n", m,
+                n, k, lda, ldb, ldc, BM, BN, gx, gy, splits, row_scale != nullptr, bias != nullptr, colstats != nullptr);
+    double* colp = nullptr;
+    int colp_chunks = 0;
+    if (colstats && h_chunks && !atomic_out) {
+        colp_chunks = gy * 2;   // WAVES_M
+        if (carve_bytes(2 * (size_t)n * colp_chunks, sizeof(double)) <= colstats_bytes) {
+            colp = static_cast<double*>(colstats);
+            *h_chunks = colp_chunks;
+        } else {
+            colp_chunks = 0;
+        }
+    }
+#define GO(BMV, BNV, MINB)                                                                                       \
+    return launch_x6<BMV, BNV, MINB>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a, \
+                                     vec_b, atomic_out, colp, colp_chunks)
+    if (pick == 0) { GO(128, 128, 2); }
+    if (pick == 1) { GO(128, 64, 2); }
+    if (pick == 2) { GO(64, 128, 2); }
+    GO(64, 64, 4);
+#undef GO
+}
+
+}  // namespace pcrcg

@@ -155,9 +155,12 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
     if (c.live()) {
         c.check(pcrcg_kpconv_aggregate(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, xp, cin, blk.kp, blk.extent,
                                        wf.p, inv_n, ws, wsb, c.st));
-        c.check(pcrcg_gemm_f32_colstats(wf.p, wf.ld, w, y.cols, 0, y.p, y.ld, nq, y.cols, wf.cols, inv_n, nullptr,
-                                        st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr,
-                                        c.st));
+        // contraction wf @ W: against the K-contiguous copy wt [cout, 15*cin] when the descriptor carries one
+        // (C = A * B^T form: both operands k-contiguous, the form the split-bf16 GEMM is built for)
+        const bool kt = blk.kp_wt != nullptr;
+        c.check(pcrcg_gemm_f32_colstats(wf.p, wf.ld, kt ? blk.kp_wt : w, kt ? wf.cols : y.cols, kt ? 1 : 0, y.p, y.ld, nq,
+                                        y.cols, wf.cols, inv_n, nullptr, st ? st->partials : nullptr, st ? st->bytes : 0,
+                                        st ? &st->chunks : nullptr, c.st));
     }
     c.release(m);
 }

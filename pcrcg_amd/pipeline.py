@@ -92,6 +92,10 @@ class PairPipeline:
         # tie-order status words of pairs in flight: (pinned host copy, event) -- read once the event has passed
         self._tie_pending = []
         self._tie_lock = threading.Lock()
+        # build the runner's weight descriptor once, here, before any worker thread can race for it
+        if getattr(net, "use_runner", False) and next(net.parameters()).is_cuda:
+            with torch.cuda.device(self.device):
+                net.runner().descriptor()
         if threaded:
             for f in range(len(self.fronts)):
                 t = threading.Thread(target=self._serve, args=(f,), name=f"pcrcg-front-end-{f}", daemon=True)

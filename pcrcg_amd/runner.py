@@ -9,6 +9,7 @@ are made once per weight version and cached:
     ref:models/gcn.py:170)
   * decoder unary weights with 1538 / 769 input channels: rows padded to a multiple of 4 floats."""
 import ctypes
+import threading
 
 import torch
 
@@ -87,6 +88,14 @@ class Runner:
         self.desc = None
         self.keep = []      # tensors the descriptor points into
         self.ws = {}
+        self._lock = threading.Lock()   # descriptor() is called from one forward-worker thread per model stream
+
+    # a copied / pickled model starts without a runner (KPFCNN.runner() re-creates it lazily)
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
 
     def _signature(self):
         return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
@@ -96,22 +105,23 @@ class Runner:
         self.keep.append(t)
         return t.data_ptr()
 
-    def _kp_wt(self, kp):
-        """K-contiguous copy [cout, 15*cin] of the KPConv weights for the fused kernel (or NULL)."""
-        if not _lib.lib().pcrcg_kpconv_fused_supported(1, kp.in_channels, kp.out_channels):
-            return None
-        return self._w(kp.weights.data.reshape(-1, kp.out_channels).t())
-
-    def _kp_w_pad(self, blk, kp):
-        """Weights with the input channels zero-padded to a multiple of 4 (see pcrcg_block.kp_w_pad)."""
+    def _kp_weights(self, blk, kp):
+        """kp_w: the weights as stored, [15, cin, cout].  kp_w_pad: input channels zero-padded to a multiple of 4
+        when cin is not one (the 129-channel PCR-CG input), else NULL.  kp_wt: K-contiguous copy
+        [cout, 15*cin_eff] of whichever of the two the gather kernel's output matches -- the contraction then is
+        a C = A @ B^T product with both operands k-contiguous."""
         cin = kp.in_channels
+        blk.kp_w = self._w(kp.weights.data)
+        w = kp.weights.data
         if cin % 4 == 0 or cin < 4:
             blk.kp_w_pad, blk.cin_pad = None, 0
-            return
-        cp = (cin + 3) // 4 * 4
-        w = torch.zeros((kp.weights.shape[0], cp, kp.out_channels), dtype=torch.float32, device=kp.weights.device)
-        w[:, :cin].copy_(kp.weights.data)
-        blk.kp_w_pad, blk.cin_pad = self._w(w), cp
+        else:
+            cp = (cin + 3) // 4 * 4
+            w = torch.zeros((kp.weights.shape[0], cp, kp.out_channels), dtype=torch.float32, device=kp.weights.device)
+            w[:, :cin].copy_(kp.weights.data)
+            blk.kp_w_pad, blk.cin_pad = self._w(w), cp
+        k = w.shape[0] * w.shape[1]
+        blk.kp_wt = self._w(w.reshape(k, kp.out_channels).t()) if k % 4 == 0 else None
 
     def _fill_block(self, blk, mod):
         if isinstance(mod, SimpleBlock):
@@ -119,17 +129,15 @@ class Runner:
             kp = mod.KPConv
             blk.in_dim, blk.out_dim, blk.mid_dim = kp.in_channels, kp.out_channels, kp.out_channels
             blk.extent = float(kp.KP_extent)
-            blk.kp, blk.kp_w = self._w(kp.kernel_points.data), self._w(kp.weights.data)
-            blk.kp_wt = self._kp_wt(kp)
-            self._kp_w_pad(blk, kp)
+            blk.kp = self._w(kp.kernel_points.data)
+            self._kp_weights(blk, kp)
         elif isinstance(mod, ResnetBottleneckBlock):
             blk.type, blk.layer, blk.strided = BLK_RESNETB, mod.layer_ind, int("strided" in mod.block_name)
             kp = mod.KPConv
             blk.in_dim, blk.out_dim, blk.mid_dim = mod.in_dim, mod.out_dim, kp.out_channels
             blk.extent = float(kp.KP_extent)
-            blk.kp, blk.kp_w = self._w(kp.kernel_points.data), self._w(kp.weights.data)
-            blk.kp_wt = self._kp_wt(kp)
-            self._kp_w_pad(blk, kp)
+            blk.kp = self._w(kp.kernel_points.data)
+            self._kp_weights(blk, kp)
             blk.unary1 = self._w(mod.unary1.mlp.weight.data) if isinstance(mod.unary1, UnaryBlock) else None
             blk.unary2 = self._w(mod.unary2.mlp.weight.data)
             blk.shortcut = (self._w(mod.unary_shortcut.mlp.weight.data)
@@ -175,11 +183,25 @@ class Runner:
             raise RuntimeError(f"pcrcg_amd.runner: unsupported GNN layer {type(layer).__name__}")
 
     def descriptor(self):
-        sig = self._signature()
-        if self.desc is not None and sig == self.sig:
-            return self.desc
+        """The model descriptor for the current weight version.  Thread-safe: built under a lock into a fresh `keep`
+        list and published together with it, so a concurrent caller never sees (or frees) a half-built one."""
+        with self._lock:
+            sig = self._signature()
+            if self.desc is not None and sig == self.sig:
+                return self.desc
+            old_keep, self.keep = self.keep, []
+            try:
+                d = self._build()
+            except BaseException:
+                self.keep = old_keep
+                raise
+            # the previous version's re-packed copies stay alive until forwards that may still use them are done
+            self._retired = old_keep
+            self.desc, self.sig = d, sig
+            return d
+
+    def _build(self):
         m = self.model
-        self.keep = []
         d = Model()
         d.n_enc, d.n_dec, d.n_gnn = len(m.encoder_blocks), len(m.decoder_blocks), len(m.gnn.layers)
         if d.n_enc > MAX_BLOCKS or d.n_dec > MAX_BLOCKS or d.n_gnn > MAX_GNN:
@@ -204,7 +226,6 @@ class Runner:
         d.proj_score_w, d.proj_score_b = (self._w(m.proj_score.weight.data.squeeze(-1)),
                                           self._w(m.proj_score.bias.data))
         d.temperature = float(torch.exp(m.epsilon.detach()).item()) + 0.03
-        self.desc, self.sig = d, sig
         return d
 
     @staticmethod
@@ -255,10 +276,11 @@ class Runner:
                                + (L.pcrcg_last_error() or b"").decode())
         stream = torch.cuda.current_stream().cuda_stream
         key = (dev.index, stream)
-        ws = self.ws.get(key)
-        if ws is None or ws.numel() < nbytes:
-            ws = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)
-            self.ws[key] = ws
+        with self._lock:
+            ws = self.ws.get(key)
+            if ws is None or ws.numel() < nbytes:
+                ws = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)
+                self.ws[key] = ws
         _lib.check(L.pcrcg_kpfcnn_forward(ctypes.byref(desc), ctypes.byref(b), ctypes.byref(o), ws.data_ptr(),
                                           ws.numel(), stream), "pcrcg_kpfcnn_forward")
         return out
