@@ -35,6 +35,7 @@ if REPO not in sys.path:
 
 from pcrcg_amd import indoor_config, kitti_config, ops, synthetic  # noqa: E402
 from pcrcg_amd.architectures import KPFCNN  # noqa: E402
+from pcrcg_amd.pairstream import PairStreams  # noqa: E402
 from pcrcg_amd.pipeline import PairPipeline  # noqa: E402
 from pcrcg_amd.sharding import pair_seeds_for_rank  # noqa: E402
 
@@ -55,6 +56,11 @@ def make_pair(recipe, seed):
     if recipe == "K120k":
         return synthetic.slab_pair(120000, seed)
     return synthetic.pair(recipe, seed)
+
+
+def _gemm_mode():
+    from pcrcg_amd import _lib
+    return int(_lib.lib().pcrcg_gemm_get_mode())
 
 
 def kpconv_algorithmic_bytes(nq, h, cin, cout, e=4):
@@ -145,16 +151,23 @@ def main():
             pool[s % 16] = (torch.from_numpy(np.concatenate([src, tgt])).to(dev),
                             torch.tensor([len(src), len(tgt)], dtype=torch.int32, device=dev))
 
-    # Multi-stream pipeline (pcrcg_amd/pipeline.py): pairs are submitted up to DEPTH ahead; a front-end
-    # thread builds their pyramids on its own stream and one forward-worker thread per model stream
-    # enqueues the forwards.  The timed region starts from an EMPTY pipeline and ends with it empty again:
-    # all K pyramid builds and all K forwards are submitted, executed and finished inside it.
-    DEPTH = int(os.environ.get("PCRCG_PIPE_DEPTH", "4"))
+    # Pair engine (pcrcg_amd/pairstream.py): W host threads, each with its own HIP stream, take pairs round-robin;
+    # a pair is two calls into the library (pyramid builder + network runner) on the worker's stream.  Pairs are
+    # submitted up to DEPTH ahead.  The timed region starts from an EMPTY engine and ends with it empty again: all K
+    # pyramid builds and all K forwards are submitted, executed and finished inside it.
+    # PCRCG_PIPELINE=legacy selects round 1's generator-interleaving pipeline (pcrcg_amd/pipeline.py) for comparison.
+    legacy = os.environ.get("PCRCG_PIPELINE", "streams") == "legacy"
+    WORKERS = int(os.environ.get("PCRCG_MODEL_STREAMS", "3"))
+    FRONTS = int(os.environ.get("PCRCG_FRONT_THREADS", "2"))
+    DEPTH = int(os.environ.get("PCRCG_PIPE_DEPTH", "6" if not legacy else "4"))
     if os.environ.get("PCRCG_SWITCH_US"):
         sys.setswitchinterval(float(os.environ["PCRCG_SWITCH_US"]) * 1e-6)
-    pipe = PairPipeline(net, cfg, limits, dev, model_streams=int(os.environ.get("PCRCG_MODEL_STREAMS", "3")),
-                        front_streams=int(os.environ.get("PCRCG_FRONT_STREAMS", "1")),
-                        interleave=int(os.environ.get("PCRCG_FRONT_INTERLEAVE", "2")))
+    if legacy:
+        pipe = PairPipeline(net, cfg, limits, dev, model_streams=int(os.environ.get("PCRCG_MODEL_STREAMS", "3")),
+                            front_streams=int(os.environ.get("PCRCG_FRONT_STREAMS", "1")),
+                            interleave=int(os.environ.get("PCRCG_FRONT_INTERLEAVE", "2")))
+    else:
+        pipe = PairStreams(net, cfg, limits, dev, model_streams=WORKERS, front_threads=FRONTS)
 
     def run_pairs(first, count):
         """Push pairs first..first+count-1 through the pipeline, at most DEPTH in flight."""
@@ -177,6 +190,8 @@ def main():
     ops.kpconv_profile_start()        # HIP events around every KPConv gather/aggregate launch from here on
     for k in getattr(pipe, "front_stats", {}):
         pipe.front_stats[k] = 0
+    for k in getattr(pipe, "stats", {}):
+        pipe.stats[k] = 0
     t0 = time.perf_counter()
     out = run_pairs(args.warmup, args.steps)
     submit = time.perf_counter() - t0      # host time until the last forward was enqueued (GPU may still be busy)
@@ -189,7 +204,8 @@ def main():
     # the same kernels once more WITHOUT any concurrent stream: the roofline of the gather kernel in isolation
     iso = None
     if rank == 0:
-        batch_iso, _ = pipe.prepare(*pool[seeds[0] % 16])
+        from pcrcg_amd.pyramid import build_pyramid
+        batch_iso = build_pyramid(*pool[seeds[0] % 16], cfg, limits)
         pipe.synchronize()
         ops.kpconv_profile_start()
         with torch.no_grad():
@@ -197,7 +213,11 @@ def main():
                 net(batch_iso)
         torch.cuda.synchronize()
         iso = ops.kpconv_profile_stop()
-    if os.environ.get("PCRCG_PIPE_STATS") and rank == 0:
+    if os.environ.get("PCRCG_PIPE_STATS") and rank == 0 and hasattr(pipe, "stats"):
+        n = max(pipe.stats["pairs"], 1)
+        print("pair engine, host ms per pair: " + ", ".join("%s %.3f" % (k[:-2], 1e3 * v / n) for k, v in pipe.stats.items()
+                                                            if k != "pairs"), file=sys.stderr, flush=True)
+    elif os.environ.get("PCRCG_PIPE_STATS") and rank == 0:
         st = front_stats
         n = max(st.get("pairs", 1), 1)
         print("front-end worker per pair: advance (python + launches) %.3f ms, waiting for round trips %.3f ms, idle (no "
@@ -266,10 +286,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOADS[RECIPE] + ", pyramid build + KPFCNN+GCN "
                                    "forward, random-init full-width weights, 1 pair/GPU/step; "
-                                   "pyramids are built by a front-end thread on its own HIP stream, forwards are enqueued by "
-                                   "one worker thread per model stream (3 streams); the timed region starts and ends with "
-                                   "an empty pipeline; neighbour tables in the reference's own order inside groups "
-                                   "of exactly equal distance (tie_order=%s)" % os.environ.get("PCRCG_TIE_ORDER", "auto"),
+                                   + ("round-1 pipeline (front-end thread + 3 model streams); " if legacy else
+                                      "%d host threads build pyramids (pcrcg_pyramid_build, one call per pair) on one front-end "
+                                      "HIP stream, %d host threads enqueue the forwards (pcrcg_kpfcnn_forward) on one model "
+                                      "stream each; " % (FRONTS, WORKERS)) +
+                                   "the timed region starts and ends with an empty engine; neighbour tables in the "
+                                   "reference's own order inside groups of exactly equal distance (tie_order=%s); "
+                                   "GEMM arithmetic mode %d (1 = exact three-term bf16 split on the bf16 matrix cores, "
+                                   "fp32-class accuracy; 0 = fp32 MFMA)" % (os.environ.get("PCRCG_TIE_ORDER", "auto"),
+                                                                            _gemm_mode()),
                        "tie_order": os.environ.get("PCRCG_TIE_ORDER", "auto"),
                        "limits": limits, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "KPConv neighbour-gather kernels (k_kpconv_mfma / k_kpconv_c1 / "
@@ -279,7 +304,7 @@ def main():
                          "avg_launch_us": round(k_ms * 1e3 / max(len(events), 1), 2),
                          "algorithmic_bytes_per_pair": int(k_bytes / max(args.steps, 1)),
                          "note": "durations are the kernels' own start/stop events (hipExtLaunchKernel); achieved/frac "
-                                 "are measured inside the timed region, where four HIP streams share the GPU; `isolated` is the same 11 launches run alone right after it",
+                                 "are measured inside the timed region, where several HIP streams share the GPU; `isolated` is the same 11 launches run alone right after it",
                          "isolated": {"achieved": round(iso_gbs, 1), "frac": round(iso_gbs / HBM_PEAK_GBS, 4),
                                       "avg_launch_us": round(iso_ms * 1e3 / max(len(iso), 1), 2),
                                       "per_launch": iso_rows},

@@ -348,6 +348,8 @@ typedef struct pcrcg_batch {
     const float* features; /* [n_points[0], feat_dim] */
     int feat_dim;
     int len_src_c;         /* stack_lengths[-1][0] */
+    const int* stack_lengths[PCRCG_MAX_LEVELS]; /* [nb] i32 per level (device); filled by pcrcg_pyramid_build,
+                                                   not read by pcrcg_kpfcnn_forward (may be NULL) */
 } pcrcg_batch;
 
 typedef struct pcrcg_outputs {
@@ -359,6 +361,62 @@ typedef struct pcrcg_outputs {
 size_t pcrcg_kpfcnn_ws_bytes(const pcrcg_model* model, const pcrcg_batch* batch);
 int pcrcg_kpfcnn_forward(const pcrcg_model* model, const pcrcg_batch* batch, const pcrcg_outputs* out, void* ws,
                          size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pyramid builder: the whole front end of one fragment pair behind one call -- the pyramid loop of
+ * collate_fn_descriptor (ref:datasets/dataloader.py:230-361: per level a conv table, then grid subsampling, a pool
+ * and an upsample table; radius and cell size double per level) with batch_grid_subsampling_kpconv /
+ * batch_neighbors_kpconv (:14-69) underneath.  It sequences the front-end entry points above over one arena and
+ * fills the pcrcg_batch that pcrcg_kpfcnn_forward consumes; every pointer in `out` points into `ws`.
+ *   cfg        level plan: r_conv / r_pool / dl per level (ref:datasets/dataloader.py:239,286,301,357), has_conv,
+ *              pooled (every level but the last), limit = neighborhood_limits; tie_order 0 = ascending index inside
+ *              groups of exactly equal distance, 1 = the reference's order (rows holding such groups are redone
+ *              through the KD-forest, as pcrcg_radius_reorder_jobs documents).
+ *   ws         arena of pcrcg_pyramid_ws_bytes(n0, nb, cfg, shrink) bytes; `shrink` in (0,1] is the caller's bound on
+ *              rows(level l+1) / rows(level l) (1.0 = always enough; 3DMatch-like clouds keep about a quarter).  A
+ *              too small arena is reported as PCRCG_EWORKSPACE -- nothing is corrupted, call again with a larger one.
+ *   h_scratch  HOST scratch of >= 256 ints, pinned for best latency; h_lengths HOST [n_levels * nb] receives the
+ *              per-level cloud lengths (stack_lengths); h_status HOST int (pinned; may be NULL) receives the tie-order
+ *              restore status word ASYNCHRONOUSLY -- valid once `stream` has drained, 0 = fine, else as documented at
+ *              pcrcg_radius_reorder_jobs.
+ *   deferred   NULL: the tie-order restore step (KD-forest + reorder of the rows holding ties) is enqueued on `stream`
+ *              by this call.  Otherwise the call only DESCRIBES it in *deferred (pointers into `ws`) and the caller
+ *              enqueues it with pcrcg_pyramid_restore_run on a stream of its choice that is ordered after `stream`'s
+ *              work and before the first reader of the tables (the pair engine runs it on the pair's model stream:
+ *              the front-end stream is the pipeline's bottleneck).
+ * The call WAITS for `stream` once per pooled level (the subsampled row count sizes what follows) and once for the
+ * tables' column counts; it holds no global state, so several host threads may build pyramids on several streams
+ * concurrently.  The last launches (tie-order restore) are still in flight when it returns.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pcrcg_pyramid_cfg {
+    int n_levels;
+    float r_conv[PCRCG_MAX_LEVELS], r_pool[PCRCG_MAX_LEVELS], dl[PCRCG_MAX_LEVELS];
+    int has_conv[PCRCG_MAX_LEVELS], pooled[PCRCG_MAX_LEVELS], limit[PCRCG_MAX_LEVELS];
+    int tie_order;
+} pcrcg_pyramid_cfg;
+typedef struct pcrcg_pyramid_restore {
+    int njobs;                                   /* 0: no row holds a tie, nothing to do but post the status word */
+    pcrcg_reorder_job jobs[PCRCG_MAX_REORDER_JOBS];
+    const float* pts_all;                        /* rows of all levels, contiguous: the KD-forest's clouds */
+    const int* lens_all;                         /* [clouds_total] */
+    int rows_total, clouds_total;
+    void* forest;                                /* pcrcg_kdforest_ws_bytes(rows_total, clouds_total) bytes in the arena */
+    size_t forest_bytes;
+    int* tie_status;                             /* device status word */
+} pcrcg_pyramid_restore;
+size_t pcrcg_pyramid_ws_bytes(int n0, int nb, const pcrcg_pyramid_cfg* cfg, double shrink);
+int pcrcg_pyramid_build(const float* pts, int n0, const int* len, int nb, const pcrcg_pyramid_cfg* cfg, void* ws,
+                        size_t ws_bytes, int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status,
+                        pcrcg_pyramid_restore* deferred, void* stream);
+int pcrcg_pyramid_restore_run(const pcrcg_pyramid_restore* r, int* h_status, void* stream);
+
+/* A HIP stream whose kernels run only on compute units [cu_first, cu_first + cu_count) of the device's CU mask
+ * (hipExtStreamCreateWithCUMask).  The front end of a pair is a serial chain of ~85 small dependent kernels; on a GPU
+ * whose every CU is held by the model streams' long-running workgroups each of them waits for slots to drain, and
+ * that wait -- not the kernels -- sets the chain's length.  A few CUs of its own take the wait away
+ * (pcrcg_amd/pairstream.py; numbers in DESIGN.md).  *stream receives a hipStream_t. */
+int pcrcg_stream_create_cu_range(void** stream, int cu_first, int cu_count);
+int pcrcg_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

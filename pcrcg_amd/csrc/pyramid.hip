@@ -1,0 +1,363 @@
+// pyramid.hip -- host-side pyramid builder: the whole front end of one fragment pair (3 grid subsamplings, 4 cell
+// grids, 10 radius searches, the tie-order restore step) enqueued by ONE C-ABI call from plain C arguments.  The
+// counterpart of collate_fn_descriptor's pyramid loop (ref:datasets/dataloader.py:230-361) and of
+// batch_grid_subsampling_kpconv / batch_neighbors_kpconv (:14-69); same sequence as pcrcg_amd/pyramid.py's
+// pyramid_steps (the Python mirror, kept for calibration and for tie_order="reference"), which this replaces on the
+// pipeline's hot path: ~85 launches cost one FFI crossing and ~0.3 ms of host time instead of ~1.7 ms of Python.
+//
+// No device code of its own: it sequences pcrcg_grid_subsample_batch, pcrcg_cellgrid_build, pcrcg_radius_query_ex,
+// pcrcg_kdforest_build and pcrcg_radius_reorder_jobs over a caller-provided arena.  The row count of a subsampled
+// level sizes the next level's tables, so the call WAITS for the stream once per pooled level (12 bytes come back
+// through the caller's pinned scratch) and once for the ten tables' column counts; callers that want the GPU busy
+// meanwhile run several pairs on several streams from several host threads (pcrcg_amd/pairstream.py) -- the call
+// holds no lock and no global state.
+//
+// Arena layout: persistent results first (points of all levels contiguous -- which is also the KD-forest's input,
+// so nothing is concatenated later --, lengths [levels][nb], features, tables, per-table counts / tie rows, cell
+// grids), transient subsampling scratch with stack discipline.  Everything the returned pcrcg_batch points to lives
+// in the arena (except level 0's points when they are used in place).
+#include <sched.h>
+#include <time.h>
+
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+
+namespace pcrcg {
+namespace {
+
+// Host round trip, three ways (PCRCG_PYR_WAIT): 0 = async copy + hipStreamSynchronize, 1 = async copy + event (default:
+// waits for the caller's own work only, so several host threads can share one stream),
+// 2 = a one-wavefront kernel stores the words straight into the caller's pinned scratch (system-scope release of a
+// sequence tag last) and the host polls the tag -- no runtime call, no runtime lock held while waiting.
+__global__ void k_post(int* __restrict__ h_dst, const int* __restrict__ src, int n, const int* __restrict__ src2, int n2,
+                       int tag) {
+    for (int i = threadIdx.x; i < n; i += 64) __hip_atomic_store(h_dst + 1 + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int i = threadIdx.x; i < n2; i += 64)
+        __hip_atomic_store(h_dst + 1 + n + i, src2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(h_dst, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// PCRCG_PYR_TRACE=1: host microseconds spent enqueueing vs waiting, per call, printed at exit (tuning aid)
+struct Trace {
+    bool on = getenv("PCRCG_PYR_TRACE") != nullptr;
+    double enq = 0, wait = 0;
+    long calls = 0, waits = 0;
+    ~Trace() {
+        if (on && calls)
+            fprintf(stderr, "pcrcg_pyramid_build: %ld calls, per call: enqueue %.1f us, waiting %.1f us in %.1f round trips\n",
+                    calls, enq / calls, wait / calls, (double)waits / calls);
+    }
+};
+Trace g_trace;
+inline double now_us() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
+int wait_mode() {
+    static const int m = [] { const char* e = getenv("PCRCG_PYR_WAIT"); return e ? atoi(e) : 1; }();
+    return m;
+}
+
+// words src[0..n) (+ src2[0..n2)) -> h_scratch[1..]; returns when they are there
+int fetch_(int* h_scratch, const int* src, int n, const int* src2, int n2, hipStream_t st);
+int fetch(int* h_scratch, const int* src, int n, const int* src2, int n2, hipStream_t st) {
+    if (!g_trace.on) return fetch_(h_scratch, src, n, src2, n2, st);
+    const double t0 = now_us();
+    const int rc = fetch_(h_scratch, src, n, src2, n2, st);
+    g_trace.wait += now_us() - t0;      // (racy across threads: a tuning aid)
+    g_trace.waits += 1;
+    return rc;
+}
+int fetch_(int* h_scratch, const int* src, int n, const int* src2, int n2, hipStream_t st) {
+    const int mode = wait_mode();
+    if (mode == 2) {
+        volatile int* flag = h_scratch;
+        const int tag = (*flag & 0x7fffffff) + 1;
+        hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, st, h_scratch, src, n, src2, n2, tag);
+        PCRCG_CHECK_LAUNCH();
+        long spins = 0;
+        while (*flag != tag) {
+            if (++spins > 64) sched_yield();
+            if (spins > 200000000L) { set_error("pcrcg_pyramid_build: device never posted its counts"); return PCRCG_ELAUNCH; }
+        }
+        __sync_synchronize();
+        return PCRCG_OK;
+    }
+    PCRCG_CHECK_HIP(hipMemcpyAsync(h_scratch + 1, src, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+    if (n2 > 0) PCRCG_CHECK_HIP(hipMemcpyAsync(h_scratch + 1 + n, src2, sizeof(int) * n2, hipMemcpyDeviceToHost, st));
+    if (mode == 1) {
+        hipEvent_t ev;
+        PCRCG_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, st);
+        if (e == hipSuccess) e = hipEventSynchronize(ev);
+        (void)hipEventDestroy(ev);
+        PCRCG_CHECK_HIP(e);
+    } else {
+        PCRCG_CHECK_HIP(hipStreamSynchronize(st));
+    }
+    return PCRCG_OK;
+}
+
+struct Arena {
+    char* base;
+    size_t cap, off = 0, peak = 0;
+    bool dry;
+    Arena(void* p, size_t bytes, bool dry_) : base(static_cast<char*>(p)), cap(bytes), dry(dry_) {}
+    void* raw(size_t bytes) {
+        bytes = (bytes + 255) & ~size_t(255);
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        if (off > peak) peak = off;
+        return p;
+    }
+    template <typename T>
+    T* take(size_t count) { return static_cast<T*>(raw((count ? count : 1) * sizeof(T))); }
+    bool ok() const { return dry || off <= cap; }
+};
+
+struct TableRec {
+    pcrcg_table* dst;      // where the finished table goes in the batch
+    int64_t* idx;
+    int* counts;           // [nq] untruncated list lengths (tie restore cross-check), or null
+    int* ties;             // [nq] rows holding a tie, or null
+    int* meta;             // device [3]: max_count, status, tie_rows
+    const float* q;
+    const int* qlen;
+    int nq, limit, sup_level;
+    float radius;
+};
+
+}  // namespace
+}  // namespace pcrcg
+
+using namespace pcrcg;
+
+static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const pcrcg_pyramid_cfg* cfg, Arena& A,
+                       int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status, pcrcg_pyramid_restore* deferred,
+                       double shrink, hipStream_t st) {
+    const int L = cfg->n_levels;
+    const bool dry = A.dry;
+    const bool want_ties = cfg->tie_order != 0;
+    // ---- persistent block 1: points of all levels, lengths, features, table metadata -----------------------
+    // level l+1 has at most as many rows as level l: L * n0 rows always suffice (12 bytes each)
+    float* pts_all = A.take<float>(3 * (size_t)L * ((size_t)n0 + 1));
+    int* lens_all = A.take<int>((size_t)L * nb);
+    float* feats = A.take<float>((size_t)n0);
+    const int max_tables = 3 * L;
+    int* metas = A.take<int>(3 * (size_t)max_tables + L);    // [3 per table] + subsample row counts [L]
+    int* m_dev = metas + 3 * max_tables;
+    int* tie_status = A.take<int>(1);
+    if (!A.ok()) return PCRCG_EWORKSPACE;
+
+    std::vector<TableRec> tables;
+    tables.reserve(max_tables);
+    if (!dry) {
+        PCRCG_CHECK_HIP(hipMemsetAsync(metas, 0, sizeof(int) * (3 * (size_t)max_tables + L), st));
+        PCRCG_CHECK_HIP(hipMemsetAsync(tie_status, 0, sizeof(int), st));
+        PCRCG_CHECK_HIP(hipMemcpyAsync(pts_all, pts0, sizeof(float) * 3 * (size_t)n0, hipMemcpyDeviceToDevice, st));
+        PCRCG_CHECK_HIP(hipMemcpyAsync(lens_all, len0, sizeof(int) * nb, hipMemcpyDeviceToDevice, st));
+        PCRCG_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(feats), 0x3f800000, (size_t)(n0 > 0 ? n0 : 1), st));
+        out->n_levels = L;
+        out->features = feats;
+        out->feat_dim = 1;
+    }
+
+    auto add_table = [&](pcrcg_table* dst, const void* grid, float radius, const float* q, const int* qlen, int nq, int ns,
+                         const int* slen, int limit, int sup_level) -> int {
+        TableRec t;
+        t.dst = dst;
+        t.idx = A.take<int64_t>((size_t)nq * limit);
+        t.counts = want_ties ? A.take<int>((size_t)nq) : nullptr;
+        t.ties = want_ties ? A.take<int>((size_t)nq) : nullptr;
+        t.meta = metas + 3 * tables.size();
+        t.q = q; t.qlen = qlen; t.nq = nq; t.limit = limit; t.sup_level = sup_level; t.radius = radius;
+        if (!A.ok()) return PCRCG_EWORKSPACE;
+        if (!dry)
+            PCRCG_PROPAGATE(pcrcg_radius_query_ex(q, nq, qlen, ns, slen, nb, radius, grid, limit, t.idx, t.counts, t.meta,
+                                                  t.meta + 1, t.ties, want_ties ? t.meta + 2 : nullptr, st));
+        tables.push_back(t);
+        return PCRCG_OK;
+    };
+    auto build_grid = [&](const float* sup, int ns, const int* slen, float radius, void** grid) -> int {
+        const size_t gb = pcrcg_cellgrid_ws_bytes(ns, nb);
+        *grid = A.raw(gb);
+        if (!A.ok()) return PCRCG_EWORKSPACE;
+        if (!dry) PCRCG_PROPAGATE(pcrcg_cellgrid_build(sup, ns, slen, nb, radius, *grid, gb, st));
+        return PCRCG_OK;
+    };
+
+    float* pts = pts_all;
+    int* lens = lens_all;
+    int n = n0;
+    size_t row_off = 0;
+    void* carried = nullptr;
+    float carried_r = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const int limit = cfg->limit[l];
+        const float r_conv = cfg->r_conv[l], r_pool = cfg->r_pool[l];
+        if (!dry) { out->points[l] = pts; out->n_points[l] = n; out->stack_lengths[l] = lens; }
+        void* grid = nullptr;
+        float grid_r = 0.f;
+        if (!dry) {
+            out->neighbors[l] = pcrcg_table{nullptr, n, 0, 1};
+            out->pools[l] = pcrcg_table{nullptr, 0, 0, 1};
+            out->upsamples[l] = pcrcg_table{nullptr, 0, 0, 1};
+        }
+        if (cfg->has_conv[l]) {
+            if (carried && carried_r == r_conv) { grid = carried; grid_r = carried_r; }
+            else { PCRCG_PROPAGATE(build_grid(pts, n, lens, r_conv, &grid)); grid_r = r_conv; }
+            PCRCG_PROPAGATE(add_table(dry ? nullptr : &out->neighbors[l], grid, r_conv, pts, lens, n, n, lens, limit, l));
+        }
+        carried = nullptr;
+        if (cfg->pooled[l] && l + 1 < L) {
+            float* sub = pts + 3 * ((size_t)n + 0);         // next level's rows directly behind this level's
+            int* sub_len = lens + nb;
+            int m = 0;
+            {
+                const size_t mark = A.off;
+                const size_t wsb = pcrcg_grid_subsample_ws_bytes(n, nb);
+                void* ws = A.raw(wsb);
+                if (!A.ok()) return PCRCG_EWORKSPACE;
+                if (!dry) {
+                    PCRCG_PROPAGATE(pcrcg_grid_subsample_batch(pts, n, lens, nb, cfg->dl[l], 0, sub, sub_len, m_dev + l, ws, wsb, st));
+                    // host round trip: the row count sizes everything that follows
+                    PCRCG_PROPAGATE(fetch(h_scratch, m_dev + l, 1, nullptr, 0, st));
+                    m = h_scratch[1];
+                } else {
+                    m = (int)((double)n * shrink);
+                }
+                A.off = mark;                                // scratch is free again (stream order protects it)
+            }
+            if (grid == nullptr || grid_r != r_pool) {
+                PCRCG_PROPAGATE(build_grid(pts, n, lens, r_pool, &grid));
+                grid_r = r_pool;
+            }
+            PCRCG_PROPAGATE(add_table(dry ? nullptr : &out->pools[l], grid, r_pool, sub, sub_len, m, n, lens, limit, l));
+            void* up_grid = nullptr;
+            PCRCG_PROPAGATE(build_grid(sub, m, sub_len, 2 * r_pool, &up_grid));
+            PCRCG_PROPAGATE(add_table(dry ? nullptr : &out->upsamples[l], up_grid, 2 * r_pool, pts, lens, n, m, sub_len, limit, l + 1));
+            carried = up_grid;
+            carried_r = 2 * r_pool;
+            row_off += (size_t)n;
+            pts = sub;
+            lens = sub_len;
+            n = m;
+        } else if (l + 1 < L) {
+            set_error("pcrcg_pyramid_build: level %d of %d is not pooled", l, L);
+            return PCRCG_EBADARG;
+        }
+    }
+    if (dry) return PCRCG_OK;
+    const size_t rows_total = row_off + (size_t)n;
+
+    // ---- one round trip for all tables: column counts, capacity status, rows holding ties -----------------
+    const int nt = (int)tables.size();
+    PCRCG_PROPAGATE(fetch(h_scratch, metas, 3 * nt, lens_all, L * nb, st));
+    const int* hm = h_scratch + 1;
+    for (int i = 0; i < L * nb; ++i) h_lengths[i] = hm[3 * nt + i];
+    pcrcg_pyramid_restore local;
+    pcrcg_pyramid_restore& R = deferred ? *deferred : local;
+    R.njobs = 0;
+    for (int i = 0; i < nt; ++i) {
+        TableRec& t = tables[i];
+        const int max_count = hm[3 * i], status = hm[3 * i + 1], tie_rows = hm[3 * i + 2];
+        if (status != 0) {
+            set_error("pcrcg_pyramid_build: radius search capacity exceeded (table %d)", i);
+            return PCRCG_ECAPACITY;
+        }
+        // neighbors[:, :limit] keeps FEWER columns when the longest list is shorter (ref:datasets/dataloader.py:65-67)
+        const int cols = max_count < t.limit ? (max_count > 0 ? max_count : 0) : t.limit;
+        *t.dst = pcrcg_table{t.idx, t.nq, cols, t.limit};
+        if (want_ties && max_count > 0 && tie_rows > 0 && R.njobs < PCRCG_MAX_REORDER_JOBS) {
+            pcrcg_reorder_job& j = R.jobs[R.njobs++];
+            j.q = t.q; j.qlen = t.qlen; j.rows = t.ties; j.count = t.counts; j.idx = t.idx;
+            j.nq = t.nq; j.nbq = nb; j.cloud0 = nb * t.sup_level; j.nrows = tie_rows; j.max_count = max_count;
+            j.cols = t.limit; j.radius = t.radius;
+        }
+    }
+    out->len_src_c = h_lengths[(size_t)(L - 1) * nb];
+    // ---- the reference's order inside groups of exactly equal distance (tieorder.hip) ----------------------
+    R.pts_all = pts_all; R.lens_all = lens_all; R.rows_total = (int)rows_total; R.clouds_total = L * nb;
+    R.forest = nullptr; R.forest_bytes = 0; R.tie_status = tie_status;
+    if (R.njobs > 0) {
+        R.forest_bytes = pcrcg_kdforest_ws_bytes((int)rows_total, L * nb);
+        R.forest = A.raw(R.forest_bytes);
+        if (!A.ok()) return PCRCG_EWORKSPACE;
+    }
+    if (!deferred) return pcrcg_pyramid_restore_run(&R, h_status, st);
+    return PCRCG_OK;
+}
+
+extern "C" {
+
+size_t pcrcg_pyramid_ws_bytes(int n0, int nb, const pcrcg_pyramid_cfg* cfg, double shrink) {
+    if (!cfg || n0 < 0 || nb < 1 || cfg->n_levels < 1 || cfg->n_levels > PCRCG_MAX_LEVELS) return 0;
+    if (!(shrink > 0.0) || shrink > 1.0) shrink = 1.0;
+    Arena A(nullptr, 0, true);
+    if (pyramid_run(nullptr, n0, nullptr, nb, cfg, A, nullptr, nullptr, nullptr, nullptr, nullptr, shrink, nullptr) != PCRCG_OK) return 0;
+    // the KD-forest of the restore step over all levels' rows
+    size_t rows = 0;
+    double r = n0;
+    for (int l = 0; l < cfg->n_levels; ++l) { rows += (size_t)r + 1; r *= shrink; }
+    return A.peak + (cfg->tie_order != 0 ? ((pcrcg_kdforest_ws_bytes((int)rows, cfg->n_levels * nb) + 255) & ~size_t(255)) : 0) + 4096;
+}
+
+// HIP stream restricted to compute units [cu_first, cu_first + cu_count) of the device's CU mask.
+int pcrcg_stream_create_cu_range(void** stream, int cu_first, int cu_count) {
+    PCRCG_CHECK_ARG(stream && cu_first >= 0 && cu_count >= 1);
+    int dev = 0, ncu = 0;
+    PCRCG_CHECK_HIP(hipGetDevice(&dev));
+    PCRCG_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    PCRCG_CHECK_ARG(cu_first + cu_count <= ncu);
+    const int words = (ncu + 31) / 32;
+    std::vector<uint32_t> mask(words, 0u);
+    for (int c = cu_first; c < cu_first + cu_count; ++c) mask[c >> 5] |= 1u << (c & 31);
+    hipStream_t st = nullptr;
+    PCRCG_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()));
+    *stream = st;
+    return PCRCG_OK;
+}
+
+int pcrcg_stream_destroy(void* stream) {
+    PCRCG_CHECK_HIP(hipStreamDestroy(as_stream(stream)));
+    return PCRCG_OK;
+}
+
+int pcrcg_pyramid_restore_run(const pcrcg_pyramid_restore* r, int* h_status, void* stream) {
+    PCRCG_CHECK_ARG(r && r->tie_status && r->njobs >= 0 && r->njobs <= PCRCG_MAX_REORDER_JOBS);
+    hipStream_t st = as_stream(stream);
+    if (r->njobs > 0) {
+        PCRCG_CHECK_ARG(r->forest && r->pts_all && r->lens_all);
+        PCRCG_PROPAGATE(pcrcg_kdforest_build(r->pts_all, r->rows_total, r->lens_all, r->clouds_total, r->forest,
+                                             r->forest_bytes, st));
+        PCRCG_PROPAGATE(pcrcg_radius_reorder_jobs(r->jobs, r->njobs, r->pts_all, r->rows_total, r->clouds_total, r->forest,
+                                                  r->tie_status, st));
+    }
+    if (h_status) PCRCG_CHECK_HIP(hipMemcpyAsync(h_status, r->tie_status, sizeof(int), hipMemcpyDeviceToHost, st));
+    return PCRCG_OK;
+}
+
+int pcrcg_pyramid_build(const float* pts, int n0, const int* len, int nb, const pcrcg_pyramid_cfg* cfg, void* ws,
+                        size_t ws_bytes, int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status,
+                        pcrcg_pyramid_restore* deferred, void* stream) {
+    PCRCG_CHECK_ARG(cfg && pts && len && ws && h_scratch && out && h_lengths);
+    PCRCG_CHECK_ARG(n0 >= 1 && nb >= 1 && nb <= 16);
+    PCRCG_CHECK_ARG(cfg->n_levels >= 1 && cfg->n_levels <= PCRCG_MAX_LEVELS && 3 * cfg->n_levels <= PCRCG_MAX_REORDER_JOBS);
+    for (int l = 0; l < cfg->n_levels; ++l)
+        PCRCG_CHECK_ARG(cfg->limit[l] >= 1 && cfg->r_conv[l] > 0.f && (l + 1 == cfg->n_levels || (cfg->dl[l] > 0.f && cfg->r_pool[l] > 0.f)));
+    Arena A(ws, ws_bytes, false);
+    hipStream_t st = as_stream(stream);
+    const double t0 = g_trace.on ? now_us() : 0.0, w0 = g_trace.wait;
+    const int rc = pyramid_run(pts, n0, len, nb, cfg, A, h_scratch, out, h_lengths, h_status, deferred, 1.0, st);
+    if (g_trace.on) { g_trace.enq += now_us() - t0 - (g_trace.wait - w0); g_trace.calls += 1; }
+    if (rc == PCRCG_EWORKSPACE)
+        set_error("pcrcg_pyramid_build: arena too small (%zu needed so far, %zu given): size it with a larger `shrink`", A.off, ws_bytes);
+    return rc;
+}
+}

@@ -20,6 +20,8 @@
 // 432-440): ((0 + dx*dx) + dy*dy) + dz*dz with every product and sum rounded to fp32, strict
 // d2 < r*r (:249-253, neighbors.cpp:226).  Compiled with -ffp-contract=off.
 #include "block_scan.h"
+#include <cstdlib>
+
 #include "common.h"
 
 namespace pcrcg {
@@ -358,7 +360,8 @@ int pcrcg_radius_query_ex(const float* q, int nq, const int* qlen, int ns, const
     GridView g = grid_view(const_cast<void*>(grid), grid_bytes(ns, nb), ns, nb, &ok);
     const float r2 = radius * radius;  // neighbors.cpp:226
     int blocks = (nq + kQueryWaves - 1) / kQueryWaves;
-    const int max_blocks = 256 * 4;    // 4 workgroups (16 wavefronts) per CU, wavefronts loop over the queries: inside the pipeline a
+    static const int max_blocks_env = [] { const char* e = getenv("PCRCG_RADIUS_BLOCKS"); return e ? atoi(e) : 0; }();
+    const int max_blocks = max_blocks_env > 0 ? max_blocks_env : 256 * 4;    // 4 workgroups (16 wavefronts) per CU, wavefronts loop over the queries: inside the pipeline a
                                        // smaller grid takes less from the model streams, and on voxelised data every workgroup
                                        // appends its tie rows with one atomic on one word (4096 workgroups: 264 us per 60k-row table)
     if (blocks > max_blocks) blocks = max_blocks;

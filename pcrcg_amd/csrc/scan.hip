@@ -99,6 +99,72 @@ __global__ void __launch_bounds__(kScanThreads) scan_apply(const int* in, int* o
     if (total_single && threadIdx.x == 0) *total_single = tot;  // single-tile case only
 }
 
+// The whole scan in ONE workgroup of 1024 threads walking 8192-item tiles with a running carry.  The front end's
+// scans cover at most a few hundred thousand items and sit on a serial chain of small dependent kernels, where every
+// launch costs its dispatch gap on top of its run time (under load ~10-15 us per kernel): one ~12 us kernel for
+// 60 000 items instead of three kernels of 5-9 us each.
+constexpr int kOneThreads = 1024;
+constexpr int kOneTiles = 8;                                  // up to 8 x 8192 = 65 536 items
+__global__ void __launch_bounds__(kOneThreads) scan_one_block(const int* in, int* out, int n, int* __restrict__ total) {
+    __shared__ int smem[kOneThreads / 64];
+    __shared__ int s_tot;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // every tile's loads are issued before the first use: one memory round trip for the whole scan
+    int v[kOneTiles][kScanItems];
+#pragma unroll
+    for (int t = 0; t < kOneTiles; ++t) {
+        const long base = (long)t * kOneThreads * kScanItems + (long)threadIdx.x * kScanItems;
+        if (base + kScanItems <= n) {                       // two 16-byte loads (in is 16-byte aligned, base % 8 == 0)
+            const int4 a = *reinterpret_cast<const int4*>(in + base), b = *reinterpret_cast<const int4*>(in + base + 4);
+            v[t][0] = a.x; v[t][1] = a.y; v[t][2] = a.z; v[t][3] = a.w;
+            v[t][4] = b.x; v[t][5] = b.y; v[t][6] = b.z; v[t][7] = b.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < kScanItems; ++i) v[t][i] = base + i < n ? in[base + i] : 0;
+        }
+    }
+    int carry = 0;
+#pragma unroll
+    for (int t = 0; t < kOneTiles; ++t) {
+        const long base = (long)t * kOneThreads * kScanItems + (long)threadIdx.x * kScanItems;
+        if ((long)t * kOneThreads * kScanItems >= n) break;                             // block-uniform
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) {
+            v[t][i] = base + i < n ? v[t][i] : 0;
+            s += v[t][i];
+        }
+        const int inc = wave_inclusive_scan(s, lane);
+        if (lane == 63) smem[wave] = inc;
+        __syncthreads();
+        if (wave == 0) {
+            const int w = lane < kOneThreads / 64 ? smem[lane] : 0;
+            const int winc = wave_inclusive_scan(w, lane);
+            if (lane < kOneThreads / 64) smem[lane] = winc - w;      // exclusive offset of each wavefront
+            if (lane == kOneThreads / 64 - 1) s_tot = winc;
+        }
+        __syncthreads();
+        int ex = carry + smem[wave] + inc - s;
+        carry += s_tot;
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) {
+            const int x = v[t][i];
+            v[t][i] = ex;
+            ex += x;
+        }
+        if (base + kScanItems <= n) {
+            *reinterpret_cast<int4*>(out + base) = make_int4(v[t][0], v[t][1], v[t][2], v[t][3]);
+            *reinterpret_cast<int4*>(out + base + 4) = make_int4(v[t][4], v[t][5], v[t][6], v[t][7]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < kScanItems; ++i)
+                if (base + i < n) out[base + i] = v[t][i];
+        }
+        __syncthreads();                                                  // smem / s_tot reused by the next tile
+    }
+    if (total && threadIdx.x == 0) *total = carry;
+}
+
 __global__ void zero_int(int* p) { *p = 0; }
 
 }  // namespace
@@ -118,6 +184,12 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
     if (nt == 1) {
         hipLaunchKernelGGL(scan_apply, dim3(1), dim3(kScanThreads), 0, stream, in, out, n,
                            (const int*)nullptr, total);
+        PCRCG_CHECK_LAUNCH();
+        return PCRCG_OK;
+    }
+    if (n <= kOneTiles * kOneThreads * kScanItems && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        hipLaunchKernelGGL(scan_one_block, dim3(1), dim3(kOneThreads), 0, stream, in, out, n, total);
         PCRCG_CHECK_LAUNCH();
         return PCRCG_OK;
     }

@@ -1,0 +1,253 @@
+"""Pair engine: independent fragment pairs through two stages of host threads, each stage a call into
+libpcrcg_hip.so that releases the GIL.
+
+  front stage   F threads share ONE front-end HIP stream.  A thread builds the pyramid of its pair with
+                pcrcg_pyramid_build (the whole front end in one call; the call waits for its four host round trips
+                itself, by event, so it only waits for its OWN kernels): the kernels of F pairs interleave on the
+                stream and keep it busy while one pair waits for a row count.  One stream on purpose: the front-end
+                kernels are latency-bound and partly persistent (the KD-forest's task queue); several pyramids side
+                by side, or pyramids on the model streams, slow everything down (measured: every pair on its own
+                stream, 4 streams: 217 pairs/s; this topology: see DESIGN.md).
+  model stage   M threads, one HIP stream each, enqueue the forwards (pcrcg_kpfcnn_forward) of pairs k, k+M, ...;
+                the coarse levels of one pair overlap the fine levels of the next.  M = 3: a fourth stream with
+                forwards is slower again on this GPU.
+
+One event per pair hands the finished tables from the front-end stream to a model stream; the arena holding them
+goes back to its front thread's ring once the forward has passed.  Pairs are independent, so nothing
+else crosses streams.  This replaces the generator-interleaving pipeline of pcrcg_amd/pipeline.py, whose front-end
+worker spent 1.7 ms of interpreter time per pair.
+
+    eng = PairStreams(net, config, limits, device)
+    eng.submit(points, lengths); ...; out = eng.result()      # results come back in submission order
+
+The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): set GPU_MAX_HW_QUEUES=8
+before the first HIP call (bench.py does)."""
+import os
+import queue
+import threading
+import time
+
+import torch
+
+from .pyramid import NativePyramid, check_tie_status
+
+
+class _Mailbox:
+    """Items keyed by sequence number; get(k) blocks until item k has been put."""
+
+    def __init__(self):
+        self._items, self._cv = {}, threading.Condition()
+
+    def put(self, key, item):
+        with self._cv:
+            self._items[key] = item
+            self._cv.notify_all()
+
+    def get(self, key):
+        with self._cv:
+            while key not in self._items and None not in self._items:
+                self._cv.wait()
+            return self._items.pop(key) if key in self._items else None
+
+
+class PairStreams:
+    ARENAS = 4        # per front thread: pairs whose tables may be alive at once (built, forward not yet passed)
+
+    def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=2, tie_order=None,
+                 front_cus=0):
+        self.net, self.config, self.limits = net, config, neighborhood_limits
+        self.device = torch.device(device if device is not None else "cuda")
+        if not getattr(net, "use_runner", False):
+            raise RuntimeError("pcrcg_amd.PairStreams needs the C++ runner path (use_batch_norm=True)")
+        self.runner = net.runner()
+        with torch.cuda.device(self.device):
+            self.runner.descriptor()           # built once, here, before any worker thread can race for it
+        nfs = int(os.environ.get("PCRCG_FRONT_STREAMS", "1"))
+        front_cus = int(os.environ.get("PCRCG_FRONT_CUS", front_cus))
+        self._raw_streams = []
+        if front_cus > 0:
+            # CU partition: the front-end stream(s) own `front_cus` compute units, the model streams the rest
+            ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            with torch.cuda.device(self.device):
+                self.fronts = [self._cu_stream(0, front_cus) for _ in range(max(1, nfs))]
+                self.models = [self._cu_stream(front_cus, ncu - front_cus) for _ in range(max(1, int(model_streams)))]
+        else:
+            self.fronts = [torch.cuda.Stream(device=self.device) for _ in range(max(1, nfs))]
+            self.models = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(model_streams)))]
+        self.front = self.fronts[0]
+        nf = max(1, int(front_threads))
+        # every front thread owns a ring of builders (arena + pinned scratch each)
+        self._pyr = [[NativePyramid(config, neighborhood_limits, tie_order) for _ in range(self.ARENAS)] for _ in range(nf)]
+        # per arena: a one-slot queue holding the event after which it may be overwritten (None: never used); the
+        # front thread TAKES it before building into the arena, the model thread puts the forward's event back
+        self._free = [[queue.Queue() for _ in range(self.ARENAS)] for _ in range(nf)]
+        for ring in self._free:
+            for q in ring:
+                q.put(None)
+        self._in = [queue.Queue() for _ in range(nf)]
+        self._mid = [_Mailbox() for _ in self.models]
+        self._out = [queue.Queue() for _ in self.models]
+        self._submitted = self._returned = 0
+        self._pending = []                     # (status tensor, slot, event) of pairs whose tie status is unread
+        self._lock = threading.Lock()
+        self.stats = {"pairs": 0, "front_idle_s": 0.0, "arena_wait_s": 0.0, "build_s": 0.0, "model_idle_s": 0.0,
+                      "launch_s": 0.0}      # host seconds per stage, summed over the threads of the stage
+        self._threads = []
+        for f in range(nf):
+            t = threading.Thread(target=self._serve_front, args=(f,), name=f"pcrcg-front-{f}", daemon=True)
+            t.start()
+            self._threads.append(t)
+        for m in range(len(self.models)):
+            t = threading.Thread(target=self._serve_model, args=(m,), name=f"pcrcg-model-{m}", daemon=True)
+            t.start()
+            self._threads.append(t)
+
+    def _cu_stream(self, first, count):
+        import ctypes
+        from . import _lib
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().pcrcg_stream_create_cu_range(ctypes.byref(h), int(first), int(count)),
+                   "pcrcg_stream_create_cu_range")
+        self._raw_streams.append(h.value)
+        return torch.cuda.ExternalStream(h.value, device=self.device)
+
+    # ---- workers -------------------------------------------------------------------------------
+    def _serve_front(self, f):
+        torch.cuda.set_device(self.device)
+        turn = 0
+        front = self.fronts[f % len(self.fronts)]
+        while True:
+            t0 = time.perf_counter()
+            item = self._in[f].get()
+            if item is None:
+                return
+            self.stats["front_idle_s"] += time.perf_counter() - t0
+            seq, points, lengths, ready = item
+            m = seq % len(self.models)
+            a = turn % self.ARENAS
+            turn += 1
+            try:
+                with torch.cuda.stream(front), torch.no_grad():
+                    front.wait_event(ready)                       # inputs may still be in flight on the caller's stream
+                    points.record_stream(front)
+                    lengths.record_stream(front)
+                    t0 = time.perf_counter()
+                    freed = self._free[f][a].get()                # blocks until that forward has been enqueued
+                    if freed is not None:
+                        front.wait_event(freed)                   # ... and the stream waits until it has passed
+                    pyr = self._pyr[f][a]
+                    t1 = time.perf_counter()
+                    b, arena, lens_h, slot, deferred = pyr.build(points, lengths, defer_restore=True)
+                    self.stats["arena_wait_s"] += t1 - t0
+                    self.stats["build_s"] += time.perf_counter() - t1
+                    self.stats["pairs"] += 1
+                    built = torch.cuda.Event()
+                    built.record(front)
+                self._mid[m].put(seq, (b, arena, built, pyr, slot, deferred, f, a))
+            except BaseException as e:                            # surfaced by result()
+                self._free[f][a].put(None)
+                self._mid[m].put(seq, e)
+
+    def _serve_model(self, m):
+        torch.cuda.set_device(self.device)
+        stream, seq = self.models[m], m
+        while True:
+            t0 = time.perf_counter()
+            item = self._mid[m].get(seq)
+            seq += len(self.models)
+            if item is None:
+                return
+            self.stats["model_idle_s"] += time.perf_counter() - t0
+            try:
+                if isinstance(item, BaseException):
+                    raise item
+                b, arena, built, pyr, slot, deferred, f, a = item
+            except BaseException as e:
+                self._out[m].put(e)
+                continue
+            try:
+                with torch.cuda.stream(stream), torch.no_grad():
+                    stream.wait_event(built)
+                    t0 = time.perf_counter()
+                    # the reference's order inside tie groups (KD-forest + reorder), here rather than on the front-end
+                    # stream: that stream's serial kernel chain is the pipeline's bottleneck, the model streams have slack
+                    pyr.restore(deferred, slot)
+                    out = self.runner.launch(b, self.device)
+                    self.stats["launch_s"] += time.perf_counter() - t0
+                    done = torch.cuda.Event()
+                    done.record(stream)
+                self._free[f][a].put(done)
+                with self._lock:
+                    self._pending.append((pyr.status, slot, done))
+                self._out[m].put((out, done))
+            except BaseException as e:
+                self._free[f][a].put(None)
+                self._out[m].put(e)
+
+    # ---- caller --------------------------------------------------------------------------------
+    def submit(self, points, lengths):
+        """Queue one pair (points [N,3] f32, lengths [2] i32 on the device) for pyramid build + forward."""
+        seq = self._submitted
+        self._submitted += 1
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        self._in[seq % len(self._in)].put((seq, points, lengths, ready))
+
+    def result(self, wait=False):
+        """Outputs of the oldest submitted pair, plus out["done_event"] (a torch.cuda.Event recorded behind their last
+        kernel).  The kernels are enqueued on a model stream, not necessarily finished: make the consuming stream wait
+        for out["done_event"] (wait=True does that for the caller's current stream), or call synchronize().
+        wait=False is the default on purpose: a wait queued on the caller's stream also delays the `ready` events that
+        later submit() calls record on it -- i.e. it would tie the start of pair k+depth's pyramid to the end of pair
+        k's forward (measured on the null stream: 240 instead of 340 pairs/s)."""
+        if self._returned >= self._submitted:
+            raise RuntimeError("PairStreams.result(): nothing submitted")
+        m = self._returned % len(self.models)
+        self._returned += 1
+        item = self._out[m].get()
+        if isinstance(item, BaseException):
+            raise item
+        out, done = item
+        cur = torch.cuda.current_stream(self.device)
+        if wait:
+            cur.wait_event(done)
+        for t in out.values():
+            t.record_stream(cur)
+        out["done_event"] = done
+        self._check_status(wait=False)
+        return out
+
+    def _check_status(self, wait):
+        """Tie-order restore status of finished pairs (pcrcg_pyramid_build writes it asynchronously)."""
+        with self._lock:
+            pending, self._pending = self._pending, []
+        bad, keep = 0, []
+        for status, slot, ev in pending:
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                bad = bad or int(status[slot])
+            else:
+                keep.append((status, slot, ev))
+        with self._lock:
+            self._pending = keep + self._pending
+        check_tie_status(bad)
+
+    def drain(self):
+        while self._returned < self._submitted:
+            self.result()
+        self.synchronize()
+
+    def synchronize(self):
+        for s in self.fronts + self.models:
+            s.synchronize()
+        self._check_status(wait=True)
+
+    def close(self):
+        for q in self._in:
+            q.put(None)
+        for mb in self._mid:
+            mb.put(None, None)
+        for t in self._threads:
+            t.join(timeout=10)
+        self._threads = []

@@ -78,6 +78,10 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
     The build needs four host round trips (three subsampled row counts, one for all table widths); this function
     waits for each of them.  pyramid_steps() is the same build as a generator that YIELDS at those points, so that a
     caller can keep the stream busy with another pair's pyramid meanwhile (PairPipeline does)."""
+    mode = tie_order if tie_order is not None else os.environ.get("PCRCG_TIE_ORDER", "auto")
+    if (not want_counts and not defer_tie_check and mode in ("auto", "index")
+            and os.environ.get("PCRCG_PY_PYRAMID", "0") != "1"):
+        return build_pyramid_native(points, lengths, config, neighborhood_limits, mode)
     steps = pyramid_steps(points, lengths, config, neighborhood_limits, want_counts, tie_order, defer_tie_check)
     try:
         while True:
@@ -212,6 +216,125 @@ def _restore_reference_order(redo, level_points, level_lens, all_rows):
                                 rows=None if all_rows else tab["ties"], nrows=None if all_rows else tie_rows)
                            for tab, tie_rows in redo], status)
     return status
+
+
+class NativePyramid:
+    """Front end of one pair through pcrcg_pyramid_build (csrc/pyramid.hip): ONE call into the library enqueues the
+    whole pyramid (the call waits for its four host round trips itself, with the GIL released).  One instance owns
+    an arena, pinned scratch and a ring of status words; it serves one host thread / one stream at a time
+    (pcrcg_amd/pairstream.py gives every worker its own).  tie_order "auto" or "index"; "reference" (every row
+    through the KD-forest, a cross-check) and want_counts stay with the Python mirror pyramid_steps."""
+
+    STATUS_RING = 64
+
+    def __init__(self, config, neighborhood_limits, tie_order=None):
+        import ctypes
+        from . import _lib
+        from .runner import Batch, PyramidCfg
+        config = as_config(config)
+        if tie_order is None:
+            tie_order = os.environ.get("PCRCG_TIE_ORDER", "auto")
+        if tie_order not in ("auto", "index"):
+            raise ValueError("pcrcg_amd.NativePyramid: tie_order must be 'auto' or 'index'")
+        self._ct, self._lib, self._Batch = ctypes, _lib, Batch
+        plan = _layer_plan(config)
+        c = PyramidCfg()
+        c.n_levels = len(plan)
+        for l, lv in enumerate(plan):
+            c.r_conv[l], c.r_pool[l], c.dl[l] = float(lv["r_conv"]), float(lv["r_pool"]), float(lv["dl"])
+            c.has_conv[l], c.pooled[l], c.limit[l] = int(lv["has_conv"]), int(lv["pooled"]), int(neighborhood_limits[l])
+        c.tie_order = 0 if tie_order == "index" else 1
+        self.cfg, self.levels = c, len(plan)
+        self.scratch = torch.empty(512, dtype=_I32, pin_memory=True)
+        self.status = torch.zeros(self.STATUS_RING, dtype=_I32, pin_memory=True)
+        self.arena, self.shrink, self.calls = None, 0.5, 0
+
+    def restore(self, deferred, slot):
+        """Enqueue a deferred tie-order restore step (build(..., defer_restore=True)) on the CURRENT stream."""
+        self._lib.check(self._lib.lib().pcrcg_pyramid_restore_run(self._ct.byref(deferred), self.status.data_ptr() + 4 * slot,
+                                                                  torch.cuda.current_stream().cuda_stream),
+                        "pcrcg_pyramid_restore_run")
+
+    def build(self, points, lengths, fresh_arena=False, defer_restore=False):
+        """points [N0,3] f32, lengths [B] i32 on the device; enqueues on the CURRENT stream.
+        -> (pcrcg_batch mirror, arena tensor it points into, per-level cloud lengths (python lists),
+            slot of this call's status word in self.status -- valid once the stream has drained).
+        defer_restore: the tie-order restore step is not enqueued; a fifth value, its descriptor, is returned for
+        restore() to run on the stream that will read the tables."""
+        ct, L = self._ct, self._lib.lib()
+        if not points.is_cuda:
+            raise RuntimeError("pcrcg_amd.build_pyramid: points must be on a HIP device (no CPU path)")
+        pts = points.to(torch.float32).contiguous()
+        lens = lengths.to(_I32).contiguous()
+        n0, nb = int(pts.shape[0]), int(lens.shape[0])
+        stream = torch.cuda.current_stream().cuda_stream
+        h_len = (ct.c_int * (self.levels * nb))()
+        from .runner import PyramidRestore
+        deferred = PyramidRestore() if defer_restore else None
+        slot = self.calls % self.STATUS_RING
+        self.calls += 1
+        while True:
+            need = L.pcrcg_pyramid_ws_bytes(n0, nb, ct.byref(self.cfg), ct.c_double(self.shrink))
+            if need == 0:
+                raise RuntimeError("pcrcg_pyramid_ws_bytes rejected the configuration")
+            arena = self.arena
+            if fresh_arena or arena is None or arena.numel() < need or arena.device != pts.device:
+                arena = torch.empty(int(need), dtype=torch.uint8, device=pts.device)
+                if not fresh_arena:
+                    self.arena = arena
+            b = self._Batch()
+            rc = L.pcrcg_pyramid_build(pts.data_ptr(), n0, lens.data_ptr(), nb, ct.byref(self.cfg), arena.data_ptr(),
+                                       arena.numel(), self.scratch.data_ptr(), ct.byref(b), h_len,
+                                       self.status.data_ptr() + 4 * slot,
+                                       ct.byref(deferred) if defer_restore else None, stream)
+            if rc == -2 and self.shrink < 1.0:      # PCRCG_EWORKSPACE: this cloud keeps more rows per level than assumed
+                self.shrink = 1.0
+                continue
+            self._lib.check(rc, "pcrcg_pyramid_build")
+            break
+        lens_h = [[int(h_len[l * nb + i]) for i in range(nb)] for l in range(self.levels)]
+        if defer_restore:
+            return b, arena, lens_h, slot, deferred
+        return b, arena, lens_h, slot
+
+    def as_dict(self, b, arena, lens_h):
+        """The reference's batch dict as zero-copy views into the arena."""
+        base = arena.data_ptr()
+        nb = len(lens_h[0])
+
+        def view(ptr, nbytes, dtype):
+            off = ptr - base
+            return arena[off:off + nbytes].view(dtype)
+
+        def table(t):
+            if t.idx and t.rows > 0 and t.cols > 0:
+                return view(t.idx, t.rows * t.ld * 8, torch.int64).view(t.rows, t.ld)[:, :t.cols]
+            if t.idx and t.rows > 0:          # every list empty: the reference's [rows, 0]
+                return torch.zeros((t.rows, 0), dtype=torch.int64, device=arena.device)
+            return torch.zeros((0, 1), dtype=torch.int64, device=arena.device)   # no table at the last level
+
+        out = {"points": [], "neighbors": [], "pools": [], "upsamples": [], "stack_lengths": []}
+        for l in range(b.n_levels):
+            n = b.n_points[l]
+            out["points"].append(view(b.points[l], n * 12, torch.float32).view(n, 3))
+            out["neighbors"].append(table(b.neighbors[l]))
+            out["pools"].append(table(b.pools[l]))
+            out["upsamples"].append(table(b.upsamples[l]))
+            out["stack_lengths"].append(view(b.stack_lengths[l], nb * 4, _I32))
+        out["features"] = view(b.features, b.n_points[0] * 4, torch.float32).view(-1, 1)
+        out["stack_lengths_host"] = lens_h
+        return out
+
+
+def build_pyramid_native(points, lengths, config, neighborhood_limits, tie_order=None):
+    """build_pyramid through the C++ builder (one FFI call); same dict, same tables entry for entry."""
+    nat = NativePyramid(config, neighborhood_limits, tie_order)
+    b, arena, lens_h, slot = nat.build(points, lengths, fresh_arena=True)
+    torch.cuda.current_stream().synchronize()
+    check_tie_status(int(nat.status[slot]))
+    out = nat.as_dict(b, arena, lens_h)
+    out["tie_status"] = None
+    return out
 
 
 def _point2node(nodes, points):

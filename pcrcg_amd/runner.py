@@ -54,7 +54,29 @@ class Table(ctypes.Structure):
 class Batch(ctypes.Structure):
     _fields_ = [("n_levels", ctypes.c_int), ("points", _fp * MAX_LEVELS), ("n_points", ctypes.c_int * MAX_LEVELS),
                 ("neighbors", Table * MAX_LEVELS), ("pools", Table * MAX_LEVELS), ("upsamples", Table * MAX_LEVELS),
-                ("features", _fp), ("feat_dim", ctypes.c_int), ("len_src_c", ctypes.c_int)]
+                ("features", _fp), ("feat_dim", ctypes.c_int), ("len_src_c", ctypes.c_int),
+                ("stack_lengths", _fp * MAX_LEVELS)]
+
+
+class PyramidCfg(ctypes.Structure):
+    """pcrcg_pyramid_cfg (include/pcrcg.h)."""
+    _fields_ = [("n_levels", ctypes.c_int), ("r_conv", ctypes.c_float * MAX_LEVELS), ("r_pool", ctypes.c_float * MAX_LEVELS),
+                ("dl", ctypes.c_float * MAX_LEVELS), ("has_conv", ctypes.c_int * MAX_LEVELS),
+                ("pooled", ctypes.c_int * MAX_LEVELS), ("limit", ctypes.c_int * MAX_LEVELS), ("tie_order", ctypes.c_int)]
+
+
+class ReorderJobC(ctypes.Structure):
+    """pcrcg_reorder_job (include/pcrcg.h)."""
+    _fields_ = [("q", _fp), ("qlen", _fp), ("rows", _fp), ("count", _fp), ("idx", _fp), ("nq", ctypes.c_int),
+                ("nbq", ctypes.c_int), ("cloud0", ctypes.c_int), ("nrows", ctypes.c_int), ("max_count", ctypes.c_int),
+                ("cols", ctypes.c_int), ("radius", ctypes.c_float)]
+
+
+class PyramidRestore(ctypes.Structure):
+    """pcrcg_pyramid_restore (include/pcrcg.h)."""
+    _fields_ = [("njobs", ctypes.c_int), ("jobs", ReorderJobC * 12), ("pts_all", _fp), ("lens_all", _fp),
+                ("rows_total", ctypes.c_int), ("clouds_total", ctypes.c_int), ("forest", _fp),
+                ("forest_bytes", ctypes.c_size_t), ("tie_status", _fp)]
 
 
 class Outputs(ctypes.Structure):
@@ -241,9 +263,8 @@ class Runner:
         dst.idx, dst.rows, dst.cols = t.data_ptr(), int(t.shape[0]), int(t.shape[1])
         dst.ld = int(t.stride(0)) if t.shape[0] > 1 else int(t.shape[1])
 
-    def forward(self, batch):
-        L = _bind()
-        desc = self.descriptor()
+    def batch_struct(self, batch):
+        """The reference's batch dict -> (pcrcg_batch mirror, tensors it points into, device)."""
         keep = []
         b = Batch()
         pts = batch["points"]
@@ -264,7 +285,17 @@ class Runner:
             b.len_src_c = int(batch["stack_lengths_host"][-1][0])
         else:
             b.len_src_c = int(batch["stack_lengths"][-1][0])
-        dev = feats.device
+        return b, keep, feats.device
+
+    def forward(self, batch):
+        b, keep, dev = self.batch_struct(batch)
+        return self.launch(b, dev)
+
+    def launch(self, b, dev):
+        """Enqueue the forward for a pcrcg_batch (from batch_struct, or filled by pcrcg_pyramid_build) on the
+        current stream; the caller keeps whatever `b` points into alive until the stream has passed."""
+        L = _bind()
+        desc = self.descriptor()
         n0 = b.n_points[0]
         out = {"feats_f": torch.empty((n0, desc.final_dim), dtype=torch.float32, device=dev),
                "scores_overlap": torch.empty(n0, dtype=torch.float32, device=dev),
