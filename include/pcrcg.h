@@ -410,12 +410,9 @@ int pcrcg_pyramid_build(const float* pts, int n0, const int* len, int nb, const 
                         pcrcg_pyramid_restore* deferred, void* stream);
 int pcrcg_pyramid_restore_run(const pcrcg_pyramid_restore* r, int* h_status, void* stream);
 
-/* A HIP stream whose kernels run only on compute units [cu_first, cu_first + cu_count) of the device's CU mask
- * (hipExtStreamCreateWithCUMask).  The front end of a pair is a serial chain of ~85 small dependent kernels; on a GPU
- * whose every CU is held by the model streams' long-running workgroups each of them waits for slots to drain, and
- * that wait -- not the kernels -- sets the chain's length.  A few CUs of its own take the wait away
- * (pcrcg_amd/pairstream.py; numbers in DESIGN.md).  *stream receives a hipStream_t. */
-int pcrcg_stream_create_cu_range(void** stream, int cu_first, int cu_count);
+/* A non-blocking HIP stream created by the library (hipStreamCreateWithPriority(hipStreamNonBlocking); priority 0 =
+ * default, -1 = high) for hosts that have no stream abstraction of their own; *stream receives a hipStream_t. */
+int pcrcg_stream_create(void** stream, int priority);
 int pcrcg_stream_destroy(void* stream);
 
 #ifdef __cplusplus

@@ -308,18 +308,11 @@ size_t pcrcg_pyramid_ws_bytes(int n0, int nb, const pcrcg_pyramid_cfg* cfg, doub
     return A.peak + (cfg->tie_order != 0 ? ((pcrcg_kdforest_ws_bytes((int)rows, cfg->n_levels * nb) + 255) & ~size_t(255)) : 0) + 4096;
 }
 
-// HIP stream restricted to compute units [cu_first, cu_first + cu_count) of the device's CU mask.
-int pcrcg_stream_create_cu_range(void** stream, int cu_first, int cu_count) {
-    PCRCG_CHECK_ARG(stream && cu_first >= 0 && cu_count >= 1);
-    int dev = 0, ncu = 0;
-    PCRCG_CHECK_HIP(hipGetDevice(&dev));
-    PCRCG_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    PCRCG_CHECK_ARG(cu_first + cu_count <= ncu);
-    const int words = (ncu + 31) / 32;
-    std::vector<uint32_t> mask(words, 0u);
-    for (int c = cu_first; c < cu_first + cu_count; ++c) mask[c >> 5] |= 1u << (c & 31);
+// A non-blocking HIP stream (hipStreamNonBlocking) with an optional priority (0 = default, -1 = high).
+int pcrcg_stream_create(void** stream, int priority) {
+    PCRCG_CHECK_ARG(stream != nullptr);
     hipStream_t st = nullptr;
-    PCRCG_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()));
+    PCRCG_CHECK_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority));
     *stream = st;
     return PCRCG_OK;
 }

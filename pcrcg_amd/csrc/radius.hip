@@ -202,8 +202,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
             const long tbase = 2l * g.soff[b];
             unsigned s = __umulhi(mix32(key), tsize);
             for (unsigned probe = 0; probe < tsize; ++probe) {
+                // key, count and start of the slot in ONE round trip (count / start of a foreign or empty slot are
+                // loaded and dropped): the lookup is a chain of dependent global loads, and that latency -- not
+                // bandwidth -- is what a query costs
                 const u64 k = g.tkey[tbase + s];
-                if (k == key) { ccount = g.tcnt[tbase + s]; cstart = g.tstart[tbase + s]; break; }
+                const int kc = g.tcnt[tbase + s], ks = g.tstart[tbase + s];
+                if (k == key) { ccount = kc; cstart = ks; break; }
                 if (k == kEmptyKey) break;
                 s = s + 1 == tsize ? 0 : s + 1;
             }
@@ -213,25 +217,37 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
         if (lane < 32) { s_excl[wave][lane] = lane < 27 ? incl - ccount : 0x7FFFFFFF; s_start[wave][lane] = cstart; }
         __builtin_amdgcn_wave_barrier();
         int nhit = 0;
-        for (int base = 0; base < total; base += 64) {
-            const int t = base + lane;
-            const int tc = t < total ? t : total - 1;   // clamped: loads stay branch-free
-            int lo = 0;   // largest j in [0,27) with excl[j] <= tc  (5-step binary search over 32 entries)
+        // candidates 256 at a time: the four gathers of a round are issued before the first is used (they are
+        // independent; one after the other each would cost a full memory round trip)
+        constexpr int SW = 4;
+        for (int base = 0; base < total; base += 64 * SW) {
+            float4 p[SW];
 #pragma unroll
-            for (int step = 16; step >= 1; step >>= 1)
-                if (s_excl[wave][lo + step] <= tc) lo += step;
-            const float4 p = g.spts[s_start[wave][lo] + (tc - s_excl[wave][lo])];
-            const float d0 = qx - p.x, d1 = qy - p.y, d2c = qz - p.z;
-            float d2 = 0.0f;
-            d2 += d0 * d0;
-            d2 += d1 * d1;
-            d2 += d2c * d2c;
-            const bool hit = t < total && d2 < r2;
-            const u64 packed = ((u64)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p.w);
-            const u64 mask = __ballot(hit);
-            const int pos = nhit + __popcll(mask & ((1ull << lane) - 1ull));
-            if (hit && pos < CAP) list[pos] = packed;
-            nhit += __popcll(mask);
+            for (int u = 0; u < SW; ++u) {
+                const int t = base + 64 * u + lane;
+                const int tc = t < total ? t : total - 1;   // clamped: loads stay branch-free
+                int lo = 0;   // largest j in [0,27) with excl[j] <= tc  (5-step binary search over 32 entries)
+#pragma unroll
+                for (int step = 16; step >= 1; step >>= 1)
+                    if (s_excl[wave][lo + step] <= tc) lo += step;
+                p[u] = g.spts[s_start[wave][lo] + (tc - s_excl[wave][lo])];
+            }
+#pragma unroll
+            for (int u = 0; u < SW; ++u) {
+                if (base + 64 * u >= total) break;          // wave-uniform
+                const int t = base + 64 * u + lane;
+                const float d0 = qx - p[u].x, d1 = qy - p[u].y, d2c = qz - p[u].z;
+                float d2 = 0.0f;
+                d2 += d0 * d0;
+                d2 += d1 * d1;
+                d2 += d2c * d2c;
+                const bool hit = t < total && d2 < r2;
+                const u64 packed = ((u64)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p[u].w);
+                const u64 mask = __ballot(hit);
+                const int pos = nhit + __popcll(mask & ((1ull << lane) - 1ull));
+                if (hit && pos < CAP) list[pos] = packed;
+                nhit += __popcll(mask);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         const int nl = nhit < CAP ? nhit : CAP;
@@ -241,11 +257,30 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
             wave_max = nhit > wave_max ? nhit : wave_max;
             return;
         }
-        for (int e = lane; e < nl; e += 64) {
-            const u64 mine = list[e];
+        // rank sort by (d2, index); keys are distinct.  Lists of up to 64 hits (nearly all) stay in registers: lane e
+        // holds entry e and entry j is broadcast through an SGPR (v_readlane), no memory operation in the loop -- the
+        // LDS version below waits for one ds_read per comparison (hipcc does not pipeline the loop: 43..77 dependent
+        // LDS round trips per query were 45 % of this kernel's time)
+        if (nl <= 64) {
+            const u64 mine = lane < nl ? list[lane] : ~0ull;
+            const unsigned mlo = (unsigned)mine, mhi = (unsigned)(mine >> 32);
             int rank = 0;
-            for (int j = 0; j < nl; ++j) rank += list[j] < mine ? 1 : 0;
-            sorted[rank] = mine;
+            for (int j = 0; j < nl; ++j) {
+                const unsigned olo = __builtin_amdgcn_readlane(mlo, j), ohi = __builtin_amdgcn_readlane(mhi, j);
+                rank += ((((u64)ohi) << 32) | olo) < mine ? 1 : 0;
+            }
+            if (lane < nl) sorted[rank] = mine;
+        } else {
+            for (int e = lane; e < nl; e += 64) {
+                const u64 mine = list[e];
+                int rank = 0, j = 0;
+                for (; j + 4 <= nl; j += 4) {          // four independent LDS reads per step
+                    const u64 a = list[j], b = list[j + 1], c = list[j + 2], d = list[j + 3];
+                    rank += (a < mine ? 1 : 0) + (b < mine ? 1 : 0) + (c < mine ? 1 : 0) + (d < mine ? 1 : 0);
+                }
+                for (; j < nl; ++j) rank += list[j] < mine ? 1 : 0;
+                sorted[rank] = mine;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         // the row in ascending (d2, index) order, padded with the shadow index (:324); a pair of neighbours with

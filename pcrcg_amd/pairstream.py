@@ -53,8 +53,7 @@ class _Mailbox:
 class PairStreams:
     ARENAS = 4        # per front thread: pairs whose tables may be alive at once (built, forward not yet passed)
 
-    def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=2, tie_order=None,
-                 front_cus=0):
+    def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=2, tie_order=None):
         self.net, self.config, self.limits = net, config, neighborhood_limits
         self.device = torch.device(device if device is not None else "cuda")
         if not getattr(net, "use_runner", False):
@@ -63,14 +62,11 @@ class PairStreams:
         with torch.cuda.device(self.device):
             self.runner.descriptor()           # built once, here, before any worker thread can race for it
         nfs = int(os.environ.get("PCRCG_FRONT_STREAMS", "1"))
-        front_cus = int(os.environ.get("PCRCG_FRONT_CUS", front_cus))
         self._raw_streams = []
-        if front_cus > 0:
-            # CU partition: the front-end stream(s) own `front_cus` compute units, the model streams the rest
-            ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if os.environ.get("PCRCG_OWN_STREAMS", "0") == "1":       # experiment: streams created by the library
             with torch.cuda.device(self.device):
-                self.fronts = [self._cu_stream(0, front_cus) for _ in range(max(1, nfs))]
-                self.models = [self._cu_stream(front_cus, ncu - front_cus) for _ in range(max(1, int(model_streams)))]
+                self.fronts = [self._own_stream() for _ in range(max(1, nfs))]
+                self.models = [self._own_stream() for _ in range(max(1, int(model_streams)))]
         else:
             self.fronts = [torch.cuda.Stream(device=self.device) for _ in range(max(1, nfs))]
             self.models = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(model_streams)))]
@@ -102,12 +98,11 @@ class PairStreams:
             t.start()
             self._threads.append(t)
 
-    def _cu_stream(self, first, count):
+    def _own_stream(self):
         import ctypes
         from . import _lib
         h = ctypes.c_void_p()
-        _lib.check(_lib.lib().pcrcg_stream_create_cu_range(ctypes.byref(h), int(first), int(count)),
-                   "pcrcg_stream_create_cu_range")
+        _lib.check(_lib.lib().pcrcg_stream_create(ctypes.byref(h), 0), "pcrcg_stream_create")
         self._raw_streams.append(h.value)
         return torch.cuda.ExternalStream(h.value, device=self.device)
 

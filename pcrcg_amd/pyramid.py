@@ -78,6 +78,8 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
     The build needs four host round trips (three subsampled row counts, one for all table widths); this function
     waits for each of them.  pyramid_steps() is the same build as a generator that YIELDS at those points, so that a
     caller can keep the stream busy with another pair's pyramid meanwhile (PairPipeline does)."""
+    if not points.is_cuda:
+        raise RuntimeError("pcrcg_amd.build_pyramid: points must be on a HIP device (no CPU path)")
     mode = tie_order if tie_order is not None else os.environ.get("PCRCG_TIE_ORDER", "auto")
     if (not want_counts and not defer_tie_check and mode in ("auto", "index")
             and os.environ.get("PCRCG_PY_PYRAMID", "0") != "1"):
