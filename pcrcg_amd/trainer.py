@@ -37,6 +37,10 @@ class GradientBucket:
 
         self._chunks = None       # overlap mode: [(start, end, n_params)] slices of the flat buffer
         self._armed = False
+        # PCRCG_FORCE_DIST=1: run the collective even in a one-rank group (RCCL all-reduce of the bucket with itself:
+        # the identity) so that the exchange path can be exercised on a single GPU
+        import os
+        self.force = os.environ.get("PCRCG_FORCE_DIST") == "1"
 
     # ---- overlap of the exchange with backward -----------------------------------------------------
     def enable_overlap(self, n_chunks=4):
@@ -62,9 +66,13 @@ class GradientBucket:
 
     def arm(self, on=True):
         """Call before the backward pass whose gradients complete the optimiser step (the last of iter_size)."""
-        self._armed = bool(on) and self._chunks is not None and self._world() > 1
+        self._armed = bool(on) and self._chunks is not None and (self._world() > 1 or self._forced())
         self._seen = [0] * len(self._chunks or [])
         self._handles = {}
+
+    def _forced(self):
+        import torch.distributed as dist
+        return self.force and dist.is_available() and dist.is_initialized()
 
     def _world(self):
         import torch.distributed as dist
@@ -87,7 +95,7 @@ class GradientBucket:
         parameter that received no gradient never complete on their own), divide by the world size."""
         import torch.distributed as dist
         world = self._world()
-        if world <= 1:
+        if world <= 1 and not self._forced():
             self._armed = False
             return
         if self._armed:

@@ -1,0 +1,114 @@
+"""Full-size fixtures from the UNMODIFIED reference (build container only):
+
+  tests/golden/model_s30k.pt        the reference's full-width KPFCNN (29.7 M parameters, default initialisation under
+                                    torch.manual_seed(0) / np.random.seed(0) -- pcrcg_amd builds the bit-identical
+                                    model from the same seeds, tests/test_host_logic.py) on the reference's own
+                                    collate of the S30k pair 0 (BASELINE.json configs[1]) with limits [43,42,47,43]:
+                                    every 97th row of feats_f / scores_overlap / scores_saliency, their means, and
+                                    the per-column means of three encoder activations.
+  tests/golden/model_s30k_lomatch.pt  the same on the 3DLoMatch-shaped pair (configs[2]): every 97th output row, plus
+                                    the reference MetricLoss's pure sub-methods on those outputs are NOT included
+                                    (lib/loss.py hard-codes 'cuda' in forward; tests/golden/loss_mini.pt pins them).
+  tests/golden/frontend_digests.json["U30k"], ["K120k"]
+                                    raw SHA-256 digests of every level and every untruncated table of the reference
+                                    C++ front end for the uniform-cube pair and the KITTI-shaped pair (configs[4]).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+from make_golden_frontend import sha  # noqa: E402
+
+REPO = ref_import.REPO
+OUT = os.path.join(REPO, "tests", "golden")
+STRIDE = 97
+
+
+def ref_forward(src, tgt, limits, corr=None, rot=None, trans=None):
+    from datasets.dataloader import collate_fn_descriptor
+    from models.architectures import KPFCNN
+    cfg = ref_import.indoor_config()
+    item = dict(rot=np.eye(3, dtype=np.float32) if rot is None else rot,
+                trans=np.zeros((3, 1), np.float32) if trans is None else trans,
+                correspondences=torch.stack([torch.arange(0, 50), torch.arange(0, 50)], 1) if corr is None else corr,
+                sample=0, src_pcd=src, tgt_pcd=tgt, src_feats=np.ones((len(src), 1), np.float32),
+                tgt_feats=np.ones((len(tgt), 1), np.float32))
+    batch = collate_fn_descriptor([item], cfg, limits)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = KPFCNN(cfg).eval()
+    inter = {}
+    hooks = [model.encoder_blocks[i].register_forward_hook(
+        lambda m, a, o, i=i: inter.__setitem__(f"enc{i}", o.detach().double().mean(0).float())) for i in (1, 4, 10)]
+    with torch.no_grad():
+        out = model(batch)
+    for h in hooks:
+        h.remove()
+    return batch, out, inter
+
+
+def digests(pts, lens, r0, dl0, F, canonicalise_table):
+    r, dl, d = r0, dl0, {}
+    for l in range(4):
+        d[f"points{l}"] = {"shape": list(pts.shape), "sha256": sha(pts)}
+        d[f"lens{l}"] = {"shape": list(lens.shape), "sha256": sha(lens)}
+        level = {"conv": (F.ref_batch_query(pts, pts, lens, lens, r), pts, pts)}
+        if l < 3:
+            sp, sl = F.ref_subsample_batch(pts, lens, dl)
+            level["pool"] = (F.ref_batch_query(sp, pts, sl, lens, r), sp, pts)
+            level["up"] = (F.ref_batch_query(pts, sp, lens, sl, 2 * r), pts, sp)
+        for name, (tab, q, s) in level.items():
+            canon, ties = canonicalise_table(tab, q, s)
+            d[f"{name}{l}"] = {"shape": list(tab.shape), "sha256": sha(tab), "sha256_canonical": sha(canon),
+                               "tie_rows": int(ties)}
+        if l < 3:
+            pts, lens, r, dl = sp, sl, r * 2, dl * 2
+    return d
+
+
+def main():
+    F = ref_import.setup()
+    F.build(ref=True)
+    from pcrcg_amd import synthetic as S
+    from tests.tieutil import canonicalise_table
+
+    if "--no-model" not in sys.argv:
+        limits = S.LIMITS["S30k"]
+        src, tgt = S.pair("S30k", 0)
+        batch, out, inter = ref_forward(src, tgt, limits)
+        torch.save({"recipe": "S30k", "seed": 0, "limits": limits, "stride": STRIDE,
+                    "levels": [int(p.shape[0]) for p in batch["points"]],
+                    "rows": {k: v[::STRIDE].clone() for k, v in out.items()},
+                    "means": {k: float(v.double().mean()) for k, v in out.items()},
+                    "absmax": {k: float(v.abs().max()) for k, v in out.items()},
+                    "enc_col_means": inter}, os.path.join(OUT, "model_s30k.pt"))
+        print("S30k levels", [int(p.shape[0]) for p in batch["points"]], {k: float(v.double().mean()) for k, v in out.items()})
+        src, tgt, rot, trans = S.lomatch_pair("S30k", 1, 0.2)
+        batch, out, inter = ref_forward(src, tgt, limits, rot=rot.astype(np.float32), trans=trans.astype(np.float32).reshape(3, 1))
+        torch.save({"recipe": "S30k-lomatch", "seed": 1, "overlap": 0.2, "limits": limits, "stride": STRIDE,
+                    "levels": [int(p.shape[0]) for p in batch["points"]],
+                    "rows": {k: v[::STRIDE].clone() for k, v in out.items()},
+                    "means": {k: float(v.double().mean()) for k, v in out.items()}},
+                   os.path.join(OUT, "model_s30k_lomatch.pt"))
+        print("S30k-lomatch levels", [int(p.shape[0]) for p in batch["points"]])
+
+    path = os.path.join(OUT, "frontend_digests.json")
+    dig = json.load(open(path))
+    a, b = S.uniform_pair(30000, 1.07, 0)
+    dig["U30k"] = digests(np.concatenate([a, b]), np.array([len(a), len(b)], np.int32), 0.0625, 0.05, F, canonicalise_table)
+    print("U30k", {k: v["shape"] for k, v in dig["U30k"].items() if k.startswith(("conv", "pool", "up"))})
+    a, b = S.slab_pair(120000, 0)
+    # KITTI hyper-parameters: first_subsampling_dl 0.3, conv_radius 4.25 (ref:configs/test/kitti.yaml:15,17)
+    dig["K120k"] = digests(np.concatenate([a, b]), np.array([len(a), len(b)], np.int32), 0.3 * 4.25, 0.6, F, canonicalise_table)
+    print("K120k", {k: v["shape"] for k, v in dig["K120k"].items() if k.startswith(("conv", "pool", "up"))})
+    json.dump(dig, open(path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
