@@ -68,38 +68,50 @@ def kpconv_algorithmic_bytes(nq, h, cin, cout, e=4):
     return nq * h * (cin * e + 8 + 12) + nq * cout * e
 
 
+def _cpu_front_end(args):
+    """One pair through the CPU oracle's front end (worker of the pair-parallel leg)."""
+    recipe, seed, cfg, limits = args
+    from oracle import frontend as OF
+    src, tgt = make_pair(recipe, seed)
+    t0 = time.perf_counter()
+    OF.oracle_pyramid(np.concatenate([src, tgt]), [len(src), len(tgt)], cfg, limits, tie_order="reference")
+    return time.perf_counter() - t0
+
+
 def cpu_baseline(cfg, state_dict, limits):
-    """CPU oracle on one pair: front end single-threaded C -- the restatement of the reference's own algorithm
-    (nanoflann KD-trees + std::sort: its tables entry for entry) --, model torch-CPU on all cores."""
+    """CPU oracle on a bounded sample: the C front end -- the restatement of the reference's own algorithm (nanoflann
+    KD-trees + std::sort: its tables entry for entry) -- on one pair single-threaded and on P pairs in P worker
+    processes (the reference's parallelism model is DataLoader worker processes, ref:main.py:82-97), the torch-CPU
+    model on all cores.  `value` = 1 / (front end of one pair on one core + model on all cores): one pair's latency
+    the way the reference runs it with num_workers = 0; the pair-parallel front-end rate is reported beside it."""
+    import multiprocessing as mp
     from oracle import frontend as OF
     from oracle import model_ref as MR
     src, tgt = make_pair(RECIPE, 12345)
-    pts = np.concatenate([src, tgt])
-    lens = np.array([len(src), len(tgt)], np.int32)
     t0 = time.perf_counter()
-    r, dl = cfg.first_subsampling_dl * cfg.conv_radius, 2 * cfg.first_subsampling_dl
-    batch = {"points": [], "neighbors": [], "pools": [], "upsamples": [], "stack_lengths": []}
-    empty = torch.zeros((0, 1), dtype=torch.int64)
-    for l in range(cfg.num_layers):
-        batch["points"].append(torch.from_numpy(pts))
-        batch["stack_lengths"].append(torch.from_numpy(lens))
-        batch["neighbors"].append(torch.from_numpy(OF.oracle_batch_query(pts, pts, lens, lens, r, tie_order="reference")[:, :limits[l]]).long())
-        if l == cfg.num_layers - 1:
-            batch["pools"].append(empty)
-            batch["upsamples"].append(empty)
-            break
-        sp, sl = OF.oracle_subsample_batch(pts, lens, dl)
-        batch["pools"].append(torch.from_numpy(OF.oracle_batch_query(sp, pts, sl, lens, r, tie_order="reference")[:, :limits[l]]).long())
-        batch["upsamples"].append(torch.from_numpy(OF.oracle_batch_query(pts, sp, lens, sl, 2 * r, tie_order="reference")[:, :limits[l]]).long())
-        pts, lens, r, dl = sp, sl, r * 2, dl * 2
-    batch["features"] = torch.ones((batch["points"][0].shape[0], 1))
+    batch = OF.oracle_pyramid(np.concatenate([src, tgt]), [len(src), len(tgt)], dict(cfg), limits, tie_order="reference")
     t1 = time.perf_counter()
     MR.kpfcnn_forward(state_dict, dict(cfg), batch)
     t2 = time.perf_counter()
+    workers = max(1, min(os.cpu_count() or 1, 16))
+    par = None
+    try:
+        with mp.get_context("spawn").Pool(workers) as pool:
+            tp = time.perf_counter()
+            pool.map(_cpu_front_end, [(RECIPE, 100 + i, dict(cfg), limits) for i in range(workers)])
+            par = workers / (time.perf_counter() - tp)
+    except Exception as e:       # the baseline is a reported number, never a reason to fail the bench
+        par = None
+        print("cpu_baseline: pair-parallel leg failed: %r" % (e,), file=sys.stderr)
     return {"value": round(1.0 / (t2 - t0), 4), "unit": "fragment-pairs/s", "cores": torch.get_num_threads(),
             "kind": "port",
+            "front_end_pairs_per_s_1_thread": round(1.0 / (t1 - t0), 3),
+            "front_end_pairs_per_s_pair_parallel": None if par is None else round(par, 3),
+            "front_end_worker_processes": workers,
+            "model_pairs_per_s": round(1.0 / (t2 - t1), 3),
             "sample": f"1 {RECIPE} pair: oracle C front end (KD-trees as in the reference) {t1 - t0:.2f}s (1 thread) + torch-CPU model "
-                      f"{t2 - t1:.2f}s ({torch.get_num_threads()} threads)"}
+                      f"{t2 - t1:.2f}s ({torch.get_num_threads()} threads); front end alone on {workers} pairs in {workers} "
+                      f"worker processes (includes process start-up)"}
 
 
 def main():
@@ -109,6 +121,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="S30k")
+    ap.add_argument("--isolated-only", action="store_true",
+                    help="no pipeline: --steps forwards of one prepared pair on one stream, nothing else running (the "
+                         "run rocprofv3 is pointed at for the KPConv gather kernel's isolated duration and PMC traffic)")
     args = ap.parse_args()
     global RECIPE
     RECIPE = args.workload
@@ -150,6 +165,30 @@ def main():
         if s % 16 not in pool:
             pool[s % 16] = (torch.from_numpy(np.concatenate([src, tgt])).to(dev),
                             torch.tensor([len(src), len(tgt)], dtype=torch.int32, device=dev))
+
+    if args.isolated_only:
+        from pcrcg_amd.pyramid import build_pyramid
+        batch_iso = build_pyramid(*pool[seeds[0] % 16], cfg, limits)
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                net(batch_iso)
+            torch.cuda.synchronize()
+            ops.kpconv_profile_start()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                net(batch_iso)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        ev = ops.kpconv_profile_stop()
+        cout_of = {blk.KPConv.in_channels: blk.KPConv.out_channels for blk in net.encoder_blocks}
+        ms = sum(e[0] for e in ev)
+        by = sum(kpconv_algorithmic_bytes(nq, h, cin, cout_of[cin]) for (_, nq, h, cin, _, _) in ev)
+        print(json.dumps({"mode": "isolated-only", "workload": RECIPE, "forwards": args.steps,
+                          "forward_ms": round(1e3 * dt / args.steps, 3),
+                          "kpconv_launches": len(ev), "kpconv_avg_launch_us": round(1e3 * ms / max(len(ev), 1), 2),
+                          "kpconv_algorithmic_GBs": round(by / (ms * 1e-3) / 1e9, 1),
+                          "kpconv_frac_of_hbm_peak": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}), flush=True)
+        return
 
     # Pair engine (pcrcg_amd/pairstream.py): W host threads, each with its own HIP stream, take pairs round-robin;
     # a pair is two calls into the library (pyramid builder + network runner) on the worker's stream.  Pairs are
@@ -216,7 +255,8 @@ def main():
     if os.environ.get("PCRCG_PIPE_STATS") and rank == 0 and hasattr(pipe, "stats"):
         n = max(pipe.stats["pairs"], 1)
         print("pair engine, host ms per pair: " + ", ".join("%s %.3f" % (k[:-2], 1e3 * v / n) for k, v in pipe.stats.items()
-                                                            if k != "pairs"), file=sys.stderr, flush=True)
+                                                            if k not in ("pairs", "builds"))
+              + "; %.2f pairs per build" % (n / max(pipe.stats.get("builds", n), 1)), file=sys.stderr, flush=True)
     elif os.environ.get("PCRCG_PIPE_STATS") and rank == 0:
         st = front_stats
         n = max(st.get("pairs", 1), 1)
@@ -265,10 +305,14 @@ def main():
             b = kpconv_algorithmic_bytes(nq, h, cin, cout_of[cin])
             iso_rows.append({"nq": nq, "h": h, "cin": cin, "cout": cout_of[cin], "us": round(ms * 1e3, 1),
                              "GBs": round(b / (ms * 1e-3) / 1e9, 0) if ms > 0 else None})
-        traffic = None
-        pmc_path = os.path.join(REPO, "profiles", "r01_pmc_kpconv.json")
-        if os.path.exists(pmc_path):        # HBM bytes per launch from the committed rocprofv3 PMC passes
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        # `traffic` (HBM bytes per launch from PMC counters) cannot be collected by this process: rocprofv3 --pmc needs
+        # its own passes.  The live line says null; the figure of the committed separate passes is quoted with its source.
+        traffic, traffic_offline = None, None
+        pmc_path = os.path.join(REPO, "profiles", "r02_pmc_kpconv.json")
+        if os.path.exists(pmc_path):
+            traffic_offline = {"hbm_bytes_per_launch": json.load(open(pmc_path)).get("hbm_bytes_per_launch"),
+                               "source": "profiles/r02_pmc_kpconv.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                         "`bench.py --isolated-only`, corrected as MI355X_MICROARCH.md prescribes; NOT measured by this run"}
         line = {
             "metric": "fragment-pairs/s KPFCNN+GCN fwd, 30k-pt pairs" if RECIPE == "S30k"
                       else f"fragment-pairs/s KPFCNN+GCN fwd, {RECIPE} pairs (secondary workload)",
@@ -300,7 +344,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "KPConv neighbour-gather kernels (k_kpconv_mfma / k_kpconv_c1 / "
                                                      "k_kpconv_fused), %d launches/pair" % per_pair,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_offline": traffic_offline,
                          "avg_launch_us": round(k_ms * 1e3 / max(len(events), 1), 2),
                          "algorithmic_bytes_per_pair": int(k_bytes / max(args.steps, 1)),
                          "note": "durations are the kernels' own start/stop events (hipExtLaunchKernel); achieved/frac "

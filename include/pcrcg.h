@@ -96,6 +96,14 @@ int pcrcg_radius_query(const float* q, int nq, const int* qlen, int ns, const in
 int pcrcg_radius_query_ex(const float* q, int nq, const int* qlen, int ns, const int* slen, int nb,
                           float radius, const void* grid, int cols, int64_t* out_idx, int* out_count,
                           int* out_max_count, int* status, int* out_tie_rows, int* out_tie_count, void* stream);
+/* pcrcg_radius_query_ex for several INDEPENDENT groups of clouds stacked into one call (e.g. two fragment pairs =
+ * four clouds, group = 2): indices are written relative to the first support of the query's group, rows are padded
+ * with the group's support count, and out_max_count is an array with one entry per group ([ceil(nb / group)], zeroed
+ * by the caller) -- the table is the groups' own tables stacked on top of each other, row for row what separate
+ * calls would have written.  group = 0: one group (pcrcg_radius_query_ex). */
+int pcrcg_radius_query_groups(const float* q, int nq, const int* qlen, int ns, const int* slen, int nb, int group,
+                              float radius, const void* grid, int cols, int64_t* out_idx, int* out_count,
+                              int* out_max_count, int* status, int* out_tie_rows, int* out_tie_count, void* stream);
 /* Convenience: zero out_max_count/status, build the grid in `ws`, run one query. */
 size_t pcrcg_radius_neighbors_ws_bytes(int ns, int nb);
 int pcrcg_radius_neighbors_batch(const float* q, int nq, const float* sup, int ns, const int* qlen,
@@ -136,6 +144,8 @@ typedef struct pcrcg_reorder_job {
     int64_t* idx;         /* [nq, cols] table, rewritten in place */
     int nq, nbq, cloud0, nrows, max_count, cols;
     float radius;
+    int group;            /* > 0: the nbq clouds are independent groups of `group` clouds (pcrcg_radius_query_groups):
+                             indices relative to the group's first support, padding = the group's support count */
 } pcrcg_reorder_job;
 size_t pcrcg_kdforest_ws_bytes(int ns, int nb);
 int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, void* forest, size_t forest_bytes,
@@ -173,6 +183,21 @@ int pcrcg_kpconv_fused_supported(int nq, int cin, int cout);
 int pcrcg_kpconv_fused(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h,
                        int ld_idx, const float* x, int cin, const float* kp, float extent, const float* wt,
                        int cout, float* out, int ld_out, void* ws, size_t ws_bytes, void* stream);
+
+/* The operator in one kernel WITHOUT the 61 KB tile: a workgroup aggregates 16 queries in registers (exact fp32 MFMA,
+ * as pcrcg_kpconv_aggregate) and contracts them kernel point by kernel point through a 7 KB LDS slab on the bf16
+ * matrix cores, with the exact three-term bf16 split of both operands (fp32-class accuracy, see pcrcg_gemm_set_mode);
+ * `wf` never reaches HBM.  w_planes = pcrcg_split_bf16x3 of the K-contiguous weights wt [cout, 15*cin].
+ * pcrcg_kpconv_x6_supported: cin in {64, 128}, cout in {64, 128, 256}, nq >= 2048 (layers whose weight set is small
+ * against their activations; elsewhere the two-stage path is faster).  ws as for pcrcg_kpconv_aggregate.
+ * pcrcg_split_bf16x3: fp32 [n, k] (row stride ld) -> three bf16 planes [3][n][k] with w = p0 + p1 + p2 exactly
+ * (pcrcg_split_bf16x3_bytes(n, k) bytes); done once per weight version. */
+size_t pcrcg_split_bf16x3_bytes(int n, int k);
+int pcrcg_split_bf16x3(const float* w, int ld, int n, int k, void* planes, void* stream);
+int pcrcg_kpconv_x6_supported(int nq, int cin, int cout);
+int pcrcg_kpconv_x6(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h, int ld_idx,
+                    const float* x, int cin, const float* kp, float extent, const void* w_planes, int cout, float* out,
+                    int ld_out, void* ws, size_t ws_bytes, void* stream);
 
 /* Measurement aid for bench.py: when enabled, the gather/aggregate kernel of every
  * pcrcg_kpconv_aggregate call (kind 0) and the fused kernel of every pcrcg_kpconv_fused call (kind 1)
@@ -309,13 +334,15 @@ typedef struct pcrcg_block {
     const float* shortcut; /* [out, in] or NULL (nn.Identity) */
     const float* mlp;    /* unary / last_unary: [out, in] with leading dimension mlp_ld (rows 16-B aligned) */
     int mlp_ld;
+    const void* kp_wsplit; /* pcrcg_split_bf16x3 planes of kp_wt (for pcrcg_kpconv_x6), or NULL */
 } pcrcg_block;
 
 typedef struct pcrcg_gnn_layer {
     int cross;             /* 0 = SelfAttention (ref:models/gcn.py:96-134), 1 = AttentionalPropagation (:176-185) */
-    /* self: 1x1 conv weights re-packed as [cin, 2*cout] = [(Wa-Wb)^T | Wb^T] (centre | neighbour term) */
-    const float* edge1;    /* [c, 2c] */
-    const float* edge2;    /* [c, 4c] */
+    /* self: 1x1 conv weights [cout, 2*cin] = [Wa | Wb] re-packed as [2*cout, cin] = [Wa-Wb ; Wb] (rows: the centre
+     * term's output channels, then the neighbour term's), k-contiguous like every other weight */
+    const float* edge1;    /* [2c, c] */
+    const float* edge2;    /* [4c, c] */
     const float* conv3;    /* [c, 4c] as stored ([out, in]) */
     /* cross: projection weights with output channels permuted head-major, [c, c] as [out, in] */
     const float *wq, *bq, *wk, *bk, *wv, *bv;
@@ -372,6 +399,7 @@ int pcrcg_kpfcnn_forward(const pcrcg_model* model, const pcrcg_batch* batch, con
  *              pooled (every level but the last), limit = neighborhood_limits; tie_order 0 = ascending index inside
  *              groups of exactly equal distance, 1 = the reference's order (rows holding such groups are redone
  *              through the KD-forest, as pcrcg_radius_reorder_jobs documents).
+ *   out        one pcrcg_batch (cfg->group == 0) or nb / cfg->group of them
  *   ws         arena of pcrcg_pyramid_ws_bytes(n0, nb, cfg, shrink) bytes; `shrink` in (0,1] is the caller's bound on
  *              rows(level l+1) / rows(level l) (1.0 = always enough; 3DMatch-like clouds keep about a quarter).  A
  *              too small arena is reported as PCRCG_EWORKSPACE -- nothing is corrupted, call again with a larger one.
@@ -393,6 +421,11 @@ typedef struct pcrcg_pyramid_cfg {
     float r_conv[PCRCG_MAX_LEVELS], r_pool[PCRCG_MAX_LEVELS], dl[PCRCG_MAX_LEVELS];
     int has_conv[PCRCG_MAX_LEVELS], pooled[PCRCG_MAX_LEVELS], limit[PCRCG_MAX_LEVELS];
     int tie_order;
+    int group;   /* 0: all nb clouds form ONE batch (the reference's contract).  g > 0: the clouds are nb / g independent
+                    groups of g clouds (g = 2: several fragment pairs stacked into one call); `out` then is an array of
+                    nb / g batches, each with its own tables (indices relative to the group's supports, the group's own
+                    column counts) -- what nb / g separate calls would have produced, from ONE chain of kernels: the
+                    chain is latency-bound, so two pairs cost little more than one */
 } pcrcg_pyramid_cfg;
 typedef struct pcrcg_pyramid_restore {
     int njobs;                                   /* 0: no row holds a tie, nothing to do but post the status word */

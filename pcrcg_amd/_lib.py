@@ -27,6 +27,8 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcrcg_radius_query_ex": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcrcg_radius_query_groups": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcrcg_kdforest_ws_bytes": (c_size_t, [c_int, c_int]),
     "pcrcg_kdforest_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "pcrcg_radius_reorder": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
@@ -42,6 +44,11 @@ SIGNATURES = {
     "pcrcg_kpconv_fused_supported": (c_int, [c_int, c_int, c_int]),
     "pcrcg_kpconv_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                    c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_split_bf16x3_bytes": (c_size_t, [c_int, c_int]),
+    "pcrcg_split_bf16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pcrcg_kpconv_x6_supported": (c_int, [c_int, c_int, c_int]),
+    "pcrcg_kpconv_x6": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "pcrcg_profile_kpconv": (None, [c_int]),
     "pcrcg_profile_kpconv_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "pcrcg_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) k_pack_c1(const float* __restrict__ x, in
 
 struct __attribute__((packed, aligned(4))) P3 { float x, y, z; };
 
-template <int NB>  // 64-channel blocks handled per wavefront (one float4 per lane and block)
+template <int NB, bool NT_STORE>  // 64-channel blocks handled per wavefront (one float4 per lane and block)
 __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
     const float* __restrict__ q_pts, int nq, const float* __restrict__ s_pts, int ns,
     const long long* __restrict__ idx, int H, int ld_idx, const float* __restrict__ x, int cin,
@@ -177,7 +177,8 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
                     // push the feature rows the gathers re-read out of L2
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     const v4f val = {acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]};
-                    __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + (long)k * cin + c));
+                    if (NT_STORE) __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + (long)k * cin + c));
+                    else *reinterpret_cast<v4f*>(o + (long)k * cin + c) = val;
                 }
             }
         }
@@ -312,6 +313,19 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_generic(
 }
 
 }  // namespace
+
+// pos / pk records of `x` (see k_row_positive) into the workspace layout of pcrcg_kpconv_ws_bytes; shared by the
+// two-stage path and the fused kernel (kpconv_x6.hip)
+int kpconv_pack(const float* x, int ns, int cin, const float* s_pts, void* ws, size_t ws_bytes, hipStream_t st) {
+    Carver cv(ws, ws_bytes);
+    unsigned char* pos = cv.take<unsigned char>((size_t)ns + 1);
+    float4* pk = cv.take<float4>((size_t)ns + 1);
+    PCRCG_CHECK_WS(cv);
+    if (ns > 0) hipLaunchKernelGGL(k_row_positive, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, s_pts, pos, pk);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
 }  // namespace pcrcg
 
 using namespace pcrcg;
@@ -347,6 +361,19 @@ size_t pcrcg_kpconv_ws_bytes(int ns) {
 int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx,
                            int h, int ld_idx, const float* x, int cin, const float* kp, float extent,
                            float* wf, float* inv_n, void* ws, size_t ws_bytes, void* stream) {
+    return kpconv_aggregate_rows(q_pts, nq, s_pts, ns, idx, h, ld_idx, x, cin, kp, extent, wf, inv_n, ws, ws_bytes,
+                                 as_stream(stream), true, true);
+}
+}
+
+namespace pcrcg {
+
+// pcrcg_kpconv_aggregate for a slice of the queries; `pack` = (re)build the support records in `ws` first (once per
+// layer), `stream_out` = non-temporal wf stores (the whole layer's wf is streamed once through HBM) or plain stores
+// (a row chunk whose wf the contraction reads back from L2 / Infinity Cache right away)
+int kpconv_aggregate_rows(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h, int ld_idx,
+                          const float* x, int cin, const float* kp, float extent, float* wf, float* inv_n, void* ws,
+                          size_t ws_bytes, hipStream_t st, bool pack, bool stream_out) {
     PCRCG_CHECK_ARG(nq >= 0 && ns >= 0 && h >= 1 && ld_idx >= h && cin >= 1);
     PCRCG_CHECK_ARG(extent > 0.0f);
     if (nq == 0) return PCRCG_OK;
@@ -356,7 +383,6 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
     unsigned char* pos = cv.take<unsigned char>((size_t)ns + 1);
     float4* pk = cv.take<float4>((size_t)ns + 1);
     PCRCG_CHECK_WS(cv);
-    hipStream_t st = as_stream(stream);
     const long long* idx_ll = reinterpret_cast<const long long*>(idx);
     const int max_blocks = 256 * 32;
     auto blocks_for = [&](long waves) {
@@ -364,7 +390,7 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
         return (int)(b > max_blocks ? max_blocks : b);
     };
     if (cin == 1) {
-        hipLaunchKernelGGL(k_pack_c1, dim3((ns + 255) / 256), dim3(256), 0, st, x, ns, s_pts, pk);
+        if (pack) hipLaunchKernelGGL(k_pack_c1, dim3((ns + 255) / 256), dim3(256), 0, st, x, ns, s_pts, pk);
         KpProfScope prof_scope(st, nq, h, cin, 0, 0);
         hipExtLaunchKernelGGL(k_kpconv_c1, dim3((int)(((long)nq * C1_PARTS + 255) / 256)), dim3(256), 0, st, prof_scope.a,
                               prof_scope.b, 0, q_pts, nq, s_pts, ns, idx_ll, h, ld_idx, (const float4*)pk, kp, extent, wf,
@@ -372,7 +398,7 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
         PCRCG_CHECK_LAUNCH();
         return PCRCG_OK;
     }
-    if (ns > 0) hipLaunchKernelGGL(k_row_positive, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, s_pts, pos, pk);
+    if (pack && ns > 0) hipLaunchKernelGGL(k_row_positive, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, s_pts, pos, pk);
     KpProfScope prof_scope(st, nq, h, cin, 0, 0);   // start / stop events of the gather/aggregate kernel itself
     const bool aligned = (cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(wf) & 15) == 0);
@@ -388,15 +414,22 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
     while (nb > 1 && ((long)nq * ((nblk + nb - 1) / nb) < 16384 || nblk % nb != 0)) nb >>= 1;
     const int nchunk = (nblk + nb - 1) / nb;
     const int blocks = blocks_for((long)nq * nchunk);
-#define LAUNCH(NBV)                                                                                             \
-    hipExtLaunchKernelGGL(k_kpconv_mfma<NBV>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, st, prof_scope.a,     \
-                          prof_scope.b, 0, q_pts, nq, s_pts, ns, idx_ll, h, ld_idx, x, cin, kp, extent,         \
+#define LAUNCH(NBV, NT)                                                                                          \
+    hipExtLaunchKernelGGL((k_kpconv_mfma<NBV, NT>), dim3(blocks), dim3(kWavesPerBlock * 64), 0, st, prof_scope.a, \
+                          prof_scope.b, 0, q_pts, nq, s_pts, ns, idx_ll, h, ld_idx, x, cin, kp, extent,          \
                           (const float4*)pk, wf, inv_n, nchunk)
-    if (nb == 4) LAUNCH(4);
-    else if (nb == 2) LAUNCH(2);
-    else LAUNCH(1);
+    if (stream_out) {
+        if (nb == 4) LAUNCH(4, true);
+        else if (nb == 2) LAUNCH(2, true);
+        else LAUNCH(1, true);
+    } else {
+        if (nb == 4) LAUNCH(4, false);
+        else if (nb == 2) LAUNCH(2, false);
+        else LAUNCH(1, false);
+    }
 #undef LAUNCH
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
-}
+
+}  // namespace pcrcg

@@ -122,11 +122,13 @@ struct Arena {
 };
 
 struct TableRec {
-    pcrcg_table* dst;      // where the finished table goes in the batch
+    int kind;              // 0 conv (neighbors), 1 pool, 2 upsample
+    int level;             // level of the table in the batch
+    int q_level;           // level whose points are the queries
     int64_t* idx;
     int* counts;           // [nq] untruncated list lengths (tie restore cross-check), or null
     int* ties;             // [nq] rows holding a tie, or null
-    int* meta;             // device [3]: max_count, status, tie_rows
+    int* meta;             // device [P + 2]: max_count per group, status, tie_rows
     const float* q;
     const int* qlen;
     int nq, limit, sup_level;
@@ -144,43 +146,43 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
     const int L = cfg->n_levels;
     const bool dry = A.dry;
     const bool want_ties = cfg->tie_order != 0;
+    const int group = cfg->group > 0 ? cfg->group : 0;
+    const int P = group > 0 ? nb / group : 1;          // output batches
+    const int MS = P + 2;                              // ints of table metadata
     // ---- persistent block 1: points of all levels, lengths, features, table metadata -----------------------
     // level l+1 has at most as many rows as level l: L * n0 rows always suffice (12 bytes each)
     float* pts_all = A.take<float>(3 * (size_t)L * ((size_t)n0 + 1));
     int* lens_all = A.take<int>((size_t)L * nb);
     float* feats = A.take<float>((size_t)n0);
     const int max_tables = 3 * L;
-    int* metas = A.take<int>(3 * (size_t)max_tables + L);    // [3 per table] + subsample row counts [L]
-    int* m_dev = metas + 3 * max_tables;
+    int* metas = A.take<int>((size_t)MS * max_tables + L);    // [MS per table] + subsample row counts [L]
+    int* m_dev = metas + MS * max_tables;
     int* tie_status = A.take<int>(1);
     if (!A.ok()) return PCRCG_EWORKSPACE;
 
     std::vector<TableRec> tables;
     tables.reserve(max_tables);
     if (!dry) {
-        PCRCG_CHECK_HIP(hipMemsetAsync(metas, 0, sizeof(int) * (3 * (size_t)max_tables + L), st));
+        PCRCG_CHECK_HIP(hipMemsetAsync(metas, 0, sizeof(int) * ((size_t)MS * max_tables + L), st));
         PCRCG_CHECK_HIP(hipMemsetAsync(tie_status, 0, sizeof(int), st));
         PCRCG_CHECK_HIP(hipMemcpyAsync(pts_all, pts0, sizeof(float) * 3 * (size_t)n0, hipMemcpyDeviceToDevice, st));
         PCRCG_CHECK_HIP(hipMemcpyAsync(lens_all, len0, sizeof(int) * nb, hipMemcpyDeviceToDevice, st));
         PCRCG_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(feats), 0x3f800000, (size_t)(n0 > 0 ? n0 : 1), st));
-        out->n_levels = L;
-        out->features = feats;
-        out->feat_dim = 1;
     }
 
-    auto add_table = [&](pcrcg_table* dst, const void* grid, float radius, const float* q, const int* qlen, int nq, int ns,
-                         const int* slen, int limit, int sup_level) -> int {
+    auto add_table = [&](int kind, int level, int q_level, const void* grid, float radius, const float* q, const int* qlen,
+                         int nq, int ns, const int* slen, int limit, int sup_level) -> int {
         TableRec t;
-        t.dst = dst;
+        t.kind = kind; t.level = level; t.q_level = q_level;
         t.idx = A.take<int64_t>((size_t)nq * limit);
         t.counts = want_ties ? A.take<int>((size_t)nq) : nullptr;
         t.ties = want_ties ? A.take<int>((size_t)nq) : nullptr;
-        t.meta = metas + 3 * tables.size();
+        t.meta = metas + MS * tables.size();
         t.q = q; t.qlen = qlen; t.nq = nq; t.limit = limit; t.sup_level = sup_level; t.radius = radius;
         if (!A.ok()) return PCRCG_EWORKSPACE;
         if (!dry)
-            PCRCG_PROPAGATE(pcrcg_radius_query_ex(q, nq, qlen, ns, slen, nb, radius, grid, limit, t.idx, t.counts, t.meta,
-                                                  t.meta + 1, t.ties, want_ties ? t.meta + 2 : nullptr, st));
+            PCRCG_PROPAGATE(pcrcg_radius_query_groups(q, nq, qlen, ns, slen, nb, group, radius, grid, limit, t.idx, t.counts,
+                                                      t.meta, t.meta + P, t.ties, want_ties ? t.meta + P + 1 : nullptr, st));
         tables.push_back(t);
         return PCRCG_OK;
     };
@@ -195,28 +197,25 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
     float* pts = pts_all;
     int* lens = lens_all;
     int n = n0;
-    size_t row_off = 0;
+    float* level_pts[PCRCG_MAX_LEVELS];
+    int level_n[PCRCG_MAX_LEVELS];
     void* carried = nullptr;
     float carried_r = 0.f;
     for (int l = 0; l < L; ++l) {
         const int limit = cfg->limit[l];
         const float r_conv = cfg->r_conv[l], r_pool = cfg->r_pool[l];
-        if (!dry) { out->points[l] = pts; out->n_points[l] = n; out->stack_lengths[l] = lens; }
+        level_pts[l] = pts;
+        level_n[l] = n;
         void* grid = nullptr;
         float grid_r = 0.f;
-        if (!dry) {
-            out->neighbors[l] = pcrcg_table{nullptr, n, 0, 1};
-            out->pools[l] = pcrcg_table{nullptr, 0, 0, 1};
-            out->upsamples[l] = pcrcg_table{nullptr, 0, 0, 1};
-        }
         if (cfg->has_conv[l]) {
             if (carried && carried_r == r_conv) { grid = carried; grid_r = carried_r; }
             else { PCRCG_PROPAGATE(build_grid(pts, n, lens, r_conv, &grid)); grid_r = r_conv; }
-            PCRCG_PROPAGATE(add_table(dry ? nullptr : &out->neighbors[l], grid, r_conv, pts, lens, n, n, lens, limit, l));
+            PCRCG_PROPAGATE(add_table(0, l, l, grid, r_conv, pts, lens, n, n, lens, limit, l));
         }
         carried = nullptr;
         if (cfg->pooled[l] && l + 1 < L) {
-            float* sub = pts + 3 * ((size_t)n + 0);         // next level's rows directly behind this level's
+            float* sub = pts + 3 * (size_t)n;               // next level's rows directly behind this level's
             int* sub_len = lens + nb;
             int m = 0;
             {
@@ -238,13 +237,12 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
                 PCRCG_PROPAGATE(build_grid(pts, n, lens, r_pool, &grid));
                 grid_r = r_pool;
             }
-            PCRCG_PROPAGATE(add_table(dry ? nullptr : &out->pools[l], grid, r_pool, sub, sub_len, m, n, lens, limit, l));
+            PCRCG_PROPAGATE(add_table(1, l, l + 1, grid, r_pool, sub, sub_len, m, n, lens, limit, l));
             void* up_grid = nullptr;
             PCRCG_PROPAGATE(build_grid(sub, m, sub_len, 2 * r_pool, &up_grid));
-            PCRCG_PROPAGATE(add_table(dry ? nullptr : &out->upsamples[l], up_grid, 2 * r_pool, pts, lens, n, m, sub_len, limit, l + 1));
+            PCRCG_PROPAGATE(add_table(2, l, l, up_grid, 2 * r_pool, pts, lens, n, m, sub_len, limit, l + 1));
             carried = up_grid;
             carried_r = 2 * r_pool;
-            row_off += (size_t)n;
             pts = sub;
             lens = sub_len;
             n = m;
@@ -254,34 +252,69 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
         }
     }
     if (dry) return PCRCG_OK;
-    const size_t rows_total = row_off + (size_t)n;
+    const size_t rows_total = (size_t)(pts - pts_all) / 3 + (size_t)n;
 
-    // ---- one round trip for all tables: column counts, capacity status, rows holding ties -----------------
+    // ---- one round trip for all tables: column counts, capacity status, rows holding ties, cloud lengths --
     const int nt = (int)tables.size();
-    PCRCG_PROPAGATE(fetch(h_scratch, metas, 3 * nt, lens_all, L * nb, st));
+    PCRCG_PROPAGATE(fetch(h_scratch, metas, MS * nt, lens_all, L * nb, st));
     const int* hm = h_scratch + 1;
-    for (int i = 0; i < L * nb; ++i) h_lengths[i] = hm[3 * nt + i];
+    for (int i = 0; i < L * nb; ++i) h_lengths[i] = hm[MS * nt + i];
+    // rows of group p at level l: [row0, row0 + rows)
+    auto group_rows = [&](int l, int p, int* row0, int* rows) {
+        const int c0 = group > 0 ? p * group : 0, c1 = group > 0 ? c0 + group : nb;
+        int a = 0, r = 0;
+        for (int c = 0; c < c1; ++c) (c < c0 ? a : r) += h_lengths[(size_t)l * nb + c];
+        *row0 = a;
+        *rows = r;
+    };
+    for (int p = 0; p < P; ++p) {
+        pcrcg_batch& o = out[p];
+        o.n_levels = L;
+        int row0, rows;
+        group_rows(0, p, &row0, &rows);
+        o.features = feats + row0;
+        o.feat_dim = 1;
+        o.len_src_c = h_lengths[(size_t)(L - 1) * nb + (group > 0 ? p * group : 0)];
+        for (int l = 0; l < L; ++l) {
+            group_rows(l, p, &row0, &rows);
+            o.points[l] = level_pts[l] + 3 * (size_t)row0;
+            o.n_points[l] = rows;
+            o.stack_lengths[l] = lens_all + (size_t)l * nb + (group > 0 ? p * group : 0);
+            o.neighbors[l] = pcrcg_table{nullptr, rows, 0, 1};
+            o.pools[l] = pcrcg_table{nullptr, 0, 0, 1};
+            o.upsamples[l] = pcrcg_table{nullptr, 0, 0, 1};
+        }
+    }
     pcrcg_pyramid_restore local;
     pcrcg_pyramid_restore& R = deferred ? *deferred : local;
     R.njobs = 0;
     for (int i = 0; i < nt; ++i) {
         TableRec& t = tables[i];
-        const int max_count = hm[3 * i], status = hm[3 * i + 1], tie_rows = hm[3 * i + 2];
+        const int status = hm[MS * i + P], tie_rows = hm[MS * i + P + 1];
         if (status != 0) {
             set_error("pcrcg_pyramid_build: radius search capacity exceeded (table %d)", i);
             return PCRCG_ECAPACITY;
         }
-        // neighbors[:, :limit] keeps FEWER columns when the longest list is shorter (ref:datasets/dataloader.py:65-67)
-        const int cols = max_count < t.limit ? (max_count > 0 ? max_count : 0) : t.limit;
-        *t.dst = pcrcg_table{t.idx, t.nq, cols, t.limit};
-        if (want_ties && max_count > 0 && tie_rows > 0 && R.njobs < PCRCG_MAX_REORDER_JOBS) {
+        int widest = 0;
+        for (int p = 0; p < P; ++p) {
+            const int max_count = hm[MS * i + p];
+            widest = max_count > widest ? max_count : widest;
+            // neighbors[:, :limit] keeps FEWER columns when the longest list is shorter (ref:datasets/dataloader.py:65-67)
+            const int cols = max_count < t.limit ? (max_count > 0 ? max_count : 0) : t.limit;
+            int row0, rows;
+            group_rows(t.q_level, p, &row0, &rows);
+            pcrcg_table tab{t.idx + (size_t)row0 * t.limit, rows, cols, t.limit};
+            if (t.kind == 0) out[p].neighbors[t.level] = tab;
+            else if (t.kind == 1) out[p].pools[t.level] = tab;
+            else out[p].upsamples[t.level] = tab;
+        }
+        if (want_ties && widest > 0 && tie_rows > 0 && R.njobs < PCRCG_MAX_REORDER_JOBS) {
             pcrcg_reorder_job& j = R.jobs[R.njobs++];
             j.q = t.q; j.qlen = t.qlen; j.rows = t.ties; j.count = t.counts; j.idx = t.idx;
-            j.nq = t.nq; j.nbq = nb; j.cloud0 = nb * t.sup_level; j.nrows = tie_rows; j.max_count = max_count;
-            j.cols = t.limit; j.radius = t.radius;
+            j.nq = t.nq; j.nbq = nb; j.cloud0 = nb * t.sup_level; j.nrows = tie_rows; j.max_count = widest;
+            j.cols = t.limit; j.radius = t.radius; j.group = group;
         }
     }
-    out->len_src_c = h_lengths[(size_t)(L - 1) * nb];
     // ---- the reference's order inside groups of exactly equal distance (tieorder.hip) ----------------------
     R.pts_all = pts_all; R.lens_all = lens_all; R.rows_total = (int)rows_total; R.clouds_total = L * nb;
     R.forest = nullptr; R.forest_bytes = 0; R.tie_status = tie_status;
@@ -341,6 +374,8 @@ int pcrcg_pyramid_build(const float* pts, int n0, const int* len, int nb, const 
                         pcrcg_pyramid_restore* deferred, void* stream) {
     PCRCG_CHECK_ARG(cfg && pts && len && ws && h_scratch && out && h_lengths);
     PCRCG_CHECK_ARG(n0 >= 1 && nb >= 1 && nb <= 16);
+    PCRCG_CHECK_ARG(cfg->group >= 0 && (cfg->group == 0 || nb % cfg->group == 0));
+    PCRCG_CHECK_ARG((cfg->group > 0 ? nb / cfg->group : 1) + 2 <= 16 && cfg->n_levels * nb <= 64);
     PCRCG_CHECK_ARG(cfg->n_levels >= 1 && cfg->n_levels <= PCRCG_MAX_LEVELS && 3 * cfg->n_levels <= PCRCG_MAX_REORDER_JOBS);
     for (int l = 0; l < cfg->n_levels; ++l)
         PCRCG_CHECK_ARG(cfg->limit[l] >= 1 && cfg->r_conv[l] > 0.f && (l + 1 == cfg->n_levels || (cfg->dl[l] > 0.f && cfg->r_pool[l] > 0.f)));

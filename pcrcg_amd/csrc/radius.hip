@@ -164,7 +164,7 @@ template <int CAP, bool REDO, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
     const float* __restrict__ q, int nq, const int* __restrict__ qlen, int nb, float r2, GridView g, int cols,
     long long* __restrict__ out_idx, int* __restrict__ out_count, int* __restrict__ out_max, int* __restrict__ status,
-    int* __restrict__ tie_rows, int* __restrict__ tie_count) {
+    int* __restrict__ tie_rows, int* __restrict__ tie_count, int group) {
     __shared__ u64 s_list[WAVES][CAP];
     __shared__ u64 s_sorted[WAVES][CAP];
     __shared__ int s_excl[WAVES][32];
@@ -183,7 +183,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
     const double inv_cell = g.hdr->inv_cell;
     u64* list = s_list[wave];
     u64* sorted = s_sorted[wave];
-    int wave_max = 0;
+    // `group` > 0: the clouds form independent groups of `group` clouds each (several fragment pairs stacked into one
+    // call): indices are written relative to the first support of the query's group, rows are padded with the
+    // group's support count and the longest list is tracked per group (out_max[g]) -- i.e. the table comes out as the
+    // groups' own tables stacked on top of each other.  group == 0: one group (the reference's contract).
+    int wave_max = 0, wave_grp = 0;
+    auto flush_max = [&]() {   // one contended word per group: only the few waves that actually raise the maximum issue an atomic
+        if (lane == 0 && wave_max > aload(out_max + wave_grp)) atomicMax(out_max + wave_grp, wave_max);
+    };
     if (REDO && blockIdx.x == 0 && threadIdx.x == 0 && g.hdr->overflow && status) *status = 2;
     auto one_query = [&](const int qi) {
         // cloud of this query: walk the (few) query lengths
@@ -193,6 +200,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
         int cx, cy, cz;
         const bool inrange = cell_coords(qx, qy, qz, inv_cell, &cx, &cy, &cz);
         const int nsb = g.soff[b + 1] - g.soff[b];
+        int base = 0, ns_out = ns;
+        if (group > 0) {
+            const int grp = b / group, last = min(grp * group + group, nb);
+            base = g.soff[grp * group];
+            ns_out = g.soff[last] - base;
+            if (grp != wave_grp) { flush_max(); wave_grp = grp; wave_max = 0; }
+        }
         // lanes 0..26: look up one neighbouring cell each
         int ccount = 0, cstart = 0;
         if (lane < 27 && inrange && nsb > 0) {
@@ -288,10 +302,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
         // depend on the reference's traversal (tieorder.hip): report the row
         bool tie = false;
         for (int e = lane; e < cols; e += 64) {
-            long long vout = (long long)ns;
+            long long vout = (long long)ns_out;
             if (e < nl) {
                 const u64 mine = sorted[e];
-                vout = (long long)(unsigned)(mine & 0xFFFFFFFFull);
+                vout = (long long)((int)(unsigned)(mine & 0xFFFFFFFFull) - base);
                 tie |= e + 1 < nl && (unsigned)(sorted[e + 1] >> 32) == (unsigned)(mine >> 32);
             }
             __builtin_nontemporal_store(vout, &row[e]);
@@ -323,8 +337,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
             }
         }
     }
-    // one contended word: only the few waves that actually raise the maximum issue an atomic
-    if (lane == 0 && wave_max > aload(out_max)) atomicMax(out_max, wave_max);
+    flush_max();
     if (tie_rows) {
         __syncthreads();
         const int n = s_ntie < kTieCap ? s_ntie : kTieCap;
@@ -384,7 +397,14 @@ int pcrcg_radius_query(const float* q, int nq, const int* qlen, int ns, const in
 int pcrcg_radius_query_ex(const float* q, int nq, const int* qlen, int ns, const int* slen, int nb,
                           float radius, const void* grid, int cols, int64_t* out_idx, int* out_count,
                           int* out_max_count, int* status, int* out_tie_rows, int* out_tie_count, void* stream) {
-    PCRCG_CHECK_ARG(nq >= 0 && ns >= 0 && nb >= 1 && cols >= 1);
+    return pcrcg_radius_query_groups(q, nq, qlen, ns, slen, nb, 0, radius, grid, cols, out_idx, out_count, out_max_count,
+                                     status, out_tie_rows, out_tie_count, stream);
+}
+
+int pcrcg_radius_query_groups(const float* q, int nq, const int* qlen, int ns, const int* slen, int nb, int group,
+                              float radius, const void* grid, int cols, int64_t* out_idx, int* out_count,
+                              int* out_max_count, int* status, int* out_tie_rows, int* out_tie_count, void* stream) {
+    PCRCG_CHECK_ARG(nq >= 0 && ns >= 0 && nb >= 1 && cols >= 1 && group >= 0);
     PCRCG_CHECK_ARG((out_tie_rows == nullptr) == (out_tie_count == nullptr));
     PCRCG_CHECK_ARG(qlen && slen && grid && out_idx && out_max_count);
     PCRCG_CHECK_ARG(nq == 0 || q);
@@ -402,13 +422,13 @@ int pcrcg_radius_query_ex(const float* q, int nq, const int* qlen, int ns, const
     if (blocks > max_blocks) blocks = max_blocks;
     hipLaunchKernelGGL((k_radius_query<kListCapFast, false, kQueryWaves>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, q, nq, qlen,
                        nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status,
-                       out_tie_rows, out_tie_count);
+                       out_tie_rows, out_tie_count, group);
     // second pass: one wavefront per workgroup, 16 KB of LDS -- it finds a free slot at once on a busy GPU and
     // normally has nothing to do
     const int redo_blocks = blocks < 64 ? blocks : 64;
     hipLaunchKernelGGL((k_radius_query<kListCapFull, true, 1>), dim3(redo_blocks), dim3(64), 0, st, q, nq, qlen, nb, r2, g,
                        cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status, out_tie_rows,
-                       out_tie_count);
+                       out_tie_count, group);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

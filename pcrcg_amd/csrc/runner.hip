@@ -130,6 +130,17 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
         c.release(m0);
         return;
     }
+    // fine levels with a small weight set: gather + aggregate + contraction in one kernel, `wf` never reaches HBM
+    if (blk.kp_wsplit && !blk.kp_w_pad && pcrcg_kpconv_x6_supported(nq, x.cols, y.cols)) {
+        const size_t m0 = c.mark();
+        const size_t wsb0 = pcrcg_kpconv_ws_bytes(ns);
+        void* ws0 = c.raw(wsb0);
+        if (c.live())
+            c.check(pcrcg_kpconv_x6(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, x.p, x.cols, blk.kp, blk.extent,
+                                    blk.kp_wsplit, y.cols, y.p, y.ld, ws0, wsb0, c.st));
+        c.release(m0);
+        return;
+    }
     const size_t m = c.mark();
     // channel counts that are not a multiple of 4 (the 129-channel PCR-CG input): zero-padded copy of the
     // features + zero-padded weights, so that the MFMA gather kernel applies (zeros change neither the sums nor
@@ -148,19 +159,37 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
         xp = pad.p;
         w = blk.kp_w_pad;
     }
-    Mat wf = c.mat(nq, PCRCG_KPOINTS * cin);
-    float* inv_n = static_cast<float*>(c.raw(sizeof(float) * (nq > 0 ? nq : 1)));
+    // Row chunks: when the layer's wf would stream through HBM (hundreds of MB), aggregate and contract a slice of the
+    // queries at a time so that the slice's wf is still in L2 / Infinity Cache when the contraction reads it, and the
+    // (reused) buffer's dirty lines are overwritten on chip instead of being written back.
+    static const long chunk_bytes = [] { const char* e = getenv("PCRCG_KPCONV_CHUNK_MB"); return (long)(e ? atoi(e) : 48) << 20; }();
+    const long row_bytes = (long)PCRCG_KPOINTS * cin * sizeof(float);
+    int chunk = nq;
+    if (chunk_bytes > 0 && (long)nq * row_bytes > 2 * chunk_bytes) {
+        chunk = (int)(chunk_bytes / row_bytes);
+        chunk = chunk / 128 * 128;
+        if (chunk < 4096) chunk = nq;
+    }
+    const bool chunked = chunk < nq;
+    Mat wf = c.mat(chunk, PCRCG_KPOINTS * cin);
+    float* inv_n = static_cast<float*>(c.raw(sizeof(float) * (chunk > 0 ? chunk : 1)));
     const size_t wsb = pcrcg_kpconv_ws_bytes(ns);
     void* ws = c.raw(wsb);
     if (c.live()) {
-        c.check(pcrcg_kpconv_aggregate(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, xp, cin, blk.kp, blk.extent,
-                                       wf.p, inv_n, ws, wsb, c.st));
         // contraction wf @ W: against the K-contiguous copy wt [cout, 15*cin] when the descriptor carries one
         // (C = A * B^T form: both operands k-contiguous, the form the split-bf16 GEMM is built for)
         const bool kt = blk.kp_wt != nullptr;
-        c.check(pcrcg_gemm_f32_colstats(wf.p, wf.ld, kt ? blk.kp_wt : w, kt ? wf.cols : y.cols, kt ? 1 : 0, y.p, y.ld, nq,
-                                        y.cols, wf.cols, inv_n, nullptr, st ? st->partials : nullptr, st ? st->bytes : 0,
-                                        st ? &st->chunks : nullptr, c.st));
+        for (int r0 = 0; r0 < nq; r0 += chunk) {
+            const int rows = nq - r0 < chunk ? nq - r0 : chunk;
+            c.check(kpconv_aggregate_rows(q + 3 * (long)r0, rows, b.points[l], ns, t.idx + (long)r0 * t.ld, t.cols, t.ld, xp, cin,
+                                          blk.kp, blk.extent, wf.p, inv_n, ws, wsb, c.st, r0 == 0, !chunked));
+            // (column statistics ride along only when the layer is one GEMM call: their chunk index is the tile row)
+            c.check(pcrcg_gemm_f32_colstats(wf.p, wf.ld, kt ? blk.kp_wt : w, kt ? wf.cols : y.cols, kt ? 1 : 0,
+                                            y.p + (long)r0 * y.ld, y.ld, rows, y.cols, wf.cols, inv_n, nullptr,
+                                            (st && !chunked) ? st->partials : nullptr, (st && !chunked) ? st->bytes : 0,
+                                            (st && !chunked) ? &st->chunks : nullptr, c.st));
+        }
+        if (st && chunked) st->chunks = 0;
     }
     c.release(m);
 }
@@ -236,12 +265,12 @@ Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, con
         c.check(pcrcg_knn(coords, n, k, idx, c.st));
         c.check(pcrcg_copy2d(f.p, f.ld, cat.p, cat.ld, n, ch, c.st));                                    // x0
         // x1 = max_k lrelu(IN2d(conv1(cat(f_i, f_j - f_i))))  (:121-125)
-        c.check(pcrcg_gemm_f32(f.p, f.ld, g.edge1, 2 * ch, 0, cn1.p, cn1.ld, n, 2 * ch, ch, nullptr, nullptr, c.st));
+        c.check(pcrcg_gemm_f32(f.p, f.ld, g.edge1, ch, 1, cn1.p, cn1.ld, n, 2 * ch, ch, nullptr, nullptr, c.st));
         c.check(pcrcg_edgeconv_reduce(cn1.p, cn1.ld, cn1.p + ch, cn1.ld, idx, n, k, ch, 1e-5f, e1.p, e1.ld, stats, ws,
                                       wsb, c.st));
         c.check(pcrcg_instnorm_apply(e1.p, n, ch, e1.ld, stats, nullptr, 0, nullptr, 0.2f, cat.p + ch, cat.ld, c.st));
         // x2 from x1 with conv2 (:127-129)
-        c.check(pcrcg_gemm_f32(cat.p + ch, cat.ld, g.edge2, 4 * ch, 0, cn2.p, cn2.ld, n, 4 * ch, ch, nullptr, nullptr,
+        c.check(pcrcg_gemm_f32(cat.p + ch, cat.ld, g.edge2, ch, 1, cn2.p, cn2.ld, n, 4 * ch, ch, nullptr, nullptr,
                                c.st));
         c.check(pcrcg_edgeconv_reduce(cn2.p, cn2.ld, cn2.p + 2 * ch, cn2.ld, idx, n, k, 2 * ch, 1e-5f, e2.p, e2.ld, stats,
                                       ws, wsb, c.st));

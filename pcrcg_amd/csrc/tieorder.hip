@@ -763,7 +763,12 @@ __global__ void __launch_bounds__(kReorderWaves * 64) k_reorder(ReorderJobs jobs
     int b = 0, qacc = 0;
     while (b < jb.nbq - 1 && qi >= qacc + jb.qlen[b]) { qacc += jb.qlen[b]; ++b; }
     const int root = jb.cloud0 + b;
-    const int seg = v.soff[jb.cloud0], pad = v.soff[jb.cloud0 + jb.nbq] - seg;
+    int seg = v.soff[jb.cloud0], pad = v.soff[jb.cloud0 + jb.nbq] - seg;
+    if (jb.group > 0) {   // independent groups of clouds: relative to the query's own group
+        const int g0 = jb.cloud0 + (b / jb.group) * jb.group, g1 = min(g0 + jb.group, jb.cloud0 + jb.nbq);
+        seg = v.soff[g0];
+        pad = v.soff[g1] - seg;
+    }
     const float r2 = jb.radius * jb.radius;      // neighbors.cpp:226
     const float vx = q[3 * (long)qi], vy = q[3 * (long)qi + 1], vz = q[3 * (long)qi + 2];
     const u64 below = (1ull << lane) - 1ull;
@@ -943,6 +948,7 @@ int pcrcg_radius_reorder(const float* q, int nq, const int* qlen, int nbq, const
     j.max_count = max_count;
     j.cols = cols;
     j.radius = radius;
+    j.group = 0;
     return pcrcg_radius_reorder_jobs(&j, 1, sup, ns, nb, forest, status, stream);
 }
 }

@@ -176,7 +176,8 @@ class ReorderJob(ctypes.Structure):
     """pcrcg_reorder_job (include/pcrcg.h)."""
     _fields_ = [("q", ctypes.c_void_p), ("qlen", ctypes.c_void_p), ("rows", ctypes.c_void_p), ("count", ctypes.c_void_p),
                 ("idx", ctypes.c_void_p), ("nq", ctypes.c_int), ("nbq", ctypes.c_int), ("cloud0", ctypes.c_int),
-                ("nrows", ctypes.c_int), ("max_count", ctypes.c_int), ("cols", ctypes.c_int), ("radius", ctypes.c_float)]
+                ("nrows", ctypes.c_int), ("max_count", ctypes.c_int), ("cols", ctypes.c_int), ("radius", ctypes.c_float),
+                ("group", ctypes.c_int)]
 
 
 class KdForest:
@@ -221,6 +222,7 @@ class KdForest:
             j.nq, j.nbq, j.cloud0 = idx.shape[0], qlen.shape[0], int(t["cloud0"])
             j.nrows = idx.shape[0] if rows is None else int(t["nrows"])
             j.max_count, j.cols, j.radius = int(t["max_count"]), idx.shape[1], float(t["radius"])
+            j.group = int(t.get("group", 0))
             if status is None:
                 status = torch.zeros(1, dtype=_I32, device=idx.device)
         if status is None:

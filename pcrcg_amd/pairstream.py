@@ -53,7 +53,8 @@ class _Mailbox:
 class PairStreams:
     ARENAS = 4        # per front thread: pairs whose tables may be alive at once (built, forward not yet passed)
 
-    def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=2, tie_order=None):
+    def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=2, tie_order=None,
+                 pairs_per_build=2):
         self.net, self.config, self.limits = net, config, neighborhood_limits
         self.device = torch.device(device if device is not None else "cuda")
         if not getattr(net, "use_runner", False):
@@ -80,13 +81,16 @@ class PairStreams:
         for ring in self._free:
             for q in ring:
                 q.put(None)
-        self._in = [queue.Queue() for _ in range(nf)]
+        self._in = queue.Queue()               # one queue: a front thread takes up to `pairs_per_build` consecutive pairs
+        self._take = threading.Lock()
+        self._per_build = max(1, int(os.environ.get("PCRCG_PAIRS_PER_BUILD", pairs_per_build)))
+        self._users = [[1] * self.ARENAS for _ in range(nf)]   # forwards that read the arena's current contents
         self._mid = [_Mailbox() for _ in self.models]
         self._out = [queue.Queue() for _ in self.models]
         self._submitted = self._returned = 0
         self._pending = []                     # (status tensor, slot, event) of pairs whose tie status is unread
         self._lock = threading.Lock()
-        self.stats = {"pairs": 0, "front_idle_s": 0.0, "arena_wait_s": 0.0, "build_s": 0.0, "model_idle_s": 0.0,
+        self.stats = {"pairs": 0, "builds": 0, "front_idle_s": 0.0, "arena_wait_s": 0.0, "build_s": 0.0, "model_idle_s": 0.0,
                       "launch_s": 0.0}      # host seconds per stage, summed over the threads of the stage
         self._threads = []
         for f in range(nf):
@@ -113,35 +117,58 @@ class PairStreams:
         front = self.fronts[f % len(self.fronts)]
         while True:
             t0 = time.perf_counter()
-            item = self._in[f].get()
-            if item is None:
-                return
+            with self._take:                   # consecutive pairs go to one thread
+                items = [self._in.get()]
+                while items[-1] is not None and len(items) < self._per_build:
+                    try:
+                        items.append(self._in.get_nowait())
+                    except queue.Empty:
+                        break
+            if items[-1] is None:
+                self._in.put(None)             # pass the shutdown token on to the other front threads
+                items.pop()
+                if not items:
+                    return
             self.stats["front_idle_s"] += time.perf_counter() - t0
-            seq, points, lengths, ready = item
-            m = seq % len(self.models)
             a = turn % self.ARENAS
             turn += 1
+            k = len(items)
             try:
                 with torch.cuda.stream(front), torch.no_grad():
-                    front.wait_event(ready)                       # inputs may still be in flight on the caller's stream
-                    points.record_stream(front)
-                    lengths.record_stream(front)
+                    for _, points, lengths, ready in items:
+                        front.wait_event(ready)                   # inputs may still be in flight on the caller's stream
+                        points.record_stream(front)
+                        lengths.record_stream(front)
                     t0 = time.perf_counter()
-                    freed = self._free[f][a].get()                # blocks until that forward has been enqueued
-                    if freed is not None:
-                        front.wait_event(freed)                   # ... and the stream waits until it has passed
+                    for _ in range(self._users[f][a]):            # blocks until those forwards have been enqueued ...
+                        freed = self._free[f][a].get()
+                        if freed is not None:
+                            front.wait_event(freed)               # ... and the stream waits until they have passed
+                    self._users[f][a] = k
                     pyr = self._pyr[f][a]
                     t1 = time.perf_counter()
-                    b, arena, lens_h, slot, deferred = pyr.build(points, lengths, defer_restore=True)
+                    if k == 1:
+                        # one pair: its tie-order restore step goes to the pair's model stream
+                        b, arena, lens_h, slot, deferred = pyr.build(items[0][1], items[0][2], defer_restore=True)
+                        batches = [b]
+                    else:
+                        # several pairs stacked into ONE kernel chain (the chain is latency-bound: k pairs cost little
+                        # more than one); the restore step covers all of them and runs here
+                        batches, arena, lens_h, slot = pyr.build(torch.cat([it[1] for it in items]),
+                                                                 torch.cat([it[2] for it in items]), group=2)
+                        deferred = None
                     self.stats["arena_wait_s"] += t1 - t0
                     self.stats["build_s"] += time.perf_counter() - t1
-                    self.stats["pairs"] += 1
+                    self.stats["pairs"] += k
+                    self.stats["builds"] += 1
                     built = torch.cuda.Event()
                     built.record(front)
-                self._mid[m].put(seq, (b, arena, built, pyr, slot, deferred, f, a))
+                for i, it in enumerate(items):
+                    self._mid[it[0] % len(self.models)].put(it[0], (batches[i], arena, built, pyr, slot, deferred, f, a))
             except BaseException as e:                            # surfaced by result()
-                self._free[f][a].put(None)
-                self._mid[m].put(seq, e)
+                for it in items:
+                    self._free[f][a].put(None)
+                    self._mid[it[0] % len(self.models)].put(it[0], e)
 
     def _serve_model(self, m):
         torch.cuda.set_device(self.device)
@@ -166,7 +193,8 @@ class PairStreams:
                     t0 = time.perf_counter()
                     # the reference's order inside tie groups (KD-forest + reorder), here rather than on the front-end
                     # stream: that stream's serial kernel chain is the pipeline's bottleneck, the model streams have slack
-                    pyr.restore(deferred, slot)
+                    if deferred is not None:
+                        pyr.restore(deferred, slot)
                     out = self.runner.launch(b, self.device)
                     self.stats["launch_s"] += time.perf_counter() - t0
                     done = torch.cuda.Event()
@@ -186,7 +214,7 @@ class PairStreams:
         self._submitted += 1
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))
-        self._in[seq % len(self._in)].put((seq, points, lengths, ready))
+        self._in.put((seq, points, lengths, ready))
 
     def result(self, wait=False):
         """Outputs of the oldest submitted pair, plus out["done_event"] (a torch.cuda.Event recorded behind their last
@@ -239,8 +267,7 @@ class PairStreams:
         self._check_status(wait=True)
 
     def close(self):
-        for q in self._in:
-            q.put(None)
+        self._in.put(None)
         for mb in self._mid:
             mb.put(None, None)
         for t in self._threads:

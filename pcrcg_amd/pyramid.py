@@ -257,12 +257,15 @@ class NativePyramid:
                                                                   torch.cuda.current_stream().cuda_stream),
                         "pcrcg_pyramid_restore_run")
 
-    def build(self, points, lengths, fresh_arena=False, defer_restore=False):
+    def build(self, points, lengths, fresh_arena=False, defer_restore=False, group=0):
         """points [N0,3] f32, lengths [B] i32 on the device; enqueues on the CURRENT stream.
         -> (pcrcg_batch mirror, arena tensor it points into, per-level cloud lengths (python lists),
             slot of this call's status word in self.status -- valid once the stream has drained).
         defer_restore: the tie-order restore step is not enqueued; a fifth value, its descriptor, is returned for
-        restore() to run on the stream that will read the tables."""
+        restore() to run on the stream that will read the tables.
+        group: 0 = the clouds form one batch.  2 = the clouds are len(lengths) / 2 independent PAIRS stacked into one
+        call (the front end's kernel chain is latency-bound: two pairs cost little more than one); the first value then
+        is a ctypes array of that many pcrcg_batch mirrors, each with its own tables."""
         ct, L = self._ct, self._lib.lib()
         if not points.is_cuda:
             raise RuntimeError("pcrcg_amd.build_pyramid: points must be on a HIP device (no CPU path)")
@@ -270,6 +273,10 @@ class NativePyramid:
         lens = lengths.to(_I32).contiguous()
         n0, nb = int(pts.shape[0]), int(lens.shape[0])
         stream = torch.cuda.current_stream().cuda_stream
+        if group and nb % group:
+            raise RuntimeError("pcrcg_amd.NativePyramid: the number of clouds is not a multiple of `group`")
+        self.cfg.group = int(group)
+        nbatch = nb // group if group else 1
         h_len = (ct.c_int * (self.levels * nb))()
         from .runner import PyramidRestore
         deferred = PyramidRestore() if defer_restore else None
@@ -284,7 +291,7 @@ class NativePyramid:
                 arena = torch.empty(int(need), dtype=torch.uint8, device=pts.device)
                 if not fresh_arena:
                     self.arena = arena
-            b = self._Batch()
+            b = (self._Batch * nbatch)() if group else self._Batch()
             rc = L.pcrcg_pyramid_build(pts.data_ptr(), n0, lens.data_ptr(), nb, ct.byref(self.cfg), arena.data_ptr(),
                                        arena.numel(), self.scratch.data_ptr(), ct.byref(b), h_len,
                                        self.status.data_ptr() + 4 * slot,
@@ -299,9 +306,12 @@ class NativePyramid:
             return b, arena, lens_h, slot, deferred
         return b, arena, lens_h, slot
 
-    def as_dict(self, b, arena, lens_h):
-        """The reference's batch dict as zero-copy views into the arena."""
+    def as_dict(self, b, arena, lens_h, part=None):
+        """The reference's batch dict as zero-copy views into the arena.  part = (first cloud, clouds) selects the
+        lengths of one group when `b` is one batch of a grouped build."""
         base = arena.data_ptr()
+        if part is not None:
+            lens_h = [row[part[0]:part[0] + part[1]] for row in lens_h]
         nb = len(lens_h[0])
 
         def view(ptr, nbytes, dtype):

@@ -4,7 +4,8 @@ and enqueues the complete forward pass with ONE call into libpcrcg_hip.so.
 
 Weights are used in place as stored in the (reference-compatible) state_dict.  Three re-packed copies
 are made once per weight version and cached:
-  * DGCNN edge convs: [Cout, 2Cin] -> [Cin, 2Cout] = [(Wa-Wb)^T | Wb^T]   (centre | neighbour term)
+  * DGCNN edge convs: [Cout, 2Cin] -> [2Cout, Cin] = [Wa-Wb ; Wb]   (centre term rows, then neighbour term rows;
+    k-contiguous like every other weight: the C = A @ B^T form the split-bf16 GEMM is built for)
   * attention projections / merge: channels permuted head-major (the reference interleaves heads,
     ref:models/gcn.py:170)
   * decoder unary weights with 1538 / 769 input channels: rows padded to a multiple of 4 floats."""
@@ -28,7 +29,7 @@ class Block(ctypes.Structure):
                 ("in_dim", ctypes.c_int), ("out_dim", ctypes.c_int), ("mid_dim", ctypes.c_int),
                 ("extent", ctypes.c_float), ("kp", _fp), ("kp_w", _fp), ("kp_wt", _fp), ("kp_w_pad", _fp),
                 ("cin_pad", ctypes.c_int), ("unary1", _fp), ("unary2", _fp),
-                ("shortcut", _fp), ("mlp", _fp), ("mlp_ld", ctypes.c_int)]
+                ("shortcut", _fp), ("mlp", _fp), ("mlp_ld", ctypes.c_int), ("kp_wsplit", _fp)]
 
 
 class GnnLayer(ctypes.Structure):
@@ -62,14 +63,15 @@ class PyramidCfg(ctypes.Structure):
     """pcrcg_pyramid_cfg (include/pcrcg.h)."""
     _fields_ = [("n_levels", ctypes.c_int), ("r_conv", ctypes.c_float * MAX_LEVELS), ("r_pool", ctypes.c_float * MAX_LEVELS),
                 ("dl", ctypes.c_float * MAX_LEVELS), ("has_conv", ctypes.c_int * MAX_LEVELS),
-                ("pooled", ctypes.c_int * MAX_LEVELS), ("limit", ctypes.c_int * MAX_LEVELS), ("tie_order", ctypes.c_int)]
+                ("pooled", ctypes.c_int * MAX_LEVELS), ("limit", ctypes.c_int * MAX_LEVELS), ("tie_order", ctypes.c_int),
+                ("group", ctypes.c_int)]
 
 
 class ReorderJobC(ctypes.Structure):
     """pcrcg_reorder_job (include/pcrcg.h)."""
     _fields_ = [("q", _fp), ("qlen", _fp), ("rows", _fp), ("count", _fp), ("idx", _fp), ("nq", ctypes.c_int),
                 ("nbq", ctypes.c_int), ("cloud0", ctypes.c_int), ("nrows", ctypes.c_int), ("max_count", ctypes.c_int),
-                ("cols", ctypes.c_int), ("radius", ctypes.c_float)]
+                ("cols", ctypes.c_int), ("radius", ctypes.c_float), ("group", ctypes.c_int)]
 
 
 class PyramidRestore(ctypes.Structure):
@@ -144,6 +146,16 @@ class Runner:
             blk.kp_w_pad, blk.cin_pad = self._w(w), cp
         k = w.shape[0] * w.shape[1]
         blk.kp_wt = self._w(w.reshape(k, kp.out_channels).t()) if k % 4 == 0 else None
+        # exact three-term bf16 split of wt for the fused kernel (csrc/kpconv_x6.hip) on the layers it supports
+        blk.kp_wsplit = None
+        L = _lib.lib()
+        if blk.kp_wt and L.pcrcg_kpconv_x6_supported(1 << 20, cin, kp.out_channels):
+            wt = self.keep[-1]
+            planes = torch.empty(int(L.pcrcg_split_bf16x3_bytes(kp.out_channels, k)), dtype=torch.uint8, device=wt.device)
+            _lib.check(L.pcrcg_split_bf16x3(wt.data_ptr(), k, kp.out_channels, k, planes.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "pcrcg_split_bf16x3")
+            self.keep.append(planes)
+            blk.kp_wsplit = planes.data_ptr()
 
     def _fill_block(self, blk, mod):
         if isinstance(mod, SimpleBlock):
@@ -185,7 +197,7 @@ class Runner:
                 w = conv.weight.data.flatten(1)
                 cin = w.shape[1] // 2
                 wa, wb = w[:, :cin], w[:, cin:]
-                return self._w(torch.cat([(wa - wb).t(), wb.t()], 1))
+                return self._w(torch.cat([wa - wb, wb], 0))      # [2Cout, Cin]: rows = output channels (centre | neighbour)
             g.edge1, g.edge2 = pack(layer.conv1), pack(layer.conv2)
             g.conv3 = self._w(layer.conv3.weight.data.flatten(1))
         elif isinstance(layer, AttentionalPropagation):

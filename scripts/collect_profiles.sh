@@ -1,0 +1,24 @@
+#!/bin/bash
+# GPU box: bench line + rocprofv3 summaries for profiles/ (run through gpurun; writes under gpurun_out/$1_*).
+# usage: scripts/collect_profiles.sh r02_v1
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py --steps 50 --warmup 5 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json
+db() { find "$1" -name "*results.db" | head -1; }
+# 1. the timed bench under the kernel tracer
+rm -rf /tmp/p1; rocprofv3 --kernel-trace --stats -d /tmp/p1 -o p -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprof.json
+python3 $R/scripts/prof_summary.py $(db /tmp/p1) $O/${TAG}_kernel_stats.csv 58
+python3 $R/scripts/front_chain.py $(db /tmp/p1) > $O/${TAG}_front_chain.txt 2>&1
+# 2. the isolated forwards (one stream, nothing else running)
+rm -rf /tmp/p2; rocprofv3 --kernel-trace --stats -d /tmp/p2 -o p -- python3 $R/bench.py --isolated-only --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/${TAG}_isolated.json
+python3 $R/scripts/prof_summary.py $(db /tmp/p2) $O/${TAG}_isolated_kernel_stats.csv 24
+# 3. PMC passes (separate runs, counters only + kernel trace)
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/p3; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/p3 -o p -- python3 $R/bench.py --isolated-only --steps 3 --warmup 1 > /dev/null 2>&1
+  cp $(find /tmp/p3 -name "*counter_collection.csv" | head -1) $O/${TAG}_pmc_$C.csv
+done
+python3 $R/scripts/pmc_summary.py $O/${TAG}_pmc_FETCH_SIZE.csv $O/${TAG}_pmc_WRITE_SIZE.csv $O/${TAG}_pmc_traffic.json
+rm -f $O/${TAG}_pmc_FETCH_SIZE.csv $O/${TAG}_pmc_WRITE_SIZE.csv
+ls -la $O | grep ${TAG}

@@ -4,8 +4,10 @@
                                     torch.manual_seed(0) / np.random.seed(0) -- pcrcg_amd builds the bit-identical
                                     model from the same seeds, tests/test_host_logic.py) on the reference's own
                                     collate of the S30k pair 0 (BASELINE.json configs[1]) with limits [43,42,47,43]:
-                                    every 97th row of feats_f / scores_overlap / scores_saliency, their means, and
-                                    the per-column means of three encoder activations.
+                                    every 97th row of feats_f / scores_overlap / scores_saliency, their means, the
+                                    per-column means of three encoder activations, the two full score vectors and
+                                    the 5000 source points the reference's test-time sampler (ref:lib/tester.py:152-164)
+                                    draws from them under np.random.seed(7).
   tests/golden/model_s30k_lomatch.pt  the same on the 3DLoMatch-shaped pair (configs[2]): every 97th output row, plus
                                     the reference MetricLoss's pure sub-methods on those outputs are NOT included
                                     (lib/loss.py hard-codes 'cuda' in forward; tests/golden/loss_mini.pt pins them).
@@ -82,7 +84,14 @@ def main():
         limits = S.LIMITS["S30k"]
         src, tgt = S.pair("S30k", 0)
         batch, out, inter = ref_forward(src, tgt, limits)
+        # test-time sampler (ref:lib/tester.py:152-164): the draw the reference makes from ITS scores under a fixed host seed
+        n_src = len(src)
+        sc = (out["scores_overlap"] * out["scores_saliency"])[:n_src]
+        np.random.seed(7)
+        picks = np.random.choice(np.arange(n_src), size=5000, replace=False, p=(sc / sc.sum()).numpy().flatten())
         torch.save({"recipe": "S30k", "seed": 0, "limits": limits, "stride": STRIDE,
+                    "scores_overlap_full": out["scores_overlap"].clone(), "scores_saliency_full": out["scores_saliency"].clone(),
+                    "sample_seed": 7, "sample_n": 5000, "sample_idx_src": torch.from_numpy(picks),
                     "levels": [int(p.shape[0]) for p in batch["points"]],
                     "rows": {k: v[::STRIDE].clone() for k, v in out.items()},
                     "means": {k: float(v.double().mean()) for k, v in out.items()},

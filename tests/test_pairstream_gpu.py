@@ -79,6 +79,31 @@ def test_native_pyramid_reference_digests(cuda, golden_dir, recipe):
                 assert sha(t, np.int32) == dig[f"{name}{l}"]["sha256"], (name, l)
 
 
+def test_two_pairs_in_one_chain_equal_two_builds(cuda):
+    """group = 2: two (different-sized) pairs stacked into one call come out as their own batches -- the tables each
+    pair gets when built alone, entry for entry, incl. the reference's order inside tie groups (T8k)."""
+    cfg = indoor_config()
+    limits = synthetic.LIMITS["C1"]
+    for ra, rb in (("C1", "T8k"), ("S30k", "C1"), ("mini", "mini")):
+        (pa, la), (pb, lb) = _pair(ra, 0, cuda), _pair(rb, 1, cuda)
+        nat = NativePyramid(cfg, limits, "auto")
+        b, arena, lens_h, slot = nat.build(torch.cat([pa, pb]), torch.cat([la, lb]), group=2)
+        torch.cuda.synchronize()
+        assert int(nat.status[slot]) == 0 and len(b) == 2
+        for i, (pts, lens) in enumerate(((pa, la), (pb, lb))):
+            got = nat.as_dict(b[i], arena, lens_h, part=(2 * i, 2))
+            want = build_pyramid_native(pts, lens, cfg, limits, "auto")
+            assert got["stack_lengths_host"] == want["stack_lengths_host"], (ra, rb, i)
+            assert b[i].len_src_c == want["stack_lengths_host"][-1][0]
+            for l in range(cfg.num_layers):
+                assert torch.equal(got["points"][l].view(torch.int32), want["points"][l].view(torch.int32)), (ra, rb, i, l)
+                assert torch.equal(got["stack_lengths"][l], want["stack_lengths"][l]), (ra, rb, i, l)
+                for key in ("neighbors", "pools", "upsamples"):
+                    assert got[key][l].shape == want[key][l].shape, (ra, rb, i, key, l, got[key][l].shape, want[key][l].shape)
+                    assert torch.equal(got[key][l], want[key][l]), (ra, rb, i, key, l)
+            assert torch.equal(got["features"], want["features"])
+
+
 def test_arena_grows_when_levels_shrink_less_than_assumed(cuda):
     """A cloud whose subsampled levels keep more than half of their rows (dl far below the point spacing)."""
     cfg = indoor_config(first_subsampling_dl=0.0005)

@@ -76,6 +76,34 @@ def test_s30k_full_width_outputs_vs_reference(cuda, golden_dir, net):
         assert rel(ops_out[k], out[k]) < TOL, k
 
 
+def test_tester_record_and_sampler_on_s30k(cuda, golden_dir, net):
+    """SURVEY.md 8f rank 3 at size: the per-pair record IndoorTester.test dumps (ref:lib/tester.py:92-102) and the
+    overlap x saliency sampler in front of RANSAC (:152-164), against what the reference produced for this pair."""
+    from pcrcg_amd.tester import probabilistic_sample, test_record
+    gold = torch.load(os.path.join(golden_dir, "model_s30k.pt"))
+    src, tgt = synthetic.pair("S30k", gold["seed"])
+    batch = build_pyramid(*_stack(src, tgt, cuda), indoor_config(), gold["limits"])
+    batch["rot"], batch["trans"] = torch.eye(3), torch.zeros(3, 1)
+    with torch.no_grad():
+        out = net(batch)
+    rec = test_record(batch, out)
+    assert rec["len_src"] == len(src) and rec["pcd"].shape == (60000, 3) and not rec["feats"].is_cuda
+    assert torch.equal(rec["pcd"], torch.from_numpy(np.concatenate([src, tgt])))
+    assert rel(rec["overlaps"], gold["scores_overlap_full"]) < TOL and rel(rec["saliency"], gold["scores_saliency_full"]) < TOL
+    n = len(src)
+    # the reference's own scores through the sampler (device tensors in, host generator as in the reference): its draw
+    sc_ref = (gold["scores_overlap_full"] * gold["scores_saliency_full"])[:n].to(cuda)
+    np.random.seed(gold["sample_seed"])
+    p, f, idx = probabilistic_sample(batch["points"][0][:n], out["feats_f"][:n], sc_ref, gold["sample_n"])
+    assert np.array_equal(idx, gold["sample_idx_src"].numpy()) and p.shape == (gold["sample_n"], 3) and p.is_cuda
+    # this path's scores: the same draw up to the few picks that sit on a cumulative-probability boundary
+    np.random.seed(gold["sample_seed"])
+    _, _, idx2 = probabilistic_sample(batch["points"][0][:n], out["feats_f"][:n],
+                                      (out["scores_overlap"] * out["scores_saliency"])[:n], gold["sample_n"])
+    same = len(set(idx2.tolist()) & set(gold["sample_idx_src"].tolist()))
+    assert same >= 0.98 * gold["sample_n"], same
+
+
 def test_s30k_lomatch_forward_and_train_step(cuda, golden_dir, monkeypatch):
     """configs[2] at its real size."""
     gold = torch.load(os.path.join(golden_dir, "model_s30k_lomatch.pt"))
