@@ -197,7 +197,7 @@ def main():
     # PCRCG_PIPELINE=legacy selects round 1's generator-interleaving pipeline (pcrcg_amd/pipeline.py) for comparison.
     legacy = os.environ.get("PCRCG_PIPELINE", "streams") == "legacy"
     WORKERS = int(os.environ.get("PCRCG_MODEL_STREAMS", "3"))
-    FRONTS = int(os.environ.get("PCRCG_FRONT_THREADS", "2"))
+    FRONTS = int(os.environ.get("PCRCG_FRONT_THREADS", "1"))
     DEPTH = int(os.environ.get("PCRCG_PIPE_DEPTH", "6" if not legacy else "4"))
     if os.environ.get("PCRCG_SWITCH_US"):
         sys.setswitchinterval(float(os.environ["PCRCG_SWITCH_US"]) * 1e-6)

@@ -268,6 +268,23 @@ int pcrcg_instnorm_apply(const float* x, int n, int c, int ldx, const float* sta
                          int ldr, const float* res_stats, float slope, float* y, int ldy, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * PCR-CG's image-feature injection (ref:models/architectures.py:195-514): the geometric input feature (a column of
+ * ones) becomes [N, c+1] = ones, and every 3-D point that projects into a colour image receives that pixel's 2-D
+ * feature in columns 0..c-1 (column c stays 1):
+ *     x[inds3d[j] + row_offset, 0:c] = fmap[:, inds2d[j,1], inds2d[j,0]] * valid[inds2d[j,0], inds2d[j,1]]
+ * fmap [c, h, w] f32 is the 2-D backbone's output for one image (the backbone itself is outside the path; any
+ * producer of such a map plugs in), valid [w, h] f32 its valid-pixel mask as the reference stores it (NULL: none,
+ * the three-image branch :196-252), inds2d [n, 2] i64 = (column, row), inds3d [n] i64 = point index inside its cloud,
+ * row_offset = 0 for the source cloud / the source cloud's size for the target cloud (:239-241).  The reference
+ * writes image 3, 2, 1 in that order so that image 1 wins where projections overlap: call once per image in the
+ * same order on the same stream.  pcrcg_fill2d writes the constant (ones) matrix first.
+ * ---------------------------------------------------------------------------------------------- */
+int pcrcg_fill2d(float* dst, int ld, int rows, int cols, float value, void* stream);
+int pcrcg_inject_image_features(const float* fmap, int c, int h, int w, const float* valid, const int64_t* inds2d,
+                                const int64_t* inds3d, int n, long row_offset, long n_rows, float* x, int ldx,
+                                void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * GNN head helpers (ref:models/gcn.py)
  * ---------------------------------------------------------------------------------------------- */
 /* get_graph_feature's kNN (ref:models/gcn.py:15-34,48-51): dist = -2ab + a^2 + b^2 clamped at 1e-12,

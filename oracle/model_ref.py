@@ -226,6 +226,21 @@ def gcn(sd, prefix, names, c0, c1, d0, d1, k, heads):
     return d0, d1
 
 
+def inject_image_features(n_points, len_src, images, channels=128):
+    """ref:models/architectures.py:195-514 (all three img_num branches reduce to this): x = ones [N, C+1]; for every
+    image in the reference's write order  x[inds3d (+ len_src for the target cloud), :] =
+    cat(fmap[:, inds2d[:,1], inds2d[:,0]].T, ones)  with fmap pre-multiplied by valid.T when a valid map exists."""
+    x = torch.ones(n_points, channels + 1)
+    for im in images:
+        fmap = im["fmap"]
+        if im.get("valid") is not None:
+            fmap = fmap * im["valid"].transpose(0, 1).unsqueeze(0)                      # :272-284
+        feats = fmap[:, im["inds2d"][:, 1], im["inds2d"][:, 0]]                         # :227-232
+        rows = im["inds3d"] + (len_src if im.get("target") else 0)                      # :239-241
+        x[rows, :] = torch.cat((feats.transpose(1, 0), torch.ones(feats.shape[1], 1)), -1)
+    return x
+
+
 # ------------------------------------------------------------------------------------------------
 # KPFCNN.forward, geometry-only branch (ref:models/architectures.py:181-191, 516-610)
 # ------------------------------------------------------------------------------------------------

@@ -66,6 +66,9 @@ SIGNATURES = {
     "pcrcg_instnorm_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pcrcg_instnorm_apply": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float,
                                      c_void_p, c_int, c_void_p]),
+    "pcrcg_fill2d": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "pcrcg_inject_image_features": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_long,
+                                            ctypes.c_long, c_void_p, c_int, c_void_p]),
     "pcrcg_knn": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pcrcg_edgeconv_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_edgeconv_reduce": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float,

@@ -23,9 +23,15 @@ class KPFCNN(nn.Module):
     def __init__(self, config):
         super().__init__()
         config = as_config(config)
-        if config.get("image_feature", False) or config.get("node_overlap", False) or config.get("quaternion", False):
-            raise NotImplementedError("pcrcg_amd.KPFCNN: the 2-D image branch and the node-overlap / quaternion "
-                                      "heads are outside the accelerated path (SURVEY.md 8f)")
+        if config.get("node_overlap", False) or config.get("quaternion", False):
+            raise NotImplementedError("pcrcg_amd.KPFCNN: the node-overlap / quaternion heads are outside the "
+                                      "accelerated path (SURVEY.md 8f)")
+        # PCR-CG's image-feature injection (ref:models/architectures.py:48-50,195-514): the 2-D backbone is the caller's
+        # (forward(batch, backbone2d)); the gather of its per-pixel features into the [N, 129] point features is ours
+        self.image_feature = bool(config.get("image_feature", False))
+        self.img_num = int(config.get("img_num", 0) or 0)
+        if self.image_feature and (self.img_num not in (1, 2, 3) or config.in_feats_dim != 129):
+            raise ValueError("pcrcg_amd.KPFCNN: image_feature needs img_num in {1, 2, 3} and in_feats_dim = 129")
         layer = 0
         r = config.first_subsampling_dl * config.conv_radius
         in_dim = config.in_feats_dim
@@ -99,7 +105,34 @@ class KPFCNN(nn.Module):
     def _conv1x1(layer, x):
         return ops.gemm(x, layer.weight.data.squeeze(-1).t(), bias=layer.bias.data)
 
+    def image_features(self, batch, backbone2d=None):
+        """ref:models/architectures.py:195-514: x = ones [N, 129] with the 2-D features of the projected points
+        scattered in (pcrcg_inject_image_features).  The 2-D feature maps come from `backbone2d` applied to
+        batch['{src,tgt}_color{i}'] as in the reference, or -- precomputed -- from batch['{src,tgt}{i}_feature2d']."""
+        n = int(batch["points"][0].shape[0])
+        len_src = int(batch["src_pcd_raw"].shape[0])
+        dev = batch["points"][0].device
+        images = []
+        for side in ("src", "tgt"):
+            for i in range(self.img_num, 0, -1):              # the reference writes image 3, 2, 1: image 1 wins (:242-247)
+                key = f"{side}{i}_feature2d"
+                if key in batch:
+                    fmap = batch[key]
+                elif backbone2d is not None:
+                    with torch.no_grad():
+                        fmap = backbone2d(batch[f"{side}_color{i}"].unsqueeze(0).to(dev)).squeeze(0)
+                else:
+                    raise RuntimeError(f"pcrcg_amd.KPFCNN: image_feature needs backbone2d or batch['{key}']")
+                valid = batch.get(f"{side}_valid_map{i}") if self.img_num < 3 else None   # :196-252 has no valid maps
+                images.append(dict(fmap=fmap.detach().to(dev, torch.float32), inds2d=batch[f"{side}{i}_inds2d"].to(dev),
+                                   inds3d=batch[f"{side}{i}_inds3d"].to(dev), target=side == "tgt",
+                                   valid=None if valid is None else valid.to(dev)))
+        return ops.inject_image_features(n, len_src, images, channels=128)
+
     def forward(self, batch, backbone2d=None):
+        if self.image_feature:
+            batch = dict(batch)
+            batch["features"] = self.image_features(batch, backbone2d)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training: the differentiable composition of the same kernels (pcrcg_amd/train_forward.py)
             from .train_forward import forward_train

@@ -48,12 +48,60 @@ __global__ void __launch_bounds__(256) k_sigmoid_scores(const float* __restrict_
     dst[r] = v;
 }
 
+__global__ void __launch_bounds__(256) k_fill2d(float* __restrict__ dst, int ld, int rows, int cols, float v) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)rows * cols) return;
+    const long r = e / cols;
+    dst[r * ld + (int)(e - r * cols)] = v;
+}
+
+// x[inds3d[j] + row_offset, 0:c] = fmap[:, inds2d[j,1], inds2d[j,0]] * valid[inds2d[j,0], inds2d[j,1]];  x[.., c] = 1
+// one wavefront per projected point: lanes run over the channels (fmap is [c, h, w]: a strided gather)
+__global__ void __launch_bounds__(256) k_inject_image(const float* __restrict__ fmap, int c, int h, int w,
+                                                       const float* __restrict__ valid, const long long* __restrict__ inds2d,
+                                                       const long long* __restrict__ inds3d, int n, long row_offset,
+                                                       long n_rows, float* __restrict__ x, int ldx) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const long px = inds2d[2 * (long)j], py = inds2d[2 * (long)j + 1], row = inds3d[j] + row_offset;
+    if (px < 0 || px >= w || py < 0 || py >= h || row < 0 || row >= n_rows) return;
+    const float m = valid ? valid[px * h + py] : 1.0f;      // valid is stored [w, h] (the reference transposes it)
+    float* dst = x + row * ldx;
+    for (int ch = lane; ch < c; ch += 64) dst[ch] = fmap[((long)ch * h + py) * w + px] * m;
+    if (lane == 0) dst[c] = 1.0f;
+}
+
 }  // namespace
 }  // namespace pcrcg
 
 using namespace pcrcg;
 
 extern "C" {
+
+int pcrcg_fill2d(float* dst, int ld, int rows, int cols, float value, void* stream) {
+    PCRCG_CHECK_ARG(rows >= 0 && cols >= 0 && ld >= cols);
+    if (rows == 0 || cols == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(dst != nullptr);
+    const long total = (long)rows * cols;
+    hipLaunchKernelGGL(k_fill2d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), dst, ld, rows,
+                       cols, value);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+int pcrcg_inject_image_features(const float* fmap, int c, int h, int w, const float* valid, const int64_t* inds2d,
+                                const int64_t* inds3d, int n, long row_offset, long n_rows, float* x, int ldx,
+                                void* stream) {
+    PCRCG_CHECK_ARG(c >= 1 && h >= 1 && w >= 1 && n >= 0 && n_rows >= 0 && ldx >= c + 1);
+    if (n == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(fmap && inds2d && inds3d && x);
+    hipLaunchKernelGGL(k_inject_image, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), fmap, c, h, w, valid,
+                       reinterpret_cast<const long long*>(inds2d), reinterpret_cast<const long long*>(inds3d), n, row_offset,
+                       n_rows, x, ldx);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
 
 int pcrcg_copy2d(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, void* stream) {
     PCRCG_CHECK_ARG(rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= cols);

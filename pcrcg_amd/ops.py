@@ -350,6 +350,33 @@ def kpconv_fused(q_pts, s_pts, idx, x, kernel_points, weights, extent):
     return out
 
 
+def inject_image_features(n_points, len_src, images, channels=128):
+    """PCR-CG's image-feature injection (ref:models/architectures.py:195-514): -> x [n_points, channels + 1] f32 = ones
+    with the 2-D features of the projected points written in.  `images`: list, IN THE REFERENCE'S WRITE ORDER (the last
+    entry wins where projections overlap), of dicts with fmap [C,H,W] f32, inds2d [n,2] i64 (column, row), inds3d [n]
+    i64, target (bool: indices are relative to the target cloud) and optionally valid [W,H] f32."""
+    L = _lib.lib()
+    dev = images[0]["fmap"].device
+    x = torch.empty((n_points, channels + 1), dtype=_F32, device=dev)
+    _lib.check(L.pcrcg_fill2d(x.data_ptr(), channels + 1, n_points, channels + 1, 1.0, _stream()), "pcrcg_fill2d")
+    for im in images:
+        fmap = _dev(im["fmap"], _F32, "fmap").contiguous()
+        if fmap.dim() != 3 or fmap.shape[0] != channels:
+            raise RuntimeError("pcrcg_amd.inject_image_features: fmap must be [channels, H, W]")
+        valid = im.get("valid")
+        if valid is not None:
+            valid = _dev(valid.to(_F32), _F32, "valid").contiguous()
+            if tuple(valid.shape) != (fmap.shape[2], fmap.shape[1]):
+                raise RuntimeError("pcrcg_amd.inject_image_features: valid must be [W, H] (the reference's layout)")
+        i2 = _dev(im["inds2d"].to(_I64), _I64, "inds2d").contiguous()
+        i3 = _dev(im["inds3d"].to(_I64), _I64, "inds3d").contiguous()
+        _lib.check(L.pcrcg_inject_image_features(fmap.data_ptr(), channels, fmap.shape[1], fmap.shape[2], _ptr(valid),
+                                                 i2.data_ptr(), i3.data_ptr(), i3.shape[0],
+                                                 int(len_src) if im.get("target") else 0, n_points, x.data_ptr(),
+                                                 channels + 1, _stream()), "pcrcg_inject_image_features")
+    return x
+
+
 def gather_max(x, idx):
     L = _lib.lib()
     x = _dev(x, _F32, "x").contiguous()

@@ -53,7 +53,7 @@ class _Mailbox:
 class PairStreams:
     ARENAS = 4        # per front thread: pairs whose tables may be alive at once (built, forward not yet passed)
 
-    def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=2, tie_order=None,
+    def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=1, tie_order=None,
                  pairs_per_build=2):
         self.net, self.config, self.limits = net, config, neighborhood_limits
         self.device = torch.device(device if device is not None else "cuda")

@@ -52,3 +52,25 @@ def test_plan_matches_reference_shapes(golden_dir):
         cout = blk["out_dim"] // 2 if "simple" in blk["name"] else blk["out_dim"] // 4
         assert tuple(w.shape) == (15, cin, cout)
     assert pl["encoder_skips"] == [2, 5, 8, 11] and pl["decoder_concats"] == [1, 3, 5]
+
+
+def _image_list(inp, img_num, with_valid):
+    images = []
+    for side in ("src", "tgt"):
+        for i in range(img_num, 0, -1):
+            images.append(dict(fmap=inp[f"{side}{i}_feature2d"], inds2d=inp[f"{side}{i}_inds2d"], inds3d=inp[f"{side}{i}_inds3d"],
+                               target=side == "tgt", valid=inp.get(f"{side}_valid_map{i}") if with_valid else None))
+    return images
+
+
+def test_image_feature_injection_vs_reference(golden_dir, batch):
+    """oracle restatement of ref:models/architectures.py:195-514 against the matrix the unmodified reference model
+    fed to its first block (tests/golden/image_mini.pt, scripts/make_golden_image.py): bit-exact."""
+    gold = torch.load(os.path.join(golden_dir, "image_mini.pt"))
+    n_src = int(batch["stack_lengths"][0][0])
+    n = int(batch["points"][0].shape[0])
+    for img_num in (2, 3):
+        g = gold[f"img{img_num}"]
+        x = MR.inject_image_features(n, n_src, _image_list(g["inputs"], img_num, img_num < 3))
+        assert torch.equal(x[::g["x_stride"]], g["x_rows"]), img_num
+        assert int((x[:, :128] != 1).any(1).sum()) > 1500
