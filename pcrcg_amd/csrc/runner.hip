@@ -159,37 +159,22 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
         xp = pad.p;
         w = blk.kp_w_pad;
     }
-    // Row chunks: when the layer's wf would stream through HBM (hundreds of MB), aggregate and contract a slice of the
-    // queries at a time so that the slice's wf is still in L2 / Infinity Cache when the contraction reads it, and the
-    // (reused) buffer's dirty lines are overwritten on chip instead of being written back.
-    static const long chunk_bytes = [] { const char* e = getenv("PCRCG_KPCONV_CHUNK_MB"); return (long)(e ? atoi(e) : 48) << 20; }();
-    const long row_bytes = (long)PCRCG_KPOINTS * cin * sizeof(float);
-    int chunk = nq;
-    if (chunk_bytes > 0 && (long)nq * row_bytes > 2 * chunk_bytes) {
-        chunk = (int)(chunk_bytes / row_bytes);
-        chunk = chunk / 128 * 128;
-        if (chunk < 4096) chunk = nq;
-    }
-    const bool chunked = chunk < nq;
-    Mat wf = c.mat(chunk, PCRCG_KPOINTS * cin);
-    float* inv_n = static_cast<float*>(c.raw(sizeof(float) * (chunk > 0 ? chunk : 1)));
+    Mat wf = c.mat(nq, PCRCG_KPOINTS * cin);
+    float* inv_n = static_cast<float*>(c.raw(sizeof(float) * (nq > 0 ? nq : 1)));
     const size_t wsb = pcrcg_kpconv_ws_bytes(ns);
     void* ws = c.raw(wsb);
     if (c.live()) {
+        c.check(pcrcg_kpconv_aggregate(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, xp, cin, blk.kp, blk.extent,
+                                       wf.p, inv_n, ws, wsb, c.st));
         // contraction wf @ W: against the K-contiguous copy wt [cout, 15*cin] when the descriptor carries one
-        // (C = A * B^T form: both operands k-contiguous, the form the split-bf16 GEMM is built for)
+        // (C = A * B^T form: both operands k-contiguous, the form the split-bf16 GEMM is built for).
+        // (Measured and not adopted: aggregating + contracting 48 MB row chunks so that wf stays in L2 / Infinity
+        // Cache between the two kernels -- 3.50 vs 3.31 ms per forward, the extra launches cost more than the
+        // on-chip re-read saves.)
         const bool kt = blk.kp_wt != nullptr;
-        for (int r0 = 0; r0 < nq; r0 += chunk) {
-            const int rows = nq - r0 < chunk ? nq - r0 : chunk;
-            c.check(kpconv_aggregate_rows(q + 3 * (long)r0, rows, b.points[l], ns, t.idx + (long)r0 * t.ld, t.cols, t.ld, xp, cin,
-                                          blk.kp, blk.extent, wf.p, inv_n, ws, wsb, c.st, r0 == 0, !chunked));
-            // (column statistics ride along only when the layer is one GEMM call: their chunk index is the tile row)
-            c.check(pcrcg_gemm_f32_colstats(wf.p, wf.ld, kt ? blk.kp_wt : w, kt ? wf.cols : y.cols, kt ? 1 : 0,
-                                            y.p + (long)r0 * y.ld, y.ld, rows, y.cols, wf.cols, inv_n, nullptr,
-                                            (st && !chunked) ? st->partials : nullptr, (st && !chunked) ? st->bytes : 0,
-                                            (st && !chunked) ? &st->chunks : nullptr, c.st));
-        }
-        if (st && chunked) st->chunks = 0;
+        c.check(pcrcg_gemm_f32_colstats(wf.p, wf.ld, kt ? blk.kp_wt : w, kt ? wf.cols : y.cols, kt ? 1 : 0, y.p, y.ld, nq,
+                                        y.cols, wf.cols, inv_n, nullptr, st ? st->partials : nullptr, st ? st->bytes : 0,
+                                        st ? &st->chunks : nullptr, c.st));
     }
     c.release(m);
 }

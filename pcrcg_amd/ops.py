@@ -377,6 +377,29 @@ def inject_image_features(n_points, len_src, images, channels=128):
     return x
 
 
+def kpconv_x6(q_pts, s_pts, idx, x, kernel_points, weights, extent):
+    """KPConv.forward in one kernel without the [nq, 15*cin] intermediate (csrc/kpconv_x6.hip): register-resident
+    aggregation + slab-wise contraction on the bf16 matrix cores with the exact three-term split.  cin % 64 == 0,
+    cout in {64, 128, 256}.  (Parity-tested; the runner uses the two-stage path, which measures faster.)"""
+    L = _lib.lib()
+    q_pts, s_pts = _dev(q_pts, _F32, "q_pts").contiguous(), _dev(s_pts, _F32, "s_pts").contiguous()
+    idx, ld_idx = _rows(idx, _I64, "idx")
+    x = _dev(x, _F32, "x").contiguous()
+    kernel_points = _dev(kernel_points, _F32, "kernel_points").contiguous()
+    nq, ns, h, cin, cout = q_pts.shape[0], s_pts.shape[0], idx.shape[1], x.shape[1], weights.shape[2]
+    wt = _dev(weights, _F32, "weights").reshape(-1, cout).t().contiguous()           # [cout, 15*cin], K-contiguous
+    planes = torch.empty(int(L.pcrcg_split_bf16x3_bytes(cout, wt.shape[1])), dtype=torch.uint8, device=x.device)
+    _lib.check(L.pcrcg_split_bf16x3(wt.data_ptr(), wt.shape[1], cout, wt.shape[1], planes.data_ptr(), _stream()),
+               "pcrcg_split_bf16x3")
+    out = torch.empty((nq, cout), dtype=_F32, device=x.device)
+    nbytes = L.pcrcg_kpconv_ws_bytes(ns)
+    ws = _ws.get("kpconv", nbytes, x.device)
+    _lib.check(L.pcrcg_kpconv_x6(q_pts.data_ptr(), nq, s_pts.data_ptr(), ns, idx.data_ptr(), h, ld_idx, x.data_ptr(), cin,
+                                 kernel_points.data_ptr(), float(extent), planes.data_ptr(), cout, out.data_ptr(), cout,
+                                 ws.data_ptr(), nbytes, _stream()), "pcrcg_kpconv_x6")
+    return out
+
+
 def gather_max(x, idx):
     L = _lib.lib()
     x = _dev(x, _F32, "x").contiguous()
