@@ -1,9 +1,10 @@
 """KPConv network blocks on the MI355X -- the host-side mirror of ref:models/blocks.py.
 
 Same class names, constructor arguments, parameter names and shapes (so a reference ``state_dict``
-loads unchanged); every forward runs in the hand-written HIP kernels behind ``pcrcg_amd.ops``.  This
-round implements inference (forward under no_grad); the backward kernels are the next row of the
-scope table."""
+loads unchanged); every forward runs in the hand-written HIP kernels behind ``pcrcg_amd.ops``.  The
+module forwards here are the inference path (forward under no_grad); training goes through
+``KPFCNN.forward`` with autograd enabled, i.e. pcrcg_amd/train_forward.py over the backward kernels of
+include/pcrcg_train.h."""
 import math
 
 import torch
