@@ -230,7 +230,29 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
         const int total = __shfl(incl, 26, 64);
         if (lane < 32) { s_excl[wave][lane] = lane < 27 ? incl - ccount : 0x7FFFFFFF; s_start[wave][lane] = cstart; }
         __builtin_amdgcn_wave_barrier();
-        int nhit = 0;
+        int nhit = 0, fill = 0;     // hits found / hits currently staged (they differ only after a compaction)
+        // Rows with more hits than the staging list holds (second pass only; the reference has no such bound): the
+        // table keeps the `cols` nearest anyway, so whenever the list is about to overflow it is cut down to its
+        // cols + 1 smallest keys (one more than is kept: the tie test at the cut needs the first dropped entry) -- a
+        // streaming selection; the true count still goes to out_count / out_max.
+        const bool can_compact = REDO && cols + 1 + 64 <= CAP;
+        auto compact = [&]() {
+            const int keep = cols + 1 < fill ? cols + 1 : fill;
+            for (int e = lane; e < fill; e += 64) {
+                const u64 mine = list[e];
+                int rank = 0, j = 0;
+                for (; j + 4 <= fill; j += 4) {
+                    const u64 a = list[j], b = list[j + 1], c = list[j + 2], d = list[j + 3];
+                    rank += (a < mine ? 1 : 0) + (b < mine ? 1 : 0) + (c < mine ? 1 : 0) + (d < mine ? 1 : 0);
+                }
+                for (; j < fill; ++j) rank += list[j] < mine ? 1 : 0;
+                if (rank < keep) sorted[rank] = mine;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < keep; e += 64) list[e] = sorted[e];
+            __builtin_amdgcn_wave_barrier();
+            fill = keep;
+        };
         // candidates 256 at a time: the four gathers of a round are issued before the first is used (they are
         // independent; one after the other each would cost a full memory round trip)
         constexpr int SW = 4;
@@ -258,13 +280,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
                 const bool hit = t < total && d2 < r2;
                 const u64 packed = ((u64)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p[u].w);
                 const u64 mask = __ballot(hit);
-                const int pos = nhit + __popcll(mask & ((1ull << lane) - 1ull));
+                if (can_compact && fill + 64 > CAP) compact();
+                const int pos = fill + __popcll(mask & ((1ull << lane) - 1ull));
                 if (hit && pos < CAP) list[pos] = packed;
                 nhit += __popcll(mask);
+                fill += __popcll(mask);
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const int nl = nhit < CAP ? nhit : CAP;
+        const int nl = fill < CAP ? fill : CAP;
         long long* row = out_idx + (long)qi * cols;
         if (!REDO && nhit > CAP) {   // leave the row to pass 2
             if (lane == 0) row[0] = kRedoMark;
@@ -317,7 +341,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
         }
         if (lane == 0) {
             if (out_count) out_count[qi] = nhit;
-            if ((nhit > CAP || !inrange) && status) *status = 1;
+            if (((fill > CAP) || !inrange) && status) *status = 1;   // (fill > CAP: more columns asked for than the list can select)
         }
         wave_max = nhit > wave_max ? nhit : wave_max;
         __builtin_amdgcn_wave_barrier();

@@ -245,3 +245,22 @@ def test_random_lattice_clouds_vs_oracle(cuda, seed):
         assert (got == OF.oracle_batch_query(q, s_, ql, sl_, r, tie_order="reference")).all()
         got = radius_neighbors.batch_query(q, s_, ql, sl_, radius=r, tie_order="index")
         assert (got == OF.oracle_batch_query(q, s_, ql, sl_, r)).all()
+
+
+def test_rows_longer_than_the_staging_list(cuda):
+    """A neighbourhood denser than the search kernel's 1024-entry staging list (the reference has no such bound): the
+    kept columns are still the nearest by (distance, index), the reported count is the true one."""
+    rng = np.random.RandomState(3)
+    pts = (rng.rand(3000, 3) * 0.02).astype(np.float32)            # every point within 0.035 of every other
+    lens = np.array([1800, 1200], np.int32)
+    want = OF.oracle_batch_query(pts, pts, lens, lens, 0.05)
+    assert want.shape[1] == 1800                                      # rows of 1800 and 1200 hits
+    t_pts, t_lens = torch.from_numpy(pts).to(cuda), torch.from_numpy(lens).to(cuda)
+    for cols in (40, 200, 905):
+        grid = ops.CellGrid(t_pts, t_lens, 0.05)
+        idx, meta, counts = grid.query(t_pts, t_lens, cols, want_counts=True)
+        torch.cuda.synchronize()
+        max_count, status = int(meta[0]), int(meta[1])
+        assert status == 0 and max_count == 1800
+        assert (counts.cpu().numpy() == np.where(np.arange(3000) < 1800, 1800, 1200)).all()
+        assert (idx.cpu().numpy() == want[:, :cols]).all(), cols
