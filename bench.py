@@ -65,7 +65,7 @@ def _gemm_mode():
 
 def kpconv_algorithmic_bytes(nq, h, cin, cout, e=4):
     """no-reuse gather model of one KPConv call."""
-    return nq * h * (cin * e + 8 + 12) + nq * cout * e
+    return nq * h * (cin * e + 8 + 12) + nq * cout * 4        # e: bytes per stored feature element (2 in the bf16 variant)
 
 
 def _cpu_front_end(args):
@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--isolated-only", action="store_true",
                     help="no pipeline: --steps forwards of one prepared pair on one stream, nothing else running (the "
                          "run rocprofv3 is pointed at for the KPConv gather kernel's isolated duration and PMC traffic)")
+    ap.add_argument("--variant", choices=["fp32", "bf16"], default="fp32",
+                    help="bf16: the bf16 feature-storage VARIANT (pcrcg_model.feature_bf16) -- a separate line with its "
+                         "measured error against the fp32 path; never the headline")
     args = ap.parse_args()
     global RECIPE
     RECIPE = args.workload
@@ -155,6 +158,8 @@ def main():
     net = KPFCNN(cfg).eval()
     state_dict = {k: v.clone() for k, v in net.state_dict().items()} if rank == 0 else None
     net = net.to(dev)
+    BF16 = args.variant == "bf16"
+    FE = 2 if BF16 else 4                 # bytes per stored feature element in the KPConv gathers
 
     # synthetic inputs, resident in HBM before the timed region; every step sees a different pair
     total = args.warmup + args.steps
@@ -165,6 +170,18 @@ def main():
         if s % 16 not in pool:
             pool[s % 16] = (torch.from_numpy(np.concatenate([src, tgt])).to(dev),
                             torch.tensor([len(src), len(tgt)], dtype=torch.int32, device=dev))
+
+    variant_error = None
+    if BF16:
+        # the variant's error against the fp32 path on the first pair, measured before anything is timed
+        from pcrcg_amd.pyramid import build_pyramid
+        b0 = build_pyramid(*pool[seeds[0] % 16], cfg, limits)
+        with torch.no_grad():
+            o32 = {k: v.double() for k, v in net(b0).items()}
+            net.feature_bf16 = True
+            o16 = {k: v.double() for k, v in net(b0).items()}
+        variant_error = {k: float((o16[k] - o32[k]).abs().max() / o32[k].abs().max()) for k in o32}
+        del b0, o32, o16
 
     if args.isolated_only:
         from pcrcg_amd.pyramid import build_pyramid
@@ -182,8 +199,8 @@ def main():
         ev = ops.kpconv_profile_stop()
         cout_of = {blk.KPConv.in_channels: blk.KPConv.out_channels for blk in net.encoder_blocks}
         ms = sum(e[0] for e in ev)
-        by = sum(kpconv_algorithmic_bytes(nq, h, cin, cout_of[cin]) for (_, nq, h, cin, _, _) in ev)
-        print(json.dumps({"mode": "isolated-only", "workload": RECIPE, "forwards": args.steps,
+        by = sum(kpconv_algorithmic_bytes(nq, h, cin, cout_of[cin], FE if kind == 2 else 4) for (_, nq, h, cin, _, kind) in ev)
+        print(json.dumps({"mode": "isolated-only", "workload": RECIPE, "variant": args.variant, "forwards": args.steps,
                           "forward_ms": round(1e3 * dt / args.steps, 3),
                           "kpconv_launches": len(ev), "kpconv_avg_launch_us": round(1e3 * ms / max(len(ev), 1), 2),
                           "kpconv_algorithmic_GBs": round(by / (ms * 1e-3) / 1e9, 1),
@@ -287,7 +304,7 @@ def main():
             co = cout if kind == 1 else cout_of[cin]
             d = fused if kind == 1 else gather
             d["ms"] += ms
-            d["bytes"] += kpconv_algorithmic_bytes(nq, h, cin, co)
+            d["bytes"] += kpconv_algorithmic_bytes(nq, h, cin, co, 2 if kind == 2 else 4)
             d["n"] += 1
             if kind == 1:
                 d["flops"] += 2 * nq * 15 * cin * (h + co)
@@ -298,11 +315,12 @@ def main():
         f_gbs = fused["bytes"] / (fused["ms"] * 1e-3) / 1e9 if fused["ms"] > 0 else 0.0
         f_tf = fused["flops"] / (fused["ms"] * 1e-3) / 1e12 if fused["ms"] > 0 else 0.0
         iso_ms = sum(e[0] for e in iso)
-        iso_bytes = sum(kpconv_algorithmic_bytes(nq, h, cin, cout_of[cin]) for (_, nq, h, cin, _, _) in iso)
+        iso_bytes = sum(kpconv_algorithmic_bytes(nq, h, cin, cout_of[cin], 2 if kind == 2 else 4)
+                        for (_, nq, h, cin, _, kind) in iso)
         iso_gbs = iso_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
         iso_rows = []                        # the last isolated forward, launch by launch
-        for i, (ms, nq, h, cin, _, _) in enumerate(iso[-per_pair:]):
-            b = kpconv_algorithmic_bytes(nq, h, cin, cout_of[cin])
+        for i, (ms, nq, h, cin, _, kind) in enumerate(iso[-per_pair:]):
+            b = kpconv_algorithmic_bytes(nq, h, cin, cout_of[cin], 2 if kind == 2 else 4)
             iso_rows.append({"nq": nq, "h": h, "cin": cin, "cout": cout_of[cin], "us": round(ms * 1e3, 1),
                              "GBs": round(b / (ms * 1e-3) / 1e9, 0) if ms > 0 else None})
         # `traffic` (HBM bytes per launch from PMC counters) cannot be collected by this process: rocprofv3 --pmc needs
@@ -314,8 +332,9 @@ def main():
                                "source": "profiles/r02_pmc_kpconv.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                          "`bench.py --isolated-only`, corrected as MI355X_MICROARCH.md prescribes; NOT measured by this run"}
         line = {
-            "metric": "fragment-pairs/s KPFCNN+GCN fwd, 30k-pt pairs" if RECIPE == "S30k"
-                      else f"fragment-pairs/s KPFCNN+GCN fwd, {RECIPE} pairs (secondary workload)",
+            "metric": ("fragment-pairs/s KPFCNN+GCN fwd, 30k-pt pairs" if RECIPE == "S30k"
+                       else f"fragment-pairs/s KPFCNN+GCN fwd, {RECIPE} pairs (secondary workload)")
+                      + (" [bf16 feature-storage VARIANT, not the fp32 headline]" if BF16 else ""),
             "value": round(args.steps * world / elapsed, 3),
             "unit": "fragment-pairs/s",
             "n_gpus": world,
@@ -326,7 +345,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16 feature storage in the KPConv gathers, f32 weights / accumulation / outputs" if BF16 else "f32",
             "data": "synthetic",
             "config": {"workload": WORKLOADS[RECIPE] + ", pyramid build + KPFCNN+GCN "
                                    "forward, random-init full-width weights, 1 pair/GPU/step; "
@@ -360,6 +379,10 @@ def main():
                                            "achieved_TFLOPs_f32_mfma": round(f_tf, 1),
                                            "frac_mfma_f32_157TF": round(f_tf / 157.3, 4)}},
         }
+        if BF16:
+            line["variant"] = {"name": "bf16 feature storage", "max_abs_error_over_max_abs_vs_fp32_path": variant_error,
+                               "note": "outside the 1e-4 parity bound of the fp32 path by construction; "
+                                       "tests/test_bf16_gpu.py states and checks the bound"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, state_dict, limits)
     if dist is not None:

@@ -173,6 +173,13 @@ size_t pcrcg_kpconv_ws_bytes(int ns);
 int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx,
                            int h, int ld_idx, const float* x, int cin, const float* kp, float extent,
                            float* wf, float* inv_n, void* ws, size_t ws_bytes, void* stream);
+/* Stage 1 of the bf16 feature-storage VARIANT (pcrcg_model.feature_bf16): x is fp32 at the boundary; x_bf16
+ * ([ns, cin] u16 scratch) receives its round-to-nearest-even bf16 copy, which is what the neighbour gathers read, and
+ * wf_bf16 ([nq, 15*cin] u16) the aggregate rounded the same way.  Geometry, influences, n_q and the accumulation are
+ * fp32.  cin % 4 == 0.  Stage 2 is pcrcg_gemm_bf16a_f32_colstats. */
+int pcrcg_kpconv_aggregate_bf16(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h,
+                                int ld_idx, const float* x, int cin, const float* kp, float extent, void* x_bf16,
+                                void* wf_bf16, float* inv_n, void* ws, size_t ws_bytes, void* stream);
 
 /* The same operator in ONE kernel (gather + aggregate + contraction + 1/n scaling) for layers whose
  * [nq, 15*cin] intermediate would dominate HBM traffic: the aggregated tile of 16 queries stays in LDS
@@ -226,6 +233,13 @@ size_t pcrcg_gemm_colstats_bytes(int m, int n);
 int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, int ldb, int trans_b, float* c, int ldc,
                             int m, int n, int k, const float* row_scale, const float* bias, void* colstats,
                             size_t colstats_bytes, int* h_chunks, void* stream);
+/* C = (A @ B^T) * row_scale + bias with A stored as bf16 ([m, k] u16, lda in ELEMENTS, lda % 8 == 0, 16-byte aligned,
+ * k % 32 == 0) and B fp32 [n, k]: B is split exactly into three bf16 terms as in mode 1 below and the three products
+ * against the single A term run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- exact in B, bf16-rounded in A
+ * only by A's storage format.  Column partials as pcrcg_gemm_f32_colstats. */
+int pcrcg_gemm_bf16a_f32_colstats(const void* a_bf16, int lda, const float* b, int ldb, float* c, int ldc, int m, int n,
+                                  int k, const float* row_scale, const float* bias, void* colstats,
+                                  size_t colstats_bytes, int* h_chunks, void* stream);
 
 /* Arithmetic of the C = A @ B^T products (trans_b = 1) behind pcrcg_gemm_f32 / _colstats / _ex:
  *   0: v_mfma_f32_32x32x2_f32 on the fp32 operands (the fp32 matrix rate, 157 TF on MI355X);
@@ -380,6 +394,12 @@ typedef struct pcrcg_model {
     const float *proj_gnn_w, *proj_gnn_b;     /* [gnn, gnn], [gnn] */
     const float *proj_score_w, *proj_score_b; /* [1, gnn], [1] */
     float temperature;                        /* exp(epsilon) + 0.03 (:561) */
+    int feature_bf16;                         /* 0: fp32 feature storage (the parity-tested path, default).  1: the
+                                                 bf16 feature-storage VARIANT (BASELINE.json configs[1] "bf16/fp32"):
+                                                 inside every KPConv with cin % 32 == 0 the neighbour gathers read a
+                                                 bf16 copy of the features and the aggregated [nq, 15*cin] matrix is
+                                                 bf16 in HBM; weights, accumulation, norms, outputs stay fp32.  NOT
+                                                 within the 1e-4 parity bound: tests/test_bf16_gpu.py states its error */
 } pcrcg_model;
 
 typedef struct pcrcg_table { const int64_t* idx; int rows, cols, ld; } pcrcg_table;

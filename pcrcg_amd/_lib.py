@@ -41,6 +41,9 @@ SIGNATURES = {
     "pcrcg_kpconv_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_kpconv_aggregate": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                        c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_kpconv_aggregate_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                            c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                            c_void_p]),
     "pcrcg_kpconv_fused_supported": (c_int, [c_int, c_int, c_int]),
     "pcrcg_kpconv_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                    c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
@@ -56,6 +59,8 @@ SIGNATURES = {
     "pcrcg_gemm_colstats_bytes": (c_size_t, [c_int, c_int]),
     "pcrcg_gemm_f32_colstats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "pcrcg_gemm_bf16a_f32_colstats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "pcrcg_gemm_set_mode": (None, [c_int]),
     "pcrcg_gemm_get_mode": (c_int, []),
     "pcrcg_instnorm_stats_from_partials": (c_int, [c_void_p, c_int, c_int, ctypes.c_double, c_float, c_void_p,

@@ -32,6 +32,9 @@ class KPFCNN(nn.Module):
         self.img_num = int(config.get("img_num", 0) or 0)
         if self.image_feature and (self.img_num not in (1, 2, 3) or config.in_feats_dim != 129):
             raise ValueError("pcrcg_amd.KPFCNN: image_feature needs img_num in {1, 2, 3} and in_feats_dim = 129")
+        # bf16 feature-storage VARIANT of the inference forward (include/pcrcg.h pcrcg_model.feature_bf16): off by
+        # default, not in the reference; outside the fp32 parity bound (tests/test_bf16_gpu.py states its error)
+        self.feature_bf16 = bool(config.get("feature_bf16", False))
         layer = 0
         r = config.first_subsampling_dl * config.conv_radius
         in_dim = config.in_feats_dim

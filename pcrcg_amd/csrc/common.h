@@ -39,10 +39,15 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
 constexpr int kWave = 64;
 
 // kpconv.hip: row-positive flags + packed (x, y, z, flag) support records into a pcrcg_kpconv_ws_bytes(ns) workspace
-int kpconv_pack(const float* x, int ns, int cin, const float* s_pts, void* ws, size_t ws_bytes, hipStream_t st);
+// (x_bf16 != NULL: also the bf16 round-to-nearest-even copy of x, [ns, cin])
+int kpconv_pack(const float* x, int ns, int cin, const float* s_pts, void* ws, size_t ws_bytes, hipStream_t st,
+                unsigned short* x_bf16 = nullptr);
 int kpconv_aggregate_rows(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h, int ld_idx,
                           const float* x, int cin, const float* kp, float extent, float* wf, float* inv_n, void* ws,
                           size_t ws_bytes, hipStream_t st, bool pack, bool stream_out);
+int kpconv_aggregate_bf16(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h, int ld_idx,
+                          const float* x, unsigned short* x_bf16, int cin, const float* kp, float extent,
+                          unsigned short* wf_bf16, float* inv_n, void* ws, size_t ws_bytes, hipStream_t st);
 
 // Optional start / stop events of a KPConv kernel (bench.py roofline); see pcrcg_profile_kpconv in
 // include/pcrcg.h.  The events are handed to hipExtLaunchKernelGGL, so they stamp the kernel's own begin and

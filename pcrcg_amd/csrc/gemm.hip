@@ -336,7 +336,7 @@ int launch(bool trans_b, dim3 grid, hipStream_t st, const float* a, int lda, con
 namespace pcrcg {
 int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
-                     hipStream_t st);   // gemm_x6.hip
+                     hipStream_t st, bool a_bf16);   // gemm_x6.hip
 }
 
 using namespace pcrcg;
@@ -377,6 +377,19 @@ extern "C" int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, 
                          stream);
 }
 
+// C = (A @ B^T) * row_scale + bias with A stored as bf16 ([m, k], lda in bf16 elements; 16-byte aligned rows, k % 32 == 0)
+// and B fp32 [n, k]: the bf16 feature-storage variant's contraction (gemm_x6.hip, ATERMS = 1).
+extern "C" int pcrcg_gemm_bf16a_f32_colstats(const void* a_bf16, int lda, const float* b, int ldb, float* c, int ldc, int m,
+                                             int n, int k, const float* row_scale, const float* bias, void* colstats,
+                                             size_t colstats_bytes, int* h_chunks, void* stream) {
+    if (h_chunks) *h_chunks = 0;
+    PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 32 && k % 32 == 0 && lda >= k && lda % 8 == 0 && ldb >= k && ldc >= n);
+    if (m == 0 || n == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(a_bf16 && b && c && (reinterpret_cast<uintptr_t>(a_bf16) & 15) == 0);
+    return gemm_x6_dispatch(static_cast<const float*>(a_bf16), lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats,
+                            colstats_bytes, h_chunks, as_stream(stream), true);
+}
+
 // Aop = A^T when trans_a (A stored [K, M] row-major): the weight-gradient products dW = X^T * dY of the
 // training rows (include/pcrcg_train.h), whose reduction dimension is the number of points.
 extern "C" int pcrcg_gemm_f32_ex(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c,
@@ -395,7 +408,7 @@ static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, i
     PCRCG_CHECK_ARG(trans_b ? ldb >= k : ldb >= n);
     hipStream_t st = as_stream(stream);
     if (!trans_a && trans_b && gemm_mode() == 1)
-        return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks, st);
+        return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks, st, false);
     const int vec_a = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     const int vec_b = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
     // Tile / split selection (sweep in scripts/gemm_tune.py on the path's shapes): these GEMMs are skinny

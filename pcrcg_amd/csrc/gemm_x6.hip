@@ -71,7 +71,10 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigne
 template <int BM, int BN>
 constexpr int lds_bytes() { return 3 * (BM + BN) * ROWB; }
 
-template <int BM, int BN, int MINB>
+// ATERMS = 3: A is fp32 and is split like B.  ATERMS = 1: A already IS bf16 in memory (the bf16 feature-storage
+// variant's wf, lda in bf16 elements): its tile is copied straight into plane 0 and only the three products a1*b3,
+// a1*b2, a1*b1 run -- exact in B, bf16-rounded in A by the storage format, fp32 accumulate.  K % 32 == 0 required.
+template <int BM, int BN, int MINB, int ATERMS>
 __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                         int ldb, float* __restrict__ C, int ldc, int M, int N, int Kdim,
                                                         const float* __restrict__ row_scale,
@@ -111,8 +114,10 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
 
     // two register sets: tile s is consumed from set s&1 while tiles s+1 (other set) and s+2 (this set, re-issued
     // right after its split) are in flight -- these GEMMs stream A from HBM, so bytes in flight are the currency
-    f32x4 ra[2][A_ITERS][2], rb[2][B_ITERS][2];
-    constexpr int TILE_LOADS = 2 * (A_ITERS + B_ITERS);     // global_load_dwordx4 per thread and tile
+    constexpr int AV = ATERMS == 1 ? 1 : 2;                  // 16-byte loads per A item: 8 bf16, or 2 x 4 fp32
+    f32x4 ra[2][A_ITERS][AV], rb[2][B_ITERS][2];
+    constexpr int TILE_LOADS = AV * A_ITERS + 2 * B_ITERS;   // global_load_dwordx4 per thread and tile
+    const unsigned short* const Ah = reinterpret_cast<const unsigned short*>(A);
 
     // unguarded 16-byte loads of a full 32-deep k-slab; rows past the matrix are CLAMPED to its last row: they only
     // feed output rows / columns the epilogue masks, so no zero fill is needed along M or N (only along K, below)
@@ -138,15 +143,24 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     // FAST: both operands 16-byte aligned and the slab k0..k0+31 inside [k_begin, k_end).  The choice is made
     // OUTSIDE the k-loop: a branch between load flavours inside it makes hipcc merge their vmcnt bookkeeping and
     // wait for (nearly) everything in flight at the top of every step, which turns prefetch distance 2 into 1.
-    auto load_tiles = [&](auto fast, int k0, f32x4 (*qa)[2], f32x4 (*qb)[2]) {
+    auto load_tiles = [&](auto fast, int k0, f32x4 (*qa)[AV], f32x4 (*qb)[2]) {
         if constexpr (decltype(fast)::value) {
 #pragma unroll
-            for (int it = 0; it < A_ITERS; ++it) load_fast(A, lda, m0, M, k0, it, qa[it]);
+            for (int it = 0; it < A_ITERS; ++it) {
+                if constexpr (ATERMS == 1) {
+                    const int e = tid + it * 256;
+                    gload16(qa[it][0], reinterpret_cast<const float*>(Ah + (long)min(m0 + (e >> 2), M - 1) * lda + k0 + (e & 3) * 8));
+                } else {
+                    load_fast(A, lda, m0, M, k0, it, qa[it]);
+                }
+            }
 #pragma unroll
             for (int it = 0; it < B_ITERS; ++it) load_fast(B, ldb, n0, N, k0, it, qb[it]);
         } else {
+            if constexpr (ATERMS != 1) {      // (the bf16-A form is dispatched only for aligned operands and K % 32 == 0)
 #pragma unroll
-            for (int it = 0; it < A_ITERS; ++it) load_edge(A, lda, m0, M, k0, it, qa[it]);
+                for (int it = 0; it < A_ITERS; ++it) load_edge(A, lda, m0, M, k0, it, qa[it]);
+            }
 #pragma unroll
             for (int it = 0; it < B_ITERS; ++it) load_edge(B, ldb, n0, N, k0, it, qb[it]);
         }
@@ -165,9 +179,16 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
         *reinterpret_cast<u32x4*>(d + plane_bytes) = p2;
         *reinterpret_cast<u32x4*>(d + 2 * plane_bytes) = p3;
     };
-    auto store_tiles = [&](f32x4 (*qa)[2], f32x4 (*qb)[2]) {
+    auto store_tiles = [&](f32x4 (*qa)[AV], f32x4 (*qb)[2]) {
 #pragma unroll
-        for (int it = 0; it < A_ITERS; ++it) store_one(As, A_PLANE, it, qa[it]);
+        for (int it = 0; it < A_ITERS; ++it) {
+            if constexpr (ATERMS == 1) {
+                const int e = tid + it * 256;
+                *reinterpret_cast<f32x4*>(As + (e >> 2) * ROWB + (e & 3) * 16) = qa[it][0];
+            } else {
+                store_one(As, A_PLANE, it, qa[it]);
+            }
+        }
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) store_one(Bs, B_PLANE, it, qb[it]);
     };
@@ -177,11 +198,11 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     auto multiply = [&]() {
 #pragma unroll
         for (int c = 0; c < BK / 16; ++c) {
-            bf16x8 a[TM][3], b[TN][3];
+            bf16x8 a[TM][ATERMS], b[TN][3];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < ATERMS; ++p)
                     a[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
                         As + p * A_PLANE + (wm * WM + i * 32 + l31) * ROWB + (c * 2 + half) * 16));
 #pragma unroll
@@ -195,6 +216,7 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
             for (int t = 0; t < 6; ++t) {
                 const int pa = (t == 0 ? 2 : t == 1 ? 1 : t == 2 ? 0 : t == 3 ? 1 : 0);
                 const int pb = (t == 0 ? 0 : t == 1 ? 1 : t == 2 ? 2 : t == 3 ? 0 : t == 4 ? 1 : 0);
+                if (pa >= ATERMS) continue;      // bf16 A: only a1*b3, a1*b2, a1*b1
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -207,15 +229,19 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     const int nfast = (vec_a && vec_b) ? (k_end - k_begin) / BK : 0;
     // Wait until only the other set's loads are in flight, then split this set into LDS.  `live` = 0 zeroes the tile
     // (the phantom second half of an odd tile count).
-    auto consume = [&](f32x4 (*qa)[2], f32x4 (*qb)[2], bool live) {
+    auto consume = [&](f32x4 (*qa)[AV], f32x4 (*qb)[2], bool live) {
         vm_wait<TILE_LOADS>();
 #pragma unroll
-        for (int it = 0; it < A_ITERS; ++it) { pin(qa[it][0]); pin(qa[it][1]); }
+        for (int it = 0; it < A_ITERS; ++it)
+#pragma unroll
+            for (int v = 0; v < AV; ++v) pin(qa[it][v]);
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) { pin(qb[it][0]); pin(qb[it][1]); }
         if (!live) {
 #pragma unroll
-            for (int it = 0; it < A_ITERS; ++it) { qa[it][0] = f32x4{0.f, 0.f, 0.f, 0.f}; qa[it][1] = qa[it][0]; }
+            for (int it = 0; it < A_ITERS; ++it)
+#pragma unroll
+                for (int v = 0; v < AV; ++v) qa[it][v] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();                                                  // previous tile fully read
         store_tiles(qa, qb);                                              // registers -> LDS (split)
@@ -301,12 +327,12 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     }
 }
 
-template <int BM, int BN, int MINB>
+template <int BM, int BN, int MINB, int ATERMS>
 int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n,
               int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b, int atomic_out,
               double* colp, int colp_chunks) {
     constexpr size_t lds = lds_bytes<BM, BN>();
-    auto kern = k_gemm_x6<BM, BN, MINB>;
+    auto kern = k_gemm_x6<BM, BN, MINB, ATERMS>;
     static bool configured = false;
     if (!configured) {
         PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -324,8 +350,8 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
 // Called by gemm_dispatch (gemm.hip) for C = A * B^T products when the split-bf16 mode is on.
 int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
-                     hipStream_t st) {
-    const int vec_a = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+                     hipStream_t st, bool a_bf16) {
+    const int vec_a = a_bf16 ? 1 : (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     const int vec_b = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
     struct Tile { int bm, bn; };
     static const Tile tiles[4] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
@@ -369,9 +395,14 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
             colp_chunks = 0;
         }
     }
-#define GO(BMV, BNV, MINB)                                                                                       \
-    return launch_x6<BMV, BNV, MINB>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a, \
-                                     vec_b, atomic_out, colp, colp_chunks)
+#define GO(BMV, BNV, MINB)                                                                                              \
+    do {                                                                                                                \
+        if (a_bf16)                                                                                                     \
+            return launch_x6<BMV, BNV, MINB, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split,    \
+                                                vec_a, vec_b, atomic_out, colp, colp_chunks);                               \
+        return launch_x6<BMV, BNV, MINB, 3>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a, \
+                                            vec_b, atomic_out, colp, colp_chunks);                                          \
+    } while (0)
     if (pick == 0) { GO(128, 128, 2); }
     if (pick == 1) { GO(128, 64, 2); }
     if (pick == 2) { GO(64, 128, 2); }

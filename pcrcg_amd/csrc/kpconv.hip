@@ -55,18 +55,27 @@ constexpr int K = PCRCG_KPOINTS;
 constexpr int kWavesPerBlock = 4;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ unsigned short bf16_rne(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
 // pos[s] = (sum_c x[s,c] > 0); one wavefront per support row.  Also writes the packed record
 // pk[s] = (x, y, z, pos ? 1 : 0): the gather kernels fetch a neighbour's coordinates and flag with ONE 16-byte
 // gather (one cache line) instead of a 12-byte and a 1-byte gather (two lines) -- random line fetches, not
 // feature bytes, are what loads L2 in this kernel.
 __global__ void __launch_bounds__(256) k_row_positive(const float* __restrict__ x, int ns, int cin,
                                                        const float* __restrict__ s_pts, unsigned char* __restrict__ pos,
-                                                       float4* __restrict__ pk) {
+                                                       float4* __restrict__ pk, unsigned short* __restrict__ xb) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= ns) return;
     float s = 0.0f;
-    for (int c = lane; c < cin; c += 64) s += x[(long)row * cin + c];
+    for (int c = lane; c < cin; c += 64) {
+        const float v = x[(long)row * cin + c];
+        s += v;
+        if (xb) xb[(long)row * cin + c] = bf16_rne(v);      // bf16 feature-storage variant: the copy the gathers read
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
     if (lane == 0) {
@@ -84,12 +93,23 @@ __global__ void __launch_bounds__(256) k_pack_c1(const float* __restrict__ x, in
 
 struct __attribute__((packed, aligned(4))) P3 { float x, y, z; };
 
-template <int NB, bool NT_STORE>  // 64-channel blocks handled per wavefront (one float4 per lane and block)
+// BF16: the bf16 feature-storage variant (BASELINE.json configs[1] "bf16/fp32"): x and wf are bf16 in memory (half the
+// gather and half the wf bytes), the aggregation still runs on the fp32 MFMA with fp32 accumulation; wf is rounded to
+// nearest-even on the way out.
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const unsigned short* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <int NB, bool NT_STORE, typename FT>  // 64-channel blocks handled per wavefront (one float4 per lane and block)
 __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
     const float* __restrict__ q_pts, int nq, const float* __restrict__ s_pts, int ns,
-    const long long* __restrict__ idx, int H, int ld_idx, const float* __restrict__ x, int cin,
-    const float* __restrict__ kp, float extent, const float4* __restrict__ pk, float* __restrict__ wf,
+    const long long* __restrict__ idx, int H, int ld_idx, const FT* __restrict__ x, int cin,
+    const float* __restrict__ kp, float extent, const float4* __restrict__ pk, FT* __restrict__ wf,
     float* __restrict__ inv_n, int nchunk) {
+    constexpr bool BF16 = sizeof(FT) == 2;
     // groups of 4 neighbours whose row reads are in flight together.  The kernel is bound by its dependent load
     // chain, so occupancy beats deeper batches: 4 groups (76 VGPRs, 6 wavefronts/SIMD) measured best for NB = 1
     // (8 groups: 96 VGPRs / 5 waves, -9 %; 12 groups: 136 / 3 waves, -40 %; 2 groups: 68 / 7 waves, -4 %)
@@ -143,11 +163,11 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
                     }
                     // unconditional loads from clamped (always valid) addresses, zeroed by select: a load
                     // inside a divergent branch would be waited for one by one
-                    const float* xrow = x + (long)(real ? ii : 0) * cin;
+                    const FT* xrow = x + (long)(real ? ii : 0) * cin;
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
                         const int c = c0 + 64 * b + 4 * j;
-                        const float4 t = *reinterpret_cast<const float4*>(xrow + (c < cin ? c : cin - 4));
+                        const float4 t = load4(xrow + (c < cin ? c : cin - 4));
                         const bool ok = real && c < cin;
                         v[s][b] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
                     }
@@ -164,7 +184,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
             }
         }
         // D layout: register r of lane (hsub, j) = kernel point 4*hsub + r, channel group j
-        float* o = wf + (long)q * K * cin + c0;
+        FT* o = wf + (long)q * K * cin + c0;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int c = 64 * b + 4 * j;
@@ -175,10 +195,17 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
                 if (k < K) {
                     // streamed once (the contraction GEMM reads it back): non-temporal, so that 230 MB of wf do not
                     // push the feature rows the gathers re-read out of L2
-                    typedef float v4f __attribute__((ext_vector_type(4)));
-                    const v4f val = {acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]};
-                    if (NT_STORE) __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + (long)k * cin + c));
-                    else *reinterpret_cast<v4f*>(o + (long)k * cin + c) = val;
+                    if constexpr (BF16) {
+                        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                        const v2u val = {(unsigned)bf16_rne(acc[b][0][r]) | ((unsigned)bf16_rne(acc[b][1][r]) << 16),
+                                         (unsigned)bf16_rne(acc[b][2][r]) | ((unsigned)bf16_rne(acc[b][3][r]) << 16)};
+                        __builtin_nontemporal_store(val, reinterpret_cast<v2u*>(o + (long)k * cin + c));
+                    } else {
+                        typedef float v4f __attribute__((ext_vector_type(4)));
+                        const v4f val = {acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]};
+                        if (NT_STORE) __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + (long)k * cin + c));
+                        else *reinterpret_cast<v4f*>(o + (long)k * cin + c) = val;
+                    }
                 }
             }
         }
@@ -316,12 +343,13 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_generic(
 
 // pos / pk records of `x` (see k_row_positive) into the workspace layout of pcrcg_kpconv_ws_bytes; shared by the
 // two-stage path and the fused kernel (kpconv_x6.hip)
-int kpconv_pack(const float* x, int ns, int cin, const float* s_pts, void* ws, size_t ws_bytes, hipStream_t st) {
+int kpconv_pack(const float* x, int ns, int cin, const float* s_pts, void* ws, size_t ws_bytes, hipStream_t st,
+                unsigned short* x_bf16) {
     Carver cv(ws, ws_bytes);
     unsigned char* pos = cv.take<unsigned char>((size_t)ns + 1);
     float4* pk = cv.take<float4>((size_t)ns + 1);
     PCRCG_CHECK_WS(cv);
-    if (ns > 0) hipLaunchKernelGGL(k_row_positive, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, s_pts, pos, pk);
+    if (ns > 0) hipLaunchKernelGGL(k_row_positive, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, s_pts, pos, pk, x_bf16);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -334,7 +362,7 @@ extern "C" {
 
 void pcrcg_profile_kpconv(int enable) {
     std::lock_guard<std::mutex> lock(g_prof_mu);
-    for (auto& r : g_prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
     g_prof_on = enable != 0;
 }
@@ -363,6 +391,17 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
                            float* wf, float* inv_n, void* ws, size_t ws_bytes, void* stream) {
     return kpconv_aggregate_rows(q_pts, nq, s_pts, ns, idx, h, ld_idx, x, cin, kp, extent, wf, inv_n, ws, ws_bytes,
                                  as_stream(stream), true, true);
+}
+
+// The bf16 feature-storage variant of pcrcg_kpconv_aggregate: x stays fp32 at the boundary; `x_bf16` ([ns, cin] u16
+// scratch) receives its round-to-nearest-even copy, which is what the neighbour gathers read, and `wf_bf16`
+// ([nq, 15*cin] u16) the aggregated features rounded the same way.  Geometry, influences, the neighbour-count
+// normaliser and the accumulation are fp32 as in the fp32 path.
+int pcrcg_kpconv_aggregate_bf16(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h,
+                                int ld_idx, const float* x, int cin, const float* kp, float extent, void* x_bf16,
+                                void* wf_bf16, float* inv_n, void* ws, size_t ws_bytes, void* stream) {
+    return kpconv_aggregate_bf16(q_pts, nq, s_pts, ns, idx, h, ld_idx, x, static_cast<unsigned short*>(x_bf16), cin, kp,
+                                 extent, static_cast<unsigned short*>(wf_bf16), inv_n, ws, ws_bytes, as_stream(stream));
 }
 }
 
@@ -398,7 +437,9 @@ int kpconv_aggregate_rows(const float* q_pts, int nq, const float* s_pts, int ns
         PCRCG_CHECK_LAUNCH();
         return PCRCG_OK;
     }
-    if (pack && ns > 0) hipLaunchKernelGGL(k_row_positive, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, s_pts, pos, pk);
+    if (pack && ns > 0)
+        hipLaunchKernelGGL(k_row_positive, dim3((ns + 3) / 4), dim3(256), 0, st, x, ns, cin, s_pts, pos, pk,
+                           (unsigned short*)nullptr);
     KpProfScope prof_scope(st, nq, h, cin, 0, 0);   // start / stop events of the gather/aggregate kernel itself
     const bool aligned = (cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(wf) & 15) == 0);
@@ -414,9 +455,9 @@ int kpconv_aggregate_rows(const float* q_pts, int nq, const float* s_pts, int ns
     while (nb > 1 && ((long)nq * ((nblk + nb - 1) / nb) < 16384 || nblk % nb != 0)) nb >>= 1;
     const int nchunk = (nblk + nb - 1) / nb;
     const int blocks = blocks_for((long)nq * nchunk);
-#define LAUNCH(NBV, NT)                                                                                          \
-    hipExtLaunchKernelGGL((k_kpconv_mfma<NBV, NT>), dim3(blocks), dim3(kWavesPerBlock * 64), 0, st, prof_scope.a, \
-                          prof_scope.b, 0, q_pts, nq, s_pts, ns, idx_ll, h, ld_idx, x, cin, kp, extent,          \
+#define LAUNCH(NBV, NT)                                                                                                 \
+    hipExtLaunchKernelGGL((k_kpconv_mfma<NBV, NT, float>), dim3(blocks), dim3(kWavesPerBlock * 64), 0, st, prof_scope.a, \
+                          prof_scope.b, 0, q_pts, nq, s_pts, ns, idx_ll, h, ld_idx, x, cin, kp, extent,                 \
                           (const float4*)pk, wf, inv_n, nchunk)
     if (stream_out) {
         if (nb == 4) LAUNCH(4, true);
@@ -428,6 +469,39 @@ int kpconv_aggregate_rows(const float* q_pts, int nq, const float* s_pts, int ns
         else LAUNCH(1, false);
     }
 #undef LAUNCH
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+// The bf16 feature-storage variant: x_bf16 [ns, cin] and wf_bf16 [nq, 15*cin] are bf16; `x` (fp32) is only read by the
+// support-record prelude (the n_q normaliser counts rows with a positive fp32 sum, exactly as the fp32 path does).
+int kpconv_aggregate_bf16(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h, int ld_idx,
+                          const float* x, unsigned short* x_bf16, int cin, const float* kp, float extent,
+                          unsigned short* wf_bf16, float* inv_n, void* ws, size_t ws_bytes, hipStream_t st) {
+    PCRCG_CHECK_ARG(nq >= 0 && ns >= 1 && h >= 1 && ld_idx >= h && cin >= 4 && cin % 4 == 0 && extent > 0.0f);
+    if (nq == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(q_pts && s_pts && idx && x && x_bf16 && kp && wf_bf16 && inv_n && ws);
+    PCRCG_CHECK_ARG((reinterpret_cast<uintptr_t>(x_bf16) & 7) == 0 && (reinterpret_cast<uintptr_t>(wf_bf16) & 7) == 0);
+    PCRCG_PROPAGATE(kpconv_pack(x, ns, cin, s_pts, ws, ws_bytes, st, x_bf16));   // also writes the bf16 copy of x
+    Carver cv(ws, ws_bytes);
+    cv.take<unsigned char>((size_t)ns + 1);
+    float4* pk = cv.take<float4>((size_t)ns + 1);
+    const long long* idx_ll = reinterpret_cast<const long long*>(idx);
+    const int nblk = (cin + 63) / 64;
+    int nb = nblk >= 4 ? 4 : (nblk >= 2 ? 2 : 1);
+    while (nb > 1 && ((long)nq * ((nblk + nb - 1) / nb) < 16384 || nblk % nb != 0)) nb >>= 1;
+    const int nchunk = (nblk + nb - 1) / nb;
+    long blocks = ((long)nq * nchunk + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    KpProfScope prof_scope(st, nq, h, cin, 0, 2);      // kind 2: bf16 storage
+#define LAUNCHB(NBV)                                                                                                      \
+    hipExtLaunchKernelGGL((k_kpconv_mfma<NBV, true, unsigned short>), dim3((int)blocks), dim3(kWavesPerBlock * 64), 0, st, \
+                          prof_scope.a, prof_scope.b, 0, q_pts, nq, s_pts, ns, idx_ll, h, ld_idx, x_bf16, cin, kp, extent, \
+                          (const float4*)pk, wf_bf16, inv_n, nchunk)
+    if (nb == 4) LAUNCHB(4);
+    else if (nb == 2) LAUNCHB(2);
+    else LAUNCHB(1);
+#undef LAUNCHB
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

@@ -40,7 +40,6 @@ __global__ void __launch_bounds__(256) k_kpconv_fused(
     const float kpx = jvalid ? kp[3 * j] : 0.f, kpy = jvalid ? kp[3 * j + 1] : 0.f, kpz = jvalid ? kp[3 * j + 2] : 0.f;
     const float inv_extent = 1.0f / extent;
     const int kdim = K * cin;
-    const int cout = 64 * NT;
 
     f32x4 acc[NT][2];
 #pragma unroll

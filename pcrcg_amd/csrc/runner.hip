@@ -28,6 +28,7 @@ struct Ctx {
     size_t cap = 0, off = 0, peak = 0;
     hipStream_t st = nullptr;
     bool dry = false;
+    bool bf16 = false;      // pcrcg_model.feature_bf16
     int rc = PCRCG_OK;
 
     void* raw(size_t bytes) {
@@ -159,10 +160,27 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
         xp = pad.p;
         w = blk.kp_w_pad;
     }
-    Mat wf = c.mat(nq, PCRCG_KPOINTS * cin);
     float* inv_n = static_cast<float*>(c.raw(sizeof(float) * (nq > 0 ? nq : 1)));
     const size_t wsb = pcrcg_kpconv_ws_bytes(ns);
     void* ws = c.raw(wsb);
+    // bf16 feature storage (pcrcg_model.feature_bf16): the gathers read a bf16 copy of x and wf is bf16 in HBM -- half
+    // the bytes of the two streams that bound the encoder; the contraction takes wf as the (single-term) bf16 operand
+    // against the exact three-term split of the fp32 weights, fp32 accumulate and fp32 output.
+    if (c.bf16 && blk.kp_wt && cin % 32 == 0) {
+        const int kk = PCRCG_KPOINTS * cin;
+        void* xb = c.raw(sizeof(unsigned short) * (size_t)(ns > 0 ? ns : 1) * cin);
+        void* wfb = c.raw(sizeof(unsigned short) * (size_t)(nq > 0 ? nq : 1) * kk);
+        if (c.live()) {
+            c.check(pcrcg_kpconv_aggregate_bf16(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, xp, cin, blk.kp, blk.extent,
+                                                xb, wfb, inv_n, ws, wsb, c.st));
+            c.check(pcrcg_gemm_bf16a_f32_colstats(wfb, kk, blk.kp_wt, kk, y.p, y.ld, nq, y.cols, kk, inv_n, nullptr,
+                                                  st ? st->partials : nullptr, st ? st->bytes : 0,
+                                                  st ? &st->chunks : nullptr, c.st));
+        }
+        c.release(m);
+        return;
+    }
+    Mat wf = c.mat(nq, PCRCG_KPOINTS * cin);
     if (c.live()) {
         c.check(pcrcg_kpconv_aggregate(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, xp, cin, blk.kp, blk.extent,
                                        wf.p, inv_n, ws, wsb, c.st));
@@ -300,6 +318,7 @@ Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, co
 
 void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_outputs& out) {
     const int L = b.n_levels;
+    c.bf16 = mdl.feature_bf16 != 0;
     Mat x;
     x.p = const_cast<float*>(b.features);
     x.rows = b.n_points[0];

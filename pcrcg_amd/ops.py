@@ -400,6 +400,57 @@ def kpconv_x6(q_pts, s_pts, idx, x, kernel_points, weights, extent):
     return out
 
 
+def kpconv_bf16(q_pts, s_pts, idx, x, kernel_points, weights, extent, intermediates=False):
+    """KPConv.forward of the bf16 feature-storage VARIANT (pcrcg_model.feature_bf16): the gathers read a bf16 copy of
+    x, the aggregate is bf16 in memory, the contraction takes it as the bf16 operand against the exactly split fp32
+    weights.  cin % 32 == 0.  intermediates=True also returns (x_bf16, wf_bf16, inv_n) as int16 / fp32 tensors."""
+    L = _lib.lib()
+    q_pts, s_pts = _dev(q_pts, _F32, "q_pts").contiguous(), _dev(s_pts, _F32, "s_pts").contiguous()
+    idx, ld_idx = _rows(idx, _I64, "idx")
+    x = _dev(x, _F32, "x").contiguous()
+    kernel_points = _dev(kernel_points, _F32, "kernel_points").contiguous()
+    nq, ns, h, cin, cout = q_pts.shape[0], s_pts.shape[0], idx.shape[1], x.shape[1], weights.shape[2]
+    if cin % 32:
+        raise RuntimeError("pcrcg_amd.kpconv_bf16: cin must be a multiple of 32")
+    kk = 15 * cin
+    wt = _dev(weights, _F32, "weights").reshape(-1, cout).t().contiguous()           # [cout, 15*cin], K-contiguous
+    xb = torch.empty((ns, cin), dtype=torch.int16, device=x.device)
+    wfb = torch.empty((nq, kk), dtype=torch.int16, device=x.device)
+    inv_n = torch.empty(nq, dtype=_F32, device=x.device)
+    out = torch.empty((nq, cout), dtype=_F32, device=x.device)
+    nbytes = L.pcrcg_kpconv_ws_bytes(ns)
+    ws = _ws.get("kpconv", nbytes, x.device)
+    _lib.check(L.pcrcg_kpconv_aggregate_bf16(q_pts.data_ptr(), nq, s_pts.data_ptr(), ns, idx.data_ptr(), h, ld_idx,
+                                             x.data_ptr(), cin, kernel_points.data_ptr(), float(extent), xb.data_ptr(),
+                                             wfb.data_ptr(), inv_n.data_ptr(), ws.data_ptr(), nbytes, _stream()),
+               "pcrcg_kpconv_aggregate_bf16")
+    _lib.check(L.pcrcg_gemm_bf16a_f32_colstats(wfb.data_ptr(), kk, wt.data_ptr(), kk, out.data_ptr(), cout, nq, cout, kk,
+                                               inv_n.data_ptr(), None, None, 0, None, _stream()),
+               "pcrcg_gemm_bf16a_f32_colstats")
+    return (out, xb, wfb, inv_n) if intermediates else out
+
+
+def gemm_bf16a(a_bf16, b, row_scale=None, bias=None):
+    """(a @ b^T) * row_scale + bias with a [m, k] torch.bfloat16 (k % 32 == 0, rows 16-byte aligned) and b [n, k]
+    fp32 (pcrcg_gemm_bf16a_f32_colstats)."""
+    L = _lib.lib()
+    if a_bf16.dtype != torch.bfloat16 or not a_bf16.is_cuda:
+        raise RuntimeError("pcrcg_amd.gemm_bf16a: `a` must be a bfloat16 tensor on the HIP device")
+    a = a_bf16.contiguous()
+    b = _dev(b, _F32, "b").contiguous()
+    m, k = a.shape
+    n = b.shape[0]
+    out = torch.empty((m, n), dtype=_F32, device=a.device)
+    if row_scale is not None:
+        row_scale = _dev(row_scale, _F32, "row_scale").contiguous()
+    if bias is not None:
+        bias = _dev(bias, _F32, "bias").contiguous()
+    _lib.check(L.pcrcg_gemm_bf16a_f32_colstats(a.data_ptr(), k, b.data_ptr(), k, out.data_ptr(), n, m, n, k,
+                                               _ptr(row_scale), _ptr(bias), None, 0, None, _stream()),
+               "pcrcg_gemm_bf16a_f32_colstats")
+    return out
+
+
 def gather_max(x, idx):
     L = _lib.lib()
     x = _dev(x, _F32, "x").contiguous()

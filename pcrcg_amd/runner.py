@@ -45,7 +45,8 @@ class Model(ctypes.Structure):
                 ("enc_out_dim", ctypes.c_int), ("gnn_dim", ctypes.c_int), ("heads", ctypes.c_int),
                 ("knn_k", ctypes.c_int), ("final_dim", ctypes.c_int),
                 ("bottle_w", _fp), ("bottle_b", _fp), ("proj_gnn_w", _fp), ("proj_gnn_b", _fp),
-                ("proj_score_w", _fp), ("proj_score_b", _fp), ("temperature", ctypes.c_float)]
+                ("proj_score_w", _fp), ("proj_score_b", _fp), ("temperature", ctypes.c_float),
+                ("feature_bf16", ctypes.c_int)]
 
 
 class Table(ctypes.Structure):
@@ -122,7 +123,8 @@ class Runner:
         return (type(None), ())
 
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        return (bool(getattr(self.model, "feature_bf16", False)),) + tuple(
+            (p.data_ptr(), p._version) for p in self.model.parameters())
 
     def _w(self, t):
         t = _dense(t)
@@ -260,6 +262,8 @@ class Runner:
         d.proj_score_w, d.proj_score_b = (self._w(m.proj_score.weight.data.squeeze(-1)),
                                           self._w(m.proj_score.bias.data))
         d.temperature = float(torch.exp(m.epsilon.detach()).item()) + 0.03
+        # the bf16 feature-storage VARIANT (include/pcrcg.h pcrcg_model.feature_bf16); off unless asked for
+        d.feature_bf16 = int(bool(getattr(m, "feature_bf16", False)))
         return d
 
     @staticmethod
