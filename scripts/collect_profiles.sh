@@ -22,3 +22,12 @@ done
 python3 $R/scripts/pmc_summary.py $O/${TAG}_pmc_FETCH_SIZE.csv $O/${TAG}_pmc_WRITE_SIZE.csv $O/${TAG}_pmc_traffic.json
 rm -f $O/${TAG}_pmc_FETCH_SIZE.csv $O/${TAG}_pmc_WRITE_SIZE.csv
 ls -la $O | grep ${TAG}
+# 4. secondary lines (no tracer): other workloads, index tie order, bf16 feature-storage variant
+if [ "${2:-}" = "all" ]; then
+  for W in U30k K120k T30k; do
+    python3 $R/bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_$W.json
+  done
+  PCRCG_TIE_ORDER=index python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_tie_index.json
+  python3 $R/bench.py --variant bf16 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_bf16_variant.json
+fi
+ls -la $O | grep ${TAG}

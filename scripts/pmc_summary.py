@@ -34,6 +34,17 @@ def main(fetch_csv, write_csv, out_json):
                   "fetch_bytes": int(2 * fk * 1024), "write_bytes": int(wk * 1024),
                   "hbm_bytes": int(2 * fk * 1024 + wk * 1024)}
     json.dump(out, open(out_json, "w"), indent=1)
+    # the dominant kernel family (bench.py's `roofline`): launch-weighted HBM bytes per KPConv gather launch
+    kp = {n: v for n, v in out.items() if isinstance(v, dict) and "k_kpconv" in n}
+    launches = sum(v["launches"] for v in kp.values())
+    if launches:
+        json.dump({"source": "%s (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes with --kernel-trace only, "
+                             "bench.py --isolated-only --steps 3 --warmup 1)" % out_json.split("/")[-1],
+                   "correction": "fetch bytes = 2 x FETCH_SIZE[KiB] x 1024 (gfx950: FETCH_SIZE reports half of wide coalesced "
+                                 "reads); write bytes = WRITE_SIZE[KiB] x 1024",
+                   "kernels": kp,
+                   "hbm_bytes_per_launch": int(sum(v["hbm_bytes"] * v["launches"] for v in kp.values()) / launches)},
+                  open(out_json.replace("_pmc_traffic.json", "_pmc_kpconv.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
