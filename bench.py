@@ -389,6 +389,15 @@ def main():
                                            "achieved_TFLOPs_f32_mfma": round(f_tf, 1),
                                            "frac_mfma_f32_157TF": round(f_tf / 157.3, 4)}},
         }
+        if hasattr(pipe, "stats") and pipe.stats.get("pairs"):
+            n = pipe.stats["pairs"]
+            line["host"] = {"note": "host_submit_ms_per_step is the main thread's time until the last pair is accepted; it blocks on "
+                                    "the engine's depth limit, so it tracks GPU throughput.  The engine threads' own times, ms "
+                                    "per pair over the whole run (warm-up included): inside pcrcg_pyramid_build (enqueue + its "
+                                    "four host round trips) / enqueueing the restore step + pcrcg_kpfcnn_forward",
+                            "front_thread_build_ms_per_pair": round(1e3 * pipe.stats["build_s"] / n, 3),
+                            "model_threads_enqueue_ms_per_pair": round(1e3 * pipe.stats["launch_s"] / n, 3),
+                            "pairs_per_pyramid_build": round(n / max(pipe.stats.get("builds", n), 1), 2)}
         if BF16:
             line["variant"] = {"name": "bf16 feature storage", "max_abs_error_over_max_abs_vs_fp32_path": variant_error,
                                "note": "outside the 1e-4 parity bound of the fp32 path by construction; "

@@ -127,7 +127,7 @@ int pcrcg_radius_neighbors_batch(const float* q, int nq, const float* sup, int n
  *                          to the first of them and rows are padded with their total size (the table's shadow
  *                          index).  rows [nrows] i32 = the rows to redo (out_tie_rows; NULL = all nq rows);
  *                          count [nq] i32 (may be NULL) = out_count of the query, cross-checked;
- *                          max_count = staging width (>= the longest list among `rows`, <= 1024);
+ *                          max_count = staging width (>= the longest list among `rows`, <= 8192);
  *                          idx [nq, cols] i64.
  *   pcrcg_radius_reorder_jobs  the same for up to PCRCG_MAX_REORDER_JOBS tables over one forest in ONE launch
  *                          (all tables of a pair).
@@ -316,6 +316,18 @@ int pcrcg_edgeconv_reduce(const float* ctr, int ld_ctr, const float* nbr, int ld
 /* Row softmax in place: x [rows, cols] (ld), x = softmax(x * scale) (ref:models/gcn.py:151-155,
  * ref:models/architectures.py:562-563). */
 int pcrcg_softmax_rows(float* x, int rows, int cols, int ld, float scale, void* stream);
+/* Multi-head attention in ONE launch (ref:models/gcn.py:151-155: scores = q k^T / sqrt(d), prob = softmax(scores),
+ * message = prob v, per head):  out[:, h*d:(h+1)*d] = softmax(scale * q_h k_h^T) v_h  for h < heads, where head h of
+ * q [n, heads*d], k / v [ms, heads*d] and out [n, heads*d] is the column block [h*d, (h+1)*d) (row-major, leading
+ * dimensions ldq/ldk/ldv multiples of 4, 16-byte aligned bases).  d in {16, 32, 48, 64}
+ * (pcrcg_attention_supported); other widths: one pcrcg_gemm_f32 / pcrcg_softmax_rows / pcrcg_gemm_f32 per head. */
+int pcrcg_attention_supported(int d);
+int pcrcg_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int n,
+                    int ms, int heads, int d, float scale, void* stream);
+/* y[r * ldy] = sum_j softmax(scale * x[r, :])_j * vec[j * ldv]: the saliency scores
+ * (ref:models/architectures.py:562-563, softmax(inner / T) @ scores) without storing the probabilities. */
+int pcrcg_softmax_matvec(const float* x, int rows, int cols, int ld, float scale, const float* vec, int ldv, float* y,
+                         int ldy, void* stream);
 
 /* Copy a device status word to the host after draining `stream`; returns PCRCG_ECAPACITY if it is
  * non-zero. */

@@ -79,6 +79,10 @@ SIGNATURES = {
     "pcrcg_edgeconv_reduce": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float,
                                       c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pcrcg_softmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "pcrcg_attention_supported": (c_int, [c_int]),
+    "pcrcg_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                c_int, c_float, c_void_p]),
+    "pcrcg_softmax_matvec": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "pcrcg_copy2d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pcrcg_add": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p]),
     "pcrcg_l2norm_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -111,6 +111,129 @@ __global__ void __launch_bounds__(256) k_softmax_rows(float* __restrict__ x, int
     for (int j = lane; j < cols; j += 64) row[j] *= inv;
 }
 
+// Multi-head attention in one launch: out[:, h*D:(h+1)*D] = softmax(scale * q_h k_h^T) v_h  (ref:models/gcn.py:151-155).
+// On the path the operands are tiny (a few hundred coarse points, D = 64): three GEMM-class launches + a softmax per
+// head and direction were 24 launches of ~20 us of latency each.  Here a workgroup owns 16 queries of one head;
+// 16 lanes share a query: each lane scores 4 of the 64 keys of a chunk (the query row lives in registers, the key
+// chunk in LDS with rows padded to D + 4 floats), the chunk's probabilities go through LDS, and each lane
+// accumulates D/16 output channels with the running-max / running-sum rescaling (softmax in one pass over the keys,
+// fp32 throughout, plain FMAs: 0.3 GFLOP per call needs no matrix core).
+template <int D>
+__global__ void __launch_bounds__(256) k_attention(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                   const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo,
+                                                   int n, int ms, float scale) {
+    constexpr int TQ = 16, KC = 64, KS = D + 4, DV = D / 16, D4 = D / 4;
+    __shared__ float4 Ks4[KC * KS / 4];
+    __shared__ float4 Vs4[KC * D / 4];
+    __shared__ float4 Ps4[TQ * KC / 4];
+    float* const Ks = reinterpret_cast<float*>(Ks4);
+    float* const Vs = reinterpret_cast<float*>(Vs4);
+    float* const Ps = reinterpret_cast<float*>(Ps4);
+    const int tid = threadIdx.x, qi = tid >> 4, j = tid & 15, head = blockIdx.y;
+    const int row = blockIdx.x * TQ + qi;
+    const float* qrow = q + (long)(row < n ? row : n - 1) * ldq + head * D;
+    float4 qr[D4];
+#pragma unroll
+    for (int c = 0; c < D4; ++c) qr[c] = *reinterpret_cast<const float4*>(qrow + 4 * c);
+    float m = -INFINITY, l = 0.f, o[DV];
+#pragma unroll
+    for (int i = 0; i < DV; ++i) o[i] = 0.f;
+    for (int kc0 = 0; kc0 < ms; kc0 += KC) {
+        __syncthreads();                                  // the previous chunk's readers are done
+#pragma unroll
+        for (int e = tid; e < KC * D4; e += 256) {
+            const int key = e / D4, c4 = e % D4;
+            const bool ok = kc0 + key < ms;
+            const long r = ok ? kc0 + key : 0;
+            const float4 kv = *reinterpret_cast<const float4*>(k + r * ldk + head * D + 4 * c4);
+            const float4 vv = *reinterpret_cast<const float4*>(v + r * ldv + head * D + 4 * c4);
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(Ks + key * KS + 4 * c4) = ok ? kv : z;
+            *reinterpret_cast<float4*>(Vs + key * D + 4 * c4) = ok ? vv : z;
+        }
+        __syncthreads();
+        float sc[4], mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int key = j + 16 * t;
+            const float* kr = Ks + key * KS;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < D4; ++c) {
+                const float4 kv = *reinterpret_cast<const float4*>(kr + 4 * c);
+                acc = fmaf(qr[c].x, kv.x, acc);
+                acc = fmaf(qr[c].y, kv.y, acc);
+                acc = fmaf(qr[c].z, kv.z, acc);
+                acc = fmaf(qr[c].w, kv.w, acc);
+            }
+            sc[t] = kc0 + key < ms ? acc * scale : -INFINITY;
+            mx = fmaxf(mx, sc[t]);
+        }
+#pragma unroll
+        for (int s = 8; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, 64));
+        const float m_new = fmaxf(m, mx);                 // finite: every chunk holds at least one key
+        const float alpha = expf(m - m_new);              // exp(-inf) = 0 on the first chunk
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float pe = expf(sc[t] - m_new);
+            Ps[qi * KC + j + 16 * t] = pe;
+            psum += pe;
+        }
+#pragma unroll
+        for (int s = 8; s >= 1; s >>= 1) psum += __shfl_xor(psum, s, 64);
+        l = l * alpha + psum;
+        m = m_new;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < DV; ++i) o[i] *= alpha;
+#pragma unroll 4
+        for (int k4 = 0; k4 < KC / 4; ++k4) {
+            const float4 pp = *reinterpret_cast<const float4*>(Ps + qi * KC + 4 * k4);
+            const float pv[4] = {pp.x, pp.y, pp.z, pp.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* vr = Vs + (4 * k4 + u) * D + j * DV;
+#pragma unroll
+                for (int i = 0; i < DV; ++i) o[i] = fmaf(pv[u], vr[i], o[i]);
+            }
+        }
+    }
+    if (row < n) {
+        const float inv = 1.0f / l;
+        float* orow = out + (long)row * ldo + head * D + j * DV;
+#pragma unroll
+        for (int i = 0; i < DV; ++i) orow[i] = o[i] * inv;
+    }
+}
+
+// y[r] = sum_j softmax(scale * x[r, :])_j * vec[j * ldv]: the saliency scores (ref:models/architectures.py:562-563)
+// without writing the probabilities back.  One wavefront per row.
+__global__ void __launch_bounds__(256) k_softmax_matvec(const float* __restrict__ x, int rows, int cols, int ld, float scale,
+                                                        const float* __restrict__ vec, int ldv, float* __restrict__ y,
+                                                        int ldy) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* row = x + (long)r * ld;
+    float m = -INFINITY;
+    for (int j = lane; j < cols; j += 64) m = fmaxf(m, row[j] * scale);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    float sum = 0.f, dot = 0.f;
+    for (int j = lane; j < cols; j += 64) {
+        const float e = expf(row[j] * scale - m);
+        sum += e;
+        dot = fmaf(e, vec[(long)j * ldv], dot);
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        sum += __shfl_xor(sum, s, 64);
+        dot += __shfl_xor(dot, s, 64);
+    }
+    if (lane == 0) y[(long)r * ldy] = dot / sum;
+}
+
 }  // namespace
 }  // namespace pcrcg
 
@@ -142,6 +265,39 @@ int pcrcg_edgeconv_reduce(const float* ctr, int ld_ctr, const float* nbr, int ld
     hipLaunchKernelGGL(k_edgeconv_reduce, dim3(chunks, (c + 63) / 64), dim3(256), 0, st, ctr, ld_ctr, nbr, ld_nbr,
                        idx, n, k, c, emax, ld_emax, partial);
     return colstats_finalize(partial, chunks, c, (double)n * (double)k, eps, stats, st);
+}
+
+int pcrcg_attention_supported(int d) { return d == 16 || d == 32 || d == 48 || d == 64; }
+
+int pcrcg_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int n,
+                    int ms, int heads, int d, float scale, void* stream) {
+    PCRCG_CHECK_ARG(n >= 0 && ms >= 1 && heads >= 1 && pcrcg_attention_supported(d));
+    PCRCG_CHECK_ARG(ldq >= heads * d && ldk >= heads * d && ldv >= heads * d && ldo >= heads * d);
+    PCRCG_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0);
+    if (n == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(q && k && v && out);
+    PCRCG_CHECK_ARG(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
+    const dim3 grid((n + 15) / 16, heads);
+    hipStream_t st = as_stream(stream);
+#define ATT(DV) hipLaunchKernelGGL(k_attention<DV>, grid, dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, n, ms, scale)
+    if (d == 64) ATT(64);
+    else if (d == 48) ATT(48);
+    else if (d == 32) ATT(32);
+    else ATT(16);
+#undef ATT
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+int pcrcg_softmax_matvec(const float* x, int rows, int cols, int ld, float scale, const float* vec, int ldv, float* y,
+                         int ldy, void* stream) {
+    PCRCG_CHECK_ARG(rows >= 0 && cols >= 1 && ld >= cols && ldv >= 1 && ldy >= 1);
+    if (rows == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(x && vec && y);
+    hipLaunchKernelGGL(k_softmax_matvec, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, rows, cols, ld, scale, vec,
+                       ldv, y, ldy);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
 }
 
 int pcrcg_softmax_rows(float* x, int rows, int cols, int ld, float scale, void* stream) {

@@ -311,7 +311,7 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
         if (want_ties && widest > 0 && tie_rows > 0 && R.njobs < PCRCG_MAX_REORDER_JOBS) {
             pcrcg_reorder_job& j = R.jobs[R.njobs++];
             j.q = t.q; j.qlen = t.qlen; j.rows = t.ties; j.count = t.counts; j.idx = t.idx;
-            j.nq = t.nq; j.nbq = nb; j.cloud0 = nb * t.sup_level; j.nrows = tie_rows; j.max_count = widest < 1024 ? widest : 1024;   // (tieorder.hip stages at most 1024 hits per row)
+            j.nq = t.nq; j.nbq = nb; j.cloud0 = nb * t.sup_level; j.nrows = tie_rows; j.max_count = widest < 8192 ? widest : 8192;   // (tieorder.hip stages at most 8192 hits per row)
             j.cols = t.limit; j.radius = t.radius; j.group = group;
         }
     }

@@ -297,8 +297,13 @@ Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, co
     linear(c, x, g.wq, ch, g.bq, q);
     linear(c, src, g.wk, ch, g.bk, kk);
     linear(c, src, g.wv, ch, g.bv, v);
-    if (c.live()) {
-        for (int i = 0; i < h; ++i) {   // heads are contiguous column blocks after the weight permutation
+    if (c.live() && pcrcg_attention_supported(d)) {
+        // all heads in one launch (heads are contiguous column blocks after the weight permutation)
+        c.check(pcrcg_attention(q.p, q.ld, kk.p, kk.ld, v.p, v.ld, msg.p, msg.ld, n, ms, h, d, 1.0f / sqrtf((float)d),
+                                c.st));
+        c.check(pcrcg_copy2d(x.p, x.ld, cat.p, cat.ld, n, ch, c.st));
+    } else if (c.live()) {
+        for (int i = 0; i < h; ++i) {
             c.check(pcrcg_gemm_f32(q.p + i * d, q.ld, kk.p + i * d, kk.ld, 1, sc.p, sc.ld, n, ms, d, nullptr, nullptr,
                                    c.st));
             c.check(pcrcg_softmax_rows(sc.p, n, ms, sc.ld, 1.0f / sqrtf((float)d), c.st));
@@ -365,15 +370,12 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
             const float inv_t = 1.0f / mdl.temperature;
             const float* fs = fn.p;
             const float* ft = fn.p + (long)ns * fn.ld;
+            // s1 = softmax(inner/T) @ tgt_scores, s2 = softmax(inner^T/T) @ src_scores  (:562-563); the softmax and
+            // the product with the score column are one pass over each inner-product matrix
             c.check(pcrcg_gemm_f32(fs, fn.ld, ft, fn.ld, 1, pst.p, pst.ld, ns, nt, g, nullptr, nullptr, c.st));
-            c.check(pcrcg_softmax_rows(pst.p, ns, nt, pst.ld, inv_t, c.st));
+            c.check(pcrcg_softmax_matvec(pst.p, ns, nt, pst.ld, inv_t, score.p + (long)ns * xc.ld, xc.ld, sal.p, xc.ld, c.st));
             c.check(pcrcg_gemm_f32(ft, fn.ld, fs, fn.ld, 1, pts.p, pts.ld, nt, ns, g, nullptr, nullptr, c.st));
-            c.check(pcrcg_softmax_rows(pts.p, nt, ns, pts.ld, inv_t, c.st));
-            // s1 = softmax(inner/T) @ tgt_scores, s2 = softmax(inner^T/T) @ src_scores  (:562-563)
-            c.check(pcrcg_gemm_f32(pst.p, pst.ld, score.p + (long)ns * xc.ld, xc.ld, 0, sal.p, xc.ld, ns, 1, nt, nullptr,
-                                   nullptr, c.st));
-            c.check(pcrcg_gemm_f32(pts.p, pts.ld, score.p, xc.ld, 0, sal.p + (long)ns * xc.ld, xc.ld, nt, 1, ns, nullptr,
-                                   nullptr, c.st));
+            c.check(pcrcg_softmax_matvec(pts.p, nt, ns, pts.ld, inv_t, score.p, xc.ld, sal.p + (long)ns * xc.ld, xc.ld, c.st));
         }
         c.release(m);
     }

@@ -60,7 +60,8 @@ constexpr int kForestBlocks = 160;    // workgroups of the forest kernel (they p
 constexpr int kSpinLimitDefault = 1 << 18;   // polls of an empty queue before a workgroup gives up (status 1)
 constexpr int kTravStack = 128;       // pending far children per query (<= tree depth)
 constexpr int kReorderWaves = 4;      // rows per workgroup of the reorder kernel
-constexpr int kMaxRow = 1024;         // longest row the reorder kernel stages (= the cell-grid search's own bound)
+constexpr int kMaxRow = 8192;         // longest row the reorder kernel stages: two lists of W u64 in the 160 KB LDS of a CU
+                                      // (rows beyond 3 500 hits: one wavefront per workgroup with more than 64 KB of dynamic LDS)
 
 constexpr int kStUnfinished = 1;      // the forest kernel gave up waiting for work (never seen)
 constexpr int kStStack = 2;           // traversal stack overflow
@@ -925,8 +926,13 @@ int pcrcg_radius_reorder_jobs(const pcrcg_reorder_job* jobs, int njobs, const fl
     KdView v = forest_view(const_cast<void*>(forest), forest_bytes(ns, nb), ns, nb, &ok);
     const size_t second = (size_t)width > (size_t)kTravStack * 5 / 2 ? (size_t)width : (size_t)kTravStack * 5 / 2;
     const size_t per_wave = (size_t)width + second + 1;
-    const int waves = width > 512 ? 2 : kReorderWaves;           // 64 KB of dynamic LDS per workgroup at most
+    // 64 KB of dynamic LDS per workgroup while that holds the widest row; beyond, one wavefront per workgroup with up to
+    // 2 * 8192 * 8 B + 8 B = 128 KB (gfx950: 160 KB per CU), which the kernel has to be granted explicitly
+    const int waves = width > 2000 ? 1 : (width > 512 ? 2 : kReorderWaves);
     const size_t lds = per_wave * waves * sizeof(u64);
+    if (lds > 64 * 1024)
+        PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reorder), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds));
     hipLaunchKernelGGL(k_reorder, dim3((total + waves - 1) / waves), dim3(waves * 64), lds, st, pack, sup, v, width, status);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;

@@ -550,6 +550,38 @@ def softmax_rows_(x, scale=1.0):
     return x
 
 
+def attention(q, k, v, heads, scale=None):
+    """Multi-head attention in one launch: head h = column block [h*d, (h+1)*d) of q [n, heads*d], k / v [ms, heads*d];
+    out = cat_h softmax(scale * q_h k_h^T) v_h, scale = 1/sqrt(d) by default.  d in {16, 32, 48, 64}."""
+    L = _lib.lib()
+    q, ldq = _rows(q, _F32, "q")
+    k, ldk = _rows(k, _F32, "k")
+    v, ldv = _rows(v, _F32, "v")
+    n, ch = q.shape
+    ms = k.shape[0]
+    d = ch // heads
+    if d * heads != ch or k.shape[1] != ch or v.shape != k.shape or not L.pcrcg_attention_supported(d):
+        raise RuntimeError(f"pcrcg_amd.attention: unsupported widths ({ch} channels, {heads} heads)")
+    out = torch.empty((n, ch), dtype=_F32, device=q.device)
+    _lib.check(L.pcrcg_attention(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(), ch, n, ms, heads,
+                                 d, float(d ** -0.5 if scale is None else scale), _stream()), "pcrcg_attention")
+    return out
+
+
+def softmax_matvec(x, vec, scale=1.0):
+    """softmax(x * scale, dim=1) @ vec for x [rows, cols], vec [cols] (any stride) -> [rows]."""
+    L = _lib.lib()
+    x, ld = _rows(x, _F32, "x")
+    vec = _dev(vec, _F32, "vec")
+    if vec.dim() != 1 or vec.shape[0] != x.shape[1]:
+        raise RuntimeError("pcrcg_amd.softmax_matvec: vec must be 1-D with x.shape[1] entries")
+    y = torch.empty(x.shape[0], dtype=_F32, device=x.device)
+    _lib.check(L.pcrcg_softmax_matvec(x.data_ptr(), x.shape[0], x.shape[1], ld, float(scale), vec.data_ptr(),
+                                      int(vec.stride(0)) if vec.shape[0] > 1 else 1, y.data_ptr(), 1, _stream()),
+               "pcrcg_softmax_matvec")
+    return y
+
+
 # ------------------------------------------------------------------------------------------------
 # training-side rows (include/pcrcg_train.h)
 # ------------------------------------------------------------------------------------------------

@@ -69,7 +69,8 @@ class PairStreams:
                 self.fronts = [self._own_stream() for _ in range(max(1, nfs))]
                 self.models = [self._own_stream() for _ in range(max(1, int(model_streams)))]
         else:
-            self.fronts = [torch.cuda.Stream(device=self.device) for _ in range(max(1, nfs))]
+            fp = int(os.environ.get("PCRCG_FRONT_PRIORITY", "0"))    # < 0: the front-end chain ahead of the forwards
+            self.fronts = [torch.cuda.Stream(device=self.device, priority=fp) for _ in range(max(1, nfs))]
             self.models = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(model_streams)))]
         self.front = self.fronts[0]
         nf = max(1, int(front_threads))

@@ -214,7 +214,7 @@ def _restore_reference_order(redo, level_points, level_lens, all_rows):
     forest = ops.KdForest(torch.cat(level_points, 0), torch.cat([l.to(_I32) for l in level_lens], 0))
     status = torch.zeros(1, dtype=_I32, device=level_points[0].device)
     forest.reorder_tables([dict(idx=tab["idx"], q=tab["q"], qlen=tab["qlen"], cloud0=nb * tab["sup_level"],
-                                radius=tab["radius"], max_count=min(tab["max_count"], 1024), counts=tab["counts"],
+                                radius=tab["radius"], max_count=min(tab["max_count"], 8192), counts=tab["counts"],
                                 rows=None if all_rows else tab["ties"], nrows=None if all_rows else tie_rows)
                            for tab, tie_rows in redo], status)
     return status

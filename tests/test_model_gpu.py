@@ -203,6 +203,45 @@ def test_softmax_rows(cuda):
     assert rel(y, torch.softmax(x / 0.0367, 1)) < 1e-5
 
 
+@pytest.mark.parametrize("n,ms,heads,d", [(381, 382, 4, 64), (1, 1, 1, 16), (17, 65, 2, 32), (100, 64, 3, 48), (763, 700, 4, 64),
+                                          (33, 1500, 4, 16)])
+def test_attention_one_launch(cuda, n, ms, heads, d):
+    """pcrcg_attention against the reference formulation (ref:models/gcn.py:151-155) in float64, and against the
+    per-head GEMM / softmax / GEMM path it replaces in the runner."""
+    g = torch.Generator().manual_seed(n + ms + d)
+    ch = heads * d
+    q, k, v = (torch.randn(r, ch, generator=g) * 1.7 for r in (n, ms, ms))
+    got = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), heads)
+    want = torch.empty(n, ch, dtype=torch.float64)
+    for h in range(heads):
+        sl = slice(h * d, (h + 1) * d)
+        prob = torch.softmax(q[:, sl].double() @ k[:, sl].double().t() / d ** 0.5, 1)
+        want[:, sl] = prob @ v[:, sl].double()
+    assert rel(got, want) < 5e-6
+    # strided operands (column slices of wider matrices, as the runner's workspace has them)
+    wide = torch.randn(max(n, ms), 3 * ch + 8, generator=g).to(cuda)
+    qs, ks, vs = wide[:n, 4:4 + ch], wide[:ms, 4 + ch:4 + 2 * ch], wide[:ms, 4 + 2 * ch:4 + 3 * ch]
+    got2 = ops.attention(qs, ks, vs, heads)
+    for h in range(heads):
+        sl = slice(h * d, (h + 1) * d)
+        sc = ops.gemm(qs[:, sl], ks[:, sl].t())
+        ops.softmax_rows_(sc, d ** -0.5)
+        assert rel(got2[:, sl], ops.gemm(sc, vs[:, sl].contiguous())) < 1e-5
+    with pytest.raises(RuntimeError):
+        ops.attention(q[:, :heads * 8].contiguous().to(cuda), k[:, :heads * 8].contiguous().to(cuda),
+                      v[:, :heads * 8].contiguous().to(cuda), heads)          # d = 8: not supported, refused
+
+
+def test_softmax_matvec(cuda):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(381, 382, generator=g)
+    cols3 = torch.rand(382, 3, generator=g).to(cuda)                # the score column of a wider matrix
+    got = ops.softmax_matvec(x.to(cuda), cols3[:, 1], 1 / 0.0367)
+    want = torch.softmax(x.double() / 0.0367, 1) @ cols3[:, 1].double().cpu()
+    assert rel(got, want) < 2e-6
+    assert ops.softmax_matvec(x[:0].to(cuda), cols3[:, 1]).shape == (0,)
+
+
 def test_gcn_golden(cuda, golden_dir):
     gc = torch.load(os.path.join(golden_dir, "gcn_mini.pt"))
     net = GCN(4, 64, 10, ["self", "cross", "self"])

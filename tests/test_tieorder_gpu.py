@@ -147,6 +147,28 @@ def test_large_nodes_and_long_rows(cuda):
     assert status == 0 and (got == want).all()
 
 
+def test_rows_of_thousands_of_hits(cuda):
+    """Tie rows far beyond the cell-grid search's 1024-entry staging list (the reference has no bound): the search
+    keeps the `cols` nearest by streaming selection and reports the true count, the restore step stages the whole row
+    (up to 8192 hits: one wavefront per workgroup with 128 KB of LDS) and replays std::sort on all of it."""
+    rng = np.random.default_rng(11)
+    s = (rng.integers(0, 12, (20000, 3)) / 16).astype(np.float32)       # ~12 duplicates per lattice site
+    q = s[:40].copy()
+    for radius, lo, hi in ((0.2, 1024, 2000), (0.3, 2500, 8192)):
+        want = OF.oracle_batch_query(q, s, [40], [20000], radius, tie_order="reference")
+        assert lo < want.shape[1] <= hi, want.shape
+        qd, sd = torch.from_numpy(q).to(cuda), torch.from_numpy(s).to(cuda)
+        qld, sld = torch.tensor([40], dtype=torch.int32, device=cuda), torch.tensor([20000], dtype=torch.int32, device=cuda)
+        grid = ops.CellGrid(sd, sld, radius)
+        for cols in (47, 300):
+            idx, meta, counts, ties = grid.query(qd, qld, cols, want_ties=True)
+            max_count, status, n_ties = meta.tolist()
+            assert status == 0 and max_count == want.shape[1] and n_ties == 40
+            st = ops.KdForest(sd, sld).reorder(idx, qd, qld, 0, radius, max_count, rows=ties, nrows=n_ties, counts=counts)
+            assert (0 if st is None else int(st.item())) == 0
+            assert (idx.cpu().numpy() == want[:, :cols]).all(), (radius, cols)
+
+
 def test_skewed_tree(cuda):
     """Exponentially spaced coordinates: every midpoint split peels off a few points, so the tree is a long chain
     (about one level per binade) instead of a balanced one."""
