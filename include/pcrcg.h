@@ -319,7 +319,7 @@ int pcrcg_softmax_rows(float* x, int rows, int cols, int ld, float scale, void* 
 /* Multi-head attention in ONE launch (ref:models/gcn.py:151-155: scores = q k^T / sqrt(d), prob = softmax(scores),
  * message = prob v, per head):  out[:, h*d:(h+1)*d] = softmax(scale * q_h k_h^T) v_h  for h < heads, where head h of
  * q [n, heads*d], k / v [ms, heads*d] and out [n, heads*d] is the column block [h*d, (h+1)*d) (row-major, leading
- * dimensions ldq/ldk/ldv multiples of 4, 16-byte aligned bases).  d in {16, 32, 48, 64}
+ * dimensions ldq/ldk/ldv multiples of 4, 16-byte aligned bases).  d in {16, 32, 48, 64, 128}
  * (pcrcg_attention_supported); other widths: one pcrcg_gemm_f32 / pcrcg_softmax_rows / pcrcg_gemm_f32 per head. */
 int pcrcg_attention_supported(int d);
 int pcrcg_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int n,

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) k_softmax_rows(float* __restrict__ x, int
 // Multi-head attention in one launch: out[:, h*D:(h+1)*D] = softmax(scale * q_h k_h^T) v_h  (ref:models/gcn.py:151-155).
 // On the path the operands are tiny (a few hundred coarse points, D = 64): three GEMM-class launches + a softmax per
 // head and direction were 24 launches of ~20 us of latency each.  Here a workgroup owns 16 queries of one head;
-// 16 lanes share a query: each lane scores 4 of the 64 keys of a chunk (the query row lives in registers, the key
+// 16 lanes share a query: each lane scores 4 of the 64 keys of a chunk (2 of 32 for D = 128) (the query row lives in registers, the key
 // chunk in LDS with rows padded to D + 4 floats), the chunk's probabilities go through LDS, and each lane
 // accumulates D/16 output channels with the running-max / running-sum rescaling (softmax in one pass over the keys,
 // fp32 throughout, plain FMAs: 0.3 GFLOP per call needs no matrix core).
@@ -122,7 +122,7 @@ template <int D>
 __global__ void __launch_bounds__(256) k_attention(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                    const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo,
                                                    int n, int ms, float scale) {
-    constexpr int TQ = 16, KC = 64, KS = D + 4, DV = D / 16, D4 = D / 4;
+    constexpr int TQ = 16, KC = D > 64 ? 32 : 64, KT = KC / 16, KS = D + 4, DV = D / 16, D4 = D / 4;
     __shared__ float4 Ks4[KC * KS / 4];
     __shared__ float4 Vs4[KC * D / 4];
     __shared__ float4 Ps4[TQ * KC / 4];
@@ -152,9 +152,9 @@ __global__ void __launch_bounds__(256) k_attention(const float* __restrict__ q, 
             *reinterpret_cast<float4*>(Vs + key * D + 4 * c4) = ok ? vv : z;
         }
         __syncthreads();
-        float sc[4], mx = -INFINITY;
+        float sc[KT], mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < KT; ++t) {
             const int key = j + 16 * t;
             const float* kr = Ks + key * KS;
             float acc = 0.f;
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256) k_attention(const float* __restrict__ q, 
         const float alpha = expf(m - m_new);              // exp(-inf) = 0 on the first chunk
         float psum = 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < KT; ++t) {
             const float pe = expf(sc[t] - m_new);
             Ps[qi * KC + j + 16 * t] = pe;
             psum += pe;
@@ -267,7 +267,7 @@ int pcrcg_edgeconv_reduce(const float* ctr, int ld_ctr, const float* nbr, int ld
     return colstats_finalize(partial, chunks, c, (double)n * (double)k, eps, stats, st);
 }
 
-int pcrcg_attention_supported(int d) { return d == 16 || d == 32 || d == 48 || d == 64; }
+int pcrcg_attention_supported(int d) { return d == 16 || d == 32 || d == 48 || d == 64 || d == 128; }
 
 int pcrcg_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int n,
                     int ms, int heads, int d, float scale, void* stream) {
@@ -280,7 +280,8 @@ int pcrcg_attention(const float* q, int ldq, const float* k, int ldk, const floa
     const dim3 grid((n + 15) / 16, heads);
     hipStream_t st = as_stream(stream);
 #define ATT(DV) hipLaunchKernelGGL(k_attention<DV>, grid, dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, n, ms, scale)
-    if (d == 64) ATT(64);
+    if (d == 128) ATT(128);
+    else if (d == 64) ATT(64);
     else if (d == 48) ATT(48);
     else if (d == 32) ATT(32);
     else ATT(16);

@@ -552,7 +552,7 @@ def softmax_rows_(x, scale=1.0):
 
 def attention(q, k, v, heads, scale=None):
     """Multi-head attention in one launch: head h = column block [h*d, (h+1)*d) of q [n, heads*d], k / v [ms, heads*d];
-    out = cat_h softmax(scale * q_h k_h^T) v_h, scale = 1/sqrt(d) by default.  d in {16, 32, 48, 64}."""
+    out = cat_h softmax(scale * q_h k_h^T) v_h, scale = 1/sqrt(d) by default.  d in {16, 32, 48, 64, 128}."""
     L = _lib.lib()
     q, ldq = _rows(q, _F32, "q")
     k, ldk = _rows(k, _F32, "k")

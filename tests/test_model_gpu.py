@@ -203,7 +203,7 @@ def test_softmax_rows(cuda):
     assert rel(y, torch.softmax(x / 0.0367, 1)) < 1e-5
 
 
-@pytest.mark.parametrize("n,ms,heads,d", [(381, 382, 4, 64), (1, 1, 1, 16), (17, 65, 2, 32), (100, 64, 3, 48), (763, 700, 4, 64),
+@pytest.mark.parametrize("n,ms,heads,d", [(381, 382, 4, 128), (381, 382, 4, 64), (1, 1, 1, 16), (17, 65, 2, 32), (100, 64, 3, 48), (763, 700, 4, 64),
                                           (33, 1500, 4, 16)])
 def test_attention_one_launch(cuda, n, ms, heads, d):
     """pcrcg_attention against the reference formulation (ref:models/gcn.py:151-155) in float64, and against the
