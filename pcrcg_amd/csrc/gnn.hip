@@ -113,23 +113,22 @@ __global__ void __launch_bounds__(256) k_softmax_rows(float* __restrict__ x, int
 
 // Multi-head attention in one launch: out[:, h*D:(h+1)*D] = softmax(scale * q_h k_h^T) v_h  (ref:models/gcn.py:151-155).
 // On the path the operands are tiny (a few hundred coarse points, D = 64): three GEMM-class launches + a softmax per
-// head and direction were 24 launches of ~20 us of latency each.  Here a workgroup owns 16 queries of one head;
-// 16 lanes share a query: each lane scores 4 of the 64 keys of a chunk (2 of 32 for D = 128) (the query row lives in registers, the key
+// head and direction were 24 launches of ~20 us of latency each.  Here a workgroup owns 8 or 16 queries of one head;
+// G = 16 or 32 lanes share a query: each lane scores 64/G of the 64 keys of a chunk (the query row lives in registers, the key
 // chunk in LDS with rows padded to D + 4 floats), the chunk's probabilities go through LDS, and each lane
-// accumulates D/16 output channels with the running-max / running-sum rescaling (softmax in one pass over the keys,
+// accumulates D/G output channels with the running-max / running-sum rescaling (softmax in one pass over the keys,
 // fp32 throughout, plain FMAs: 0.3 GFLOP per call needs no matrix core).
-template <int D>
+template <int D, int TQ>      // TQ queries per workgroup, G = 256 / TQ lanes per query
 __global__ void __launch_bounds__(256) k_attention(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                    const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo,
                                                    int n, int ms, float scale) {
-    constexpr int TQ = 16, KC = D > 64 ? 32 : 64, KT = KC / 16, KS = D + 4, DV = D / 16, D4 = D / 4;
-    __shared__ float4 Ks4[KC * KS / 4];
-    __shared__ float4 Vs4[KC * D / 4];
-    __shared__ float4 Ps4[TQ * KC / 4];
-    float* const Ks = reinterpret_cast<float*>(Ks4);
-    float* const Vs = reinterpret_cast<float*>(Vs4);
-    float* const Ps = reinterpret_cast<float*>(Ps4);
-    const int tid = threadIdx.x, qi = tid >> 4, j = tid & 15, head = blockIdx.y;
+    constexpr int G = 256 / TQ, KC = 64, KT = KC / G, KS = D + 4, DV = D / G, D4 = D / 4;
+    static_assert(KC % G == 0 && D % G == 0 && G <= 64, "lane groups must tile the chunk and the head");
+    extern __shared__ float4 att_lds[];                   // Ks [KC][D + 4] | Vs [KC][D] | Ps [TQ][KC]
+    float* const Ks = reinterpret_cast<float*>(att_lds);
+    float* const Vs = Ks + KC * KS;
+    float* const Ps = Vs + KC * D;
+    const int tid = threadIdx.x, qi = tid / G, j = tid % G, head = blockIdx.y;
     const int row = blockIdx.x * TQ + qi;
     const float* qrow = q + (long)(row < n ? row : n - 1) * ldq + head * D;
     float4 qr[D4];
@@ -155,7 +154,7 @@ __global__ void __launch_bounds__(256) k_attention(const float* __restrict__ q, 
         float sc[KT], mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
-            const int key = j + 16 * t;
+            const int key = j + G * t;
             const float* kr = Ks + key * KS;
             float acc = 0.f;
 #pragma unroll
@@ -170,18 +169,18 @@ __global__ void __launch_bounds__(256) k_attention(const float* __restrict__ q, 
             mx = fmaxf(mx, sc[t]);
         }
 #pragma unroll
-        for (int s = 8; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, 64));
+        for (int s = G / 2; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, 64));
         const float m_new = fmaxf(m, mx);                 // finite: every chunk holds at least one key
         const float alpha = expf(m - m_new);              // exp(-inf) = 0 on the first chunk
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
             const float pe = expf(sc[t] - m_new);
-            Ps[qi * KC + j + 16 * t] = pe;
+            Ps[qi * KC + j + G * t] = pe;
             psum += pe;
         }
 #pragma unroll
-        for (int s = 8; s >= 1; s >>= 1) psum += __shfl_xor(psum, s, 64);
+        for (int s = G / 2; s >= 1; s >>= 1) psum += __shfl_xor(psum, s, 64);
         l = l * alpha + psum;
         m = m_new;
         __syncthreads();
@@ -277,14 +276,25 @@ int pcrcg_attention(const float* q, int ldq, const float* k, int ldk, const floa
     if (n == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(q && k && v && out);
     PCRCG_CHECK_ARG(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
-    const dim3 grid((n + 15) / 16, heads);
     hipStream_t st = as_stream(stream);
-#define ATT(DV) hipLaunchKernelGGL(k_attention<DV>, grid, dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, ldo, n, ms, scale)
-    if (d == 128) ATT(128);
-    else if (d == 64) ATT(64);
-    else if (d == 48) ATT(48);
-    else if (d == 32) ATT(32);
-    else ATT(16);
+    // wide heads: 8 queries per workgroup, 32 lanes each (twice the workgroups, half the work per lane)
+#define ATT(DD, TQ)                                                                                                  \
+    do {                                                                                                             \
+        constexpr size_t lds = sizeof(float) * (64 * (DD + 4) + 64 * DD + TQ * 64);                                  \
+        static bool configured = false;                                                                              \
+        if (!configured && lds > 64 * 1024) {                                                                        \
+            PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention<DD, TQ>),                  \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+            configured = true;                                                                                       \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_attention<DD, TQ>), dim3((n + TQ - 1) / TQ, heads), dim3(256), lds, st, q, ldq, k, ldk, v, \
+                           ldv, out, ldo, n, ms, scale);                                                             \
+    } while (0)
+    if (d == 128) ATT(128, 8);
+    else if (d == 64) ATT(64, 8);
+    else if (d == 48) ATT(48, 16);
+    else if (d == 32) ATT(32, 16);
+    else ATT(16, 16);
 #undef ATT
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;

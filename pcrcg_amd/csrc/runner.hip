@@ -297,8 +297,10 @@ Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, co
     linear(c, x, g.wq, ch, g.bq, q);
     linear(c, src, g.wk, ch, g.bk, kk);
     linear(c, src, g.wv, ch, g.bv, v);
-    if (c.live() && pcrcg_attention_supported(d)) {
-        // all heads in one launch (heads are contiguous column blocks after the weight permutation)
+    if (c.live() && pcrcg_attention_supported(d) && (long)n * ms <= 1000000) {
+        // all heads in one launch (heads are contiguous column blocks after the weight permutation); a latency win on
+        // the few hundred coarse points of an indoor pair (49 vs 138 us of kernels + 11 launches less per call,
+        // scripts/attention_bench.py) -- beyond ~1000 x 1000 the GEMM path below is faster (1900 x 1900: 228 vs 640 us)
         c.check(pcrcg_attention(q.p, q.ld, kk.p, kk.ld, v.p, v.ld, msg.p, msg.ld, n, ms, h, d, 1.0f / sqrtf((float)d),
                                 c.st));
         c.check(pcrcg_copy2d(x.p, x.ld, cat.p, cat.ld, n, ch, c.st));
