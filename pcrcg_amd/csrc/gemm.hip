@@ -336,7 +336,8 @@ int launch(bool trans_b, dim3 grid, hipStream_t st, const float* a, int lda, con
 namespace pcrcg {
 int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
-                     hipStream_t st, bool a_bf16);   // gemm_x6.hip
+                     hipStream_t st, bool a_bf16, bool c_zeroed);   // gemm_x6.hip
+int gemm_x6_splits(int m, int n, int k);
 }
 
 using namespace pcrcg;
@@ -357,7 +358,30 @@ extern "C" int pcrcg_gemm_get_mode(void) { return gemm_mode(); }
 
 static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc,
                          int m, int n, int k, const float* row_scale, const float* bias, void* colstats,
-                         size_t colstats_bytes, int* h_chunks, void* stream);
+                         size_t colstats_bytes, int* h_chunks, void* stream, bool c_zeroed = false);
+
+namespace pcrcg {
+// For the network runner (runner.hip): does a C = A * B^T product of this shape accumulate split-K partial sums into C
+// (so that a C taken from the runner's pre-zeroed arena saves the product's own memset)?  Only the default arithmetic.
+bool gemm_bt_accumulates(int m, int n, int k) { return gemm_mode() == 1 && gemm_x6_splits(m, n, k) > 1; }
+// pcrcg_gemm_f32_colstats (trans_b = 1) / pcrcg_gemm_bf16a_f32_colstats with the promise that C is all zeros
+int gemm_bt_colstats(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
+                     const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
+                     hipStream_t st, bool c_zeroed) {
+    return gemm_dispatch(a, lda, 0, b, ldb, 1, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks, st,
+                         c_zeroed);
+}
+int gemm_bf16a_bt_colstats(const void* a_bf16, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
+                           const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes,
+                           int* h_chunks, hipStream_t st, bool c_zeroed) {
+    if (h_chunks) *h_chunks = 0;
+    PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 32 && k % 32 == 0 && lda >= k && lda % 8 == 0 && ldb >= k && ldc >= n);
+    if (m == 0 || n == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(a_bf16 && b && c && (reinterpret_cast<uintptr_t>(a_bf16) & 15) == 0);
+    return gemm_x6_dispatch(static_cast<const float*>(a_bf16), lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats,
+                            colstats_bytes, h_chunks, st, true, c_zeroed);
+}
+}  // namespace pcrcg
 
 extern "C" size_t pcrcg_gemm_colstats_bytes(int m, int n) {
     const size_t chunks = (size_t)((m > 0 ? m : 1) + 31) / 32 + 4;
@@ -382,12 +406,8 @@ extern "C" int pcrcg_gemm_f32_colstats(const float* a, int lda, const float* b, 
 extern "C" int pcrcg_gemm_bf16a_f32_colstats(const void* a_bf16, int lda, const float* b, int ldb, float* c, int ldc, int m,
                                              int n, int k, const float* row_scale, const float* bias, void* colstats,
                                              size_t colstats_bytes, int* h_chunks, void* stream) {
-    if (h_chunks) *h_chunks = 0;
-    PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 32 && k % 32 == 0 && lda >= k && lda % 8 == 0 && ldb >= k && ldc >= n);
-    if (m == 0 || n == 0) return PCRCG_OK;
-    PCRCG_CHECK_ARG(a_bf16 && b && c && (reinterpret_cast<uintptr_t>(a_bf16) & 15) == 0);
-    return gemm_x6_dispatch(static_cast<const float*>(a_bf16), lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats,
-                            colstats_bytes, h_chunks, as_stream(stream), true);
+    return gemm_bf16a_bt_colstats(a_bf16, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks,
+                                  as_stream(stream), false);
 }
 
 // Aop = A^T when trans_a (A stored [K, M] row-major): the weight-gradient products dW = X^T * dY of the
@@ -399,7 +419,7 @@ extern "C" int pcrcg_gemm_f32_ex(const float* a, int lda, int trans_a, const flo
 
 static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc,
                          int m, int n, int k, const float* row_scale, const float* bias, void* colstats,
-                         size_t colstats_bytes, int* h_chunks, void* stream) {
+                         size_t colstats_bytes, int* h_chunks, void* stream, bool c_zeroed) {
     if (h_chunks) *h_chunks = 0;
     PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 0);
     if (m == 0 || n == 0) return PCRCG_OK;
@@ -408,7 +428,8 @@ static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, i
     PCRCG_CHECK_ARG(trans_b ? ldb >= k : ldb >= n);
     hipStream_t st = as_stream(stream);
     if (!trans_a && trans_b && gemm_mode() == 1)
-        return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks, st, false);
+        return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks, st, false,
+                                c_zeroed);
     const int vec_a = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     const int vec_b = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
     // Tile / split selection (sweep in scripts/gemm_tune.py on the path's shapes): these GEMMs are skinny

@@ -347,35 +347,50 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
 
 }  // namespace
 
-// Called by gemm_dispatch (gemm.hip) for C = A * B^T products when the split-bf16 mode is on.
-int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
-                     const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
-                     hipStream_t st, bool a_bf16) {
-    const int vec_a = a_bf16 ? 1 : (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
-    const int vec_b = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
-    struct Tile { int bm, bn; };
-    static const Tile tiles[4] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    // Tile / split choice from the sweep of scripts/gemm_x6_bench.py over the path's shapes: the 64x64 tile wins or
-    // ties everywhere (the kernel is bound by per-block latency, so many small blocks beat few large ones) except
-    // for very tall N <= 64 products, where 128x64 halves the re-reads of B.  K is split (fp32 atomics into a
-    // zeroed C) only when the tiles alone leave most CUs idle, or when K is so long that one block's k-loop
-    // dominates; each split costs a memset and atomic traffic, so never below 256 k per split.
-    int pick = -1;
-    if (const char* e = getenv("PCRCG_X6_TILE")) pick = atoi(e);          // tuning aid
-    if (pick < 0 || pick > 3) pick = (n <= 64 && m >= 32768) ? 1 : 3;
-    const int BM = tiles[pick].bm, BN = tiles[pick].bn;
-    const int gx = (n + BN - 1) / BN, gy = (m + BM - 1) / BM;
+// Tile / split choice from the sweep of scripts/gemm_x6_bench.py over the path's shapes: the 64x64 tile wins or
+// ties everywhere (the kernel is bound by per-block latency, so many small blocks beat few large ones) except
+// for very tall N <= 64 products, where 128x64 halves the re-reads of B.  K is split (fp32 atomics into a
+// zeroed C) only when the tiles alone leave most CUs idle, or when K is so long that one block's k-loop
+// dominates; each split costs atomic traffic (and a memset unless the caller hands over a zeroed C), so never
+// below 256 k per split.
+struct X6Plan { int pick, bm, bn, gx, gy, splits, k_per_split; };
+static X6Plan x6_plan(int m, int n, int k) {
+    static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    X6Plan p;
+    p.pick = -1;
+    if (const char* e = getenv("PCRCG_X6_TILE")) p.pick = atoi(e);          // tuning aid
+    if (p.pick < 0 || p.pick > 3) p.pick = (n <= 64 && m >= 32768) ? 1 : 3;
+    p.bm = tiles[p.pick][0];
+    p.bn = tiles[p.pick][1];
+    p.gx = (n + p.bn - 1) / p.bn;
+    p.gy = (m + p.bm - 1) / p.bm;
     int splits = 1;
     const int ktiles = (k + BK - 1) / BK;
-    while ((long)gx * gy * splits < 200 && k / (2 * splits) >= 256 && splits < 32) splits *= 2;
-    while ((long)gx * gy * splits < 1024 && k / splits > 1024 && splits < 32) splits *= 2;
+    while ((long)p.gx * p.gy * splits < 200 && k / (2 * splits) >= 256 && splits < 32) splits *= 2;
+    while ((long)p.gx * p.gy * splits < 1024 && k / splits > 1024 && splits < 32) splits *= 2;
     if (const char* e = getenv("PCRCG_X6_SPLITK")) splits = atoi(e) > 0 ? atoi(e) : splits;   // tuning aid
-    int k_per_split = ((ktiles + splits - 1) / splits) * BK;
-    if (k_per_split < BK) k_per_split = BK;
-    splits = k > 0 ? (k + k_per_split - 1) / k_per_split : 1;
-    if (splits < 1) splits = 1;
+    p.k_per_split = ((ktiles + splits - 1) / splits) * BK;
+    if (p.k_per_split < BK) p.k_per_split = BK;
+    p.splits = k > 0 ? (k + p.k_per_split - 1) / p.k_per_split : 1;
+    if (p.splits < 1) p.splits = 1;
+    return p;
+}
+
+// the split-K factor gemm_x6_dispatch uses for an [m, n, k] product (> 1: it accumulates into a zeroed C)
+int gemm_x6_splits(int m, int n, int k) { return (m > 0 && n > 0) ? x6_plan(m, n, k).splits : 1; }
+
+// Called by gemm_dispatch (gemm.hip) for C = A * B^T products when the split-bf16 mode is on.  c_zeroed: C is
+// already all zeros (the runner's zero arena), so a split-K product needs no memset of its own.
+int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
+                     const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
+                     hipStream_t st, bool a_bf16, bool c_zeroed) {
+    const int vec_a = a_bf16 ? 1 : (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+    const int vec_b = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+    const X6Plan plan = x6_plan(m, n, k);
+    const int pick = plan.pick, BM = plan.bm, BN = plan.bn, gx = plan.gx, gy = plan.gy, splits = plan.splits;
+    const int k_per_split = plan.k_per_split;
     const int atomic_out = splits > 1;
-    if (atomic_out) {
+    if (atomic_out && !c_zeroed) {
         if (ldc == n) PCRCG_CHECK_HIP(hipMemsetAsync(c, 0, (size_t)m * n * sizeof(float), st));
         else PCRCG_CHECK_HIP(hipMemset2DAsync(c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), m, st));
     }

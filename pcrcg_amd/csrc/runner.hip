@@ -16,11 +16,20 @@
 #include "common.h"
 
 namespace pcrcg {
+// gemm.hip
+bool gemm_bt_accumulates(int m, int n, int k);
+int gemm_bt_colstats(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
+                     const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
+                     hipStream_t st, bool c_zeroed);
+int gemm_bf16a_bt_colstats(const void* a_bf16, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
+                           const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes,
+                           int* h_chunks, hipStream_t st, bool c_zeroed);
 namespace {
 
 struct Mat {          // row-major fp32 matrix view
     float* p = nullptr;
     int rows = 0, cols = 0, ld = 0;
+    bool zeroed = false;   // lives in the zero arena and has not been written yet
 };
 
 struct Ctx {
@@ -46,6 +55,31 @@ struct Ctx {
         Mat m;
         m.rows = rows; m.cols = cols; m.ld = ld ? ld : cols;
         m.p = static_cast<float*>(raw((size_t)(rows > 0 ? rows : 1) * m.ld * sizeof(float)));
+        return m;
+    }
+    // Zero arena: the front part of the workspace, cleared by ONE memset at the start of the forward and handed out
+    // without reuse.  Outputs of split-K products come from it (the product accumulates into C with atomics and would
+    // otherwise clear C itself: 39 memset launches per S30k forward).
+    char* zbase = nullptr;
+    size_t zcap = 0, zoff = 0;
+    void* zraw(size_t bytes) {
+        bytes = (bytes + 255) & ~size_t(255);
+        void* p = zbase ? zbase + zoff : nullptr;
+        zoff += bytes;
+        if (!dry && zoff > zcap && rc == PCRCG_OK) {
+            set_error("pcrcg_kpfcnn_forward: zero arena too small (%zu needed so far, %zu reserved)", zoff, zcap);
+            rc = PCRCG_EWORKSPACE;
+        }
+        return p;
+    }
+    // the output of a [rows, k] x [cols, k]^T product
+    Mat gemm_out(int rows, int cols, int k) {
+        static const bool off = getenv("PCRCG_ZERO_ARENA") && atoi(getenv("PCRCG_ZERO_ARENA")) == 0;   // A/B aid
+        if (off || !gemm_bt_accumulates(rows, cols, k)) return mat(rows, cols);
+        Mat m;
+        m.rows = rows; m.cols = cols; m.ld = cols;
+        m.p = static_cast<float*>(zraw((size_t)(rows > 0 ? rows : 1) * cols * sizeof(float)));
+        m.zeroed = true;
         return m;
     }
     size_t mark() const { return off; }
@@ -110,8 +144,8 @@ void norm_act(Ctx& c, const Mat& x, float slope, const Mat& y, const Stat* xs = 
 
 void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, const Mat& y, Stat* st) {
     if (!c.live()) return;
-    c.check(pcrcg_gemm_f32_colstats(x.p, x.ld, w, ldw, 1, y.p, y.ld, x.rows, y.cols, x.cols, nullptr, bias,
-                                    st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr, c.st));
+    c.check(gemm_bt_colstats(x.p, x.ld, w, ldw, y.p, y.ld, x.rows, y.cols, x.cols, nullptr, bias,
+                             st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr, c.st, y.zeroed));
 }
 
 void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, const Mat& y, Stat* st = nullptr) {
@@ -173,9 +207,9 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
         if (c.live()) {
             c.check(pcrcg_kpconv_aggregate_bf16(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, xp, cin, blk.kp, blk.extent,
                                                 xb, wfb, inv_n, ws, wsb, c.st));
-            c.check(pcrcg_gemm_bf16a_f32_colstats(wfb, kk, blk.kp_wt, kk, y.p, y.ld, nq, y.cols, kk, inv_n, nullptr,
-                                                  st ? st->partials : nullptr, st ? st->bytes : 0,
-                                                  st ? &st->chunks : nullptr, c.st));
+            c.check(gemm_bf16a_bt_colstats(wfb, kk, blk.kp_wt, kk, y.p, y.ld, nq, y.cols, kk, inv_n, nullptr,
+                                           st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr,
+                                           c.st, y.zeroed));
         }
         c.release(m);
         return;
@@ -189,13 +223,20 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
         // (Measured and not adopted: aggregating + contracting 48 MB row chunks so that wf stays in L2 / Infinity
         // Cache between the two kernels -- 3.50 vs 3.31 ms per forward, the extra launches cost more than the
         // on-chip re-read saves.)
-        const bool kt = blk.kp_wt != nullptr;
-        c.check(pcrcg_gemm_f32_colstats(wf.p, wf.ld, kt ? blk.kp_wt : w, kt ? wf.cols : y.cols, kt ? 1 : 0, y.p, y.ld, nq,
-                                        y.cols, wf.cols, inv_n, nullptr, st ? st->partials : nullptr, st ? st->bytes : 0,
-                                        st ? &st->chunks : nullptr, c.st));
+        if (blk.kp_wt)
+            c.check(gemm_bt_colstats(wf.p, wf.ld, blk.kp_wt, wf.cols, y.p, y.ld, nq, y.cols, wf.cols, inv_n, nullptr,
+                                     st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr, c.st,
+                                     y.zeroed));
+        else
+            c.check(pcrcg_gemm_f32_colstats(wf.p, wf.ld, w, y.cols, 0, y.p, y.ld, nq, y.cols, wf.cols, inv_n, nullptr,
+                                            st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr,
+                                            c.st));
     }
     c.release(m);
 }
+
+// input channels of the block's KPConv as the gather kernel sees them (padded to a multiple of 4)
+int kp_cin(const pcrcg_block& blk, const Mat& x) { return (blk.kp_w_pad && blk.cin_pad > x.cols) ? blk.cin_pad : x.cols; }
 
 int out_rows(const pcrcg_batch& b, const pcrcg_block& blk) {
     return blk.strided ? b.n_points[blk.layer + 1] : b.n_points[blk.layer];
@@ -205,7 +246,7 @@ int out_rows(const pcrcg_batch& b, const pcrcg_block& blk) {
 Mat simple_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x) {
     Mat y = c.mat(out_rows(b, blk), blk.mid_dim);
     const size_t m = c.mark();
-    Mat t = c.mat(y.rows, y.cols);
+    Mat t = c.gemm_out(y.rows, y.cols, PCRCG_KPOINTS * kp_cin(blk, x));
     Stat ts = stat_buffer(c, t.rows, t.cols);
     kpconv(c, b, blk, x, t, &ts);
     norm_act(c, t, 0.1f, y, &ts);
@@ -220,17 +261,17 @@ Mat resnet_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat
     const size_t m = c.mark();
     Mat x = feats;
     if (blk.unary1) {
-        Mat t = c.mat(feats.rows, blk.mid_dim), u = c.mat(feats.rows, blk.mid_dim);
+        Mat t = c.gemm_out(feats.rows, blk.mid_dim, feats.cols), u = c.mat(feats.rows, blk.mid_dim);
         Stat ts = stat_buffer(c, t.rows, t.cols);
         linear(c, feats, blk.unary1, feats.cols, nullptr, t, &ts);
         norm_act(c, t, 0.1f, u, &ts);
         x = u;
     }
-    Mat k = c.mat(nq, blk.mid_dim), kn = c.mat(nq, blk.mid_dim);
+    Mat k = c.gemm_out(nq, blk.mid_dim, PCRCG_KPOINTS * kp_cin(blk, x)), kn = c.mat(nq, blk.mid_dim);
     Stat ks = stat_buffer(c, nq, blk.mid_dim);
     kpconv(c, b, blk, x, k, &ks);
     norm_act(c, k, 0.1f, kn, &ks);
-    Mat u2 = c.mat(nq, blk.out_dim);
+    Mat u2 = c.gemm_out(nq, blk.out_dim, blk.mid_dim);
     Stat u2s = stat_buffer(c, nq, blk.out_dim);
     linear(c, kn, blk.unary2, blk.mid_dim, nullptr, u2, &u2s);
     Mat sc = feats;
@@ -241,7 +282,7 @@ Mat resnet_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat
             c.check(pcrcg_gather_max(feats.p, feats.rows, feats.cols, t.idx, nq, t.cols, t.ld, sc.p, c.st));
     }
     if (blk.shortcut) {
-        Mat s2 = c.mat(nq, blk.out_dim);
+        Mat s2 = c.gemm_out(nq, blk.out_dim, sc.cols);
         Stat s2s = stat_buffer(c, nq, blk.out_dim);
         linear(c, sc, blk.shortcut, sc.cols, nullptr, s2, &s2s);
         norm_act(c, u2, 0.1f, y, &u2s, &s2, true, &s2s);      // lrelu(IN(unary2) + IN(shortcut))
@@ -263,24 +304,27 @@ Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, con
     const size_t wsb = pcrcg_edgeconv_ws_bytes(2 * ch);
     void* ws = c.raw(wsb);
     float* stats = static_cast<float*>(c.raw(sizeof(float) * 4 * ch));
-    Mat cn1 = c.mat(n, 2 * ch), e1 = c.mat(n, ch), cn2 = c.mat(n, 4 * ch), e2 = c.mat(n, 2 * ch), x3 = c.mat(n, ch);
+    Mat cn1 = c.gemm_out(n, 2 * ch, ch), e1 = c.mat(n, ch), cn2 = c.gemm_out(n, 4 * ch, ch), e2 = c.mat(n, 2 * ch);
+    Mat x3 = c.gemm_out(n, ch, 4 * ch);
     if (c.live()) {
         c.check(pcrcg_knn(coords, n, k, idx, c.st));
         c.check(pcrcg_copy2d(f.p, f.ld, cat.p, cat.ld, n, ch, c.st));                                    // x0
         // x1 = max_k lrelu(IN2d(conv1(cat(f_i, f_j - f_i))))  (:121-125)
-        c.check(pcrcg_gemm_f32(f.p, f.ld, g.edge1, ch, 1, cn1.p, cn1.ld, n, 2 * ch, ch, nullptr, nullptr, c.st));
+        c.check(gemm_bt_colstats(f.p, f.ld, g.edge1, ch, cn1.p, cn1.ld, n, 2 * ch, ch, nullptr, nullptr, nullptr, 0, nullptr,
+                                 c.st, cn1.zeroed));
         c.check(pcrcg_edgeconv_reduce(cn1.p, cn1.ld, cn1.p + ch, cn1.ld, idx, n, k, ch, 1e-5f, e1.p, e1.ld, stats, ws,
                                       wsb, c.st));
         c.check(pcrcg_instnorm_apply(e1.p, n, ch, e1.ld, stats, nullptr, 0, nullptr, 0.2f, cat.p + ch, cat.ld, c.st));
         // x2 from x1 with conv2 (:127-129)
-        c.check(pcrcg_gemm_f32(cat.p + ch, cat.ld, g.edge2, ch, 1, cn2.p, cn2.ld, n, 4 * ch, ch, nullptr, nullptr,
-                               c.st));
+        c.check(gemm_bt_colstats(cat.p + ch, cat.ld, g.edge2, ch, cn2.p, cn2.ld, n, 4 * ch, ch, nullptr, nullptr, nullptr, 0,
+                                 nullptr, c.st, cn2.zeroed));
         c.check(pcrcg_edgeconv_reduce(cn2.p, cn2.ld, cn2.p + 2 * ch, cn2.ld, idx, n, k, 2 * ch, 1e-5f, e2.p, e2.ld, stats,
                                       ws, wsb, c.st));
         c.check(pcrcg_instnorm_apply(e2.p, n, 2 * ch, e2.ld, stats, nullptr, 0, nullptr, 0.2f, cat.p + 2 * ch, cat.ld,
                                      c.st));
         // x3 = lrelu(IN(conv3(cat(x0,x1,x2))))  (:131-132)
-        c.check(pcrcg_gemm_f32(cat.p, cat.ld, g.conv3, 4 * ch, 1, x3.p, x3.ld, n, ch, 4 * ch, nullptr, nullptr, c.st));
+        c.check(gemm_bt_colstats(cat.p, cat.ld, g.conv3, 4 * ch, x3.p, x3.ld, n, ch, 4 * ch, nullptr, nullptr, nullptr, 0,
+                                 nullptr, c.st, x3.zeroed));
     }
     norm_act(c, x3, 0.2f, y);
     c.release(m);
@@ -292,8 +336,9 @@ Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, co
     const int n = x.rows, ms = src.rows, ch = x.cols, h = mdl.heads, d = ch / h;
     Mat y = c.mat(n, ch);
     const size_t m = c.mark();
-    Mat q = c.mat(n, ch), kk = c.mat(ms, ch), v = c.mat(ms, ch), msg = c.mat(n, ch), sc = c.mat(n, ms);
-    Mat cat = c.mat(n, 2 * ch), h0 = c.mat(n, 2 * ch), h1 = c.mat(n, 2 * ch), delta = c.mat(n, ch);
+    Mat q = c.gemm_out(n, ch, ch), kk = c.gemm_out(ms, ch, ch), v = c.gemm_out(ms, ch, ch), msg = c.mat(n, ch);
+    Mat sc = c.mat(n, ms);
+    Mat cat = c.mat(n, 2 * ch), h0 = c.gemm_out(n, 2 * ch, 2 * ch), h1 = c.mat(n, 2 * ch), delta = c.gemm_out(n, ch, 2 * ch);
     linear(c, x, g.wq, ch, g.bq, q);
     linear(c, src, g.wk, ch, g.bk, kk);
     linear(c, src, g.wv, ch, g.bv, v);
@@ -339,7 +384,7 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
     }
     // 2. bottleneck (:527-528) and 3. GNN (:532-536)
     const int nc = b.n_points[L - 1], ns = b.len_src_c, nt = nc - ns, g = mdl.gnn_dim;
-    Mat fc = c.mat(nc, g);
+    Mat fc = c.gemm_out(nc, g, mdl.enc_out_dim);
     linear(c, x, mdl.bottle_w, mdl.enc_out_dim, mdl.bottle_b, fc);
     Mat d0 = rows(fc, 0, ns), d1 = rows(fc, ns, nt);
     const float* c0 = b.points[L - 1];
@@ -405,7 +450,7 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
             if (concat) skips.pop_back();
             x = y;
         } else if (blk.type == PCRCG_BLK_UNARY) {
-            Mat t = c.mat(x.rows, blk.out_dim), y = c.mat(x.rows, blk.out_dim);
+            Mat t = c.gemm_out(x.rows, blk.out_dim, x.cols), y = c.mat(x.rows, blk.out_dim);
             Stat ts = stat_buffer(c, t.rows, t.cols);
             linear(c, x, blk.mlp, blk.mlp_ld, nullptr, t, &ts);
             norm_act(c, t, 0.1f, y, &ts);
@@ -449,17 +494,29 @@ size_t pcrcg_kpfcnn_ws_bytes(const pcrcg_model* model, const pcrcg_batch* batch)
     c.dry = true;
     pcrcg_outputs none = {nullptr, nullptr, nullptr};
     forward(c, *model, *batch, none);
-    return c.peak + 4096;
+    return c.peak + c.zoff + 4096;
 }
 
 int pcrcg_kpfcnn_forward(const pcrcg_model* model, const pcrcg_batch* batch, const pcrcg_outputs* out, void* ws,
                          size_t ws_bytes, void* stream) {
     PCRCG_PROPAGATE(validate(model, batch));
     PCRCG_CHECK_ARG(out && out->feats_f && out->scores_overlap && out->scores_saliency && ws);
+    // pass 1 (no launches): how much of the workspace the zero arena takes for this batch
+    Ctx d;
+    d.dry = true;
+    pcrcg_outputs none = {nullptr, nullptr, nullptr};
+    forward(d, *model, *batch, none);
+    if (d.zoff + d.peak > ws_bytes) {
+        set_error("pcrcg_kpfcnn_forward: workspace too small (%zu needed, %zu given)", d.zoff + d.peak, ws_bytes);
+        return PCRCG_EWORKSPACE;
+    }
     Ctx c;
-    c.base = static_cast<char*>(ws);
-    c.cap = ws_bytes;
+    c.zbase = static_cast<char*>(ws);
+    c.zcap = d.zoff;
+    c.base = c.zbase + d.zoff;
+    c.cap = ws_bytes - d.zoff;
     c.st = as_stream(stream);
+    if (d.zoff > 0) PCRCG_CHECK_HIP(hipMemsetAsync(ws, 0, d.zoff, c.st));
     forward(c, *model, *batch, *out);
     return c.rc;
 }
