@@ -336,7 +336,7 @@ int launch(bool trans_b, dim3 grid, hipStream_t st, const float* a, int lda, con
 namespace pcrcg {
 int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
-                     hipStream_t st, bool a_bf16, bool c_zeroed);   // gemm_x6.hip
+                     hipStream_t st, bool a_bf16, bool c_zeroed, int a_kmajor = 0, int b_kmajor = 0);   // gemm_x6.hip
 int gemm_x6_splits(int m, int n, int k);
 }
 
@@ -427,9 +427,10 @@ static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, i
     PCRCG_CHECK_ARG((trans_a ? lda >= m : lda >= k) && ldc >= n);
     PCRCG_CHECK_ARG(trans_b ? ldb >= k : ldb >= n);
     hipStream_t st = as_stream(stream);
-    if (!trans_a && trans_b && gemm_mode() == 1)
+    // split-bf16 arithmetic for A * B^T (the forward), A * B (dX = dY * W) and A^T * B (dW = X^T * dY); A^T * B^T stays fp32
+    if (gemm_mode() == 1 && !(trans_a && trans_b))
         return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks, st, false,
-                                c_zeroed);
+                                c_zeroed, trans_a ? 1 : 0, trans_b ? 0 : 1);
     const int vec_a = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     const int vec_b = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
     // Tile / split selection (sweep in scripts/gemm_tune.py on the path's shapes): these GEMMs are skinny

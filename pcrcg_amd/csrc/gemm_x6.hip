@@ -52,6 +52,71 @@ __device__ __forceinline__ void vm_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void pin(f32x4& r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ void gload4(float& dst, const float* p) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void pin(float& r) { asm volatile("" : "+v"(r)); }
+
+// Operand layouts.  LAY = 0: element (row, k) at P[row * ld + k] (k-contiguous: activations, nn.Linear weights, the
+// K-contiguous KPConv weights).  LAY = 1: element (row, k) at P[k * ld + row] (k-major: the operands of the training
+// rows' products dX = dY * W and dW = X^T * dY, include/pcrcg_train.h).  An Item is 8 consecutive k of one tile row as
+// the loads deliver it: two 16-byte loads for LAY 0, eight 4-byte loads (consecutive lanes = consecutive rows, 256
+// contiguous bytes per instruction) for LAY 1.  Item e of a tile with ROWS rows: LAY 0 -> row e / 4, k-group e % 4;
+// LAY 1 -> row e % ROWS, k-group e / ROWS; both land at LDS row * ROWB + k-group * 16 (conflict-free either way).
+template <int LAY> struct Item;
+template <> struct Item<0> {
+    f32x4 v[2];
+    static constexpr int LOADS = 2;
+    __device__ __forceinline__ float get(int i) const { return v[i >> 2][i & 3]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i >> 2][i & 3] = x; }
+    __device__ __forceinline__ void hold() { pin(v[0]); pin(v[1]); }
+};
+template <> struct Item<1> {
+    float s[8];
+    static constexpr int LOADS = 8;
+    __device__ __forceinline__ float get(int i) const { return s[i]; }
+    __device__ __forceinline__ void set(int i, float x) { s[i] = x; }
+    __device__ __forceinline__ void hold() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pin(s[i]);
+    }
+};
+template <int LAY, int ROWS>
+__device__ __forceinline__ void item_pos(int e, int& row, int& kg) {
+    if (LAY == 0) { row = e >> 2; kg = e & 3; }
+    else { row = e % ROWS; kg = e / ROWS; }
+}
+// unguarded loads of a full 32-deep k-slab; rows past the matrix are CLAMPED to its last row: they only feed output
+// rows / columns the epilogue masks, so no zero fill is needed along M or N (only along K, in the guarded form)
+template <int LAY, int ROWS>
+__device__ __forceinline__ void item_load_fast(Item<LAY>& d, const float* __restrict__ P, int ld, int row0, int rows, int k0,
+                                               int e) {
+    int row, kg;
+    item_pos<LAY, ROWS>(e, row, kg);
+    if constexpr (LAY == 0) {
+        const float* p = P + (long)min(row0 + row, rows - 1) * ld + k0 + kg * 8;
+        gload16(d.v[0], p);
+        gload16(d.v[1], p + 4);
+    } else {
+        const float* p = P + (long)(k0 + kg * 8) * ld + min(row0 + row, rows - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gload4(d.s[j], p + (long)j * ld);
+    }
+}
+template <int LAY, int ROWS>
+__device__ __forceinline__ void item_load_edge(Item<LAY>& d, const float* __restrict__ P, int ld, int row0, int rows, int k0,
+                                               int k_end, int e) {
+    int row, kg;
+    item_pos<LAY, ROWS>(e, row, kg);
+    const int gr = row0 + row, gk = k0 + kg * 8, ke = k_end - 1;
+    const bool rok = gr < rows;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)                                  // always a valid address
+        v[j] = LAY == 0 ? P[(long)min(gr, rows - 1) * ld + min(gk + j, ke)] : P[(long)min(gk + j, ke) * ld + min(gr, rows - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d.set(j, (rok && gk + j < k_end) ? v[j] : 0.f);
+}
 
 constexpr int ROWB = 80;   // bytes per LDS row of one plane: 32 bf16 + 16 B pad
 
@@ -74,7 +139,7 @@ constexpr int lds_bytes() { return 3 * (BM + BN) * ROWB; }
 // ATERMS = 3: A is fp32 and is split like B.  ATERMS = 1: A already IS bf16 in memory (the bf16 feature-storage
 // variant's wf, lda in bf16 elements): its tile is copied straight into plane 0 and only the three products a1*b3,
 // a1*b2, a1*b1 run -- exact in B, bf16-rounded in A by the storage format, fp32 accumulate.  K % 32 == 0 required.
-template <int BM, int BN, int MINB, int ATERMS>
+template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY>
 __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                         int ldb, float* __restrict__ C, int ldc, int M, int N, int Kdim,
                                                         const float* __restrict__ row_scale,
@@ -114,83 +179,62 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
 
     // two register sets: tile s is consumed from set s&1 while tiles s+1 (other set) and s+2 (this set, re-issued
     // right after its split) are in flight -- these GEMMs stream A from HBM, so bytes in flight are the currency
-    constexpr int AV = ATERMS == 1 ? 1 : 2;                  // 16-byte loads per A item: 8 bf16, or 2 x 4 fp32
-    f32x4 ra[2][A_ITERS][AV], rb[2][B_ITERS][2];
-    constexpr int TILE_LOADS = AV * A_ITERS + 2 * B_ITERS;   // global_load_dwordx4 per thread and tile
+    Item<ALAY> ra[2][A_ITERS];
+    Item<BLAY> rb[2][B_ITERS];
+    // global loads per thread and tile (the bf16-A form issues one 16-byte load per item)
+    constexpr int TILE_LOADS = (ATERMS == 1 ? 1 : Item<ALAY>::LOADS) * A_ITERS + Item<BLAY>::LOADS * B_ITERS;
     const unsigned short* const Ah = reinterpret_cast<const unsigned short*>(A);
 
-    // unguarded 16-byte loads of a full 32-deep k-slab; rows past the matrix are CLAMPED to its last row: they only
-    // feed output rows / columns the epilogue masks, so no zero fill is needed along M or N (only along K, below)
-    auto load_fast = [&](const float* __restrict__ P, int ld, int row0, int rows, int k0, int it, f32x4* dst) {
-        const int e = tid + it * 256;
-        const float* p = P + (long)min(row0 + (e >> 2), rows - 1) * ld + k0 + (e & 3) * 8;
-        gload16(dst[0], p);
-        gload16(dst[1], p + 4);
-    };
-    auto load_edge = [&](const float* __restrict__ P, int ld, int row0, int rows, int k0, int it, f32x4* dst) {
-        const int e = tid + it * 256;
-        const int gr = row0 + (e >> 2), gk = k0 + (e & 3) * 8, ke = k_end - 1;
-        const float* p = P + (long)min(gr, rows - 1) * ld;      // always a valid address
-        const bool rok = gr < rows;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = p[min(gk + j, ke)];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (rok && gk + j < k_end) ? v[j] : 0.f;
-        dst[0] = f32x4{v[0], v[1], v[2], v[3]};
-        dst[1] = f32x4{v[4], v[5], v[6], v[7]};
-    };
-    // FAST: both operands 16-byte aligned and the slab k0..k0+31 inside [k_begin, k_end).  The choice is made
+    // FAST: both operands aligned for their loads and the slab k0..k0+31 inside [k_begin, k_end).  The choice is made
     // OUTSIDE the k-loop: a branch between load flavours inside it makes hipcc merge their vmcnt bookkeeping and
     // wait for (nearly) everything in flight at the top of every step, which turns prefetch distance 2 into 1.
-    auto load_tiles = [&](auto fast, int k0, f32x4 (*qa)[AV], f32x4 (*qb)[2]) {
+    auto load_tiles = [&](auto fast, int k0, Item<ALAY>* qa, Item<BLAY>* qb) {
         if constexpr (decltype(fast)::value) {
 #pragma unroll
             for (int it = 0; it < A_ITERS; ++it) {
                 if constexpr (ATERMS == 1) {
                     const int e = tid + it * 256;
-                    gload16(qa[it][0], reinterpret_cast<const float*>(Ah + (long)min(m0 + (e >> 2), M - 1) * lda + k0 + (e & 3) * 8));
+                    gload16(qa[it].v[0], reinterpret_cast<const float*>(Ah + (long)min(m0 + (e >> 2), M - 1) * lda + k0 + (e & 3) * 8));
                 } else {
-                    load_fast(A, lda, m0, M, k0, it, qa[it]);
+                    item_load_fast<ALAY, BM>(qa[it], A, lda, m0, M, k0, tid + it * 256);
                 }
             }
 #pragma unroll
-            for (int it = 0; it < B_ITERS; ++it) load_fast(B, ldb, n0, N, k0, it, qb[it]);
+            for (int it = 0; it < B_ITERS; ++it) item_load_fast<BLAY, BN>(qb[it], B, ldb, n0, N, k0, tid + it * 256);
         } else {
             if constexpr (ATERMS != 1) {      // (the bf16-A form is dispatched only for aligned operands and K % 32 == 0)
 #pragma unroll
-                for (int it = 0; it < A_ITERS; ++it) load_edge(A, lda, m0, M, k0, it, qa[it]);
+                for (int it = 0; it < A_ITERS; ++it) item_load_edge<ALAY, BM>(qa[it], A, lda, m0, M, k0, k_end, tid + it * 256);
             }
 #pragma unroll
-            for (int it = 0; it < B_ITERS; ++it) load_edge(B, ldb, n0, N, k0, it, qb[it]);
+            for (int it = 0; it < B_ITERS; ++it) item_load_edge<BLAY, BN>(qb[it], B, ldb, n0, N, k0, k_end, tid + it * 256);
         }
     };
-    auto store_one = [&](unsigned char* base, int plane_bytes, int it, const f32x4* src) {
-        const int e = tid + it * 256;
+    auto store_one = [&](unsigned char* base, int plane_bytes, int row, int kg, auto& src) {
         unsigned q1[4], q2[4], q3[4];
-        split2(src[0].x, src[0].y, q1[0], q2[0], q3[0]);
-        split2(src[0].z, src[0].w, q1[1], q2[1], q3[1]);
-        split2(src[1].x, src[1].y, q1[2], q2[2], q3[2]);
-        split2(src[1].z, src[1].w, q1[3], q2[3], q3[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split2(src.get(2 * j), src.get(2 * j + 1), q1[j], q2[j], q3[j]);
         const u32x4 p1 = {q1[0], q1[1], q1[2], q1[3]}, p2 = {q2[0], q2[1], q2[2], q2[3]},
                     p3 = {q3[0], q3[1], q3[2], q3[3]};
-        unsigned char* d = base + (e >> 2) * ROWB + (e & 3) * 16;
+        unsigned char* d = base + row * ROWB + kg * 16;
         *reinterpret_cast<u32x4*>(d) = p1;
         *reinterpret_cast<u32x4*>(d + plane_bytes) = p2;
         *reinterpret_cast<u32x4*>(d + 2 * plane_bytes) = p3;
     };
-    auto store_tiles = [&](f32x4 (*qa)[AV], f32x4 (*qb)[2]) {
+    auto store_tiles = [&](Item<ALAY>* qa, Item<BLAY>* qb) {
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) {
-            if constexpr (ATERMS == 1) {
-                const int e = tid + it * 256;
-                *reinterpret_cast<f32x4*>(As + (e >> 2) * ROWB + (e & 3) * 16) = qa[it][0];
-            } else {
-                store_one(As, A_PLANE, it, qa[it]);
-            }
+            int row, kg;
+            item_pos<ALAY, BM>(tid + it * 256, row, kg);
+            if constexpr (ATERMS == 1) *reinterpret_cast<f32x4*>(As + row * ROWB + kg * 16) = qa[it].v[0];
+            else store_one(As, A_PLANE, row, kg, qa[it]);
         }
 #pragma unroll
-        for (int it = 0; it < B_ITERS; ++it) store_one(Bs, B_PLANE, it, qb[it]);
+        for (int it = 0; it < B_ITERS; ++it) {
+            int row, kg;
+            item_pos<BLAY, BN>(tid + it * 256, row, kg);
+            store_one(Bs, B_PLANE, row, kg, qb[it]);
+        }
     };
 
     const int half = lane >> 5, l31 = lane & 31;
@@ -229,19 +273,20 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     const int nfast = (vec_a && vec_b) ? (k_end - k_begin) / BK : 0;
     // Wait until only the other set's loads are in flight, then split this set into LDS.  `live` = 0 zeroes the tile
     // (the phantom second half of an odd tile count).
-    auto consume = [&](f32x4 (*qa)[AV], f32x4 (*qb)[2], bool live) {
+    auto consume = [&](Item<ALAY>* qa, Item<BLAY>* qb, bool live) {
         vm_wait<TILE_LOADS>();
 #pragma unroll
-        for (int it = 0; it < A_ITERS; ++it)
+        for (int it = 0; it < A_ITERS; ++it) {
+            if constexpr (ATERMS == 1) pin(qa[it].v[0]);
+            else qa[it].hold();
+        }
 #pragma unroll
-            for (int v = 0; v < AV; ++v) pin(qa[it][v]);
-#pragma unroll
-        for (int it = 0; it < B_ITERS; ++it) { pin(qb[it][0]); pin(qb[it][1]); }
+        for (int it = 0; it < B_ITERS; ++it) qb[it].hold();
         if (!live) {
 #pragma unroll
             for (int it = 0; it < A_ITERS; ++it)
 #pragma unroll
-                for (int v = 0; v < AV; ++v) qa[it][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < (ATERMS == 1 ? 4 : 8); ++j) qa[it].set(j, 0.f);
         }
         __syncthreads();                                                  // previous tile fully read
         store_tiles(qa, qb);                                              // registers -> LDS (split)
@@ -327,12 +372,12 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     }
 }
 
-template <int BM, int BN, int MINB, int ATERMS>
+template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY>
 int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n,
               int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b, int atomic_out,
               double* colp, int colp_chunks) {
     constexpr size_t lds = lds_bytes<BM, BN>();
-    auto kern = k_gemm_x6<BM, BN, MINB, ATERMS>;
+    auto kern = k_gemm_x6<BM, BN, MINB, ATERMS, ALAY, BLAY>;
     static bool configured = false;
     if (!configured) {
         PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -354,20 +399,22 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
 // dominates; each split costs atomic traffic (and a memset unless the caller hands over a zeroed C), so never
 // below 256 k per split.
 struct X6Plan { int pick, bm, bn, gx, gy, splits, k_per_split; };
-static X6Plan x6_plan(int m, int n, int k) {
+static X6Plan x6_plan(int m, int n, int k, bool kmajor = false, bool reduce_rows = false) {
     static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     X6Plan p;
     p.pick = -1;
     if (const char* e = getenv("PCRCG_X6_TILE")) p.pick = atoi(e);          // tuning aid
     if (p.pick < 0 || p.pick > 3) p.pick = (n <= 64 && m >= 32768) ? 1 : 3;
+    if (kmajor) p.pick = 3;                                   // the k-major operand forms are built for 64 x 64 only
     p.bm = tiles[p.pick][0];
     p.bn = tiles[p.pick][1];
     p.gx = (n + p.bn - 1) / p.bn;
     p.gy = (m + p.bm - 1) / p.bm;
     int splits = 1;
     const int ktiles = (k + BK - 1) / BK;
-    while ((long)p.gx * p.gy * splits < 200 && k / (2 * splits) >= 256 && splits < 32) splits *= 2;
-    while ((long)p.gx * p.gy * splits < 1024 && k / splits > 1024 && splits < 32) splits *= 2;
+    const int max_splits = reduce_rows ? 128 : 32;            // dW = X^T dY reduces over the points: few tiles, very long K
+    while ((long)p.gx * p.gy * splits < 200 && k / (2 * splits) >= 256 && splits < max_splits) splits *= 2;
+    while ((long)p.gx * p.gy * splits < 1024 && k / splits > 1024 && splits < max_splits) splits *= 2;
     if (const char* e = getenv("PCRCG_X6_SPLITK")) splits = atoi(e) > 0 ? atoi(e) : splits;   // tuning aid
     p.k_per_split = ((ktiles + splits - 1) / splits) * BK;
     if (p.k_per_split < BK) p.k_per_split = BK;
@@ -383,10 +430,12 @@ int gemm_x6_splits(int m, int n, int k) { return (m > 0 && n > 0) ? x6_plan(m, n
 // already all zeros (the runner's zero arena), so a split-K product needs no memset of its own.
 int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
-                     hipStream_t st, bool a_bf16, bool c_zeroed) {
-    const int vec_a = a_bf16 ? 1 : (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
-    const int vec_b = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
-    const X6Plan plan = x6_plan(m, n, k);
+                     hipStream_t st, bool a_bf16, bool c_zeroed, int a_kmajor, int b_kmajor) {
+    // k-major operands (a_kmajor: A stored [K, M]; b_kmajor: B stored [K, N]) are read with 4-byte loads: no alignment rule
+    const int vec_a = (a_bf16 || a_kmajor) ? 1 : (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+    const int vec_b = b_kmajor ? 1 : (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+    if (a_kmajor && !b_kmajor) { set_error("gemm_x6: A^T * B^T is not built"); return PCRCG_EBADARG; }
+    const X6Plan plan = x6_plan(m, n, k, a_kmajor || b_kmajor, a_kmajor != 0);
     const int pick = plan.pick, BM = plan.bm, BN = plan.bn, gx = plan.gx, gy = plan.gy, splits = plan.splits;
     const int k_per_split = plan.k_per_split;
     const int atomic_out = splits > 1;
@@ -410,13 +459,19 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
             colp_chunks = 0;
         }
     }
+    if (a_kmajor)   // dW = X^T * dY
+        return launch_x6<64, 64, 3, 3, 1, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
+                                             vec_b, atomic_out, colp, colp_chunks);
+    if (b_kmajor)   // dX = dY * W
+        return launch_x6<64, 64, 4, 3, 0, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
+                                             vec_b, atomic_out, colp, colp_chunks);
 #define GO(BMV, BNV, MINB)                                                                                              \
     do {                                                                                                                \
         if (a_bf16)                                                                                                     \
-            return launch_x6<BMV, BNV, MINB, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split,    \
-                                                vec_a, vec_b, atomic_out, colp, colp_chunks);                               \
-        return launch_x6<BMV, BNV, MINB, 3>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a, \
-                                            vec_b, atomic_out, colp, colp_chunks);                                          \
+            return launch_x6<BMV, BNV, MINB, 1, 0, 0>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,           \
+                                                      k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks);            \
+        return launch_x6<BMV, BNV, MINB, 3, 0, 0>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split,  \
+                                                  vec_a, vec_b, atomic_out, colp, colp_chunks);                             \
     } while (0)
     if (pick == 0) { GO(128, 128, 2); }
     if (pick == 1) { GO(128, 64, 2); }
