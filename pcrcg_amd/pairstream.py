@@ -201,6 +201,7 @@ class PairStreams:
                     done = torch.cuda.Event()
                     done.record(stream)
                 self._free[f][a].put(done)
+                out["_tie_status"] = (pyr.status, slot)
                 with self._lock:
                     self._pending.append((pyr.status, slot, done))
                 self._out[m].put((out, done))
@@ -236,9 +237,20 @@ class PairStreams:
         if wait:
             cur.wait_event(done)
         for t in out.values():
-            t.record_stream(cur)
+            if isinstance(t, torch.Tensor):
+                t.record_stream(cur)
         out["done_event"] = done
         self._check_status(wait=False)
+        return out
+
+    @staticmethod
+    def check(out):
+        """Wait for THIS pair's kernels and raise if its tie-order restore step reported a capacity status (the status
+        word is written on the device after result() has returned the dict; result() / synchronize() raise it too, but
+        for whichever pair has finished by then -- use this to tie the check to one pair)."""
+        out["done_event"].synchronize()
+        status, slot = out["_tie_status"]
+        check_tie_status(int(status[slot]))
         return out
 
     def _check_status(self, wait):

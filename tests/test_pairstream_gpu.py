@@ -145,6 +145,8 @@ def test_pair_engine_matches_sequential(cuda):
                 submitted += 1
             outs.append(eng.result())
             assert isinstance(outs[-1]["done_event"], torch.cuda.Event)
+            if i % 3 == 0:
+                assert PairStreams.check(outs[-1]) is outs[-1]        # this pair's own tie-restore status, after its kernels
         eng.drain()
         with pytest.raises(RuntimeError):
             eng.result()
