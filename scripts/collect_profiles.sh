@@ -11,6 +11,7 @@ db() { find "$1" -name "*results.db" | head -1; }
 rm -rf /tmp/p1; rocprofv3 --kernel-trace --stats -d /tmp/p1 -o p -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprof.json
 python3 $R/scripts/prof_summary.py $(db /tmp/p1) $O/${TAG}_kernel_stats.csv 58
 python3 $R/scripts/front_chain.py $(db /tmp/p1) > $O/${TAG}_front_chain.txt 2>&1
+python3 $R/scripts/concurrency.py $(db /tmp/p1) > $O/${TAG}_concurrency.txt 2>&1
 # 2. the isolated forwards (one stream, nothing else running)
 rm -rf /tmp/p2; rocprofv3 --kernel-trace --stats -d /tmp/p2 -o p -- python3 $R/bench.py --isolated-only --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/${TAG}_isolated.json
 python3 $R/scripts/prof_summary.py $(db /tmp/p2) $O/${TAG}_isolated_kernel_stats.csv 24
