@@ -227,8 +227,18 @@ class PairPipeline:
             except BaseException as e:
                 self._fwd_out[w].put(e)
 
+    def _order_inputs(self, points, lengths, f):
+        """The front-end stream reads the inputs: make it wait for whatever the caller's stream still has in flight on
+        them (an asynchronous upload, a preprocessing kernel) and keep their memory from being reused under it."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.fronts[f].wait_event(ev)             # enqueued before the worker can enqueue this pair's first kernel
+        points.record_stream(self.fronts[f])
+        lengths.record_stream(self.fronts[f])
+
     def request(self, points, lengths):
         """Ask the front-end worker for the pyramid of one more pair (served in order)."""
+        self._order_inputs(points, lengths, 0)
         self._outstanding += 1
         if self._worker is None:
             self._ready.put(self.prepare(points, lengths))
@@ -276,6 +286,7 @@ class PairPipeline:
         seq = self._submitted
         w = seq % len(self.models)
         self._submitted += 1
+        self._order_inputs(points, lengths, seq % len(self.fronts) if self._threaded else 0)
         if self._threaded:
             self._requests[seq % len(self.fronts)].put((points, lengths, w, seq))
         else:

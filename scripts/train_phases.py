@@ -1,3 +1,5 @@
+"""GPU box: the train step by phase (differentiable forward, MetricLoss, backward, optimiser), each drained before the
+next is timed, host time to enqueue vs time to completion."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
