@@ -336,7 +336,8 @@ int launch(bool trans_b, dim3 grid, hipStream_t st, const float* a, int lda, con
 namespace pcrcg {
 int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
-                     hipStream_t st, bool a_bf16, bool c_zeroed, int a_kmajor = 0, int b_kmajor = 0);   // gemm_x6.hip
+                     hipStream_t st, bool a_bf16, bool c_zeroed, int a_kmajor = 0, int b_kmajor = 0,
+                     bool colstats_sums = false);   // gemm_x6.hip
 int gemm_x6_splits(int m, int n, int k);
 }
 
@@ -358,28 +359,32 @@ extern "C" int pcrcg_gemm_get_mode(void) { return gemm_mode(); }
 
 static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc,
                          int m, int n, int k, const float* row_scale, const float* bias, void* colstats,
-                         size_t colstats_bytes, int* h_chunks, void* stream, bool c_zeroed = false);
+                         size_t colstats_bytes, int* h_chunks, void* stream, bool c_zeroed = false,
+                         bool colstats_sums = false);
 
 namespace pcrcg {
 // For the network runner (runner.hip): does a C = A * B^T product of this shape accumulate split-K partial sums into C
 // (so that a C taken from the runner's pre-zeroed arena saves the product's own memset)?  Only the default arithmetic.
 bool gemm_bt_accumulates(int m, int n, int k) { return gemm_mode() == 1 && gemm_x6_splits(m, n, k) > 1; }
-// pcrcg_gemm_f32_colstats (trans_b = 1) / pcrcg_gemm_bf16a_f32_colstats with the promise that C is all zeros
+// pcrcg_gemm_f32_colstats (trans_b = 1) / pcrcg_gemm_bf16a_f32_colstats with the promise that C is all zeros.
+// colstats_sums: `colstats` is a ZEROED [2][n] fp64 accumulator; when the product writes every element once, its epilogue
+// adds the column sums / sums of squares there with atomics and reports *h_chunks = -1 (else 0: nothing was added).
+bool gemm_colstats_sums_ok() { return gemm_mode() == 1; }
 int gemm_bt_colstats(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
-                     hipStream_t st, bool c_zeroed) {
+                     hipStream_t st, bool c_zeroed, bool colstats_sums) {
     return gemm_dispatch(a, lda, 0, b, ldb, 1, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks, st,
-                         c_zeroed);
+                         c_zeroed, colstats_sums);
 }
 int gemm_bf16a_bt_colstats(const void* a_bf16, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                            const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes,
-                           int* h_chunks, hipStream_t st, bool c_zeroed) {
+                           int* h_chunks, hipStream_t st, bool c_zeroed, bool colstats_sums) {
     if (h_chunks) *h_chunks = 0;
     PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 32 && k % 32 == 0 && lda >= k && lda % 8 == 0 && ldb >= k && ldc >= n);
     if (m == 0 || n == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(a_bf16 && b && c && (reinterpret_cast<uintptr_t>(a_bf16) & 15) == 0);
     return gemm_x6_dispatch(static_cast<const float*>(a_bf16), lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats,
-                            colstats_bytes, h_chunks, st, true, c_zeroed);
+                            colstats_bytes, h_chunks, st, true, c_zeroed, 0, 0, colstats_sums);
 }
 }  // namespace pcrcg
 
@@ -407,7 +412,7 @@ extern "C" int pcrcg_gemm_bf16a_f32_colstats(const void* a_bf16, int lda, const 
                                              int n, int k, const float* row_scale, const float* bias, void* colstats,
                                              size_t colstats_bytes, int* h_chunks, void* stream) {
     return gemm_bf16a_bt_colstats(a_bf16, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks,
-                                  as_stream(stream), false);
+                                  as_stream(stream), false, false);
 }
 
 // Aop = A^T when trans_a (A stored [K, M] row-major): the weight-gradient products dW = X^T * dY of the
@@ -419,7 +424,7 @@ extern "C" int pcrcg_gemm_f32_ex(const float* a, int lda, int trans_a, const flo
 
 static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc,
                          int m, int n, int k, const float* row_scale, const float* bias, void* colstats,
-                         size_t colstats_bytes, int* h_chunks, void* stream, bool c_zeroed) {
+                         size_t colstats_bytes, int* h_chunks, void* stream, bool c_zeroed, bool colstats_sums) {
     if (h_chunks) *h_chunks = 0;
     PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 0);
     if (m == 0 || n == 0) return PCRCG_OK;
@@ -430,7 +435,8 @@ static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, i
     // split-bf16 arithmetic for A * B^T (the forward), A * B (dX = dY * W) and A^T * B (dW = X^T * dY); A^T * B^T stays fp32
     if (gemm_mode() == 1 && !(trans_a && trans_b))
         return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks, st, false,
-                                c_zeroed, trans_a ? 1 : 0, trans_b ? 0 : 1);
+                                c_zeroed, trans_a ? 1 : 0, trans_b ? 0 : 1, colstats_sums);
+    if (colstats_sums) { colstats = nullptr; colstats_bytes = 0; }     // (the fp32 kernels only know the partials layout)
     const int vec_a = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     const int vec_b = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
     // Tile / split selection (sweep in scripts/gemm_tune.py on the path's shapes): these GEMMs are skinny

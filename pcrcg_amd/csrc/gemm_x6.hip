@@ -365,8 +365,13 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
             const float s = cs[j] + __shfl_xor(cs[j], 32, 64), q2 = cq[j] + __shfl_xor(cq[j], 32, 64);
             const int gn = n0 + wn * WN + j * 32 + l31;
             if (half == 0 && gn < N) {
-                colp[(long)gn * colp_chunks + chunk] = (double)s;
-                colp[((long)N + gn) * colp_chunks + chunk] = (double)q2;
+                if (colp_chunks < 0) {          // sums mode: [2][N] accumulators zeroed by the caller
+                    unsafeAtomicAdd(&colp[gn], (double)s);
+                    unsafeAtomicAdd(&colp[(long)N + gn], (double)q2);
+                } else {
+                    colp[(long)gn * colp_chunks + chunk] = (double)s;
+                    colp[((long)N + gn) * colp_chunks + chunk] = (double)q2;
+                }
             }
         }
     }
@@ -430,7 +435,7 @@ int gemm_x6_splits(int m, int n, int k) { return (m > 0 && n > 0) ? x6_plan(m, n
 // already all zeros (the runner's zero arena), so a split-K product needs no memset of its own.
 int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
-                     hipStream_t st, bool a_bf16, bool c_zeroed, int a_kmajor, int b_kmajor) {
+                     hipStream_t st, bool a_bf16, bool c_zeroed, int a_kmajor, int b_kmajor, bool colstats_sums) {
     // k-major operands (a_kmajor: A stored [K, M]; b_kmajor: B stored [K, N]) are read with 4-byte loads: no alignment rule
     const int vec_a = (a_bf16 || a_kmajor) ? 1 : (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     const int vec_b = b_kmajor ? 1 : (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
@@ -450,7 +455,15 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
                 n, k, lda, ldb, ldc, BM, BN, gx, gy, splits, row_scale != nullptr, bias != nullptr, colstats != nullptr);
     double* colp = nullptr;
     int colp_chunks = 0;
-    if (colstats && h_chunks && !atomic_out) {
+    if (colstats && h_chunks && !atomic_out && colstats_sums) {
+        // column sums by fp64 atomics into [2][n] accumulators the caller has zeroed (few row tiles: no contention to
+        // speak of); *h_chunks = -1 tells the caller that the buffer holds sums, not partials
+        if (2 * (size_t)n * sizeof(double) <= colstats_bytes) {
+            colp = static_cast<double*>(colstats);
+            colp_chunks = -1;
+            *h_chunks = -1;
+        }
+    } else if (colstats && h_chunks && !atomic_out) {
         colp_chunks = gy * 2;   // WAVES_M
         if (carve_bytes(2 * (size_t)n * colp_chunks, sizeof(double)) <= colstats_bytes) {
             colp = static_cast<double*>(colstats);

@@ -170,6 +170,56 @@ __global__ void __launch_bounds__(256) k_instnorm_apply4(const float* __restrict
     *reinterpret_cast<float4*>(y + r * ldy + 4 * q) = v;
 }
 
+// (mean, rstd) of four consecutive channels from [2][c] fp64 column sums over `count` rows (as k_colstats_final)
+__device__ __forceinline__ void stats4_from_sums(const double* __restrict__ sums, int c, int ch, double count, float eps,
+                                                 float4& mean, float4& rstd) {
+    float m[4], r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double mu = sums[ch + i] / count;
+        double var = sums[c + ch + i] / count - mu * mu;   // biased variance (InstanceNorm)
+        if (var < 0.0) var = 0.0;
+        m[i] = (float)mu;
+        r[i] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    mean = make_float4(m[0], m[1], m[2], m[3]);
+    rstd = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+// k_instnorm_apply4 with the statistics taken from fp64 column SUMS (what the GEMM epilogue's sums mode leaves): no
+// finishing launch in between.  A thread keeps four channels and walks rows, so the fp64 arithmetic is paid once per
+// thread.  RES: 0 none, 1 residual as is, 2 residual normalised by its own sums.
+template <int RES>
+__global__ void __launch_bounds__(256) k_instnorm_apply4_sums(const float* __restrict__ x, int n, int c4, int ldx,
+                                                               const double* __restrict__ sums, double count, float eps,
+                                                               const float* __restrict__ res, int ldr,
+                                                               const double* __restrict__ res_sums, float slope,
+                                                               float* __restrict__ y, int ldy, int rows_per_block) {
+    const int cb = c4 < 256 ? c4 : 256;          // channel groups per pass (c4 is a power of two times ... see host check)
+    const int rp = 256 / cb;                     // rows handled at once
+    const int r_lo = blockIdx.x * rows_per_block, r_hi = min(n, r_lo + rows_per_block);
+    for (int qb = 0; qb < c4; qb += cb) {
+        const int q = qb + (int)(threadIdx.x % cb);
+        float4 m0, s0, m1 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = make_float4(1.f, 1.f, 1.f, 1.f);
+        stats4_from_sums(sums, 4 * c4, 4 * q, count, eps, m0, s0);
+        if (RES == 2) stats4_from_sums(res_sums, 4 * c4, 4 * q, count, eps, m1, s1);
+        for (long r = r_lo + (int)(threadIdx.x / cb); r < r_hi; r += rp) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + 4 * q);
+            float4 v = make_float4((xv.x - m0.x) * s0.x, (xv.y - m0.y) * s0.y, (xv.z - m0.z) * s0.z, (xv.w - m0.w) * s0.w);
+            if (RES) {
+                float4 rv = *reinterpret_cast<const float4*>(res + r * ldr + 4 * q);
+                if (RES == 2) rv = make_float4((rv.x - m1.x) * s1.x, (rv.y - m1.y) * s1.y, (rv.z - m1.z) * s1.z, (rv.w - m1.w) * s1.w);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            v.x = v.x >= 0.f ? v.x : v.x * slope;
+            v.y = v.y >= 0.f ? v.y : v.y * slope;
+            v.z = v.z >= 0.f ? v.z : v.z * slope;
+            v.w = v.w >= 0.f ? v.w : v.w * slope;
+            *reinterpret_cast<float4*>(y + r * ldy + 4 * q) = v;
+        }
+    }
+}
+
 }  // namespace
 
 size_t colstats_ws_bytes(int c) { return carve_bytes((size_t)kStatChunks * 2 * (size_t)(c > 0 ? c : 1), sizeof(double)); }
@@ -239,6 +289,38 @@ int pcrcg_instnorm_stats(const float* x, int n, int c, int ldx, float eps, float
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(k_colstats_partial, dim3(kStatChunks, (c + 63) / 64), dim3(256), 0, st, x, n, c, ldx, partial);
     return colstats_finalize(partial, kStatChunks, c, (double)n, eps, stats, st);
+}
+
+int pcrcg_instnorm_apply_sums(const float* x, int n, int c, int ldx, const void* sums, double count, float eps,
+                              const float* res, int ldr, const void* res_sums, float slope, float* y, int ldy,
+                              void* stream) {
+    PCRCG_CHECK_ARG(n >= 0 && c >= 4 && c % 4 == 0 && ldx >= c && ldy >= c && count >= 1.0);
+    if (n == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(x && sums && y && (!res || ldr >= c) && (!res_sums || res));
+    const int c4 = c / 4;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    // the kernel's thread -> channel-group map needs the groups to tile 256 threads (or be a multiple of 256)
+    PCRCG_CHECK_ARG((c4 <= 256 ? 256 % c4 == 0 : c4 % 256 == 0) && ldx % 4 == 0 && ldy % 4 == 0 && al16(x) && al16(y) &&
+                    (!res || (ldr % 4 == 0 && al16(res))));
+    const int rp = 256 / (c4 < 256 ? c4 : 256);
+    // ~8 rows per thread, but at least ~256 workgroups' worth of parallelism on small inputs
+    int rows_per_block = rp * 8;
+    while (rows_per_block > rp && (long)(n + rows_per_block - 1) / rows_per_block < 256) rows_per_block -= rp;
+    const unsigned blocks = (unsigned)((n + rows_per_block - 1) / rows_per_block);
+    hipStream_t st = as_stream(stream);
+    const double* s = static_cast<const double*>(sums);
+    const double* rs = static_cast<const double*>(res_sums);
+    if (!res)
+        hipLaunchKernelGGL(k_instnorm_apply4_sums<0>, dim3(blocks), dim3(256), 0, st, x, n, c4, ldx, s, count, eps, res, ldr, rs,
+                           slope, y, ldy, rows_per_block);
+    else if (!res_sums)
+        hipLaunchKernelGGL(k_instnorm_apply4_sums<1>, dim3(blocks), dim3(256), 0, st, x, n, c4, ldx, s, count, eps, res, ldr, rs,
+                           slope, y, ldy, rows_per_block);
+    else
+        hipLaunchKernelGGL(k_instnorm_apply4_sums<2>, dim3(blocks), dim3(256), 0, st, x, n, c4, ldx, s, count, eps, res, ldr, rs,
+                           slope, y, ldy, rows_per_block);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
 }
 
 int pcrcg_instnorm_apply(const float* x, int n, int c, int ldx, const float* stats, const float* res,

@@ -20,10 +20,11 @@ namespace pcrcg {
 bool gemm_bt_accumulates(int m, int n, int k);
 int gemm_bt_colstats(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
-                     hipStream_t st, bool c_zeroed);
+                     hipStream_t st, bool c_zeroed, bool colstats_sums = false);
 int gemm_bf16a_bt_colstats(const void* a_bf16, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                            const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes,
-                           int* h_chunks, hipStream_t st, bool c_zeroed);
+                           int* h_chunks, hipStream_t st, bool c_zeroed, bool colstats_sums);
+bool gemm_colstats_sums_ok();
 namespace {
 
 struct Mat {          // row-major fp32 matrix view
@@ -105,21 +106,43 @@ void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, co
 
 // A GEMM output together with the InstanceNorm column partials its epilogue may have produced.
 struct Stat {
-    void* partials = nullptr;   // [2][cols][chunks] fp64, valid when chunks > 0
+    void* partials = nullptr;   // [2][cols][chunks] fp64 partials, valid when chunks > 0; or, when `sums`, zeroed
+                                // [2][cols] fp64 accumulators that hold the column sums when chunks == -1
     size_t bytes = 0;
     int chunks = 0;
+    bool sums = false;
 };
 
+// Outputs of up to 8192 rows: the GEMM epilogue adds its column sums into accumulators from the zero arena with fp64
+// atomics (at most 256 per address) and the normalisation derives mean / rstd from them itself -- no partial buffers, no
+// finishing launch (51 per S30k forward before).  Taller outputs keep the deterministic partials + finishing kernel:
+// thousands of atomics per address would queue up behind each other.
 Stat stat_buffer(Ctx& c, int rows, int cols) {
     Stat s;
+    static const bool off = getenv("PCRCG_STAT_SUMS") && atoi(getenv("PCRCG_STAT_SUMS")) == 0;   // A/B aid
+    if (!off && rows <= 8192 && gemm_colstats_sums_ok()) {
+        s.sums = true;
+        s.bytes = 2 * sizeof(double) * (size_t)cols;
+        s.partials = c.zraw(s.bytes);
+        return s;
+    }
     s.bytes = pcrcg_gemm_colstats_bytes(rows, cols);
     s.partials = c.raw(s.bytes);
     return s;
 }
 
+// widths the sums form of the normalisation kernel serves (its thread -> channel-group map)
+inline bool sums_apply_ok(const Mat& x, const Mat& y, const Mat* res) {
+    const int c4 = x.cols / 4;
+    return x.cols % 4 == 0 && x.cols >= 4 && (c4 <= 256 ? 256 % c4 == 0 : c4 % 256 == 0) && x.ld % 4 == 0 && y.ld % 4 == 0 &&
+           (!res || res->ld % 4 == 0);
+}
+
 // (mean, rstd) of x: from the producing GEMM's partials when it left some, else by a pass over x
 void col_stats(Ctx& c, const Mat& x, const Stat* s, float* stats, void* ws, size_t wsb) {
-    if (s && s->chunks > 0)
+    if (s && s->chunks == -1)      // column sums: the finishing kernel reads them as one chunk per column
+        c.check(pcrcg_instnorm_stats_from_partials(s->partials, 1, x.cols, (double)x.rows, 1e-5f, stats, c.st));
+    else if (s && s->chunks > 0)
         c.check(pcrcg_instnorm_stats_from_partials(s->partials, s->chunks, x.cols, (double)x.rows, 1e-5f, stats, c.st));
     else
         c.check(pcrcg_instnorm_stats(x.p, x.rows, x.cols, x.ld, 1e-5f, stats, ws, wsb, c.st));
@@ -128,6 +151,12 @@ void col_stats(Ctx& c, const Mat& x, const Stat* s, float* stats, void* ws, size
 // y = lrelu(IN(x) [+ IN(res) | + res], slope)
 void norm_act(Ctx& c, const Mat& x, float slope, const Mat& y, const Stat* xs = nullptr, const Mat* res = nullptr,
               bool norm_res = false, const Stat* rs = nullptr) {
+    if (c.live() && xs && xs->chunks == -1 && (!res || !norm_res || (rs && rs->chunks == -1)) && sums_apply_ok(x, y, res)) {
+        c.check(pcrcg_instnorm_apply_sums(x.p, x.rows, x.cols, x.ld, xs->partials, (double)x.rows, 1e-5f, res ? res->p : nullptr,
+                                          res ? res->ld : 0, (res && norm_res) ? rs->partials : nullptr, slope, y.p, y.ld,
+                                          c.st));
+        return;
+    }
     const size_t m = c.mark();
     float* stats = static_cast<float*>(c.raw(sizeof(float) * 2 * x.cols));
     float* rstats = (res && norm_res) ? static_cast<float*>(c.raw(sizeof(float) * 2 * x.cols)) : nullptr;
@@ -145,7 +174,8 @@ void norm_act(Ctx& c, const Mat& x, float slope, const Mat& y, const Stat* xs = 
 void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, const Mat& y, Stat* st) {
     if (!c.live()) return;
     c.check(gemm_bt_colstats(x.p, x.ld, w, ldw, y.p, y.ld, x.rows, y.cols, x.cols, nullptr, bias,
-                             st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr, c.st, y.zeroed));
+                             st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr, c.st, y.zeroed,
+                             st && st->sums));
 }
 
 void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, const Mat& y, Stat* st = nullptr) {
@@ -209,7 +239,7 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
                                                 xb, wfb, inv_n, ws, wsb, c.st));
             c.check(gemm_bf16a_bt_colstats(wfb, kk, blk.kp_wt, kk, y.p, y.ld, nq, y.cols, kk, inv_n, nullptr,
                                            st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr,
-                                           c.st, y.zeroed));
+                                           c.st, y.zeroed, st && st->sums));
         }
         c.release(m);
         return;
@@ -226,11 +256,11 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
         if (blk.kp_wt)
             c.check(gemm_bt_colstats(wf.p, wf.ld, blk.kp_wt, wf.cols, y.p, y.ld, nq, y.cols, wf.cols, inv_n, nullptr,
                                      st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr, c.st,
-                                     y.zeroed));
-        else
+                                     y.zeroed, st && st->sums));
+        else   // (descriptor without the K-contiguous weight copy: the plain entry point knows only the partials layout)
             c.check(pcrcg_gemm_f32_colstats(wf.p, wf.ld, w, y.cols, 0, y.p, y.ld, nq, y.cols, wf.cols, inv_n, nullptr,
-                                            st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr,
-                                            c.st));
+                                            (st && !st->sums) ? st->partials : nullptr, (st && !st->sums) ? st->bytes : 0,
+                                            (st && !st->sums) ? &st->chunks : nullptr, c.st));
     }
     c.release(m);
 }

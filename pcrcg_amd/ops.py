@@ -507,6 +507,26 @@ def instnorm_apply(x, stats, slope=1.0, res=None, res_stats=None, out=None):
     return out
 
 
+def instnorm_apply_sums(x, sums, slope=1.0, res=None, res_sums=None, eps=1e-5, out=None):
+    """lrelu(IN(x) [+ res | + IN(res)], slope) with the statistics given as float64 column sums [2, c] =
+    (sum_r x, sum_r x^2) -- the form the runner's GEMM epilogues leave (pcrcg_instnorm_apply_sums)."""
+    L = _lib.lib()
+    x, ldx = _rows(x, _F32, "x")
+    n, c = x.shape
+    if sums.dtype != torch.float64 or tuple(sums.shape) != (2, c) or not sums.is_contiguous():
+        raise RuntimeError("pcrcg_amd.instnorm_apply_sums: sums must be a contiguous float64 [2, c] tensor")
+    ldr = 0
+    if res is not None:
+        res, ldr = _rows(res, _F32, "res")
+    if out is None:
+        out = torch.empty((n, c), dtype=_F32, device=x.device)
+    ldy = out.stride(0) if n > 1 else max(c, out.stride(0))
+    _lib.check(L.pcrcg_instnorm_apply_sums(x.data_ptr(), n, c, ldx, sums.data_ptr(), float(n), float(eps), _ptr(res), ldr,
+                                           _ptr(res_sums), float(slope), out.data_ptr(), ldy, _stream()),
+               "pcrcg_instnorm_apply_sums")
+    return out
+
+
 def instnorm_lrelu(x, slope, eps=1e-5):
     """InstanceNorm over rows followed by LeakyReLU(slope); slope 1.0 = identity."""
     return instnorm_apply(x, instnorm_stats(x, eps), slope)

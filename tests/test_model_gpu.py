@@ -196,6 +196,33 @@ def test_knn_and_edgeconv(cuda):
         assert rel(y, ref) < TOL
 
 
+@pytest.mark.parametrize("n,c", [(763, 512), (1, 8), (3934, 2048), (8192, 64), (100, 1024), (381, 32)])
+def test_instnorm_apply_from_sums(cuda, n, c):
+    """pcrcg_instnorm_apply_sums (statistics as float64 column sums, the form the runner's GEMM epilogues leave for
+    outputs of up to 8192 rows) against the reference formulation (ref:models/blocks.py:456-463: InstanceNorm1d over the
+    points, eps 1e-5, biased variance) and against the two-launch path it replaces."""
+    g = torch.Generator().manual_seed(n + c)
+    x = (torch.randn(n, c, generator=g) * 3 + 1).to(cuda)
+    r = torch.randn(n, c, generator=g).to(cuda)
+    sums = torch.stack([x.double().sum(0), (x.double() ** 2).sum(0)]).contiguous()
+    rsums = torch.stack([r.double().sum(0), (r.double() ** 2).sum(0)]).contiguous()
+
+    def inorm(t):
+        t = t.double()
+        return (t - t.mean(0)) / torch.sqrt(t.var(0, unbiased=False) + 1e-5)
+
+    lrelu = torch.nn.functional.leaky_relu
+    assert rel(ops.instnorm_apply_sums(x, sums, 0.1), lrelu(inorm(x), 0.1)) < 2e-6
+    assert rel(ops.instnorm_apply_sums(x, sums, 0.1, res=r), lrelu(inorm(x) + r.double(), 0.1)) < 2e-6
+    assert rel(ops.instnorm_apply_sums(x, sums, 0.2, res=r, res_sums=rsums), lrelu(inorm(x) + inorm(r), 0.2)) < 2e-6
+    assert rel(ops.instnorm_apply_sums(x, sums, 0.1), ops.instnorm_lrelu(x, 0.1)) < 1e-6
+    wide = torch.zeros(n, c + 8, device=cuda)                       # strided output (a column block of a wider matrix)
+    ops.instnorm_apply_sums(x, sums, 1.0, out=wide[:, 4:4 + c])
+    assert rel(wide[:, 4:4 + c], inorm(x)) < 2e-6 and float(wide[:, :4].abs().max()) == 0
+    with pytest.raises(RuntimeError):
+        ops.instnorm_apply_sums(x[:, :c - 4].contiguous() if c == 1024 else x[:, :3], sums)   # 255 groups / 3 channels
+
+
 def test_softmax_rows(cuda):
     g = torch.Generator().manual_seed(8)
     x = torch.randn(381, 382, generator=g) * 4
