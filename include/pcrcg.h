@@ -285,6 +285,9 @@ int pcrcg_instnorm_apply(const float* x, int n, int c, int ldx, const float* sta
  * derived on the fly -- no finishing launch between the producing GEMM and the normalisation.  res_sums (may be NULL):
  * the residual is normalised by its own sums, else added as is.  c % 4 == 0 and c / 4 a divisor or a multiple of 256
  * (every width of the architecture); rows 16-byte aligned. */
+/* sums [2][c] f64 += (column sums, column sums of squares) of x [n, c]; the caller zeroes `sums` (one launch: the
+ * statistics pass for outputs whose producing GEMM could not leave them, e.g. split-K products). */
+int pcrcg_instnorm_colsums(const float* x, int n, int c, int ldx, void* sums, void* stream);
 int pcrcg_instnorm_apply_sums(const float* x, int n, int c, int ldx, const void* sums, double count, float eps,
                               const float* res, int ldr, const void* res_sums, float slope, float* y, int ldy,
                               void* stream);

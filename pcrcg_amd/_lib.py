@@ -71,6 +71,7 @@ SIGNATURES = {
     "pcrcg_instnorm_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pcrcg_instnorm_apply": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float,
                                      c_void_p, c_int, c_void_p]),
+    "pcrcg_instnorm_colsums": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pcrcg_instnorm_apply_sums": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_double, c_float, c_void_p, c_int,
                                           c_void_p, c_float, c_void_p, c_int, c_void_p]),
     "pcrcg_fill2d": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p]),

@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(256) k_gather_first(const float* __restrict__ 
 // ---- InstanceNorm statistics: deterministic two-stage column reduction in fp64 -----------------
 constexpr int kStatChunks = 128;   // row chunks (= partial sums per channel)
 
+template <bool ATOMIC>      // ATOMIC: add the chunk's sums into zeroed [2][c] accumulators instead of storing partials
 __global__ void __launch_bounds__(256) k_colstats_partial(const float* __restrict__ x, int n, int c, int ldx,
                                                            double* __restrict__ partial /* [2][c][chunks] */) {
     __shared__ double s_sum[4][64], s_sq[4][64];
@@ -96,8 +97,15 @@ __global__ void __launch_bounds__(256) k_colstats_partial(const float* __restric
     if (rl == 0 && ch < c) {
         s = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
         sq = (s_sq[0][lane] + s_sq[1][lane]) + (s_sq[2][lane] + s_sq[3][lane]);
-        partial[(long)ch * nchunks + chunk] = s;                       // layout [2][c][nchunks]
-        partial[((long)c + ch) * nchunks + chunk] = sq;
+        if (ATOMIC) {
+            if (r0 < r1) {
+                unsafeAtomicAdd(&partial[ch], s);
+                unsafeAtomicAdd(&partial[(long)c + ch], sq);
+            }
+        } else {
+            partial[(long)ch * nchunks + chunk] = s;                   // layout [2][c][nchunks]
+            partial[((long)c + ch) * nchunks + chunk] = sq;
+        }
     }
 }
 
@@ -287,8 +295,19 @@ int pcrcg_instnorm_stats(const float* x, int n, int c, int ldx, float eps, float
     double* partial = cv.take<double>((size_t)kStatChunks * 2 * c);
     PCRCG_CHECK_WS(cv);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(k_colstats_partial, dim3(kStatChunks, (c + 63) / 64), dim3(256), 0, st, x, n, c, ldx, partial);
+    hipLaunchKernelGGL(k_colstats_partial<false>, dim3(kStatChunks, (c + 63) / 64), dim3(256), 0, st, x, n, c, ldx, partial);
     return colstats_finalize(partial, kStatChunks, c, (double)n, eps, stats, st);
+}
+
+int pcrcg_instnorm_colsums(const float* x, int n, int c, int ldx, void* sums, void* stream) {
+    PCRCG_CHECK_ARG(n >= 1 && c >= 1 && ldx >= c && x && sums);
+    // enough row chunks to fill the chip on tall inputs, few on short ones (each adds 2 atomics per channel)
+    int chunks = (n + 63) / 64;
+    if (chunks > kStatChunks) chunks = kStatChunks;
+    hipLaunchKernelGGL(k_colstats_partial<true>, dim3(chunks, (c + 63) / 64), dim3(256), 0, as_stream(stream), x, n, c, ldx,
+                       static_cast<double*>(sums));
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
 }
 
 int pcrcg_instnorm_apply_sums(const float* x, int n, int c, int ldx, const void* sums, double count, float eps,

@@ -151,8 +151,17 @@ void col_stats(Ctx& c, const Mat& x, const Stat* s, float* stats, void* ws, size
 }
 
 // y = lrelu(IN(x) [+ IN(res) | + res], slope)
-void norm_act(Ctx& c, const Mat& x, float slope, const Mat& y, const Stat* xs = nullptr, const Mat* res = nullptr,
-              bool norm_res = false, const Stat* rs = nullptr) {
+void norm_act(Ctx& c, const Mat& x, float slope, const Mat& y, Stat* xs = nullptr, const Mat* res = nullptr,
+              bool norm_res = false, Stat* rs = nullptr) {
+    // sums-mode statistics the producing GEMM could not leave (a split-K product): one pass into the same accumulators
+    if (c.live() && xs && xs->sums && xs->chunks == 0) {
+        c.check(pcrcg_instnorm_colsums(x.p, x.rows, x.cols, x.ld, xs->partials, c.st));
+        xs->chunks = -1;
+    }
+    if (c.live() && res && norm_res && rs && rs->sums && rs->chunks == 0) {
+        c.check(pcrcg_instnorm_colsums(res->p, res->rows, res->cols, res->ld, rs->partials, c.st));
+        rs->chunks = -1;
+    }
     if (c.live() && xs && xs->chunks == -1 && (!res || !norm_res || (rs && rs->chunks == -1)) && sums_apply_ok(x, y, res)) {
         c.check(pcrcg_instnorm_apply_sums(x.p, x.rows, x.cols, x.ld, xs->partials, (double)x.rows, 1e-5f, res ? res->p : nullptr,
                                           res ? res->ld : 0, (res && norm_res) ? rs->partials : nullptr, slope, y.p, y.ld,
@@ -338,6 +347,7 @@ Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, con
     float* stats = static_cast<float*>(c.raw(sizeof(float) * 4 * ch));
     Mat cn1 = c.gemm_out(n, 2 * ch, ch), e1 = c.mat(n, ch), cn2 = c.gemm_out(n, 4 * ch, ch), e2 = c.mat(n, 2 * ch);
     Mat x3 = c.gemm_out(n, ch, 4 * ch);
+    Stat x3s = stat_buffer(c, n, ch);
     if (c.live()) {
         c.check(pcrcg_knn(coords, n, k, idx, c.st));
         c.check(pcrcg_copy2d(f.p, f.ld, cat.p, cat.ld, n, ch, c.st));                                    // x0
@@ -355,10 +365,10 @@ Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, con
         c.check(pcrcg_instnorm_apply(e2.p, n, 2 * ch, e2.ld, stats, nullptr, 0, nullptr, 0.2f, cat.p + 2 * ch, cat.ld,
                                      c.st));
         // x3 = lrelu(IN(conv3(cat(x0,x1,x2))))  (:131-132)
-        c.check(gemm_bt_colstats(cat.p, cat.ld, g.conv3, 4 * ch, x3.p, x3.ld, n, ch, 4 * ch, nullptr, nullptr, nullptr, 0,
-                                 nullptr, c.st, x3.zeroed));
+        c.check(gemm_bt_colstats(cat.p, cat.ld, g.conv3, 4 * ch, x3.p, x3.ld, n, ch, 4 * ch, nullptr, nullptr, x3s.partials,
+                                 x3s.bytes, &x3s.chunks, c.st, x3.zeroed, x3s.sums));
     }
-    norm_act(c, x3, 0.2f, y);
+    norm_act(c, x3, 0.2f, y, &x3s);
     c.release(m);
     return y;
 }
@@ -392,8 +402,9 @@ Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, co
         c.check(pcrcg_copy2d(x.p, x.ld, cat.p, cat.ld, n, ch, c.st));
     }
     linear(c, msg, g.wm, ch, g.bm, cols(cat, ch, ch));       // merge, written next to x: cat([x, message])
-    linear(c, cat, g.w0, 2 * ch, g.b0, h0);
-    norm_act(c, h0, 0.0f, h1);                              // InstanceNorm1d + ReLU
+    Stat h0s = stat_buffer(c, n, 2 * ch);
+    linear(c, cat, g.w0, 2 * ch, g.b0, h0, &h0s);
+    norm_act(c, h0, 0.0f, h1, &h0s);                        // InstanceNorm1d + ReLU
     linear(c, h1, g.w3, 2 * ch, g.b3, delta);
     if (c.live()) c.check(pcrcg_add(x.p, delta.p, y.p, (long)n * ch, c.st));
     c.release(m);

@@ -507,6 +507,17 @@ def instnorm_apply(x, stats, slope=1.0, res=None, res_stats=None, out=None):
     return out
 
 
+def instnorm_colsums(x):
+    """float64 [2, c]: column sums and column sums of squares of x [n, c] (one launch, fp64 atomics)."""
+    L = _lib.lib()
+    x, ldx = _rows(x, _F32, "x")
+    sums = torch.zeros((2, x.shape[1]), dtype=torch.float64, device=x.device)
+    if x.shape[0] > 0:
+        _lib.check(L.pcrcg_instnorm_colsums(x.data_ptr(), x.shape[0], x.shape[1], ldx, sums.data_ptr(), _stream()),
+                   "pcrcg_instnorm_colsums")
+    return sums
+
+
 def instnorm_apply_sums(x, sums, slope=1.0, res=None, res_sums=None, eps=1e-5, out=None):
     """lrelu(IN(x) [+ res | + IN(res)], slope) with the statistics given as float64 column sums [2, c] =
     (sum_r x, sum_r x^2) -- the form the runner's GEMM epilogues leave (pcrcg_instnorm_apply_sums)."""

@@ -212,6 +212,9 @@ def test_instnorm_apply_from_sums(cuda, n, c):
         return (t - t.mean(0)) / torch.sqrt(t.var(0, unbiased=False) + 1e-5)
 
     lrelu = torch.nn.functional.leaky_relu
+    got_sums = ops.instnorm_colsums(x)                       # the one-launch statistics pass (split-K outputs)
+    assert rel(got_sums, sums) < 1e-12
+    assert rel(ops.instnorm_colsums(torch.cat([x, r], 1)[:, 4:c + 4]), torch.cat([sums, rsums], 1)[:, 4:c + 4]) < 1e-12
     assert rel(ops.instnorm_apply_sums(x, sums, 0.1), lrelu(inorm(x), 0.1)) < 2e-6
     assert rel(ops.instnorm_apply_sums(x, sums, 0.1, res=r), lrelu(inorm(x) + r.double(), 0.1)) < 2e-6
     assert rel(ops.instnorm_apply_sums(x, sums, 0.2, res=r, res_sums=rsums), lrelu(inorm(x) + inorm(r), 0.2)) < 2e-6
