@@ -54,6 +54,44 @@ __global__ void __launch_bounds__(256) k_knn(const float* __restrict__ coords, i
     }
 }
 
+// The same selection with the candidate keys of a query kept in registers (n <= 64 * PER): the distances are formed
+// once instead of once per round (same expression, same keys, same result), and a round is a register scan plus the
+// wavefront reduction.  The coarse level of an indoor pair has a few hundred points.
+template <int PER>
+__global__ void __launch_bounds__(256) k_knn_reg(const float* __restrict__ coords, int n, int k, int* __restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float ax = coords[3 * (long)i], ay = coords[3 * (long)i + 1], az = coords[3 * (long)i + 2];
+    const float sa = ax * ax + ay * ay + az * az;
+    u64 key[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int j = lane + 64 * t;
+        const int jc = j < n ? j : n - 1;
+        const float bx = coords[3 * (long)jc], by = coords[3 * (long)jc + 1], bz = coords[3 * (long)jc + 2];
+        const float dot = ax * bx + ay * by + az * bz;
+        const float sb = bx * bx + by * by + bz * bz;
+        float d = (-2.0f * dot + sa) + sb;            // square_distance :26-31
+        d = fmaxf(d, 1e-12f);                         // clamp :33
+        key[t] = j < n ? (((u64)__float_as_uint(d) << 32) | (unsigned)j) : ~0ull;
+    }
+    u64 last = 0;
+    for (int round = 0; round <= k; ++round) {
+        u64 best = ~0ull;
+#pragma unroll
+        for (int t = 0; t < PER; ++t)
+            if ((round == 0 || key[t] > last) && key[t] < best) best = key[t];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            const u64 o = __shfl_xor(best, s, 64);
+            best = o < best ? o : best;
+        }
+        last = best;
+        if (round >= 1 && lane == 0) idx[(long)i * k + (round - 1)] = best == ~0ull ? i : (int)(best & 0xFFFFFFFFull);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_edgeconv_reduce(const float* __restrict__ ctr, int ld_ctr,
                                                           const float* __restrict__ nbr, int ld_nbr,
                                                           const int* __restrict__ idx, int n, int k, int c,
@@ -244,7 +282,12 @@ int pcrcg_knn(const float* coords, int n, int k, int* idx, void* stream) {
     PCRCG_CHECK_ARG(n >= 0 && k >= 1);
     if (n == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(coords && idx);
-    hipLaunchKernelGGL(k_knn, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), coords, n, k, idx);
+    if (n <= 64 * 8)
+        hipLaunchKernelGGL(k_knn_reg<8>, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), coords, n, k, idx);
+    else if (n <= 64 * 16)
+        hipLaunchKernelGGL(k_knn_reg<16>, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), coords, n, k, idx);
+    else
+        hipLaunchKernelGGL(k_knn, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), coords, n, k, idx);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

@@ -178,7 +178,7 @@ def test_residual_norm_tail(cuda):
 
 def test_knn_and_edgeconv(cuda):
     g = torch.Generator().manual_seed(6)
-    for n in (12, 381, 940):
+    for n in (12, 381, 512, 513, 940, 1500):     # register-resident selection up to 1024 points, rescanning kernel above
         coords = torch.rand(n, 3, generator=g)
         k = min(10, n - 1)
         got = ops.knn(coords.to(cuda), k).cpu().long()
