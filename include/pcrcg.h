@@ -324,6 +324,10 @@ size_t pcrcg_edgeconv_ws_bytes(int c);
 int pcrcg_edgeconv_reduce(const float* ctr, int ld_ctr, const float* nbr, int ld_nbr, const int* idx,
                           int n, int k, int c, float eps, float* emax, int ld_emax, float* stats,
                           void* ws, size_t ws_bytes, void* stream);
+/* The same reduction leaving the statistics as fp64 sums: sums [2][c] f64 (zeroed by the caller) += (sum, sum of squares)
+ * of e over all (i,j); finish with pcrcg_instnorm_apply_sums(emax, ..., sums, count = n * k, ...).  One launch. */
+int pcrcg_edgeconv_reduce_sums(const float* ctr, int ld_ctr, const float* nbr, int ld_nbr, const int* idx, int n, int k,
+                               int c, float* emax, int ld_emax, void* sums, void* stream);
 /* Row softmax in place: x [rows, cols] (ld), x = softmax(x * scale) (ref:models/gcn.py:151-155,
  * ref:models/architectures.py:562-563). */
 int pcrcg_softmax_rows(float* x, int rows, int cols, int ld, float scale, void* stream);

@@ -81,6 +81,8 @@ SIGNATURES = {
     "pcrcg_edgeconv_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_edgeconv_reduce": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float,
                                       c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_edgeconv_reduce_sums": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                                           c_void_p, c_void_p]),
     "pcrcg_softmax_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "pcrcg_attention_supported": (c_int, [c_int]),
     "pcrcg_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,

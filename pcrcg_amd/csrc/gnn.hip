@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(256) k_knn_reg(const float* __restrict__ coord
     }
 }
 
+template <bool ATOMIC>      // ATOMIC: the chunk's sums are added into zeroed [2][c] accumulators instead of stored as partials
 __global__ void __launch_bounds__(256) k_edgeconv_reduce(const float* __restrict__ ctr, int ld_ctr,
                                                           const float* __restrict__ nbr, int ld_nbr,
                                                           const int* __restrict__ idx, int n, int k, int c,
@@ -122,8 +123,15 @@ __global__ void __launch_bounds__(256) k_edgeconv_reduce(const float* __restrict
     if (rl == 0 && ch < c) {
         s = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
         sq = (s_sq[0][lane] + s_sq[1][lane]) + (s_sq[2][lane] + s_sq[3][lane]);
-        partial[(long)ch * nchunks + chunk] = s;                       // layout [2][c][nchunks]
-        partial[((long)c + ch) * nchunks + chunk] = sq;
+        if (ATOMIC) {
+            if (r0 < r1) {
+                unsafeAtomicAdd(&partial[ch], s);
+                unsafeAtomicAdd(&partial[(long)c + ch], sq);
+            }
+        } else {
+            partial[(long)ch * nchunks + chunk] = s;                   // layout [2][c][nchunks]
+            partial[((long)c + ch) * nchunks + chunk] = sq;
+        }
     }
 }
 
@@ -304,9 +312,21 @@ int pcrcg_edgeconv_reduce(const float* ctr, int ld_ctr, const float* nbr, int ld
     double* partial = cv.take<double>((size_t)chunks * 2 * c);
     PCRCG_CHECK_WS(cv);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(k_edgeconv_reduce, dim3(chunks, (c + 63) / 64), dim3(256), 0, st, ctr, ld_ctr, nbr, ld_nbr,
+    hipLaunchKernelGGL(k_edgeconv_reduce<false>, dim3(chunks, (c + 63) / 64), dim3(256), 0, st, ctr, ld_ctr, nbr, ld_nbr,
                        idx, n, k, c, emax, ld_emax, partial);
     return colstats_finalize(partial, chunks, c, (double)n * (double)k, eps, stats, st);
+}
+
+int pcrcg_edgeconv_reduce_sums(const float* ctr, int ld_ctr, const float* nbr, int ld_nbr, const int* idx, int n, int k,
+                               int c, float* emax, int ld_emax, void* sums, void* stream) {
+    PCRCG_CHECK_ARG(n >= 1 && k >= 1 && c >= 1 && ld_ctr >= c && ld_nbr >= c && ld_emax >= c);
+    PCRCG_CHECK_ARG(ctr && nbr && idx && emax && sums);
+    int chunks = (n + 15) / 16;                      // ~16 rows per workgroup row slice
+    if (chunks > colstats_chunks()) chunks = colstats_chunks();
+    hipLaunchKernelGGL(k_edgeconv_reduce<true>, dim3(chunks, (c + 63) / 64), dim3(256), 0, as_stream(stream), ctr, ld_ctr,
+                       nbr, ld_nbr, idx, n, k, c, emax, ld_emax, static_cast<double*>(sums));
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
 }
 
 int pcrcg_attention_supported(int d) { return d == 16 || d == 32 || d == 48 || d == 64 || d == 128; }

@@ -334,6 +334,20 @@ Mat resnet_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat
     return y;
 }
 
+// x_out = lrelu(IN2d(max_j e), 0.2) for e[i,j,:] = cn[i, :cw] + cn[idx[i,j], cw:2cw]: reduction + normalisation
+// (max commutes with the monotone normalise + LeakyReLU); statistics as fp64 sums when the widths allow, else as pairs
+void edge_norm(Ctx& c, const Mat& cn, int cw, const int* idx, int n, int k, const Mat& emax, const Mat& out, void* sums,
+               float* stats, void* ws, size_t wsb) {
+    if (sums && sums_apply_ok(emax, out, nullptr)) {
+        c.check(pcrcg_edgeconv_reduce_sums(cn.p, cn.ld, cn.p + cw, cn.ld, idx, n, k, cw, emax.p, emax.ld, sums, c.st));
+        c.check(pcrcg_instnorm_apply_sums(emax.p, n, cw, emax.ld, sums, (double)n * (double)k, 1e-5f, nullptr, 0, nullptr, 0.2f,
+                                          out.p, out.ld, c.st));
+        return;
+    }
+    c.check(pcrcg_edgeconv_reduce(cn.p, cn.ld, cn.p + cw, cn.ld, idx, n, k, cw, 1e-5f, emax.p, emax.ld, stats, ws, wsb, c.st));
+    c.check(pcrcg_instnorm_apply(emax.p, n, cw, emax.ld, stats, nullptr, 0, nullptr, 0.2f, out.p, out.ld, c.st));
+}
+
 // SelfAttention.forward (ref:models/gcn.py:110-134) on row-major [n, ch]
 Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, const float* coords, const Mat& f) {
     const int n = f.rows, ch = f.cols;
@@ -348,22 +362,20 @@ Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, con
     Mat cn1 = c.gemm_out(n, 2 * ch, ch), e1 = c.mat(n, ch), cn2 = c.gemm_out(n, 4 * ch, ch), e2 = c.mat(n, 2 * ch);
     Mat x3 = c.gemm_out(n, ch, 4 * ch);
     Stat x3s = stat_buffer(c, n, ch);
+    // InstanceNorm2d statistics of the two edge convolutions as fp64 sums (zero arena) when that form applies
+    void* sums1 = gemm_colstats_sums_ok() ? c.zraw(2 * sizeof(double) * (size_t)ch) : nullptr;
+    void* sums2 = gemm_colstats_sums_ok() ? c.zraw(2 * sizeof(double) * (size_t)(2 * ch)) : nullptr;
     if (c.live()) {
         c.check(pcrcg_knn(coords, n, k, idx, c.st));
         c.check(pcrcg_copy2d(f.p, f.ld, cat.p, cat.ld, n, ch, c.st));                                    // x0
         // x1 = max_k lrelu(IN2d(conv1(cat(f_i, f_j - f_i))))  (:121-125)
         c.check(gemm_bt_colstats(f.p, f.ld, g.edge1, ch, cn1.p, cn1.ld, n, 2 * ch, ch, nullptr, nullptr, nullptr, 0, nullptr,
                                  c.st, cn1.zeroed));
-        c.check(pcrcg_edgeconv_reduce(cn1.p, cn1.ld, cn1.p + ch, cn1.ld, idx, n, k, ch, 1e-5f, e1.p, e1.ld, stats, ws,
-                                      wsb, c.st));
-        c.check(pcrcg_instnorm_apply(e1.p, n, ch, e1.ld, stats, nullptr, 0, nullptr, 0.2f, cat.p + ch, cat.ld, c.st));
+        edge_norm(c, cn1, ch, idx, n, k, e1, cols(cat, ch, ch), sums1, stats, ws, wsb);
         // x2 from x1 with conv2 (:127-129)
         c.check(gemm_bt_colstats(cat.p + ch, cat.ld, g.edge2, ch, cn2.p, cn2.ld, n, 4 * ch, ch, nullptr, nullptr, nullptr, 0,
                                  nullptr, c.st, cn2.zeroed));
-        c.check(pcrcg_edgeconv_reduce(cn2.p, cn2.ld, cn2.p + 2 * ch, cn2.ld, idx, n, k, 2 * ch, 1e-5f, e2.p, e2.ld, stats,
-                                      ws, wsb, c.st));
-        c.check(pcrcg_instnorm_apply(e2.p, n, 2 * ch, e2.ld, stats, nullptr, 0, nullptr, 0.2f, cat.p + 2 * ch, cat.ld,
-                                     c.st));
+        edge_norm(c, cn2, 2 * ch, idx, n, k, e2, cols(cat, 2 * ch, 2 * ch), sums2, stats, ws, wsb);
         // x3 = lrelu(IN(conv3(cat(x0,x1,x2))))  (:131-132)
         c.check(gemm_bt_colstats(cat.p, cat.ld, g.conv3, 4 * ch, x3.p, x3.ld, n, ch, 4 * ch, nullptr, nullptr, x3s.partials,
                                  x3s.bytes, &x3s.chunks, c.st, x3.zeroed, x3s.sums));

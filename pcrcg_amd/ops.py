@@ -518,7 +518,7 @@ def instnorm_colsums(x):
     return sums
 
 
-def instnorm_apply_sums(x, sums, slope=1.0, res=None, res_sums=None, eps=1e-5, out=None):
+def instnorm_apply_sums(x, sums, slope=1.0, res=None, res_sums=None, eps=1e-5, out=None, count=None):
     """lrelu(IN(x) [+ res | + IN(res)], slope) with the statistics given as float64 column sums [2, c] =
     (sum_r x, sum_r x^2) -- the form the runner's GEMM epilogues leave (pcrcg_instnorm_apply_sums)."""
     L = _lib.lib()
@@ -532,7 +532,8 @@ def instnorm_apply_sums(x, sums, slope=1.0, res=None, res_sums=None, eps=1e-5, o
     if out is None:
         out = torch.empty((n, c), dtype=_F32, device=x.device)
     ldy = out.stride(0) if n > 1 else max(c, out.stride(0))
-    _lib.check(L.pcrcg_instnorm_apply_sums(x.data_ptr(), n, c, ldx, sums.data_ptr(), float(n), float(eps), _ptr(res), ldr,
+    _lib.check(L.pcrcg_instnorm_apply_sums(x.data_ptr(), n, c, ldx, sums.data_ptr(), float(n if count is None else count),
+                                           float(eps), _ptr(res), ldr,
                                            _ptr(res_sums), float(slope), out.data_ptr(), ldy, _stream()),
                "pcrcg_instnorm_apply_sums")
     return out
@@ -568,6 +569,21 @@ def edgeconv_reduce(ctr, nbr, idx, eps=1e-5):
                                        float(eps), emax.data_ptr(), c, stats.data_ptr(), ws.data_ptr(), nbytes,
                                        _stream()), "pcrcg_edgeconv_reduce")
     return emax, stats
+
+
+def edgeconv_reduce_sums(ctr, nbr, idx):
+    """-> (emax [n,c], sums f64 [2,c]) for e[i,j,:] = ctr[i,:] + nbr[idx[i,j],:]: the statistics as sums over all (i,j)
+    (finish with instnorm_apply_sums(emax, sums, count = n * k))."""
+    L = _lib.lib()
+    ctr, ld_ctr = _rows(ctr, _F32, "ctr")
+    nbr, ld_nbr = _rows(nbr, _F32, "nbr")
+    idx = _dev(idx, _I32, "idx").contiguous()
+    n, c = ctr.shape
+    emax = torch.empty((n, c), dtype=_F32, device=ctr.device)
+    sums = torch.zeros((2, c), dtype=torch.float64, device=ctr.device)
+    _lib.check(L.pcrcg_edgeconv_reduce_sums(ctr.data_ptr(), ld_ctr, nbr.data_ptr(), ld_nbr, idx.data_ptr(), n, idx.shape[1],
+                                            c, emax.data_ptr(), c, sums.data_ptr(), _stream()), "pcrcg_edgeconv_reduce_sums")
+    return emax, sums
 
 
 def softmax_rows_(x, scale=1.0):

@@ -194,6 +194,16 @@ def test_knn_and_edgeconv(cuda):
         emax, stats = ops.edgeconv_reduce(cn[:, :48], cn[:, 48:], got.int().to(cuda))
         y = ops.instnorm_apply(emax, stats, 0.2)
         assert rel(y, ref) < TOL
+        # the one-launch form: statistics as fp64 sums over all (i, j), normalised by pcrcg_instnorm_apply_sums
+        emax2, sums = ops.edgeconv_reduce_sums(cn[:, :48], cn[:, 48:], got.int().to(cuda))
+        assert torch.equal(emax2, emax)
+        e = (cn[:, None, :48] + cn[got.to(cuda)][:, :, 48:]).double()                  # [n, k, 48]
+        assert rel(sums, torch.stack([e.sum((0, 1)), (e * e).sum((0, 1))])) < 1e-12
+        w64 = torch.randn(64, 64, generator=g) * 0.2                                   # a width the sums kernel serves
+        both = torch.cat([(w64[:, :32] - w64[:, 32:]).t(), w64[:, 32:].t()], 1).contiguous().to(cuda)
+        cn64 = ops.gemm(feats.to(cuda), both)
+        emax3, sums3 = ops.edgeconv_reduce_sums(cn64[:, :64], cn64[:, 64:], got.int().to(cuda))
+        assert rel(ops.instnorm_apply_sums(emax3, sums3, 0.2, count=n * k), MR._edge_conv(feats, got, w64)) < TOL
 
 
 @pytest.mark.parametrize("n,c", [(763, 512), (1, 8), (3934, 2048), (8192, 64), (100, 1024), (381, 32)])
