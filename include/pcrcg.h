@@ -241,6 +241,15 @@ int pcrcg_gemm_bf16a_f32_colstats(const void* a_bf16, int lda, const float* b, i
                                   int k, const float* row_scale, const float* bias, void* colstats,
                                   size_t colstats_bytes, int* h_chunks, void* stream);
 
+/* C (+)= A[rows] @ B^T with B [n, k] k-contiguous: output row r uses row idx[r * ld_idx] of A [ns, k] (idx may be NULL:
+ * row r itself), the zero row `zero_row` (>= k floats of 0) when that index is outside [0, ns) -- the shadow neighbour of
+ * an upsample table; accumulate != 0 adds the product to C (fp32 atomics) instead of storing it.  With the two together
+ * pcrcg_kpfcnn_forward runs nearest_upsample -> cat(skip) -> unary (ref:models/blocks.py:77-87,
+ * ref:models/architectures.py:568-569) as two products into one output without writing the upsampled matrix or the
+ * concatenation.  Split-bf16 arithmetic only (mode 1 below). */
+int pcrcg_gemm_f32_gather(const float* a, int lda, const int64_t* idx, int ld_idx, int ns, const float* zero_row,
+                          const float* b, int ldb, float* c, int ldc, int m, int n, int k, int accumulate, void* stream);
+
 /* Arithmetic of the C = A @ B^T products (trans_b = 1) behind pcrcg_gemm_f32 / _colstats / _ex:
  *   0: v_mfma_f32_32x32x2_f32 on the fp32 operands (the fp32 matrix rate, 157 TF on MI355X);
  *   1: (default) every fp32 operand value is split EXACTLY into three bf16 terms and the six leading
@@ -393,6 +402,12 @@ typedef struct pcrcg_block {
     const float* mlp;    /* unary / last_unary: [out, in] with leading dimension mlp_ld (rows 16-B aligned) */
     int mlp_ld;
     const void* kp_wsplit; /* pcrcg_split_bf16x3 planes of kp_wt (for pcrcg_kpconv_x6), or NULL */
+    const float* mlp_skip; /* unary / last_unary that consumes cat([upsampled x, skip]) (model.dec_concat): a dense,
+                              16-byte aligned copy of the weight's skip columns [out, skip_dim] (= mlp[:, in - skip_dim:]),
+                              or NULL.  With it the runner never materialises the upsampled matrix or the concatenation:
+                              it runs mlp[:, :in - skip_dim] on rows gathered through the upsample table and adds the
+                              skip part's product (ref:models/blocks.py:77-87, ref:models/architectures.py:568-569). */
+    int mlp_skip_ld, skip_dim;
 } pcrcg_block;
 
 typedef struct pcrcg_gnn_layer {

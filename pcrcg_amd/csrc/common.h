@@ -38,6 +38,14 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
 
 constexpr int kWave = 64;
 
+// gemm_x6.hip: optional extras of a C = A * B^T product (the decoder's fused upsample + concat, runner.hip)
+struct GemmExtra {
+    const long long* a_idx = nullptr;   // != NULL: output row r reads A row a_idx[r * a_idx_ld] (first column of a table)
+    int a_idx_ld = 0, a_ns = 0;         // an index outside [0, a_ns) reads a_zero instead (the shadow row)
+    const float* a_zero = nullptr;      // >= k zero floats
+    bool accumulate = false;            // C += product (fp32 atomics) instead of C = product
+};
+
 // kpconv.hip: row-positive flags + packed (x, y, z, flag) support records into a pcrcg_kpconv_ws_bytes(ns) workspace
 // (x_bf16 != NULL: also the bf16 round-to-nearest-even copy of x, [ns, cin])
 int kpconv_pack(const float* x, int ns, int cin, const float* s_pts, void* ws, size_t ws_bytes, hipStream_t st,

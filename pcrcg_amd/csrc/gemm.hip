@@ -337,7 +337,7 @@ namespace pcrcg {
 int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
                      hipStream_t st, bool a_bf16, bool c_zeroed, int a_kmajor = 0, int b_kmajor = 0,
-                     bool colstats_sums = false);   // gemm_x6.hip
+                     bool colstats_sums = false, const GemmExtra* ex = nullptr);   // gemm_x6.hip
 int gemm_x6_splits(int m, int n, int k);
 }
 
@@ -370,6 +370,16 @@ bool gemm_bt_accumulates(int m, int n, int k) { return gemm_mode() == 1 && gemm_
 // colstats_sums: `colstats` is a ZEROED [2][n] fp64 accumulator; when the product writes every element once, its epilogue
 // adds the column sums / sums of squares there with atomics and reports *h_chunks = -1 (else 0: nothing was added).
 bool gemm_colstats_sums_ok() { return gemm_mode() == 1; }
+// C (+)= A[gathered rows] * B^T for k-contiguous fp32 operands (GemmExtra, common.h); split-bf16 arithmetic only
+bool gemm_extra_ok() { return gemm_mode() == 1; }
+int gemm_bt_extra(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, hipStream_t st,
+                  bool c_zeroed, const GemmExtra& ex) {
+    PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 1 && lda >= k && ldb >= k && ldc >= n);
+    if (m == 0 || n == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(a && b && c && gemm_mode() == 1);
+    return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, nullptr, nullptr, nullptr, 0, nullptr, st, false, c_zeroed, 0, 0,
+                            false, &ex);
+}
 int gemm_bt_colstats(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
                      hipStream_t st, bool c_zeroed, bool colstats_sums) {
@@ -413,6 +423,26 @@ extern "C" int pcrcg_gemm_bf16a_f32_colstats(const void* a_bf16, int lda, const 
                                              size_t colstats_bytes, int* h_chunks, void* stream) {
     return gemm_bf16a_bt_colstats(a_bf16, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks,
                                   as_stream(stream), false, false);
+}
+
+// C (+)= A[rows] * B^T: the decoder's upsample + concat + unary as products (runner.hip).  Output row r uses row
+// idx[r * ld_idx] of A ([ns, k], lda) when idx != NULL -- the zero row `zero_row` (>= k floats of 0) when that index is
+// outside [0, ns), the shadow neighbour -- and accumulate != 0 adds the product to C instead of storing it.
+extern "C" int pcrcg_gemm_f32_gather(const float* a, int lda, const int64_t* idx, int ld_idx, int ns, const float* zero_row,
+                                     const float* b, int ldb, float* c, int ldc, int m, int n, int k, int accumulate,
+                                     void* stream) {
+    PCRCG_CHECK_ARG(!idx || (ld_idx >= 1 && ns >= 0 && zero_row));
+    if (gemm_mode() != 1) {
+        set_error("pcrcg_gemm_f32_gather: only the split-bf16 arithmetic (pcrcg_gemm_set_mode(1)) implements it");
+        return PCRCG_EBADARG;
+    }
+    GemmExtra ex;
+    ex.a_idx = reinterpret_cast<const long long*>(idx);
+    ex.a_idx_ld = ld_idx;
+    ex.a_ns = ns;
+    ex.a_zero = zero_row;
+    ex.accumulate = accumulate != 0;
+    return gemm_bt_extra(a, lda, b, ldb, c, ldc, m, n, k, as_stream(stream), false, ex);
 }
 
 // Aop = A^T when trans_a (A stored [K, M] row-major): the weight-gradient products dW = X^T * dY of the

@@ -145,7 +145,8 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
                                                         const float* __restrict__ row_scale,
                                                         const float* __restrict__ bias, int k_per_split, int vec_a,
                                                         int vec_b, int atomic_out, double* __restrict__ colp,
-                                                        int colp_chunks) {
+                                                        int colp_chunks, const long long* __restrict__ a_idx,
+                                                        int a_idx_ld, int a_ns, const float* __restrict__ a_zero) {
     constexpr int WAVES_M = 2, WAVES_N = 2;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -177,6 +178,27 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // k-contiguous fp32 A: the row of every A item of this thread is the same in all k-steps, so its address is formed
+    // once -- and may come through a gather: a_idx != NULL reads row a_idx[r * a_idx_ld] of A for output row r, a zero
+    // row (a_zero, >= K floats) when that index is not in [0, a_ns) (nearest-neighbour upsampling with its shadow index
+    // folded into the product: ref:models/blocks.py:77-87 closest_pool followed by the decoder's unary block)
+    const float* arow[A_ITERS];
+    bool arok[A_ITERS];
+    if constexpr (ALAY == 0 && ATERMS == 3) {
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) {
+            const int gr = m0 + ((tid + it * 256) >> 2);
+            const int r = min(gr, M - 1);
+            arok[it] = gr < M;
+            if (a_idx) {
+                const long long g = a_idx[(long)r * a_idx_ld];
+                arow[it] = (g >= 0 && g < a_ns) ? A + g * lda : a_zero;
+            } else {
+                arow[it] = A + (long)r * lda;
+            }
+        }
+    }
+
     // two register sets: tile s is consumed from set s&1 while tiles s+1 (other set) and s+2 (this set, re-issued
     // right after its split) are in flight -- these GEMMs stream A from HBM, so bytes in flight are the currency
     Item<ALAY> ra[2][A_ITERS];
@@ -195,6 +217,10 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
                 if constexpr (ATERMS == 1) {
                     const int e = tid + it * 256;
                     gload16(qa[it].v[0], reinterpret_cast<const float*>(Ah + (long)min(m0 + (e >> 2), M - 1) * lda + k0 + (e & 3) * 8));
+                } else if constexpr (ALAY == 0) {
+                    const float* p = arow[it] + k0 + ((tid + it * 256) & 3) * 8;
+                    gload16(qa[it].v[0], p);
+                    gload16(qa[it].v[1], p + 4);
                 } else {
                     item_load_fast<ALAY, BM>(qa[it], A, lda, m0, M, k0, tid + it * 256);
                 }
@@ -204,7 +230,18 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
         } else {
             if constexpr (ATERMS != 1) {      // (the bf16-A form is dispatched only for aligned operands and K % 32 == 0)
 #pragma unroll
-                for (int it = 0; it < A_ITERS; ++it) item_load_edge<ALAY, BM>(qa[it], A, lda, m0, M, k0, k_end, tid + it * 256);
+                for (int it = 0; it < A_ITERS; ++it) {
+                    if constexpr (ALAY == 0) {
+                        const int gk = k0 + ((tid + it * 256) & 3) * 8, ke = k_end - 1;
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = arow[it][min(gk + j, ke)];          // always a valid address
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) qa[it].set(j, (arok[it] && gk + j < k_end) ? v[j] : 0.f);
+                    } else {
+                        item_load_edge<ALAY, BM>(qa[it], A, lda, m0, M, k0, k_end, tid + it * 256);
+                    }
+                }
             }
 #pragma unroll
             for (int it = 0; it < B_ITERS; ++it) item_load_edge<BLAY, BN>(qb[it], B, ldb, n0, N, k0, k_end, tid + it * 256);
@@ -380,7 +417,8 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
 template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY>
 int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n,
               int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b, int atomic_out,
-              double* colp, int colp_chunks) {
+              double* colp, int colp_chunks, const long long* a_idx = nullptr, int a_idx_ld = 0, int a_ns = 0,
+              const float* a_zero = nullptr) {
     constexpr size_t lds = lds_bytes<BM, BN>();
     auto kern = k_gemm_x6<BM, BN, MINB, ATERMS, ALAY, BLAY>;
     static bool configured = false;
@@ -390,7 +428,7 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
         configured = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split,
-                       vec_a, vec_b, atomic_out, colp, colp_chunks);
+                       vec_a, vec_b, atomic_out, colp, colp_chunks, a_idx, a_idx_ld, a_ns, a_zero);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -435,7 +473,8 @@ int gemm_x6_splits(int m, int n, int k) { return (m > 0 && n > 0) ? x6_plan(m, n
 // already all zeros (the runner's zero arena), so a split-K product needs no memset of its own.
 int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
-                     hipStream_t st, bool a_bf16, bool c_zeroed, int a_kmajor, int b_kmajor, bool colstats_sums) {
+                     hipStream_t st, bool a_bf16, bool c_zeroed, int a_kmajor, int b_kmajor, bool colstats_sums,
+                     const GemmExtra* ex) {
     // k-major operands (a_kmajor: A stored [K, M]; b_kmajor: B stored [K, N]) are read with 4-byte loads: no alignment rule
     const int vec_a = (a_bf16 || a_kmajor) ? 1 : (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     const int vec_b = b_kmajor ? 1 : (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
@@ -443,8 +482,15 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
     const X6Plan plan = x6_plan(m, n, k, a_kmajor || b_kmajor, a_kmajor != 0);
     const int pick = plan.pick, BM = plan.bm, BN = plan.bn, gx = plan.gx, gy = plan.gy, splits = plan.splits;
     const int k_per_split = plan.k_per_split;
-    const int atomic_out = splits > 1;
-    if (atomic_out && !c_zeroed) {
+    const bool accumulate = ex && ex->accumulate;
+    const bool gather = ex && ex->a_idx;
+    if ((gather || accumulate) && (a_bf16 || a_kmajor || b_kmajor)) {
+        set_error("gemm_x6: gather / accumulate are built for k-contiguous fp32 operands");
+        return PCRCG_EBADARG;
+    }
+    if (gather && !ex->a_zero) { set_error("gemm_x6: gather needs a zero row"); return PCRCG_EBADARG; }
+    const int atomic_out = splits > 1 || accumulate;
+    if (splits > 1 && !c_zeroed && !accumulate) {
         if (ldc == n) PCRCG_CHECK_HIP(hipMemsetAsync(c, 0, (size_t)m * n * sizeof(float), st));
         else PCRCG_CHECK_HIP(hipMemset2DAsync(c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), m, st));
     }
@@ -484,7 +530,9 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
             return launch_x6<BMV, BNV, MINB, 1, 0, 0>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,           \
                                                       k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks);            \
         return launch_x6<BMV, BNV, MINB, 3, 0, 0>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split,  \
-                                                  vec_a, vec_b, atomic_out, colp, colp_chunks);                             \
+                                                  vec_a, vec_b, atomic_out, colp, colp_chunks, gather ? ex->a_idx : nullptr,\
+                                                  gather ? ex->a_idx_ld : 0, gather ? ex->a_ns : 0,                         \
+                                                  gather ? ex->a_zero : nullptr);                                           \
     } while (0)
     if (pick == 0) { GO(128, 128, 2); }
     if (pick == 1) { GO(128, 64, 2); }

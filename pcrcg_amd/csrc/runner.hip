@@ -25,6 +25,9 @@ int gemm_bf16a_bt_colstats(const void* a_bf16, int lda, const float* b, int ldb,
                            const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes,
                            int* h_chunks, hipStream_t st, bool c_zeroed, bool colstats_sums);
 bool gemm_colstats_sums_ok();
+bool gemm_extra_ok();
+int gemm_bt_extra(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, hipStream_t st,
+                  bool c_zeroed, const GemmExtra& ex);
 namespace {
 
 struct Mat {          // row-major fp32 matrix view
@@ -483,12 +486,49 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
     }
     x = xc;
     // 4. decoder (:567-570)
+    static const bool fuse_off = getenv("PCRCG_FUSE_UPSAMPLE") && atoi(getenv("PCRCG_FUSE_UPSAMPLE")) == 0;   // A/B aid
     for (int j = 0; j < mdl.n_dec; ++j) {
         const pcrcg_block& blk = mdl.dec[j];
         if (blk.type == PCRCG_BLK_UPSAMPLE) {
             const pcrcg_table& t = b.upsamples[blk.layer - 1];
             const bool concat = j + 1 < mdl.n_dec && mdl.dec_concat[j + 1];
             const int cs = concat ? skips.back().cols : 0;
+            const pcrcg_block* next = j + 1 < mdl.n_dec ? &mdl.dec[j + 1] : nullptr;
+            // nearest_upsample -> cat(skip) -> unary as TWO products into one output: the unary's first columns on rows
+            // of x gathered through the table (closest_pool, the shadow index reads a zero row), plus its skip columns on
+            // the skip features.  Neither the upsampled matrix nor the concatenation is written: at level 0 that is
+            // 31 + 61 MB of stores and 92 MB of loads that the product no longer waits for.
+            if (!fuse_off && concat && next && next->mlp_skip && next->skip_dim == cs && gemm_extra_ok() &&
+                (next->type == PCRCG_BLK_UNARY || next->type == PCRCG_BLK_LAST_UNARY) && x.ld % 4 == 0 &&
+                skips.back().ld % 4 == 0) {
+                const Mat& sk = skips.back();
+                const bool last = next->type == PCRCG_BLK_LAST_UNARY;
+                Mat tt = last ? c.mat(t.rows, next->out_dim, pad4(next->out_dim)) : c.mat(t.rows, next->out_dim);
+                float* zero_row = static_cast<float*>(c.zraw(sizeof(float) * (size_t)(x.cols + 8)));
+                if (c.live()) {
+                    GemmExtra g1, g2;
+                    g1.a_idx = reinterpret_cast<const long long*>(t.idx);
+                    g1.a_idx_ld = t.ld;
+                    g1.a_ns = x.rows;
+                    g1.a_zero = zero_row;
+                    g2.accumulate = true;
+                    c.check(gemm_bt_extra(x.p, x.ld, next->mlp, next->mlp_ld, tt.p, tt.ld, t.rows, next->out_dim, x.cols, c.st,
+                                          false, g1));
+                    c.check(gemm_bt_extra(sk.p, sk.ld, next->mlp_skip, next->mlp_skip_ld, tt.p, tt.ld, t.rows, next->out_dim,
+                                          cs, c.st, true, g2));
+                }
+                skips.pop_back();
+                if (last) {
+                    x = tt;
+                } else {
+                    Mat y = c.mat(tt.rows, tt.cols);
+                    Stat ts = stat_buffer(c, tt.rows, tt.cols);      // (filled by one pass over tt: two products wrote it)
+                    norm_act(c, tt, 0.1f, y, &ts);
+                    x = y;
+                }
+                ++j;                                                 // the unary block is done
+                continue;
+            }
             Mat y = c.mat(t.rows, x.cols + cs, pad4(x.cols + cs));
             Mat xs = x;
             if (x.ld != x.cols) {   // gather_first reads dense rows

@@ -293,6 +293,29 @@ def gemm(a, b, row_scale=None, bias=None, out=None):
     return out
 
 
+def gemm_gather(a, w, idx=None, out=None, accumulate=False):
+    """out (+)= a[idx[:, 0]] @ w^T for a [ns, k], w [n, k] (both k-contiguous), idx an int64 table whose first column
+    selects the row of `a` for every output row (an index outside [0, ns) selects zeros: the shadow neighbour)."""
+    L = _lib.lib()
+    a, lda = _rows(a, _F32, "a")
+    w, ldb = _rows(w, _F32, "w")
+    k, n = a.shape[1], w.shape[0]
+    if idx is not None:
+        idx, ld_idx = _rows(idx, _I64, "idx")
+        m = idx.shape[0]
+    else:
+        ld_idx, m = 0, a.shape[0]
+    if out is None:
+        if accumulate:
+            raise RuntimeError("pcrcg_amd.gemm_gather: accumulate needs `out`")
+        out = torch.empty((m, n), dtype=_F32, device=a.device)
+    zero = torch.zeros(k + 8, dtype=_F32, device=a.device)
+    _lib.check(L.pcrcg_gemm_f32_gather(a.data_ptr(), lda, _ptr(idx), ld_idx, a.shape[0], zero.data_ptr(), w.data_ptr(), ldb,
+                                       out.data_ptr(), out.stride(0) if m > 1 else max(n, out.stride(0)), m, n, k,
+                                       int(accumulate), _stream()), "pcrcg_gemm_f32_gather")
+    return out
+
+
 def kpconv(q_pts, s_pts, idx, x, kernel_points, weights, extent):
     """KPConv.forward (rigid / linear / sum): aggregate kernel + MFMA contraction with 1/n row scale.
     weights: [15, cin, cout] as stored in the reference state_dict."""

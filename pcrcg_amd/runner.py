@@ -29,7 +29,8 @@ class Block(ctypes.Structure):
                 ("in_dim", ctypes.c_int), ("out_dim", ctypes.c_int), ("mid_dim", ctypes.c_int),
                 ("extent", ctypes.c_float), ("kp", _fp), ("kp_w", _fp), ("kp_wt", _fp), ("kp_w_pad", _fp),
                 ("cin_pad", ctypes.c_int), ("unary1", _fp), ("unary2", _fp),
-                ("shortcut", _fp), ("mlp", _fp), ("mlp_ld", ctypes.c_int), ("kp_wsplit", _fp)]
+                ("shortcut", _fp), ("mlp", _fp), ("mlp_ld", ctypes.c_int), ("kp_wsplit", _fp),
+                ("mlp_skip", _fp), ("mlp_skip_ld", ctypes.c_int), ("skip_dim", ctypes.c_int)]
 
 
 class GnnLayer(ctypes.Structure):
@@ -245,9 +246,20 @@ class Runner:
         for i, mod in enumerate(m.encoder_blocks):
             self._fill_block(d.enc[i], mod)
             d.enc_skip[i] = int(i in m.encoder_skips)
+        cur_dim = m.bottle.out_channels + 2                     # width entering the decoder (:538-565)
         for j, mod in enumerate(m.decoder_blocks):
             self._fill_block(d.dec[j], mod)
             d.dec_concat[j] = int(j in m.decoder_concats)
+            if isinstance(mod, (UnaryBlock, LastUnaryBlock)):
+                if j in m.decoder_concats and mod.in_dim > cur_dim:
+                    # the skip columns of the weight as their own aligned matrix (fused upsample + concat in the runner)
+                    cs = mod.in_dim - cur_dim
+                    ws = mod.mlp.weight.data[:, cur_dim:]
+                    pad = (-cs) % 4
+                    ws = torch.nn.functional.pad(ws, (0, pad)).contiguous() if pad else ws.contiguous()
+                    self.keep.append(ws)
+                    d.dec[j].mlp_skip, d.dec[j].mlp_skip_ld, d.dec[j].skip_dim = ws.data_ptr(), cs + pad, cs
+                cur_dim = mod.out_dim
         heads = None
         for i, layer in enumerate(m.gnn.layers):
             self._fill_gnn(d.gnn[i], layer, heads)

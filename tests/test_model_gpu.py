@@ -56,6 +56,29 @@ def test_gemm_vs_torch(cuda, m, n, k):
     assert rel(out, ref2) < 2e-6 * max(1, k) ** 0.5
 
 
+@pytest.mark.parametrize("m,ns,n,k1,k2", [(3934, 763, 257, 514, 1024), (60000, 15456, 34, 128, 256), (100, 7, 5, 6, 12),
+                                         (15456, 3934, 128, 257, 512)])
+def test_gemm_gather_and_accumulate(cuda, m, ns, n, k1, k2):
+    """The decoder's nearest_upsample -> cat(skip) -> unary as two products (pcrcg_gemm_f32_gather): rows gathered
+    through the first column of an upsample table (shadow index -> zeros), the skip part added into the same output --
+    against the materialised formulation (ref:models/blocks.py:77-87, ref:models/architectures.py:568-569) in float64."""
+    g = torch.Generator().manual_seed(m + n)
+    lda = (k1 + 3) // 4 * 4 + 4
+    xa = torch.randn(ns, lda, generator=g)[:, :k1].to(cuda)             # padded rows, as the runner's matrices
+    skip = torch.randn(m, k2, generator=g).to(cuda)
+    w = torch.randn(n, k1 + k2, generator=g) / (k1 + k2) ** 0.5
+    idx = torch.randint(0, ns + 1, (m, 3), generator=g)                  # ns = shadow
+    w1 = torch.zeros(n, lda)
+    w1[:, :k1] = w[:, :k1]
+    w1, w2 = w1.to(cuda)[:, :k1], w[:, k1:].contiguous().to(cuda)
+    out = ops.gemm_gather(xa, w1, idx.to(cuda))
+    ops.gemm_gather(skip, w2, out=out, accumulate=True)
+    xpad = torch.cat([xa.double().cpu(), torch.zeros(1, k1, dtype=torch.float64)])
+    want = torch.cat([xpad[idx[:, 0]], skip.double().cpu()], 1) @ w.double().t()
+    assert rel(out, want) < 3e-6
+    assert rel(ops.gemm_gather(skip, w2), skip.double().cpu() @ w[:, k1:].double().t()) < 3e-6      # no table: a plain product
+
+
 def test_gemm_strided_operands(cuda):
     g = torch.Generator().manual_seed(3)
     big = torch.randn(300, 200, generator=g).to(cuda)
