@@ -38,6 +38,13 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
 
 constexpr int kWave = 64;
 
+// radius.hip: pcrcg_radius_query_groups by pass (0 both kernels, 1 the first, 2 the redo of rows with > radius_fast_cap()
+// hits that the first one marked)
+int radius_fast_cap();
+int radius_query_pass(const float* q, int nq, const int* qlen, int ns, const int* slen, int nb, int group, float radius,
+                      const void* grid, int cols, int64_t* out_idx, int* out_count, int* out_max_count, int* status,
+                      int* out_tie_rows, int* out_tie_count, hipStream_t st, int pass);
+
 // gemm_x6.hip: optional extras of a C = A * B^T product (the decoder's fused upsample + concat, runner.hip)
 struct GemmExtra {
     const long long* a_idx = nullptr;   // != NULL: output row r reads A row a_idx[r * a_idx_ld] (first column of a table)

@@ -133,6 +133,9 @@ struct TableRec {
     const int* qlen;
     int nq, limit, sup_level;
     float radius;
+    const void* grid;      // cell grid of the supports, their count and cloud lengths (for the redo pass)
+    int ns;
+    const int* slen;
 };
 
 }  // namespace
@@ -160,6 +163,7 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
     int* tie_status = A.take<int>(1);
     if (!A.ok()) return PCRCG_EWORKSPACE;
 
+    static const bool eager = getenv("PCRCG_RADIUS_EAGER_REDO") && atoi(getenv("PCRCG_RADIUS_EAGER_REDO")) != 0;   // A/B aid
     std::vector<TableRec> tables;
     tables.reserve(max_tables);
     if (!dry) {
@@ -179,10 +183,13 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
         t.ties = want_ties ? A.take<int>((size_t)nq) : nullptr;
         t.meta = metas + MS * tables.size();
         t.q = q; t.qlen = qlen; t.nq = nq; t.limit = limit; t.sup_level = sup_level; t.radius = radius;
+        t.grid = grid; t.ns = ns; t.slen = slen;
         if (!A.ok()) return PCRCG_EWORKSPACE;
+        // first pass only: rows with more than 256 hits are marked and counted; whether any table has one is known
+        // with the metadata round trip below, and only then (normally never) the redo pass runs
         if (!dry)
-            PCRCG_PROPAGATE(pcrcg_radius_query_groups(q, nq, qlen, ns, slen, nb, group, radius, grid, limit, t.idx, t.counts,
-                                                      t.meta, t.meta + P, t.ties, want_ties ? t.meta + P + 1 : nullptr, st));
+            PCRCG_PROPAGATE(radius_query_pass(q, nq, qlen, ns, slen, nb, group, radius, grid, limit, t.idx, t.counts, t.meta,
+                                              t.meta + P, t.ties, want_ties ? t.meta + P + 1 : nullptr, st, eager ? 0 : 1));
         tables.push_back(t);
         return PCRCG_OK;
     };
@@ -258,6 +265,20 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
     const int nt = (int)tables.size();
     PCRCG_PROPAGATE(fetch(h_scratch, metas, MS * nt, lens_all, L * nb, st));
     const int* hm = h_scratch + 1;
+    {   // tables with a row of more than 256 hits: redo pass now, then the metadata once more (it appends tie rows)
+        int redone = 0;
+        for (int i = 0; i < nt; ++i) {
+            int widest = 0;
+            for (int p = 0; p < P; ++p) widest = hm[MS * i + p] > widest ? hm[MS * i + p] : widest;
+            if (widest <= radius_fast_cap() || eager) continue;
+            const TableRec& t = tables[i];
+            PCRCG_PROPAGATE(radius_query_pass(t.q, t.nq, t.qlen, t.ns, t.slen, nb, group, t.radius, t.grid, t.limit, t.idx,
+                                              t.counts, t.meta, t.meta + P, t.ties, want_ties ? t.meta + P + 1 : nullptr, st,
+                                              2));
+            ++redone;
+        }
+        if (redone) PCRCG_PROPAGATE(fetch(h_scratch, metas, MS * nt, lens_all, L * nb, st));
+    }
     for (int i = 0; i < L * nb; ++i) h_lengths[i] = hm[MS * nt + i];
     // rows of group p at level l: [row0, row0 + rows)
     auto group_rows = [&](int l, int p, int* row0, int* rows) {

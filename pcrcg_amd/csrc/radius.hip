@@ -428,13 +428,26 @@ int pcrcg_radius_query_ex(const float* q, int nq, const int* qlen, int ns, const
 int pcrcg_radius_query_groups(const float* q, int nq, const int* qlen, int ns, const int* slen, int nb, int group,
                               float radius, const void* grid, int cols, int64_t* out_idx, int* out_count,
                               int* out_max_count, int* status, int* out_tie_rows, int* out_tie_count, void* stream) {
+    return pcrcg::radius_query_pass(q, nq, qlen, ns, slen, nb, group, radius, grid, cols, out_idx, out_count, out_max_count,
+                                    status, out_tie_rows, out_tie_count, as_stream(stream), 0);
+}
+}
+
+namespace pcrcg {
+int radius_fast_cap() { return kListCapFast; }
+
+// pass 0: both kernels (the public entry point).  pass 1: the first kernel only -- rows whose list does not fit its
+// 256-entry staging are marked, and out_max_count receives their true length, so a caller that reads out_max_count
+// anyway (the pyramid builder) launches pass 2 only for tables that need it: normally none.  pass 2: the redo kernel.
+int radius_query_pass(const float* q, int nq, const int* qlen, int ns, const int* slen, int nb, int group, float radius,
+                      const void* grid, int cols, int64_t* out_idx, int* out_count, int* out_max_count, int* status,
+                      int* out_tie_rows, int* out_tie_count, hipStream_t st, int pass) {
     PCRCG_CHECK_ARG(nq >= 0 && ns >= 0 && nb >= 1 && cols >= 1 && group >= 0);
     PCRCG_CHECK_ARG((out_tie_rows == nullptr) == (out_tie_count == nullptr));
     PCRCG_CHECK_ARG(qlen && slen && grid && out_idx && out_max_count);
     PCRCG_CHECK_ARG(nq == 0 || q);
     (void)slen;
     if (nq == 0) return PCRCG_OK;
-    hipStream_t st = as_stream(stream);
     bool ok;
     GridView g = grid_view(const_cast<void*>(grid), grid_bytes(ns, nb), ns, nb, &ok);
     const float r2 = radius * radius;  // neighbors.cpp:226
@@ -444,18 +457,23 @@ int pcrcg_radius_query_groups(const float* q, int nq, const int* qlen, int ns, c
                                        // smaller grid takes less from the model streams, and on voxelised data every workgroup
                                        // appends its tie rows with one atomic on one word (4096 workgroups: 264 us per 60k-row table)
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL((k_radius_query<kListCapFast, false, kQueryWaves>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, q, nq, qlen,
-                       nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status,
-                       out_tie_rows, out_tie_count, group);
+    if (pass != 2)
+        hipLaunchKernelGGL((k_radius_query<kListCapFast, false, kQueryWaves>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, q, nq,
+                           qlen, nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status,
+                           out_tie_rows, out_tie_count, group);
     // second pass: one wavefront per workgroup, 16 KB of LDS -- it finds a free slot at once on a busy GPU and
     // normally has nothing to do
     const int redo_blocks = blocks < 64 ? blocks : 64;
-    hipLaunchKernelGGL((k_radius_query<kListCapFull, true, 1>), dim3(redo_blocks), dim3(64), 0, st, q, nq, qlen, nb, r2, g,
-                       cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status, out_tie_rows,
-                       out_tie_count, group);
+    if (pass != 1)
+        hipLaunchKernelGGL((k_radius_query<kListCapFull, true, 1>), dim3(redo_blocks), dim3(64), 0, st, q, nq, qlen, nb, r2, g,
+                           cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status, out_tie_rows,
+                           out_tie_count, group);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
+}  // namespace pcrcg
+
+extern "C" {
 
 size_t pcrcg_radius_neighbors_ws_bytes(int ns, int nb) { return pcrcg_cellgrid_ws_bytes(ns, nb); }
 

@@ -56,6 +56,28 @@ def test_native_pyramid_equals_python_mirror(cuda, recipe, tie_order):
     assert torch.equal(got["features"], want["features"])
 
 
+@pytest.mark.parametrize("tie_order", ["auto", "index"])
+def test_native_pyramid_redo_pass_for_dense_rows(cuda, tie_order):
+    """Rows with more than 256 hits: the builder launches the search's redo pass only after the metadata round trip has
+    shown that a table needs it (normally none does).  Two dense clouds (about 400 hits per level-0 row, half of the
+    points snapped to a lattice so that tie rows are among them) against the op-by-op mirror, whose searches always run
+    both passes."""
+    rng = np.random.RandomState(21)
+    a = (rng.rand(3200, 3) * 0.16).astype(np.float32)
+    b = (rng.rand(2800, 3) * 0.15).astype(np.float32)
+    a[::2] = np.round(a[::2] * 64) / 64
+    pts = torch.from_numpy(np.concatenate([a, b])).to(cuda)
+    lens = torch.tensor([len(a), len(b)], dtype=torch.int32, device=cuda)
+    cfg, limits = indoor_config(), [600, 300, 200, 100]
+    want = _python_pyramid(pts, lens, cfg, limits, tie_order)
+    assert want["neighbors"][0].shape[1] > 256                       # the case is what it claims to be
+    got = build_pyramid_native(pts, lens, cfg, limits, tie_order)
+    torch.cuda.synchronize()
+    for l in range(cfg.num_layers):
+        for key in ("neighbors", "pools", "upsamples"):
+            assert torch.equal(got[key][l], want[key][l]), (key, l)
+
+
 @pytest.mark.parametrize("recipe", ["C1", "S30k", "T8k"])
 def test_native_pyramid_reference_digests(cuda, golden_dir, recipe):
     """Straight against the reference's own raw output: SHA-256 of every subsampled level and of every untruncated
