@@ -178,3 +178,61 @@ def test_pair_engine_matches_sequential(cuda):
                 # (split-K GEMMs accumulate with fp32 atomics: results are equal up to summation order)
                 r = ref[i % len(pairs)][k]
                 assert float((a[k] - r).abs().max()) <= 1e-5 * float(r.abs().max()), (workers, i, k)
+
+
+def test_network_call_refuses_a_short_workspace(cuda):
+    """pcrcg_kpfcnn_forward with less workspace than pcrcg_kpfcnn_ws_bytes asks for: status -2 and a message, nothing
+    launched past the end of the buffer; bad descriptors are refused by both entry points."""
+    import ctypes
+    from pcrcg_amd import _lib
+    from pcrcg_amd.runner import Outputs
+    cfg = indoor_config(first_feats_dim=32, gnn_feats_dim=64)
+    torch.manual_seed(0)
+    net = KPFCNN(cfg).to(cuda).eval()
+    pts, lens = _pair("mini", 0, cuda)
+    batch = build_pyramid(pts, lens, cfg, [20, 26, 30, 32])
+    runner = net.runner()
+    b, keep, dev = runner.batch_struct(batch)
+    desc = runner.descriptor()
+    L = _lib.lib()
+    need = L.pcrcg_kpfcnn_ws_bytes(ctypes.byref(desc), ctypes.byref(b))
+    assert need > 4096
+    n0 = b.n_points[0]
+    outs = [torch.full((n0, desc.final_dim), 7.0, device=cuda), torch.full((n0,), 7.0, device=cuda), torch.full((n0,), 7.0, device=cuda)]
+    o = Outputs(*(t.data_ptr() for t in outs))
+    ws = torch.empty(need, dtype=torch.uint8, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = L.pcrcg_kpfcnn_forward(ctypes.byref(desc), ctypes.byref(b), ctypes.byref(o), ws.data_ptr(), need // 2, st)
+    assert rc == -2 and b"workspace too small" in L.pcrcg_last_error()
+    torch.cuda.synchronize()
+    assert all(float(t.min()) == 7.0 and float(t.max()) == 7.0 for t in outs)        # untouched
+    assert L.pcrcg_kpfcnn_forward(ctypes.byref(desc), ctypes.byref(b), ctypes.byref(o), ws.data_ptr(), need, st) == 0
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want = net(batch)
+    assert torch.equal(outs[1], want["scores_overlap"]) or float((outs[1] - want["scores_overlap"]).abs().max()) < 1e-6
+    b.len_src_c = 0                                                                     # a descriptor that cannot be right
+    assert L.pcrcg_kpfcnn_ws_bytes(ctypes.byref(desc), ctypes.byref(b)) == 0
+    assert L.pcrcg_kpfcnn_forward(ctypes.byref(desc), ctypes.byref(b), ctypes.byref(o), ws.data_ptr(), need, st) == -1
+
+
+def test_engine_surfaces_bad_input_on_result(cuda):
+    """A pair the front end cannot take (CPU tensor) does not hang the engine: its result() raises, later pairs work."""
+    from pcrcg_amd.pairstream import PairStreams
+    cfg = indoor_config(first_feats_dim=32, gnn_feats_dim=64)
+    torch.manual_seed(0)
+    net = KPFCNN(cfg).to(cuda).eval()
+    good = _pair("mini", 0, cuda)
+    eng = PairStreams(net, cfg, [20, 26, 30, 32], cuda, pairs_per_build=1)
+    try:
+        eng.submit(good[0].cpu(), good[1].cpu())
+        eng.submit(*good)
+        with pytest.raises(Exception):
+            eng.result()
+        out = PairStreams.check(eng.result())
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            ref = net(build_pyramid(*good, cfg, [20, 26, 30, 32]))
+        assert float((out["scores_overlap"] - ref["scores_overlap"]).abs().max()) <= 1e-5
+    finally:
+        eng.close()
