@@ -245,3 +245,25 @@ def test_front_end_digests_u30k_k120k(cuda, golden_dir, recipe):
                 t = b[key][l]
                 assert list(t.shape) == dig[f"{name}{l}"]["shape"], (name, l, t.shape)
                 assert sha(t, np.int32) == dig[f"{name}{l}"]["sha256"], (name, l)
+
+
+@pytest.mark.parametrize("recipe", ["K120k", "U30k"])
+def test_secondary_workloads_forward_runner_equals_mirror(cuda, recipe):
+    """configs[4]-shaped pairs through the whole path at full width: the C++ runner (one-launch attention only below
+    ~1000 x 1000 coarse points -- K120k has 1936 per cloud and takes the GEMM path --, column-sum statistics, fused decoder
+    products) against the op-by-op mirror, which uses none of those."""
+    cfg = kitti_config() if recipe == "K120k" else indoor_config()
+    a, b = synthetic.slab_pair(120000, 0) if recipe == "K120k" else synthetic.uniform_pair(30000, 1.07, 0)
+    pts, lens = _stack(a, b, cuda)
+    from pcrcg_amd.pyramid import calibrate_neighbors
+    limits = [int(v) for v in calibrate_neighbors([(pts, lens)], cfg, samples_threshold=0)]
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = KPFCNN(cfg).to(cuda).eval()
+    batch = build_pyramid(pts, lens, cfg, limits)
+    with torch.no_grad():
+        out = model(batch)
+        ref = model.forward_ops(batch)
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.isfinite(out[k]).all() and rel(out[k], ref[k]) < 1e-5, (recipe, k)
