@@ -38,6 +38,13 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
 
 constexpr int kWave = 64;
 
+// pointops.hip: InstanceNorm + LeakyReLU that also leaves the KPConv support records of its output (kpconv.hip: pk)
+bool instnorm_pack_ok(int c, int ldx, int ldy);
+int instnorm_apply_pack(const float* x, int n, int c, int ldx, const float* stats, const double* sums, double count, float eps,
+                        float slope, float* y, int ldy, const float* s_pts, float4* pk, hipStream_t st);
+// kpconv.hip: where the support records live inside a pcrcg_kpconv_ws_bytes(ns) workspace
+float4* kpconv_pk_ptr(void* ws, size_t ws_bytes, int ns);
+
 // radius.hip: pcrcg_radius_query_groups by pass (0 both kernels, 1 the first, 2 the redo of rows with > radius_fast_cap()
 // hits that the first one marked)
 int radius_fast_cap();

@@ -341,6 +341,13 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_generic(
 
 }  // namespace
 
+float4* kpconv_pk_ptr(void* ws, size_t ws_bytes, int ns) {
+    Carver cv(ws, ws_bytes);
+    cv.take<unsigned char>((size_t)ns + 1);
+    float4* pk = cv.take<float4>((size_t)ns + 1);
+    return cv.ok() ? pk : nullptr;
+}
+
 // pos / pk records of `x` (see k_row_positive) into the workspace layout of pcrcg_kpconv_ws_bytes; shared by the
 // two-stage path and the fused kernel (kpconv_x6.hip)
 int kpconv_pack(const float* x, int ns, int cin, const float* s_pts, void* ws, size_t ws_bytes, hipStream_t st,

@@ -228,7 +228,83 @@ __global__ void __launch_bounds__(256) k_instnorm_apply4_sums(const float* __res
     }
 }
 
+// The two normalisation kernels (no residual) that ALSO leave the KPConv support records of their output rows:
+// pk[r] = (s_pts[r], sum_c y[r,c] > 0 ? 1 : 0) -- what k_row_positive (kpconv.hip) computes from y in a launch of its
+// own when y is the input of a KPConv (ref:models/blocks.py:350-356: neighbours whose feature row sums to zero do not
+// count).  The c4 <= 64 lanes that hold a row are contiguous in a wavefront: their partial sums meet in a butterfly.
+__global__ void __launch_bounds__(256) k_instnorm_apply4_pack(const float* __restrict__ x, int n, int c4, int ldx,
+                                                               const float* __restrict__ stats, float slope,
+                                                               float* __restrict__ y, int ldy,
+                                                               const float* __restrict__ s_pts, float4* __restrict__ pk) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)n * c4) return;                     // n * c4 is a multiple of c4: whole rows leave together
+    const long r = e / c4;
+    const int q = (int)(e - r * c4);
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + 4 * q);
+    const float4 s0 = *reinterpret_cast<const float4*>(stats + 8 * q), s1 = *reinterpret_cast<const float4*>(stats + 8 * q + 4);
+    float4 v = make_float4((xv.x - s0.x) * s0.y, (xv.y - s0.z) * s0.w, (xv.z - s1.x) * s1.y, (xv.w - s1.z) * s1.w);
+    v.x = v.x >= 0.f ? v.x : v.x * slope;
+    v.y = v.y >= 0.f ? v.y : v.y * slope;
+    v.z = v.z >= 0.f ? v.z : v.z * slope;
+    v.w = v.w >= 0.f ? v.w : v.w * slope;
+    *reinterpret_cast<float4*>(y + r * ldy + 4 * q) = v;
+    float part = (v.x + v.y) + (v.z + v.w);
+    for (int sh = c4 >> 1; sh >= 1; sh >>= 1) part += __shfl_xor(part, sh, 64);
+    if (q == 0) pk[r] = make_float4(s_pts[3 * r], s_pts[3 * r + 1], s_pts[3 * r + 2], part > 0.0f ? 1.f : 0.f);
+}
+
+__global__ void __launch_bounds__(256) k_instnorm_apply4_sums_pack(const float* __restrict__ x, int n, int c4, int ldx,
+                                                                    const double* __restrict__ sums, double count, float eps,
+                                                                    float slope, float* __restrict__ y, int ldy,
+                                                                    int rows_per_block, const float* __restrict__ s_pts,
+                                                                    float4* __restrict__ pk) {
+    const int rp = 256 / c4;                           // c4 <= 64 divides 64: one pass over the channel groups
+    const int r_lo = blockIdx.x * rows_per_block, r_hi = min(n, r_lo + rows_per_block);
+    const int q = (int)(threadIdx.x % c4);
+    float4 m0, s0;
+    stats4_from_sums(sums, 4 * c4, 4 * q, count, eps, m0, s0);
+    for (long r = r_lo + (int)(threadIdx.x / c4); r < r_hi; r += rp) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + 4 * q);
+        float4 v = make_float4((xv.x - m0.x) * s0.x, (xv.y - m0.y) * s0.y, (xv.z - m0.z) * s0.z, (xv.w - m0.w) * s0.w);
+        v.x = v.x >= 0.f ? v.x : v.x * slope;
+        v.y = v.y >= 0.f ? v.y : v.y * slope;
+        v.z = v.z >= 0.f ? v.z : v.z * slope;
+        v.w = v.w >= 0.f ? v.w : v.w * slope;
+        *reinterpret_cast<float4*>(y + r * ldy + 4 * q) = v;
+        float part = (v.x + v.y) + (v.z + v.w);
+        for (int sh = c4 >> 1; sh >= 1; sh >>= 1) part += __shfl_xor(part, sh, 64);
+        if (q == 0) pk[r] = make_float4(s_pts[3 * r], s_pts[3 * r + 1], s_pts[3 * r + 2], part > 0.0f ? 1.f : 0.f);
+    }
+}
+
 }  // namespace
+
+// Normalise + LeakyReLU (no residual) and leave the KPConv support records of the output rows in `pk` (see the kernels).
+// Statistics as (mean, rstd) pairs (`stats`) or as fp64 column sums (`sums`, `count`); exactly one of the two.
+bool instnorm_pack_ok(int c, int ldx, int ldy) {
+    const int c4 = c / 4;
+    return c % 4 == 0 && c4 >= 1 && c4 <= 64 && (c4 & (c4 - 1)) == 0 && ldx % 4 == 0 && ldy % 4 == 0;
+}
+int instnorm_apply_pack(const float* x, int n, int c, int ldx, const float* stats, const double* sums, double count, float eps,
+                        float slope, float* y, int ldy, const float* s_pts, float4* pk, hipStream_t st) {
+    PCRCG_CHECK_ARG(n >= 0 && instnorm_pack_ok(c, ldx, ldy) && ldx >= c && ldy >= c && (stats != nullptr) != (sums != nullptr));
+    if (n == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(x && y && s_pts && pk && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+    const int c4 = c / 4;
+    if (stats) {
+        const long total = (long)n * c4;
+        hipLaunchKernelGGL(k_instnorm_apply4_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, n, c4, ldx, stats,
+                           slope, y, ldy, s_pts, pk);
+    } else {
+        const int rp = 256 / c4;
+        int rows_per_block = rp * 8;
+        while (rows_per_block > rp && (long)(n + rows_per_block - 1) / rows_per_block < 256) rows_per_block -= rp;
+        hipLaunchKernelGGL(k_instnorm_apply4_sums_pack, dim3((unsigned)((n + rows_per_block - 1) / rows_per_block)), dim3(256), 0,
+                           st, x, n, c4, ldx, sums, count, eps, slope, y, ldy, rows_per_block, s_pts, pk);
+    }
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
 
 size_t colstats_ws_bytes(int c) { return carve_bytes((size_t)kStatChunks * 2 * (size_t)(c > 0 ? c : 1), sizeof(double)); }
 

@@ -192,7 +192,10 @@ void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, co
                              st && st->sums));
 }
 
-void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, const Mat& y, Stat* st = nullptr) {
+// packed_ws != NULL: a pcrcg_kpconv_ws_bytes(ns) workspace whose support records the producer of x has already filled
+// (norm_act_pack): the aggregate kernel starts without the row-positive pass
+void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, const Mat& y, Stat* st = nullptr,
+            void* packed_ws = nullptr) {
     const int l = blk.layer;
     const pcrcg_table& t = blk.strided ? b.pools[l] : b.neighbors[l];
     const float* q = blk.strided ? b.points[l + 1] : b.points[l];
@@ -240,7 +243,7 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
     }
     float* inv_n = static_cast<float*>(c.raw(sizeof(float) * (nq > 0 ? nq : 1)));
     const size_t wsb = pcrcg_kpconv_ws_bytes(ns);
-    void* ws = c.raw(wsb);
+    void* ws = packed_ws ? packed_ws : c.raw(wsb);
     // bf16 feature storage (pcrcg_model.feature_bf16): the gathers read a bf16 copy of x and wf is bf16 in HBM -- half
     // the bytes of the two streams that bound the encoder; the contraction takes wf as the (single-term) bf16 operand
     // against the exact three-term split of the fp32 weights, fp32 accumulate and fp32 output.
@@ -260,8 +263,12 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
     }
     Mat wf = c.mat(nq, PCRCG_KPOINTS * cin);
     if (c.live()) {
-        c.check(pcrcg_kpconv_aggregate(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, xp, cin, blk.kp, blk.extent,
-                                       wf.p, inv_n, ws, wsb, c.st));
+        if (packed_ws && xp == x.p)
+            c.check(kpconv_aggregate_rows(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, xp, cin, blk.kp, blk.extent, wf.p, inv_n,
+                                          ws, wsb, c.st, /*pack=*/false, /*stream_out=*/true));
+        else
+            c.check(pcrcg_kpconv_aggregate(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, xp, cin, blk.kp, blk.extent,
+                                           wf.p, inv_n, ws, wsb, c.st));
         // contraction wf @ W: against the K-contiguous copy wt [cout, 15*cin] when the descriptor carries one
         // (C = A * B^T form: both operands k-contiguous, the form the split-bf16 GEMM is built for).
         // (Measured and not adopted: aggregating + contracting 48 MB row chunks so that wf stays in L2 / Infinity
@@ -298,22 +305,60 @@ Mat simple_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat
     return y;
 }
 
+// u = lrelu(IN(t), slope) for a u that is the input of the block's KPConv: the normalisation kernel leaves the KPConv's
+// support records (coordinates + "feature row sums to a positive value" flag) in kp_ws as it goes, so the KPConv needs no
+// pass over u of its own (10 launches per S30k forward: +4 % pairs/s with them knocked out).  False: not applicable.
+bool norm_act_pack(Ctx& c, const Mat& t, float slope, const Mat& u, Stat* ts, const float* s_pts, void* kp_ws,
+                   size_t kp_ws_bytes) {
+    static const bool off = getenv("PCRCG_FUSE_PACK") && atoi(getenv("PCRCG_FUSE_PACK")) == 0;   // A/B aid
+    if (off || c.bf16 || !instnorm_pack_ok(t.cols, t.ld, u.ld) || u.ld != u.cols) return false;
+    const size_t m = c.mark();
+    float* stats = static_cast<float*>(c.raw(sizeof(float) * 2 * t.cols));
+    const size_t wsb = pcrcg_instnorm_ws_bytes(t.cols);
+    void* ws = c.raw(wsb);
+    if (c.live()) {
+        if (ts && ts->sums && ts->chunks == 0) {        // a split-K product left nothing: one pass into the accumulators
+            c.check(pcrcg_instnorm_colsums(t.p, t.rows, t.cols, t.ld, ts->partials, c.st));
+            ts->chunks = -1;
+        }
+        float4* pk = kpconv_pk_ptr(kp_ws, kp_ws_bytes, t.rows);
+        if (!pk) c.check(PCRCG_EWORKSPACE);
+        else if (ts && ts->chunks == -1)
+            c.check(instnorm_apply_pack(t.p, t.rows, t.cols, t.ld, nullptr, static_cast<const double*>(ts->partials),
+                                        (double)t.rows, 1e-5f, slope, u.p, u.ld, s_pts, pk, c.st));
+        else {
+            col_stats(c, t, ts, stats, ws, wsb);
+            c.check(instnorm_apply_pack(t.p, t.rows, t.cols, t.ld, stats, nullptr, 0.0, 1e-5f, slope, u.p, u.ld, s_pts, pk, c.st));
+        }
+    }
+    c.release(m);
+    return true;
+}
+
 // ResnetBottleneckBlock.forward (ref:models/blocks.py:650-678)
 Mat resnet_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& feats) {
     const int nq = out_rows(b, blk);
     Mat y = c.mat(nq, blk.out_dim);
     const size_t m = c.mark();
     Mat x = feats;
+    void* kp_ws = nullptr;
+    size_t kp_wsb = 0;
     if (blk.unary1) {
         Mat t = c.gemm_out(feats.rows, blk.mid_dim, feats.cols), u = c.mat(feats.rows, blk.mid_dim);
         Stat ts = stat_buffer(c, t.rows, t.cols);
         linear(c, feats, blk.unary1, feats.cols, nullptr, t, &ts);
-        norm_act(c, t, 0.1f, u, &ts);
+        // u feeds the KPConv whose supports are this block's input rows: pack its support records on the way
+        if (blk.mid_dim % 4 == 0 && !(blk.kp_w_pad && blk.cin_pad > blk.mid_dim)) {
+            kp_wsb = pcrcg_kpconv_ws_bytes(feats.rows);
+            kp_ws = c.raw(kp_wsb);
+            if (!norm_act_pack(c, t, 0.1f, u, &ts, b.points[blk.layer], kp_ws, kp_wsb)) kp_ws = nullptr;
+        }
+        if (!kp_ws) norm_act(c, t, 0.1f, u, &ts);
         x = u;
     }
     Mat k = c.gemm_out(nq, blk.mid_dim, PCRCG_KPOINTS * kp_cin(blk, x)), kn = c.mat(nq, blk.mid_dim);
     Stat ks = stat_buffer(c, nq, blk.mid_dim);
-    kpconv(c, b, blk, x, k, &ks);
+    kpconv(c, b, blk, x, k, &ks, kp_ws);
     norm_act(c, k, 0.1f, kn, &ks);
     Mat u2 = c.gemm_out(nq, blk.out_dim, blk.mid_dim);
     Stat u2s = stat_buffer(c, nq, blk.out_dim);
