@@ -241,14 +241,21 @@ int pcrcg_gemm_bf16a_f32_colstats(const void* a_bf16, int lda, const float* b, i
                                   int k, const float* row_scale, const float* bias, void* colstats,
                                   size_t colstats_bytes, int* h_chunks, void* stream);
 
-/* C (+)= A[rows] @ B^T with B [n, k] k-contiguous: output row r uses row idx[r * ld_idx] of A [ns, k] (idx may be NULL:
- * row r itself), the zero row `zero_row` (>= k floats of 0) when that index is outside [0, ns) -- the shadow neighbour of
- * an upsample table; accumulate != 0 adds the product to C (fp32 atomics) instead of storing it.  With the two together
- * pcrcg_kpfcnn_forward runs nearest_upsample -> cat(skip) -> unary (ref:models/blocks.py:77-87,
- * ref:models/architectures.py:568-569) as two products into one output without writing the upsampled matrix or the
- * concatenation.  Split-bf16 arithmetic only (mode 1 below). */
-int pcrcg_gemm_f32_gather(const float* a, int lda, const int64_t* idx, int ld_idx, int ns, const float* zero_row,
-                          const float* b, int ldb, float* c, int ldc, int m, int n, int k, int accumulate, void* stream);
+/* C (+)= f(A)[rows] @ B^T + bias with B [n, k] k-contiguous: the products with which pcrcg_kpfcnn_forward folds a
+ * neighbouring operator into a GEMM's A loads instead of running it as a pass of its own.
+ *   idx != NULL    output row r uses row idx[r * ld_idx] of A [ns, k] (lda), the zero row `zero_row` (>= k floats of 0)
+ *                  when that index is outside [0, ns) -- nearest_upsample with its shadow index
+ *                  (ref:models/blocks.py:77-87); with accumulate the decoder's nearest_upsample -> cat(skip) -> unary
+ *                  (ref:models/architectures.py:568-569) is two products into one output and neither the upsampled
+ *                  matrix nor the concatenation is written;
+ *   a_sums != NULL A is the RAW output of a product; its InstanceNorm + LeakyReLU (ref:models/blocks.py:456-470) is
+ *                  applied on load, f(a) = lrelu((a - mean_k) * rstd_k, a_slope), from the fp64 column sums
+ *                  a_sums [2][k] over a_count rows (biased variance, a_eps); a gathered shadow row stays zero;
+ *   accumulate     != 0 adds the product to C (fp32 atomics) instead of storing it.
+ * Split-bf16 arithmetic only (mode 1 below). */
+int pcrcg_gemm_f32_fused(const float* a, int lda, const int64_t* idx, int ld_idx, int ns, const float* zero_row,
+                         const void* a_sums, double a_count, float a_eps, float a_slope, const float* b, int ldb,
+                         const float* bias, float* c, int ldc, int m, int n, int k, int accumulate, void* stream);
 
 /* Arithmetic of the C = A @ B^T products (trans_b = 1) behind pcrcg_gemm_f32 / _colstats / _ex:
  *   0: v_mfma_f32_32x32x2_f32 on the fp32 operands (the fp32 matrix rate, 157 TF on MI355X);

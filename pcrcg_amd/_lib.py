@@ -61,8 +61,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "pcrcg_gemm_bf16a_f32_colstats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
-    "pcrcg_gemm_f32_gather": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
-                                      c_int, c_int, c_int, c_int, c_void_p]),
+    "pcrcg_gemm_f32_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_double, c_float,
+                                     c_float, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "pcrcg_gemm_set_mode": (None, [c_int]),
     "pcrcg_gemm_get_mode": (c_int, []),
     "pcrcg_instnorm_stats_from_partials": (c_int, [c_void_p, c_int, c_int, ctypes.c_double, c_float, c_void_p,

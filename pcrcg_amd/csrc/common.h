@@ -58,6 +58,9 @@ struct GemmExtra {
     int a_idx_ld = 0, a_ns = 0;         // an index outside [0, a_ns) reads a_zero instead (the shadow row)
     const float* a_zero = nullptr;      // >= k zero floats
     bool accumulate = false;            // C += product (fp32 atomics) instead of C = product
+    const double* a_sums = nullptr;     // != NULL: A is normalised on load, a' = lrelu((a - mean_k) * rstd_k, a_slope), with
+    double a_count = 0.0;               // the statistics of its columns given as fp64 sums [2][k] over a_count rows
+    float a_eps = 1e-5f, a_slope = 1.0f;
 };
 
 // kpconv.hip: row-positive flags + packed (x, y, z, flag) support records into a pcrcg_kpconv_ws_bytes(ns) workspace

@@ -373,12 +373,14 @@ bool gemm_colstats_sums_ok() { return gemm_mode() == 1; }
 // C (+)= A[gathered rows] * B^T for k-contiguous fp32 operands (GemmExtra, common.h); split-bf16 arithmetic only
 bool gemm_extra_ok() { return gemm_mode() == 1; }
 int gemm_bt_extra(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, hipStream_t st,
-                  bool c_zeroed, const GemmExtra& ex) {
+                  bool c_zeroed, const GemmExtra& ex, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
+                  bool colstats_sums) {
+    if (h_chunks) *h_chunks = 0;
     PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 1 && lda >= k && ldb >= k && ldc >= n);
     if (m == 0 || n == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(a && b && c && gemm_mode() == 1);
-    return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, nullptr, nullptr, nullptr, 0, nullptr, st, false, c_zeroed, 0, 0,
-                            false, &ex);
+    return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, nullptr, bias, colstats, colstats_bytes, h_chunks, st, false,
+                            c_zeroed, 0, 0, colstats_sums, &ex);
 }
 int gemm_bt_colstats(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
@@ -425,15 +427,20 @@ extern "C" int pcrcg_gemm_bf16a_f32_colstats(const void* a_bf16, int lda, const 
                                   as_stream(stream), false, false);
 }
 
-// C (+)= A[rows] * B^T: the decoder's upsample + concat + unary as products (runner.hip).  Output row r uses row
-// idx[r * ld_idx] of A ([ns, k], lda) when idx != NULL -- the zero row `zero_row` (>= k floats of 0) when that index is
-// outside [0, ns), the shadow neighbour -- and accumulate != 0 adds the product to C instead of storing it.
-extern "C" int pcrcg_gemm_f32_gather(const float* a, int lda, const int64_t* idx, int ld_idx, int ns, const float* zero_row,
-                                     const float* b, int ldb, float* c, int ldc, int m, int n, int k, int accumulate,
-                                     void* stream) {
+// C (+)= f(A)[rows] * B^T + bias: the products of the runner that fold a neighbouring operator into their A loads.
+//  * idx != NULL: output row r uses row idx[r * ld_idx] of A ([ns, k], lda) -- the zero row `zero_row` (>= k floats of 0)
+//    when that index is outside [0, ns), the shadow neighbour (nearest_upsample, ref:models/blocks.py:77-87);
+//  * a_sums != NULL: A is the raw output of a product whose InstanceNorm + LeakyReLU is applied on load,
+//    f(a) = lrelu((a - mean_k) * rstd_k, a_slope), from the fp64 column sums a_sums [2][k] over a_count rows
+//    (ref:models/blocks.py:456-470); a gathered shadow row stays zero;
+//  * accumulate != 0 adds the product to C instead of storing it (cat(skip) as a second product).
+extern "C" int pcrcg_gemm_f32_fused(const float* a, int lda, const int64_t* idx, int ld_idx, int ns, const float* zero_row,
+                                    const void* a_sums, double a_count, float a_eps, float a_slope, const float* b, int ldb,
+                                    const float* bias, float* c, int ldc, int m, int n, int k, int accumulate, void* stream) {
     PCRCG_CHECK_ARG(!idx || (ld_idx >= 1 && ns >= 0 && zero_row));
+    PCRCG_CHECK_ARG(!a_sums || a_count >= 1.0);
     if (gemm_mode() != 1) {
-        set_error("pcrcg_gemm_f32_gather: only the split-bf16 arithmetic (pcrcg_gemm_set_mode(1)) implements it");
+        set_error("pcrcg_gemm_f32_fused: only the split-bf16 arithmetic (pcrcg_gemm_set_mode(1)) implements it");
         return PCRCG_EBADARG;
     }
     GemmExtra ex;
@@ -442,7 +449,11 @@ extern "C" int pcrcg_gemm_f32_gather(const float* a, int lda, const int64_t* idx
     ex.a_ns = ns;
     ex.a_zero = zero_row;
     ex.accumulate = accumulate != 0;
-    return gemm_bt_extra(a, lda, b, ldb, c, ldc, m, n, k, as_stream(stream), false, ex);
+    ex.a_sums = static_cast<const double*>(a_sums);
+    ex.a_count = a_count;
+    ex.a_eps = a_eps;
+    ex.a_slope = a_slope;
+    return gemm_bt_extra(a, lda, b, ldb, c, ldc, m, n, k, as_stream(stream), false, ex, bias, nullptr, 0, nullptr, false);
 }
 
 // Aop = A^T when trans_a (A stored [K, M] row-major): the weight-gradient products dW = X^T * dY of the

@@ -139,14 +139,16 @@ constexpr int lds_bytes() { return 3 * (BM + BN) * ROWB; }
 // ATERMS = 3: A is fp32 and is split like B.  ATERMS = 1: A already IS bf16 in memory (the bf16 feature-storage
 // variant's wf, lda in bf16 elements): its tile is copied straight into plane 0 and only the three products a1*b3,
 // a1*b2, a1*b1 run -- exact in B, bf16-rounded in A by the storage format, fp32 accumulate.  K % 32 == 0 required.
-template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY>
+template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY, int ANORM = 0>
 __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                         int ldb, float* __restrict__ C, int ldc, int M, int N, int Kdim,
                                                         const float* __restrict__ row_scale,
                                                         const float* __restrict__ bias, int k_per_split, int vec_a,
                                                         int vec_b, int atomic_out, double* __restrict__ colp,
                                                         int colp_chunks, const long long* __restrict__ a_idx,
-                                                        int a_idx_ld, int a_ns, const float* __restrict__ a_zero) {
+                                                        int a_idx_ld, int a_ns, const float* __restrict__ a_zero,
+                                                        const double* __restrict__ a_sums, double a_count, float a_eps,
+                                                        float a_slope) {
     constexpr int WAVES_M = 2, WAVES_N = 2;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -183,21 +185,56 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     // row (a_zero, >= K floats) when that index is not in [0, a_ns) (nearest-neighbour upsampling with its shadow index
     // folded into the product: ref:models/blocks.py:77-87 closest_pool followed by the decoder's unary block)
     const float* arow[A_ITERS];
-    bool arok[A_ITERS];
+    bool arok[A_ITERS], azero[A_ITERS];
     if constexpr (ALAY == 0 && ATERMS == 3) {
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) {
             const int gr = m0 + ((tid + it * 256) >> 2);
             const int r = min(gr, M - 1);
             arok[it] = gr < M;
+            azero[it] = false;
             if (a_idx) {
                 const long long g = a_idx[(long)r * a_idx_ld];
-                arow[it] = (g >= 0 && g < a_ns) ? A + g * lda : a_zero;
+                azero[it] = !(g >= 0 && g < a_ns);
+                arow[it] = azero[it] ? a_zero : A + g * lda;
             } else {
                 arow[it] = A + (long)r * lda;
             }
         }
     }
+    // ANORM: A is the RAW output of a product whose InstanceNorm + LeakyReLU has not been applied: the statistics come
+    // as fp64 column sums (a_sums [2][K] over a_count rows) and every A element is normalised on its way into the split,
+    // a' = lrelu((a - mean_k) * rstd_k, a_slope) -- the consumer does the producer's normalisation pass (ref:models/
+    // blocks.py:456-470 followed by the next block's nn.Linear).  (mean, rstd) of this block's k range live in LDS
+    // behind the operand planes.  A gathered shadow row stays zero (closest_pool pads AFTER the normalisation).
+    float* const s_mean = reinterpret_cast<float*>(smem + 3 * (A_PLANE + B_PLANE));
+    float* const s_rstd = s_mean + (ANORM ? ((k_per_split + BK - 1) / BK) * BK : 0);
+    if constexpr (ANORM) {
+        for (int kk = tid; kk < k_end - k_begin; kk += 256) {
+            const double mu = a_sums[k_begin + kk] / a_count;
+            double var = a_sums[(long)Kdim + k_begin + kk] / a_count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            s_mean[kk] = (float)mu;
+            s_rstd[kk] = (float)(1.0 / sqrt(var + (double)a_eps));
+        }
+        __syncthreads();
+    }
+    auto normalise = [&](Item<ALAY>* qa, int k0, bool guard) {      // in registers, before the split
+        if constexpr (ANORM && ALAY == 0 && ATERMS == 3) {
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) {
+                const int kb = k0 - k_begin + ((tid + it * 256) & 3) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = guard ? min(kb + j, k_end - k_begin - 1) : kb + j;
+                    float v = (qa[it].get(j) - s_mean[kk]) * s_rstd[kk];
+                    v = v >= 0.f ? v : v * a_slope;
+                    const bool keep = !azero[it] && (!guard || kb + j < k_end - k_begin);
+                    qa[it].set(j, keep ? v : 0.f);
+                }
+            }
+        }
+    };
 
     // two register sets: tile s is consumed from set s&1 while tiles s+1 (other set) and s+2 (this set, re-issued
     // right after its split) are in flight -- these GEMMs stream A from HBM, so bytes in flight are the currency
@@ -310,7 +347,7 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     const int nfast = (vec_a && vec_b) ? (k_end - k_begin) / BK : 0;
     // Wait until only the other set's loads are in flight, then split this set into LDS.  `live` = 0 zeroes the tile
     // (the phantom second half of an odd tile count).
-    auto consume = [&](Item<ALAY>* qa, Item<BLAY>* qb, bool live) {
+    auto consume = [&](Item<ALAY>* qa, Item<BLAY>* qb, bool live, int k0) {
         vm_wait<TILE_LOADS>();
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) {
@@ -324,6 +361,8 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
             for (int it = 0; it < A_ITERS; ++it)
 #pragma unroll
                 for (int j = 0; j < (ATERMS == 1 ? 4 : 8); ++j) qa[it].set(j, 0.f);
+        } else {
+            normalise(qa, k0, false);
         }
         __syncthreads();                                                  // previous tile fully read
         store_tiles(qa, qb);                                              // registers -> LDS (split)
@@ -339,11 +378,11 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
         load_tiles(fast, k_begin, ra[0], rb[0]);
         load_tiles(fast, min(k_begin + BK, k_last), ra[1], rb[1]);
         for (int s = 0; s < nfast; s += 2) {
-            consume(ra[0], rb[0], true);
+            consume(ra[0], rb[0], true, k_begin + s * BK);
             load_tiles(fast, min(k_begin + (s + 2) * BK, k_last), ra[0], rb[0]);   // tile s+2 into the freed set
             __syncthreads();
             multiply();
-            consume(ra[1], rb[1], s + 1 < nfast);
+            consume(ra[1], rb[1], s + 1 < nfast, k_begin + (s + 1) * BK);
             load_tiles(fast, min(k_begin + (s + 3) * BK, k_last), ra[1], rb[1]);
             __syncthreads();
             multiply();
@@ -353,6 +392,7 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     for (int s = nfast; s < nsteps; ++s) {       // k tail / unaligned operands: guarded loads hipcc counts itself
         std::false_type slow;
         load_tiles(slow, k_begin + s * BK, ra[0], rb[0]);
+        normalise(ra[0], k_begin + s * BK, true);
         __syncthreads();
         store_tiles(ra[0], rb[0]);
         __syncthreads();
@@ -414,21 +454,23 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     }
 }
 
-template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY>
+template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY, int ANORM = 0>
 int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n,
               int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b, int atomic_out,
               double* colp, int colp_chunks, const long long* a_idx = nullptr, int a_idx_ld = 0, int a_ns = 0,
-              const float* a_zero = nullptr) {
-    constexpr size_t lds = lds_bytes<BM, BN>();
-    auto kern = k_gemm_x6<BM, BN, MINB, ATERMS, ALAY, BLAY>;
-    static bool configured = false;
-    if (!configured) {
+              const float* a_zero = nullptr, const double* a_sums = nullptr, double a_count = 0.0, float a_eps = 0.f,
+              float a_slope = 1.f) {
+    const size_t lds = lds_bytes<BM, BN>() + (ANORM ? 2 * sizeof(float) * (size_t)(((k_per_split + BK - 1) / BK) * BK) : 0);
+    auto kern = k_gemm_x6<BM, BN, MINB, ATERMS, ALAY, BLAY, ANORM>;
+    static size_t configured = 0;
+    if (lds > configured) {
         PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
+        configured = lds;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split,
-                       vec_a, vec_b, atomic_out, colp, colp_chunks, a_idx, a_idx_ld, a_ns, a_zero);
+                       vec_a, vec_b, atomic_out, colp, colp_chunks, a_idx, a_idx_ld, a_ns, a_zero, a_sums, a_count, a_eps,
+                       a_slope);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -479,7 +521,7 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
     const int vec_a = (a_bf16 || a_kmajor) ? 1 : (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     const int vec_b = b_kmajor ? 1 : (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
     if (a_kmajor && !b_kmajor) { set_error("gemm_x6: A^T * B^T is not built"); return PCRCG_EBADARG; }
-    const X6Plan plan = x6_plan(m, n, k, a_kmajor || b_kmajor, a_kmajor != 0);
+    const X6Plan plan = x6_plan(m, n, k, a_kmajor || b_kmajor || (ex && ex->a_sums), a_kmajor != 0);
     const int pick = plan.pick, BM = plan.bm, BN = plan.bn, gx = plan.gx, gy = plan.gy, splits = plan.splits;
     const int k_per_split = plan.k_per_split;
     const bool accumulate = ex && ex->accumulate;
@@ -489,6 +531,11 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
         return PCRCG_EBADARG;
     }
     if (gather && !ex->a_zero) { set_error("gemm_x6: gather needs a zero row"); return PCRCG_EBADARG; }
+    const bool anorm = ex && ex->a_sums;
+    if (anorm && (a_bf16 || a_kmajor || b_kmajor || pick != 3)) {
+        set_error("gemm_x6: normalise-on-load is built for the 64 x 64 tile of k-contiguous fp32 operands");
+        return PCRCG_EBADARG;
+    }
     const int atomic_out = splits > 1 || accumulate;
     if (splits > 1 && !c_zeroed && !accumulate) {
         if (ldc == n) PCRCG_CHECK_HIP(hipMemsetAsync(c, 0, (size_t)m * n * sizeof(float), st));
@@ -534,6 +581,11 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
                                                   gather ? ex->a_idx_ld : 0, gather ? ex->a_ns : 0,                         \
                                                   gather ? ex->a_zero : nullptr);                                           \
     } while (0)
+    if (anorm)
+        return launch_x6<64, 64, 4, 3, 0, 0, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
+                                                vec_b, atomic_out, colp, colp_chunks, gather ? ex->a_idx : nullptr,
+                                                gather ? ex->a_idx_ld : 0, gather ? ex->a_ns : 0,
+                                                gather ? ex->a_zero : nullptr, ex->a_sums, ex->a_count, ex->a_eps, ex->a_slope);
     if (pick == 0) { GO(128, 128, 2); }
     if (pick == 1) { GO(128, 64, 2); }
     if (pick == 2) { GO(64, 128, 2); }

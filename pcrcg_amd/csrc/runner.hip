@@ -27,7 +27,8 @@ int gemm_bf16a_bt_colstats(const void* a_bf16, int lda, const float* b, int ldb,
 bool gemm_colstats_sums_ok();
 bool gemm_extra_ok();
 int gemm_bt_extra(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, hipStream_t st,
-                  bool c_zeroed, const GemmExtra& ex);
+                  bool c_zeroed, const GemmExtra& ex, const float* bias = nullptr, void* colstats = nullptr,
+                  size_t colstats_bytes = 0, int* h_chunks = nullptr, bool colstats_sums = false);
 namespace {
 
 struct Mat {          // row-major fp32 matrix view
@@ -194,6 +195,34 @@ void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, co
 
 // packed_ws != NULL: a pcrcg_kpconv_ws_bytes(ns) workspace whose support records the producer of x has already filled
 // (norm_act_pack): the aggregate kernel starts without the row-positive pass
+// y = lrelu(IN(x), slope) @ w^T (+ bias) with the normalisation done inside the product's A loads (GemmExtra::a_sums):
+// x is the RAW output of the producing product and xs its column sums.  Returns false when that form does not apply
+// (the caller then normalises into a matrix of its own and calls linear()).
+bool norm_fuse_on() {
+    static const bool off = getenv("PCRCG_FUSE_NORM") && atoi(getenv("PCRCG_FUSE_NORM")) == 0;   // A/B aid
+    return !off && gemm_extra_ok();
+}
+bool lazy_stats_ready(Ctx& c, const Mat& x, Stat* xs) {
+    if (!xs || !xs->sums || x.ld % 4 != 0 || x.cols > 4096) return false;
+    if (c.live() && xs->chunks == 0) {               // nobody left the sums yet (split-K or accumulated output): one pass
+        c.check(pcrcg_instnorm_colsums(x.p, x.rows, x.cols, x.ld, xs->partials, c.st));
+        xs->chunks = -1;
+    }
+    return true;
+}
+bool linear_norm(Ctx& c, const Mat& x, Stat* xs, float slope, const float* w, int ldw, const float* bias, const Mat& y,
+                 Stat* st = nullptr) {
+    if (!norm_fuse_on() || !lazy_stats_ready(c, x, xs)) return false;
+    if (!c.live()) return true;
+    GemmExtra ex;
+    ex.a_sums = static_cast<const double*>(xs->partials);
+    ex.a_count = (double)x.rows;
+    ex.a_slope = slope;
+    c.check(gemm_bt_extra(x.p, x.ld, w, ldw, y.p, y.ld, x.rows, y.cols, x.cols, c.st, y.zeroed, ex, bias,
+                          st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr, st && st->sums));
+    return true;
+}
+
 void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, const Mat& y, Stat* st = nullptr,
             void* packed_ws = nullptr) {
     const int l = blk.layer;
@@ -359,10 +388,13 @@ Mat resnet_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat
     Mat k = c.gemm_out(nq, blk.mid_dim, PCRCG_KPOINTS * kp_cin(blk, x)), kn = c.mat(nq, blk.mid_dim);
     Stat ks = stat_buffer(c, nq, blk.mid_dim);
     kpconv(c, b, blk, x, k, &ks, kp_ws);
-    norm_act(c, k, 0.1f, kn, &ks);
     Mat u2 = c.gemm_out(nq, blk.out_dim, blk.mid_dim);
     Stat u2s = stat_buffer(c, nq, blk.out_dim);
-    linear(c, kn, blk.unary2, blk.mid_dim, nullptr, u2, &u2s);
+    // lrelu(IN(k)) is read by unary2 alone: its product normalises k on load when k's statistics are column sums
+    if (!linear_norm(c, k, &ks, 0.1f, blk.unary2, blk.mid_dim, nullptr, u2, &u2s)) {
+        norm_act(c, k, 0.1f, kn, &ks);
+        linear(c, kn, blk.unary2, blk.mid_dim, nullptr, u2, &u2s);
+    }
     Mat sc = feats;
     if (blk.strided) {   // max_pool shortcut (:672-673)
         const pcrcg_table& t = b.pools[blk.layer];
@@ -464,8 +496,10 @@ Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, co
     linear(c, msg, g.wm, ch, g.bm, cols(cat, ch, ch));       // merge, written next to x: cat([x, message])
     Stat h0s = stat_buffer(c, n, 2 * ch);
     linear(c, cat, g.w0, 2 * ch, g.b0, h0, &h0s);
-    norm_act(c, h0, 0.0f, h1, &h0s);                        // InstanceNorm1d + ReLU
-    linear(c, h1, g.w3, 2 * ch, g.b3, delta);
+    if (!linear_norm(c, h0, &h0s, 0.0f, g.w3, 2 * ch, g.b3, delta)) {      // InstanceNorm1d + ReLU, inside w3's A loads
+        norm_act(c, h0, 0.0f, h1, &h0s);
+        linear(c, h1, g.w3, 2 * ch, g.b3, delta);
+    }
     if (c.live()) c.check(pcrcg_add(x.p, delta.p, y.p, (long)n * ch, c.st));
     c.release(m);
     return y;
@@ -532,6 +566,17 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
     x = xc;
     // 4. decoder (:567-570)
     static const bool fuse_off = getenv("PCRCG_FUSE_UPSAMPLE") && atoi(getenv("PCRCG_FUSE_UPSAMPLE")) == 0;   // A/B aid
+    // `x` may be LAZY between two decoder stages: the raw output of a unary's products whose InstanceNorm + LeakyReLU the
+    // next stage's gathering product applies on load (xs = its column sums); materialise() applies it for anyone else
+    Stat xs;
+    bool lazy = false;
+    auto materialise = [&]() {
+        if (!lazy) return;
+        Mat y = c.mat(x.rows, x.cols);
+        norm_act(c, x, 0.1f, y, &xs);
+        x = y;
+        lazy = false;
+    };
     for (int j = 0; j < mdl.n_dec; ++j) {
         const pcrcg_block& blk = mdl.dec[j];
         if (blk.type == PCRCG_BLK_UPSAMPLE) {
@@ -548,10 +593,16 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
                 skips.back().ld % 4 == 0) {
                 const Mat& sk = skips.back();
                 const bool last = next->type == PCRCG_BLK_LAST_UNARY;
-                Mat tt = last ? c.mat(t.rows, next->out_dim, pad4(next->out_dim)) : c.mat(t.rows, next->out_dim);
+                Mat tt = c.mat(t.rows, next->out_dim, pad4(next->out_dim));    // rows 16-byte aligned: it may be gathered next
                 float* zero_row = static_cast<float*>(c.zraw(sizeof(float) * (size_t)(x.cols + 8)));
+                if (lazy && !(norm_fuse_on() && lazy_stats_ready(c, x, &xs))) materialise();
                 if (c.live()) {
                     GemmExtra g1, g2;
+                    if (lazy) {                              // the producer's normalisation, applied to the gathered rows
+                        g1.a_sums = static_cast<const double*>(xs.partials);
+                        g1.a_count = (double)x.rows;
+                        g1.a_slope = 0.1f;
+                    }
                     g1.a_idx = reinterpret_cast<const long long*>(t.idx);
                     g1.a_idx_ld = t.ld;
                     g1.a_ns = x.rows;
@@ -563,25 +614,24 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
                                           cs, c.st, true, g2));
                 }
                 skips.pop_back();
-                if (last) {
-                    x = tt;
-                } else {
-                    Mat y = c.mat(tt.rows, tt.cols);
-                    Stat ts = stat_buffer(c, tt.rows, tt.cols);      // (filled by one pass over tt: two products wrote it)
-                    norm_act(c, tt, 0.1f, y, &ts);
-                    x = y;
+                lazy = false;
+                x = tt;
+                if (!last) {                                         // its normalisation is left to the next consumer
+                    xs = stat_buffer(c, tt.rows, tt.cols);           // (filled by one pass over tt: two products wrote it)
+                    lazy = true;
                 }
                 ++j;                                                 // the unary block is done
                 continue;
             }
+            materialise();
             Mat y = c.mat(t.rows, x.cols + cs, pad4(x.cols + cs));
-            Mat xs = x;
+            Mat xd = x;
             if (x.ld != x.cols) {   // gather_first reads dense rows
-                xs = c.mat(x.rows, x.cols);
-                if (c.live()) c.check(pcrcg_copy2d(x.p, x.ld, xs.p, xs.ld, x.rows, x.cols, c.st));
+                xd = c.mat(x.rows, x.cols);
+                if (c.live()) c.check(pcrcg_copy2d(x.p, x.ld, xd.p, xd.ld, x.rows, x.cols, c.st));
             }
             if (c.live()) {
-                c.check(pcrcg_gather_first(xs.p, xs.rows, xs.cols, t.idx, t.rows, t.ld, y.p, y.ld, c.st));
+                c.check(pcrcg_gather_first(xd.p, xd.rows, xd.cols, t.idx, t.rows, t.ld, y.p, y.ld, c.st));
                 if (concat) {
                     const Mat& s = skips.back();
                     c.check(pcrcg_copy2d(s.p, s.ld, y.p + x.cols, y.ld, s.rows, s.cols, c.st));
@@ -590,17 +640,20 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
             if (concat) skips.pop_back();
             x = y;
         } else if (blk.type == PCRCG_BLK_UNARY) {
+            materialise();
             Mat t = c.gemm_out(x.rows, blk.out_dim, x.cols), y = c.mat(x.rows, blk.out_dim);
             Stat ts = stat_buffer(c, t.rows, t.cols);
             linear(c, x, blk.mlp, blk.mlp_ld, nullptr, t, &ts);
             norm_act(c, t, 0.1f, y, &ts);
             x = y;
         } else {   // last_unary
+            materialise();
             Mat y = c.mat(x.rows, blk.out_dim, pad4(blk.out_dim));
             linear(c, x, blk.mlp, blk.mlp_ld, nullptr, y);
             x = y;
         }
     }
+    materialise();
     // heads (:571-582)
     if (c.live()) {
         const int fd = mdl.final_dim;

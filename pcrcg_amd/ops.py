@@ -293,9 +293,10 @@ def gemm(a, b, row_scale=None, bias=None, out=None):
     return out
 
 
-def gemm_gather(a, w, idx=None, out=None, accumulate=False):
-    """out (+)= a[idx[:, 0]] @ w^T for a [ns, k], w [n, k] (both k-contiguous), idx an int64 table whose first column
-    selects the row of `a` for every output row (an index outside [0, ns) selects zeros: the shadow neighbour)."""
+def gemm_fused(a, w, idx=None, out=None, accumulate=False, sums=None, slope=1.0, bias=None, eps=1e-5):
+    """out (+)= f(a)[idx[:, 0]] @ w^T + bias for a [ns, k], w [n, k] (both k-contiguous).  idx: an int64 table whose first
+    column selects the row of `a` for every output row (an index outside [0, ns) selects zeros: the shadow neighbour).
+    sums: float64 [2, k] column sums of `a` -- then f(a) = lrelu(IN(a), slope) is applied on load (pcrcg_gemm_f32_fused)."""
     L = _lib.lib()
     a, lda = _rows(a, _F32, "a")
     w, ldb = _rows(w, _F32, "w")
@@ -307,12 +308,17 @@ def gemm_gather(a, w, idx=None, out=None, accumulate=False):
         ld_idx, m = 0, a.shape[0]
     if out is None:
         if accumulate:
-            raise RuntimeError("pcrcg_amd.gemm_gather: accumulate needs `out`")
+            raise RuntimeError("pcrcg_amd.gemm_fused: accumulate needs `out`")
         out = torch.empty((m, n), dtype=_F32, device=a.device)
+    if sums is not None and (sums.dtype != torch.float64 or tuple(sums.shape) != (2, k) or not sums.is_contiguous()):
+        raise RuntimeError("pcrcg_amd.gemm_fused: sums must be a contiguous float64 [2, k] tensor")
+    if bias is not None:
+        bias = _dev(bias, _F32, "bias").contiguous()
     zero = torch.zeros(k + 8, dtype=_F32, device=a.device)
-    _lib.check(L.pcrcg_gemm_f32_gather(a.data_ptr(), lda, _ptr(idx), ld_idx, a.shape[0], zero.data_ptr(), w.data_ptr(), ldb,
-                                       out.data_ptr(), out.stride(0) if m > 1 else max(n, out.stride(0)), m, n, k,
-                                       int(accumulate), _stream()), "pcrcg_gemm_f32_gather")
+    _lib.check(L.pcrcg_gemm_f32_fused(a.data_ptr(), lda, _ptr(idx), ld_idx, a.shape[0], zero.data_ptr(), _ptr(sums),
+                                      float(a.shape[0]), float(eps), float(slope), w.data_ptr(), ldb, _ptr(bias),
+                                      out.data_ptr(), out.stride(0) if m > 1 else max(n, out.stride(0)), m, n, k,
+                                      int(accumulate), _stream()), "pcrcg_gemm_f32_fused")
     return out
 
 

@@ -59,7 +59,7 @@ def test_gemm_vs_torch(cuda, m, n, k):
 @pytest.mark.parametrize("m,ns,n,k1,k2", [(3934, 763, 257, 514, 1024), (60000, 15456, 34, 128, 256), (100, 7, 5, 6, 12),
                                          (15456, 3934, 128, 257, 512)])
 def test_gemm_gather_and_accumulate(cuda, m, ns, n, k1, k2):
-    """The decoder's nearest_upsample -> cat(skip) -> unary as two products (pcrcg_gemm_f32_gather): rows gathered
+    """The decoder's nearest_upsample -> cat(skip) -> unary as two products (pcrcg_gemm_f32_fused): rows gathered
     through the first column of an upsample table (shadow index -> zeros), the skip part added into the same output --
     against the materialised formulation (ref:models/blocks.py:77-87, ref:models/architectures.py:568-569) in float64."""
     g = torch.Generator().manual_seed(m + n)
@@ -71,12 +71,22 @@ def test_gemm_gather_and_accumulate(cuda, m, ns, n, k1, k2):
     w1 = torch.zeros(n, lda)
     w1[:, :k1] = w[:, :k1]
     w1, w2 = w1.to(cuda)[:, :k1], w[:, k1:].contiguous().to(cuda)
-    out = ops.gemm_gather(xa, w1, idx.to(cuda))
-    ops.gemm_gather(skip, w2, out=out, accumulate=True)
+    out = ops.gemm_fused(xa, w1, idx.to(cuda))
+    ops.gemm_fused(skip, w2, out=out, accumulate=True)
     xpad = torch.cat([xa.double().cpu(), torch.zeros(1, k1, dtype=torch.float64)])
     want = torch.cat([xpad[idx[:, 0]], skip.double().cpu()], 1) @ w.double().t()
     assert rel(out, want) < 3e-6
-    assert rel(ops.gemm_gather(skip, w2), skip.double().cpu() @ w[:, k1:].double().t()) < 3e-6      # no table: a plain product
+    assert rel(ops.gemm_fused(skip, w2), skip.double().cpu() @ w[:, k1:].double().t()) < 3e-6      # no table: a plain product
+    # normalise-on-load: the gathered operand is the RAW output of a product, lrelu(IN(.), 0.1) applied inside the A loads
+    sums = torch.stack([xa.double().sum(0), (xa.double() ** 2).sum(0)]).contiguous()
+    xd = xa.double().cpu()
+    xn = torch.nn.functional.leaky_relu((xd - xd.mean(0)) / torch.sqrt(xd.var(0, unbiased=False) + 1e-5), 0.1)
+    bias = torch.randn(n, generator=g).to(cuda)
+    got = ops.gemm_fused(xa, w1, idx.to(cuda), sums=sums, slope=0.1, bias=bias)
+    want = torch.cat([xn, torch.zeros(1, k1, dtype=torch.float64)])[idx[:, 0]] @ w[:, :k1].double().t() + bias.double().cpu()
+    assert rel(got, want) < 3e-6                                     # (shadow rows stay zero: padding follows the norm)
+    xr = torch.relu((xd - xd.mean(0)) / torch.sqrt(xd.var(0, unbiased=False) + 1e-5))
+    assert rel(ops.gemm_fused(xa, w1, sums=sums, slope=0.0), xr @ w[:, :k1].double().t()) < 3e-6        # ReLU: slope 0
 
 
 def test_gemm_strided_operands(cuda):
