@@ -340,7 +340,6 @@ int pcrcg_attention(const float* q, int ldq, const float* k, int ldk, const floa
     PCRCG_CHECK_ARG(q && k && v && out);
     PCRCG_CHECK_ARG(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
     hipStream_t st = as_stream(stream);
-    // wide heads: 8 queries per workgroup, 32 lanes each (twice the workgroups, half the work per lane)
 #define ATT(DD, TQ)                                                                                                  \
     do {                                                                                                             \
         constexpr size_t lds = sizeof(float) * (64 * (DD + 4) + 64 * DD + TQ * 64);                                  \
@@ -353,7 +352,12 @@ int pcrcg_attention(const float* q, int ldq, const float* k, int ldk, const floa
         hipLaunchKernelGGL((k_attention<DD, TQ>), dim3((n + TQ - 1) / TQ, heads), dim3(256), lds, st, q, ldq, k, ldk, v, \
                            ldv, out, ldo, n, ms, scale);                                                             \
     } while (0)
-    if (d == 128) ATT(128, 8);
+    // d = 128: 16 queries x 16 lanes.  8 x 32 is faster alone (50 vs 62 us on 381 x 382 x 4 heads) but takes twice the
+    // workgroups and re-reads K / V twice as often, and inside the four-stream engine that costs more than it gains
+    // (440 vs 446 pairs/s; 32 x 8 lanes: 89 us alone, 443) -- PCRCG_ATT_TQ=8 selects it for a lone forward.
+    static const int att_tq = getenv("PCRCG_ATT_TQ") ? atoi(getenv("PCRCG_ATT_TQ")) : 16;
+    if (d == 128 && att_tq == 8) ATT(128, 8);
+    else if (d == 128) ATT(128, 16);
     else if (d == 64) ATT(64, 8);
     else if (d == 48) ATT(48, 16);
     else if (d == 32) ATT(32, 16);
