@@ -498,8 +498,10 @@ static X6Plan x6_plan(int m, int n, int k, bool kmajor = false, bool reduce_rows
     int splits = 1;
     const int ktiles = (k + BK - 1) / BK;
     const int max_splits = reduce_rows ? 128 : 32;            // dW = X^T dY reduces over the points: few tiles, very long K
-    while ((long)p.gx * p.gy * splits < 200 && k / (2 * splits) >= 256 && splits < max_splits) splits *= 2;
-    while ((long)p.gx * p.gy * splits < 1024 && k / splits > 1024 && splits < max_splits) splits *= 2;
+    static const int t1 = getenv("PCRCG_X6_T1") ? atoi(getenv("PCRCG_X6_T1")) : 200;      // tuning aids
+    static const int t2 = getenv("PCRCG_X6_T2") ? atoi(getenv("PCRCG_X6_T2")) : 1024;
+    while ((long)p.gx * p.gy * splits < t1 && k / (2 * splits) >= 256 && splits < max_splits) splits *= 2;
+    while ((long)p.gx * p.gy * splits < t2 && k / splits > 1024 && splits < max_splits) splits *= 2;
     if (const char* e = getenv("PCRCG_X6_SPLITK")) splits = atoi(e) > 0 ? atoi(e) : splits;   // tuning aid
     p.k_per_split = ((ktiles + splits - 1) / splits) * BK;
     if (p.k_per_split < BK) p.k_per_split = BK;
