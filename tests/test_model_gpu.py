@@ -176,7 +176,7 @@ def test_kpconv_x6_fused_vs_two_stage_and_oracle(cuda, mini):
 def test_pools_and_norm(cuda, mini):
     batch, _ = mini
     g = torch.Generator().manual_seed(4)
-    for c in (7, 64, 256):
+    for c in (7, 32, 64, 128, 256, 512):         # 32 / 64 / 128: several query rows per wavefront; 512: two chunks per row
         x = torch.randn(batch["points"][0].shape[0], c, generator=g)
         inds = batch["pools"][0]
         assert torch.equal(ops.gather_max(x.to(cuda), inds.to(cuda)).cpu(), MR.max_pool(x, inds))
@@ -194,6 +194,10 @@ def test_pools_and_norm(cuda, mini):
     neg = -torch.rand(10, 8, generator=g) - 1
     mixed = torch.tensor([[0, 1, 10, 10]], dtype=torch.int64)
     assert ops.gather_max(neg.to(cuda), mixed.to(cuda)).abs().max() == 0   # shadow zero beats negatives
+    neg128 = -torch.rand(10, 128, generator=g) - 1
+    mixed9 = torch.tensor([[0, 1, 10, 10, 3, 4, 5, 6, 7], [9, 8, 7, 6, 5, 4, 3, 2, 1], [10] * 9], dtype=torch.int64)
+    got = ops.gather_max(neg128.to(cuda), mixed9.to(cuda)).cpu()          # the narrow-row kernel, nine neighbours (two rounds)
+    assert torch.equal(got, MR.max_pool(neg128, mixed9)) and float(got[0].abs().max()) == 0 and float(got[2].abs().max()) == 0
 
 
 def test_residual_norm_tail(cuda):
