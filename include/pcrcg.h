@@ -512,6 +512,11 @@ typedef struct pcrcg_pyramid_cfg {
                     nb / g batches, each with its own tables (indices relative to the group's supports, the group's own
                     column counts) -- what nb / g separate calls would have produced, from ONE chain of kernels: the
                     chain is latency-bound, so two pairs cost little more than one */
+    int up_nearest; /* 0: upsample tables with `limit` columns, as collate_fn_descriptor builds them
+                       (ref:datasets/dataloader.py:287-297).  1: ONE column -- the nearest coarse point within the radius
+                       (the reference's order among equidistant ones), which is all that the network reads of them
+                       (closest_pool, ref:models/blocks.py:77-87): for hosts that feed pcrcg_kpfcnn_forward and nothing
+                       else, the search keeps one candidate per row instead of sorting and writing `limit` of them */
 } pcrcg_pyramid_cfg;
 typedef struct pcrcg_pyramid_restore {
     int njobs;                                   /* 0: no row holds a tie, nothing to do but post the status word */

@@ -247,7 +247,7 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
             PCRCG_PROPAGATE(add_table(1, l, l + 1, grid, r_pool, sub, sub_len, m, n, lens, limit, l));
             void* up_grid = nullptr;
             PCRCG_PROPAGATE(build_grid(sub, m, sub_len, 2 * r_pool, &up_grid));
-            PCRCG_PROPAGATE(add_table(2, l, l, up_grid, 2 * r_pool, pts, lens, n, m, sub_len, limit, l + 1));
+            PCRCG_PROPAGATE(add_table(2, l, l, up_grid, 2 * r_pool, pts, lens, n, m, sub_len, cfg->up_nearest ? 1 : limit, l + 1));
             carried = up_grid;
             carried_r = 2 * r_pool;
             pts = sub;

@@ -75,7 +75,9 @@ class PairStreams:
         self.front = self.fronts[0]
         nf = max(1, int(front_threads))
         # every front thread owns a ring of builders (arena + pinned scratch each)
-        self._pyr = [[NativePyramid(config, neighborhood_limits, tie_order) for _ in range(self.ARENAS)] for _ in range(nf)]
+        up1 = os.environ.get("PCRCG_UP_NEAREST", "1") != "0"       # one-column upsample tables (the forward reads column 0)
+        self._pyr = [[NativePyramid(config, neighborhood_limits, tie_order, up_nearest=up1) for _ in range(self.ARENAS)]
+                     for _ in range(nf)]
         # per arena: a one-slot queue holding the event after which it may be overwritten (None: never used); the
         # front thread TAKES it before building into the arena, the model thread puts the forward's event back
         self._free = [[queue.Queue() for _ in range(self.ARENAS)] for _ in range(nf)]

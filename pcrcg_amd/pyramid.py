@@ -229,7 +229,7 @@ class NativePyramid:
 
     STATUS_RING = 64
 
-    def __init__(self, config, neighborhood_limits, tie_order=None):
+    def __init__(self, config, neighborhood_limits, tie_order=None, up_nearest=False):
         import ctypes
         from . import _lib
         from .runner import Batch, PyramidCfg
@@ -246,6 +246,9 @@ class NativePyramid:
             c.r_conv[l], c.r_pool[l], c.dl[l] = float(lv["r_conv"]), float(lv["r_pool"]), float(lv["dl"])
             c.has_conv[l], c.pooled[l], c.limit[l] = int(lv["has_conv"]), int(lv["pooled"]), int(neighborhood_limits[l])
         c.tie_order = 0 if tie_order == "index" else 1
+        # one-column upsample tables (the nearest coarse point: all the network reads of them) -- for the pair engine,
+        # whose batches go to pcrcg_kpfcnn_forward only; the batch-dict builders keep the reference's full tables
+        c.up_nearest = int(bool(up_nearest))
         self.cfg, self.levels = c, len(plan)
         self.scratch = torch.empty(512, dtype=_I32, pin_memory=True)
         self.status = torch.zeros(self.STATUS_RING, dtype=_I32, pin_memory=True)

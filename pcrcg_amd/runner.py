@@ -66,7 +66,7 @@ class PyramidCfg(ctypes.Structure):
     _fields_ = [("n_levels", ctypes.c_int), ("r_conv", ctypes.c_float * MAX_LEVELS), ("r_pool", ctypes.c_float * MAX_LEVELS),
                 ("dl", ctypes.c_float * MAX_LEVELS), ("has_conv", ctypes.c_int * MAX_LEVELS),
                 ("pooled", ctypes.c_int * MAX_LEVELS), ("limit", ctypes.c_int * MAX_LEVELS), ("tie_order", ctypes.c_int),
-                ("group", ctypes.c_int)]
+                ("group", ctypes.c_int), ("up_nearest", ctypes.c_int)]
 
 
 class ReorderJobC(ctypes.Structure):

@@ -236,3 +236,23 @@ def test_engine_surfaces_bad_input_on_result(cuda):
         assert float((out["scores_overlap"] - ref["scores_overlap"]).abs().max()) <= 1e-5
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("recipe", ["T8k", "S30k"])
+def test_one_column_upsample_tables_are_column_zero(cuda, recipe):
+    """pcrcg_pyramid_cfg.up_nearest (what the pair engine builds): the upsample tables have ONE column, the nearest coarse
+    point in the reference's order among equidistant ones -- column 0 of the full tables, entry for entry (T8k: thousands of
+    rows where two coarse points are exactly equidistant); everything else is unchanged."""
+    cfg, limits = indoor_config(), synthetic.LIMITS.get(recipe, synthetic.LIMITS["C1"])
+    pts, lens = _pair(recipe, 0, cuda)
+    full = build_pyramid_native(pts, lens, cfg, limits)
+    nat = NativePyramid(cfg, limits, up_nearest=True)
+    b, arena, lens_h, slot = nat.build(pts, lens, fresh_arena=True)
+    torch.cuda.synchronize()
+    assert int(nat.status[slot]) == 0
+    got = nat.as_dict(b, arena, lens_h)
+    for l in range(cfg.num_layers):
+        assert torch.equal(got["neighbors"][l], full["neighbors"][l]) and torch.equal(got["pools"][l], full["pools"][l])
+        if l + 1 < cfg.num_layers:
+            assert got["upsamples"][l].shape == (full["upsamples"][l].shape[0], 1)
+            assert torch.equal(got["upsamples"][l][:, 0], full["upsamples"][l][:, 0]), l
