@@ -211,11 +211,9 @@ __global__ void __launch_bounds__(256) k_instnorm_apply4_sums(const float* __res
         float4 m0, s0, m1 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = make_float4(1.f, 1.f, 1.f, 1.f);
         stats4_from_sums(sums, 4 * c4, 4 * q, count, eps, m0, s0);
         if (RES == 2) stats4_from_sums(res_sums, 4 * c4, 4 * q, count, eps, m1, s1);
-        for (long r = r_lo + (int)(threadIdx.x / cb); r < r_hi; r += rp) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + 4 * q);
+        auto finish = [&](const float4& xv, float4 rv, long r) {
             float4 v = make_float4((xv.x - m0.x) * s0.x, (xv.y - m0.y) * s0.y, (xv.z - m0.z) * s0.z, (xv.w - m0.w) * s0.w);
             if (RES) {
-                float4 rv = *reinterpret_cast<const float4*>(res + r * ldr + 4 * q);
                 if (RES == 2) rv = make_float4((rv.x - m1.x) * s1.x, (rv.y - m1.y) * s1.y, (rv.z - m1.z) * s1.z, (rv.w - m1.w) * s1.w);
                 v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
@@ -224,6 +222,22 @@ __global__ void __launch_bounds__(256) k_instnorm_apply4_sums(const float* __res
             v.z = v.z >= 0.f ? v.z : v.z * slope;
             v.w = v.w >= 0.f ? v.w : v.w * slope;
             *reinterpret_cast<float4*>(y + r * ldy + 4 * q) = v;
+        };
+        long r = r_lo + (int)(threadIdx.x / cb);
+        for (; r + 3 * rp < r_hi; r += 4 * rp) {             // four rows in flight per thread
+            float4 xv[4], rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xv[u] = *reinterpret_cast<const float4*>(x + (r + u * rp) * ldx + 4 * q);
+                rv[u] = RES ? *reinterpret_cast<const float4*>(res + (r + u * rp) * ldr + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) finish(xv[u], rv[u], r + u * rp);
+        }
+        for (; r < r_hi; r += rp) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + 4 * q);
+            const float4 rv = RES ? *reinterpret_cast<const float4*>(res + r * ldr + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            finish(xv, rv, r);
         }
     }
 }
