@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcrcg_hip.so")
+# PCRCG_LIB: another build of the same ABI (scripts/knockout.py); the default is the in-tree library
+LIB_PATH = os.environ.get("PCRCG_LIB") or os.path.join(_HERE, "libpcrcg_hip.so")
 
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 

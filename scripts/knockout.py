@@ -1,0 +1,56 @@
+"""Knock-out accounting of the forward's kernel families: what does the pair engine's throughput
+gain when a family of launches simply does not happen?  Results are wrong, timing is meaningful -- it tells which
+fusion is worth building before it is built (round 2: the row-positive pass +4 %, the normalisation passes +11 %, the
+finishing launches of tall statistics +5.6 % that no rewrite could realise, the concat copies +0.3 %).
+
+    python scripts/knockout.py build      (build container or GPU box: writes pcrcg_amd/libpcrcg_hip_knock.so)
+    python scripts/knockout.py run        (GPU box: bench.py once per family with PCRCG_KNOCK=<family>)
+
+The knock-out library is the normal library with runner.hip patched so that the wrapped calls return PCRCG_OK without
+launching when their token is in $PCRCG_KNOCK.  Index-producing kernels are never knocked out (garbage indices would
+fault).  bench.py picks the library up through PCRCG_LIB."""
+import os
+import re
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "pcrcg_amd", "csrc")
+LIB = os.path.join(REPO, "pcrcg_amd", "libpcrcg_hip_knock.so")
+FAMILIES = [("pcrcg_copy2d(", "K_COPY"), ("pcrcg_gather_max(", "K_GMAX"), ("pcrcg_instnorm_colsums(", "K_CSUM"),
+            ("pcrcg_instnorm_stats_from_partials(", "K_CFIN"), ("pcrcg_instnorm_apply_sums(", "K_APPLY"),
+            ("pcrcg_instnorm_apply(", "K_APPLY"), ("instnorm_apply_pack(t.p", "K_PACK"), ("pcrcg_attention(q.p", "K_ATT"),
+            ("pcrcg_edgeconv_reduce_sums(", "K_EDGE"), ("kpconv_aggregate_rows(q, nq", "K_GATH"),
+            ("pcrcg_kpconv_aggregate(q, nq", "K_GATH")]
+
+
+def build():
+    src = open(os.path.join(CSRC, "runner.hip")).read()
+    src = src.replace("namespace pcrcg {\n// gemm.hip", '#include <cstring>\nstatic bool ko(const char* name) { static const char* e = '
+                      'getenv("PCRCG_KNOCK"); return e && strstr(e, name); }\nnamespace pcrcg {\n// gemm.hip', 1)
+    for pat, tok in FAMILIES:
+        n = src.count(pat)
+        src = src.replace(pat, 'ko("%s") ? PCRCG_OK : %s' % (tok, pat))
+        print("%-8s %d call sites" % (tok, n))
+    tmp = os.path.join(CSRC, "build", "knock")
+    os.makedirs(tmp, exist_ok=True)
+    open(os.path.join(tmp, "runner_knock.hip"), "w").write(src)
+    objs = [os.path.join(CSRC, "build", f) for f in os.listdir(os.path.join(CSRC, "build")) if f.endswith(".o") and f != "runner.o"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
+    subprocess.check_call(["hipcc", *flags, "-c", os.path.join(tmp, "runner_knock.hip"), "-o", os.path.join(tmp, "runner_knock.o")])
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, os.path.join(tmp, "runner_knock.o"), *objs])
+    print("built", LIB)
+
+
+def run():
+    import json
+    toks = ["none"] + sorted({t for _, t in FAMILIES}) + ["none"]
+    for t in toks:
+        env = dict(os.environ, PCRCG_LIB=LIB, PCRCG_KNOCK=t)
+        out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--steps", "150"], env=env,
+                             capture_output=True, text=True).stdout.strip().splitlines()
+        print("%-8s %s" % (t, json.loads(out[-1])["value"] if out else "failed"), flush=True)
+
+
+if __name__ == "__main__":
+    {"build": build, "run": run}[sys.argv[1] if len(sys.argv) > 1 else "build"]()
