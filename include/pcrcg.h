@@ -297,7 +297,7 @@ int pcrcg_instnorm_stats(const float* x, int n, int c, int ldx, float eps, float
 int pcrcg_instnorm_apply(const float* x, int n, int c, int ldx, const float* stats, const float* res,
                          int ldr, const float* res_stats, float slope, float* y, int ldy, void* stream);
 /* The same with the statistics given as fp64 column SUMS: sums [2][c] = (sum_r x[r,ch], sum_r x[r,ch]^2) over `count`
- * rows (what pcrcg_kpfcnn_forward's GEMM epilogues leave for outputs of up to 20 000 rows), mean / biased variance / rstd
+ * rows (what pcrcg_kpfcnn_forward's GEMM epilogues leave), mean / biased variance / rstd
  * derived on the fly -- no finishing launch between the producing GEMM and the normalisation.  res_sums (may be NULL):
  * the residual is normalised by its own sums, else added as is.  c % 4 == 0 and c / 4 a divisor or a multiple of 256
  * (every width of the architecture); rows 16-byte aligned. */

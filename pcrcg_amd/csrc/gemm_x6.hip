@@ -435,17 +435,37 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
                 }
             }
         }
-    if (colp) {
+    if (colp && colp_chunks < 0) {
+        // sums mode: [2][N] accumulators zeroed by the caller.  The workgroup's two row halves meet in LDS first (the operand
+        // planes are free now), so a row tile costs one pair of atomics per column, not two
+        float* const red = reinterpret_cast<float*>(smem);
+        __syncthreads();                                   // every wavefront is past its last operand read
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float s = cs[j] + __shfl_xor(cs[j], 32, 64), q2 = cq[j] + __shfl_xor(cq[j], 32, 64);
+            if (wm == 1 && half == 0) {
+                red[2 * (wn * WN + j * 32 + l31)] = s;
+                red[2 * (wn * WN + j * 32 + l31) + 1] = q2;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float s = cs[j] + __shfl_xor(cs[j], 32, 64), q2 = cq[j] + __shfl_xor(cq[j], 32, 64);
+            const int gn = n0 + wn * WN + j * 32 + l31;
+            if (wm == 0 && half == 0 && gn < N) {
+                unsafeAtomicAdd(&colp[gn], (double)s + (double)red[2 * (wn * WN + j * 32 + l31)]);
+                unsafeAtomicAdd(&colp[(long)N + gn], (double)q2 + (double)red[2 * (wn * WN + j * 32 + l31) + 1]);
+            }
+        }
+    } else if (colp) {
         const int chunk = tile_y * WAVES_M + wm;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const float s = cs[j] + __shfl_xor(cs[j], 32, 64), q2 = cq[j] + __shfl_xor(cq[j], 32, 64);
             const int gn = n0 + wn * WN + j * 32 + l31;
             if (half == 0 && gn < N) {
-                if (colp_chunks < 0) {          // sums mode: [2][N] accumulators zeroed by the caller
-                    unsafeAtomicAdd(&colp[gn], (double)s);
-                    unsafeAtomicAdd(&colp[(long)N + gn], (double)q2);
-                } else {
+                {
                     colp[(long)gn * colp_chunks + chunk] = (double)s;
                     colp[((long)N + gn) * colp_chunks + chunk] = (double)q2;
                 }

@@ -117,15 +117,16 @@ struct Stat {
     bool sums = false;
 };
 
-// Outputs of up to 20 000 rows: the GEMM epilogue adds its column sums into accumulators from the zero arena with fp64
-// atomics (a few hundred per address) and the normalisation derives mean / rstd from them itself -- no partial buffers,
-// no finishing launch (51 per S30k forward before, 6 now).  Taller outputs keep the deterministic partials + finishing
-// kernel: with the 1 876 atomics per address of a 60 000-row output the forward measured slower again (3.09 vs 3.02 ms;
-// engine 415 vs 418 pairs/s at 20 000, 415 at 8 192).
+// The GEMM epilogue adds its output's column sums into accumulators from the zero arena with fp64 atomics -- one pair per
+// column and 64-row tile, the workgroup's two row halves meet in LDS first -- and the normalisation derives mean / rstd
+// from them itself: no partial buffers, no finishing launch (51 per S30k forward before).  With the per-wavefront
+// atomics of the first version the 60 000-row outputs (1 876 per address) measured slower than partials + finishing
+// kernel and kept those; with one per tile (938) the sums win everywhere: 470-473 vs 457-466 pairs/s.
+// (PCRCG_STAT_SUMS_ROWS: outputs above that many rows keep the deterministic partials.)
 Stat stat_buffer(Ctx& c, int rows, int cols) {
     Stat s;
     static const bool off = getenv("PCRCG_STAT_SUMS") && atoi(getenv("PCRCG_STAT_SUMS")) == 0;   // A/B aid
-    static const int max_rows = getenv("PCRCG_STAT_SUMS_ROWS") ? atoi(getenv("PCRCG_STAT_SUMS_ROWS")) : 20000;   // tuning aid
+    static const int max_rows = getenv("PCRCG_STAT_SUMS_ROWS") ? atoi(getenv("PCRCG_STAT_SUMS_ROWS")) : (1 << 30);   // tuning aid
     if (!off && rows <= max_rows && gemm_colstats_sums_ok()) {
         s.sums = true;
         s.bytes = 2 * sizeof(double) * (size_t)cols;

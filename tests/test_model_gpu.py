@@ -245,8 +245,8 @@ def test_knn_and_edgeconv(cuda):
 
 @pytest.mark.parametrize("n,c", [(763, 512), (1, 8), (3934, 2048), (8192, 64), (100, 1024), (381, 32)])
 def test_instnorm_apply_from_sums(cuda, n, c):
-    """pcrcg_instnorm_apply_sums (statistics as float64 column sums, the form the runner's GEMM epilogues leave for
-    outputs of up to 20 000 rows) against the reference formulation (ref:models/blocks.py:456-463: InstanceNorm1d over the
+    """pcrcg_instnorm_apply_sums (statistics as float64 column sums, the form the runner's GEMM epilogues
+    leave) against the reference formulation (ref:models/blocks.py:456-463: InstanceNorm1d over the
     points, eps 1e-5, biased variance) and against the two-launch path it replaces."""
     g = torch.Generator().manual_seed(n + c)
     x = (torch.randn(n, c, generator=g) * 3 + 1).to(cuda)
