@@ -23,22 +23,37 @@ namespace {
 
 typedef unsigned long long u64;
 
+// The reference's kNN distance (ref:models/gcn.py:15-34) is badly conditioned -- -2ab + a^2 + b^2 in fp32 cancels to a few
+// ulps of |a|^2, 1e-3 m^2 on KITTI-sized coordinates -- so WHICH points are the k nearest depends on every rounding.
+// The expression is therefore evaluated exactly as the reference's CPU run rounds it (probed entry for entry on the
+// 1936-point coarse clouds of the K120k pair): the [N,3]x[3,N] product as an FMA chain over x, y, z (MKL sgemm),
+// |a|^2 as (x^2 + y^2) + z^2 from rounded squares (torch.sum of src**2), then (-2*dot + |a|^2) + |b|^2 and the clamp,
+// each step rounded.  No contraction of the written operations.
+__device__ __forceinline__ float knn_sq(float x, float y, float z) {
+#pragma clang fp contract(off)
+    return (x * x + y * y) + z * z;
+}
+__device__ __forceinline__ float knn_dist(float ax, float ay, float az, float sa, float bx, float by, float bz) {
+#pragma clang fp contract(off)
+    const float dot = __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
+    const float sb = (bx * bx + by * by) + bz * bz;
+    const float d = (-2.0f * dot + sa) + sb;          // square_distance :26-31
+    return fmaxf(d, 1e-12f);                          // clamp :33
+}
+
 __global__ void __launch_bounds__(256) k_knn(const float* __restrict__ coords, int n, int k, int* __restrict__ idx) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const float ax = coords[3 * (long)i], ay = coords[3 * (long)i + 1], az = coords[3 * (long)i + 2];
-    const float sa = ax * ax + ay * ay + az * az;
+    const float sa = knn_sq(ax, ay, az);
     u64 last = 0;
     bool have_last = false;
     for (int round = 0; round <= k; ++round) {
         u64 best = ~0ull;
         for (int j = lane; j < n; j += 64) {
             const float bx = coords[3 * (long)j], by = coords[3 * (long)j + 1], bz = coords[3 * (long)j + 2];
-            const float dot = ax * bx + ay * by + az * bz;
-            const float sb = bx * bx + by * by + bz * bz;
-            float d = (-2.0f * dot + sa) + sb;            // square_distance :26-31
-            d = fmaxf(d, 1e-12f);                         // clamp :33
+            float d = knn_dist(ax, ay, az, sa, bx, by, bz);
             const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)j;
             if ((!have_last || key > last) && key < best) best = key;
         }
@@ -63,17 +78,14 @@ __global__ void __launch_bounds__(256) k_knn_reg(const float* __restrict__ coord
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const float ax = coords[3 * (long)i], ay = coords[3 * (long)i + 1], az = coords[3 * (long)i + 2];
-    const float sa = ax * ax + ay * ay + az * az;
+    const float sa = knn_sq(ax, ay, az);
     u64 key[PER];
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
         const int j = lane + 64 * t;
         const int jc = j < n ? j : n - 1;
         const float bx = coords[3 * (long)jc], by = coords[3 * (long)jc + 1], bz = coords[3 * (long)jc + 2];
-        const float dot = ax * bx + ay * by + az * bz;
-        const float sb = bx * bx + by * by + bz * bz;
-        float d = (-2.0f * dot + sa) + sb;            // square_distance :26-31
-        d = fmaxf(d, 1e-12f);                         // clamp :33
+        float d = knn_dist(ax, ay, az, sa, bx, by, bz);
         key[t] = j < n ? (((u64)__float_as_uint(d) << 32) | (unsigned)j) : ~0ull;
     }
     u64 last = 0;

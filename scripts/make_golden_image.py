@@ -1,7 +1,7 @@
 """tests/golden/image_mini.pt: PCR-CG's image-feature injection (ref:models/architectures.py:195-514) from the
 UNMODIFIED reference model (build container only).
 
-The reference KPFCNN is built with image_feature=True, in_feats_dim=129 and img_num = 2 (valid maps) / 3 (no valid maps)
+The reference KPFCNN is built with image_feature=True, in_feats_dim=129 and img_num = 1 / 2 (valid maps) / 3 (no valid maps)
 at the reduced width of the other mini fixtures and run on the `mini` pair's collate with synthetic projections: per
 cloud and image a random subset of the points (overlapping between images, so the write order matters), random pixel
 coordinates and -- for img_num = 2 -- random valid masks.  The 2-D backbone is a stand-in (a seeded 3x3 convolution to
@@ -33,7 +33,7 @@ def main():
     batch0 = col["batch"]
     n_src, n_tgt = (int(v) for v in batch0["stack_lengths"][0])
     out = {}
-    for img_num in (2, 3):
+    for img_num in (1, 2, 3):
         cfg = ref_import.indoor_config(first_feats_dim=32, gnn_feats_dim=64, image_feature=True, img_num=img_num,
                                        in_feats_dim=129)
         torch.manual_seed(10 + img_num)

@@ -55,8 +55,11 @@ def one_case(MetricLoss, cfg, seed, n_keep_corr):
     feats = torch.nn.functional.normalize(torch.randn(n, 32, generator=g), dim=1)
     # make descriptors of corresponding points similar so that recall / saliency labels are non-trivial
     c = torch.from_numpy(corr)
-    feats[len(src) + c[:, 1]] = torch.nn.functional.normalize(
-        feats[c[:, 0]] + 0.35 * torch.randn(len(c), 32, generator=g), dim=1)
+    # (one write per target row -- the first correspondence that names it: an indexed assignment through duplicate
+    # indices has no defined winner, and the fixture must regenerate bit for bit)
+    first = np.sort(np.unique(corr[:, 1], return_index=True)[1])
+    noise = torch.randn(len(c), 32, generator=g)
+    feats[len(src) + c[first, 1]] = torch.nn.functional.normalize(feats[c[first, 0]] + 0.35 * noise[first], dim=1)
     scores_overlap = torch.rand(n, generator=g) * 0.98 + 0.01
     scores_saliency = torch.rand(n, generator=g) * 0.98 + 0.01
     inputs = dict(rot=torch.from_numpy(rot), trans=torch.from_numpy(trans), src_feats=feats[:len(src)],

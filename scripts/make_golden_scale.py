@@ -11,6 +11,11 @@
   tests/golden/model_s30k_lomatch.pt  the same on the 3DLoMatch-shaped pair (configs[2]): every 97th output row, plus
                                     the reference MetricLoss's pure sub-methods on those outputs are NOT included
                                     (lib/loss.py hard-codes 'cuda' in forward; tests/golden/loss_mini.pt pins them).
+  tests/golden/model_k120k.pt       configs[4]: the reference's KITTI model (configs/test/kitti.yaml, architectures['kitti'],
+                                    seeds 0/0) on its own collate of the K120k pair 0 with limits [62,58,60,60]: every
+                                    97th output row, means, encoder column means and the kNN index rows of the coarse
+                                    clouds (the reference's get_graph_feature, ref:models/gcn.py:48-51).  model_s30k.pt
+                                    carries the same kNN rows for the S30k coarse clouds.
   tests/golden/frontend_digests.json["U30k"], ["K120k"]
                                     raw SHA-256 digests of every level and every untruncated table of the reference
                                     C++ front end for the uniform-cube pair and the KITTI-shaped pair (configs[4]).
@@ -32,10 +37,18 @@ OUT = os.path.join(REPO, "tests", "golden")
 STRIDE = 97
 
 
-def ref_forward(src, tgt, limits, corr=None, rot=None, trans=None):
+def ref_knn(coords, k=10):
+    """The index rows the reference's get_graph_feature builds (ref:models/gcn.py:48-51): its own square_distance,
+    topk(k+1) smallest, first column dropped."""
+    from models.gcn import square_distance
+    c = coords.unsqueeze(0)
+    return square_distance(c, c).topk(k=k + 1, dim=-1, largest=False, sorted=True)[1][0, :, 1:].contiguous()
+
+
+def ref_forward(src, tgt, limits, corr=None, rot=None, trans=None, cfg=None):
     from datasets.dataloader import collate_fn_descriptor
     from models.architectures import KPFCNN
-    cfg = ref_import.indoor_config()
+    cfg = ref_import.indoor_config() if cfg is None else cfg
     item = dict(rot=np.eye(3, dtype=np.float32) if rot is None else rot,
                 trans=np.zeros((3, 1), np.float32) if trans is None else trans,
                 correspondences=torch.stack([torch.arange(0, 50), torch.arange(0, 50)], 1) if corr is None else corr,
@@ -89,7 +102,10 @@ def main():
         sc = (out["scores_overlap"] * out["scores_saliency"])[:n_src]
         np.random.seed(7)
         picks = np.random.choice(np.arange(n_src), size=5000, replace=False, p=(sc / sc.sum()).numpy().flatten())
+        ns_c = int(batch["stack_lengths"][-1][0])
+        coarse = batch["points"][-1]
         torch.save({"recipe": "S30k", "seed": 0, "limits": limits, "stride": STRIDE,
+                    "knn_src": ref_knn(coarse[:ns_c]).to(torch.int32), "knn_tgt": ref_knn(coarse[ns_c:]).to(torch.int32),
                     "scores_overlap_full": out["scores_overlap"].clone(), "scores_saliency_full": out["scores_saliency"].clone(),
                     "sample_seed": 7, "sample_n": 5000, "sample_idx_src": torch.from_numpy(picks),
                     "levels": [int(p.shape[0]) for p in batch["points"]],
@@ -107,6 +123,24 @@ def main():
                    os.path.join(OUT, "model_s30k_lomatch.pt"))
         print("S30k-lomatch levels", [int(p.shape[0]) for p in batch["points"]])
 
+    if "--no-model" not in sys.argv and "--no-k120k" not in sys.argv:
+        # configs[4]: the reference's KITTI model (configs/test/kitti.yaml + architectures['kitti']) on the K120k pair
+        limits = S.LIMITS["K120k"]
+        src, tgt = S.slab_pair(120000, 0)
+        batch, out, inter = ref_forward(src, tgt, limits, cfg=ref_import.kitti_config())
+        ns_c = int(batch["stack_lengths"][-1][0])
+        coarse = batch["points"][-1]
+        torch.save({"recipe": "K120k", "seed": 0, "limits": limits, "stride": STRIDE,
+                    "levels": [int(p.shape[0]) for p in batch["points"]],
+                    "knn_src": ref_knn(coarse[:ns_c]).to(torch.int32), "knn_tgt": ref_knn(coarse[ns_c:]).to(torch.int32),
+                    "rows": {k: v[::STRIDE].clone() for k, v in out.items()},
+                    "means": {k: float(v.double().mean()) for k, v in out.items()},
+                    "absmax": {k: float(v.abs().max()) for k, v in out.items()},
+                    "enc_col_means": inter}, os.path.join(OUT, "model_k120k.pt"))
+        print("K120k levels", [int(p.shape[0]) for p in batch["points"]], {k: float(v.double().mean()) for k, v in out.items()})
+
+    if "--no-digests" in sys.argv:
+        return
     path = os.path.join(OUT, "frontend_digests.json")
     dig = json.load(open(path))
     a, b = S.uniform_pair(30000, 1.07, 0)

@@ -67,11 +67,20 @@ def setup():
     return F
 
 
-def indoor_config(**over):
+def kitti_config(**over):
+    """Flattened configs/test/kitti.yaml (ref:lib/utils.py:46-65), geometry-only like indoor_config().  The reference's
+    kitti.yaml predates PCR-CG's image branch and lacks the five keys KPFCNN.__init__ reads for it
+    (ref:models/architectures.py:48-52); they are supplied here with their "branch off" values."""
+    base = dict(img_num=0, init_mode="", node_overlap=False, quaternion=False)
+    base.update(over)
+    return indoor_config(_yaml="configs/test/kitti.yaml", **base)
+
+
+def indoor_config(_yaml="configs/test/indoor.yaml", **over):
     """Flattened configs/test/indoor.yaml (ref:lib/utils.py:46-65) with the geometry-only overrides
     named in BASELINE.json configs[0] (image_feature False, in_feats_dim 1)."""
     import yaml
-    with open(os.path.join(REF, "configs/test/indoor.yaml")) as f:
+    with open(os.path.join(REF, _yaml)) as f:
         cfg = yaml.safe_load(f)
     flat = AttrDict()
     for _, v in cfg.items():

@@ -20,7 +20,7 @@ def _to(v, dev):
     return v.to(dev) if isinstance(v, torch.Tensor) else v
 
 
-@pytest.mark.parametrize("img_num", [2, 3])
+@pytest.mark.parametrize("img_num", [1, 2, 3])
 def test_image_feature_forward_vs_reference(cuda, golden_dir, img_num):
     gold = torch.load(os.path.join(golden_dir, "image_mini.pt"))[f"img{img_num}"]
     col = torch.load(os.path.join(golden_dir, "collate_mini.pt"))["batch"]

@@ -69,8 +69,8 @@ def test_image_feature_injection_vs_reference(golden_dir, batch):
     gold = torch.load(os.path.join(golden_dir, "image_mini.pt"))
     n_src = int(batch["stack_lengths"][0][0])
     n = int(batch["points"][0].shape[0])
-    for img_num in (2, 3):
+    for img_num in (1, 2, 3):
         g = gold[f"img{img_num}"]
         x = MR.inject_image_features(n, n_src, _image_list(g["inputs"], img_num, img_num < 3))
         assert torch.equal(x[::g["x_stride"]], g["x_rows"]), img_num
-        assert int((x[:, :128] != 1).any(1).sum()) > 1500
+        assert int((x[:, :128] != 1).any(1).sum()) > (1500 if img_num > 1 else 1200)
