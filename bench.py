@@ -6,14 +6,17 @@ resident in HBM -> point pyramid (3 grid subsamplings, 10 radius searches) -> KP
 per-point descriptors / overlap / saliency.  Independent pairs shard across ranks with no data-path
 collective: weak scaling, one pair per rank per step.
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 1 --steps 20 --warmup 3 [--repeats 5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP start/stop events of every launch of the
-dominant kernel (the KPConv neighbour-gather/aggregate kernel) inside the timed region; `cpu_baseline`
-times the CPU oracle (oracle/: C front end + torch-CPU model, a restatement pinned against the
-reference) on a bounded sample on rank 0 at N=1.
+Rank 0 prints ONE JSON line.  The timed region -- exactly --steps steps between two barrier + synchronize fences,
+starting and ending with an empty engine, MAX over ranks -- is run --repeats times back to back; `value` is the MEDIAN
+region and every region's figure is listed (a 50-step region lasts ~0.1 s: one shot of it has a few percent of noise).
+`roofline` is measured live with HIP start/stop events of every launch of the dominant kernel (the KPConv
+neighbour-gather/aggregate kernel) inside those regions; `roofline.gemm` does the same for the GEMM family in one extra
+region of the same engine; `cpu_baseline` times the CPU oracle (oracle/: C front end + torch-CPU model, a restatement
+pinned against the reference) on a bounded sample on rank 0 at N=1.
 """
 import argparse
 import json
@@ -21,7 +24,7 @@ import os
 import sys
 import time
 
-# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The pipeline
+# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The pair engine
 # uses a front-end stream + three model streams (+ the default stream): with 4 queues two of them share
 # one and serialise (measured: 260 vs 338 pairs/s).  Must be set before the first HIP call.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -36,10 +39,11 @@ if REPO not in sys.path:
 from pcrcg_amd import indoor_config, kitti_config, ops, synthetic  # noqa: E402
 from pcrcg_amd.architectures import KPFCNN  # noqa: E402
 from pcrcg_amd.pairstream import PairStreams  # noqa: E402
-from pcrcg_amd.pipeline import PairPipeline  # noqa: E402
 from pcrcg_amd.sharding import pair_seeds_for_rank  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F32_TF = 157.3    # dense fp32 matrix peak (MI355X_MICROARCH.md)
+MFMA_BF16_TF = 2500.0  # dense bf16 matrix peak; the exact three-term split spends 6 bf16 products per fp32 product
 RECIPE = "S30k"       # the workload BASELINE.json's metric is quoted on (configs[1]); --workload picks a secondary one
 WORKLOADS = {
     "S30k": "S30k: 2x30000-pt shell pairs (3DMatch-shaped), indoor hyper-parameters",
@@ -124,16 +128,56 @@ def cpu_baseline(cfg, state_dict, limits):
                       f"warm worker processes"}
 
 
+def kpconv_roofline(events, cout_of):
+    """KPConv kernels bracketed by HIP events on their own stream (pcrcg_profile_kpconv): kind 0 = gather/aggregate
+    kernel of the two-stage path, 1 = one-kernel KPConv (gather + aggregate + contraction), 2 = bf16-storage gather.
+    Algorithmic bytes: SURVEY.md 8d no-reuse gather model of one KPConv call.  (Forwards are enqueued by several
+    threads, so records of different pairs interleave: the output width of a gather launch is looked up by its input
+    width, which is unique per KPConv in this architecture.)"""
+    gather = {"ms": 0.0, "bytes": 0, "n": 0}
+    fused = {"ms": 0.0, "bytes": 0, "flops": 0, "n": 0}
+    for (ms, nq, h, cin, cout, kind) in events:
+        if kind == 3:
+            continue
+        co = cout if kind == 1 else cout_of[cin]
+        d = fused if kind == 1 else gather
+        d["ms"] += ms
+        d["bytes"] += kpconv_algorithmic_bytes(nq, h, cin, co, 2 if kind == 2 else 4)
+        d["n"] += 1
+        if kind == 1:
+            d["flops"] += 2 * nq * 15 * cin * (h + co)
+    return gather, fused
+
+
+def gemm_roofline(events, pairs):
+    """Every GEMM of the split-bf16 family (kind 3 records: M, N, K, bf16 products per element), timed by its own
+    start / stop events: fp32-equivalent TFLOP/s against the fp32 matrix peak and against the split's own ceiling."""
+    ms = sum(e[0] for e in events if e[5] == 3)
+    flops = sum(2.0 * e[1] * e[2] * e[3] for e in events if e[5] == 3)
+    n = sum(1 for e in events if e[5] == 3)
+    if ms <= 0 or n == 0:
+        return None
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"launches_per_pair": round(n / max(pairs, 1), 1), "GFLOP_per_pair": round(flops / max(pairs, 1) / 1e9, 1),
+            "kernel_ms_per_pair": round(ms / max(pairs, 1), 3), "achieved_TFLOPs": round(tf, 1),
+            "frac_of_fp32_mfma_peak_%.1fTF" % MFMA_F32_TF: round(tf / MFMA_F32_TF, 4),
+            "frac_of_split_bf16_ceiling_%.0fTF" % (MFMA_BF16_TF / 6): round(tf / (MFMA_BF16_TF / 6), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps steps each, run back to back; `value` is the median region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary regions (GEMM events, one-column upsample tables, pinned-host inputs)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="S30k")
     ap.add_argument("--isolated-only", action="store_true",
-                    help="no pipeline: --steps forwards of one prepared pair on one stream, nothing else running (the "
-                         "run rocprofv3 is pointed at for the KPConv gather kernel's isolated duration and PMC traffic)")
+                    help="no engine: --steps forwards of one prepared pair on one stream, nothing else running (the "
+                         "run rocprofv3 is pointed at for the kernels' isolated durations and PMC traffic)")
     ap.add_argument("--variant", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: the bf16 feature-storage VARIANT (pcrcg_model.feature_bf16) -- a separate line with its "
                          "measured error against the fp32 path; never the headline")
@@ -170,16 +214,20 @@ def main():
     net = net.to(dev)
     BF16 = args.variant == "bf16"
     FE = 2 if BF16 else 4                 # bytes per stored feature element in the KPConv gathers
+    R = max(1, args.repeats)
 
-    # synthetic inputs, resident in HBM before the timed region; every step sees a different pair
-    total = args.warmup + args.steps
+    # synthetic inputs; every step sees a different pair (16 distinct pairs per rank, cycled).  `pool`: resident in HBM
+    # before the timed regions (the headline).  `host_pool`: the same pairs in pinned host memory, for the one extra
+    # region that uploads every pair inside the clock (PCIe-inclusive figure, never `value`).
+    total = args.warmup + args.steps * (R + 3)
     seeds = pair_seeds_for_rank(total, rank, world)
-    pool = {}
-    for s in sorted(set(seeds)):
-        src, tgt = make_pair(RECIPE, s % 16)          # 16 distinct pairs per rank, cycled
-        if s % 16 not in pool:
-            pool[s % 16] = (torch.from_numpy(np.concatenate([src, tgt])).to(dev),
-                            torch.tensor([len(src), len(tgt)], dtype=torch.int32, device=dev))
+    pool, host_pool = {}, {}
+    for s in sorted(set(x % 16 for x in seeds)):
+        src, tgt = make_pair(RECIPE, s)
+        pts = torch.from_numpy(np.concatenate([src, tgt]))
+        lens = torch.tensor([len(src), len(tgt)], dtype=torch.int32)
+        host_pool[s] = (pts.pin_memory(), lens.pin_memory())
+        pool[s] = (pts.to(dev), lens.to(dev))
 
     variant_error = None
     if BF16:
@@ -193,6 +241,10 @@ def main():
         variant_error = {k: float((o16[k] - o32[k]).abs().max() / o32[k].abs().max()) for k in o32}
         del b0, o32, o16
 
+    cout_of = {blk.KPConv.in_channels: blk.KPConv.out_channels for blk in net.encoder_blocks}
+    assert all(cout_of[blk.KPConv.in_channels] == blk.KPConv.out_channels for blk in net.encoder_blocks)
+    per_pair = len(net.encoder_blocks)
+
     if args.isolated_only:
         from pcrcg_amd.pyramid import build_pyramid
         batch_iso = build_pyramid(*pool[seeds[0] % 16], cfg, limits)
@@ -200,147 +252,155 @@ def main():
             for _ in range(args.warmup):
                 net(batch_iso)
             torch.cuda.synchronize()
-            ops.kpconv_profile_start()
+            ops.kpconv_profile_start(gemm=True)
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 net(batch_iso)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         ev = ops.kpconv_profile_stop()
-        cout_of = {blk.KPConv.in_channels: blk.KPConv.out_channels for blk in net.encoder_blocks}
-        ms = sum(e[0] for e in ev)
-        by = sum(kpconv_algorithmic_bytes(nq, h, cin, cout_of[cin], FE if kind == 2 else 4) for (_, nq, h, cin, _, kind) in ev)
+        g, f = kpconv_roofline(ev, cout_of)
+        ms, by = g["ms"] + f["ms"], g["bytes"] + f["bytes"]
         print(json.dumps({"mode": "isolated-only", "workload": RECIPE, "variant": args.variant, "forwards": args.steps,
                           "forward_ms": round(1e3 * dt / args.steps, 3),
-                          "kpconv_launches": len(ev), "kpconv_avg_launch_us": round(1e3 * ms / max(len(ev), 1), 2),
+                          "kpconv_launches": g["n"] + f["n"], "kpconv_avg_launch_us": round(1e3 * ms / max(g["n"] + f["n"], 1), 2),
                           "kpconv_algorithmic_GBs": round(by / (ms * 1e-3) / 1e9, 1),
-                          "kpconv_frac_of_hbm_peak": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}), flush=True)
+                          "kpconv_frac_of_hbm_peak": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "gemm": gemm_roofline(ev, args.steps)}), flush=True)
         return
 
-    # Pair engine (pcrcg_amd/pairstream.py): W host threads, each with its own HIP stream, take pairs round-robin;
-    # a pair is two calls into the library (pyramid builder + network runner) on the worker's stream.  Pairs are
-    # submitted up to DEPTH ahead.  The timed region starts from an EMPTY engine and ends with it empty again: all K
-    # pyramid builds and all K forwards are submitted, executed and finished inside it.
-    # PCRCG_PIPELINE=legacy selects round 1's generator-interleaving pipeline (pcrcg_amd/pipeline.py) for comparison.
-    legacy = os.environ.get("PCRCG_PIPELINE", "streams") == "legacy"
+    # Pair engine (pcrcg_amd/pairstream.py): a front thread builds pyramids on the front-end stream, WORKERS threads with
+    # one HIP stream each enqueue the forwards; pairs are submitted up to DEPTH ahead.
     WORKERS = int(os.environ.get("PCRCG_MODEL_STREAMS", "3"))
     FRONTS = int(os.environ.get("PCRCG_FRONT_THREADS", "1"))
-    DEPTH = int(os.environ.get("PCRCG_PIPE_DEPTH", "6" if not legacy else "4"))
-    if os.environ.get("PCRCG_SWITCH_US"):
-        sys.setswitchinterval(float(os.environ["PCRCG_SWITCH_US"]) * 1e-6)
-    if legacy:
-        pipe = PairPipeline(net, cfg, limits, dev, model_streams=int(os.environ.get("PCRCG_MODEL_STREAMS", "3")),
-                            front_streams=int(os.environ.get("PCRCG_FRONT_STREAMS", "1")),
-                            interleave=int(os.environ.get("PCRCG_FRONT_INTERLEAVE", "2")))
-    else:
-        pipe = PairStreams(net, cfg, limits, dev, model_streams=WORKERS, front_threads=FRONTS)
+    DEPTH = int(os.environ.get("PCRCG_PIPE_DEPTH", "6"))
+    cursor = [0]
 
-    def run_pairs(first, count):
-        """Push pairs first..first+count-1 through the pipeline, at most DEPTH in flight."""
-        out, submitted = None, 0
+    def run_pairs(pipe, count, from_host=False):
+        """Push `count` pairs through the engine, at most DEPTH in flight.  from_host: every pair is uploaded from pinned
+        host memory (two async copies on the caller's stream) inside this call."""
+        out, submitted, first = None, 0, cursor[0]
+        cursor[0] += count
         for i in range(count):
             while submitted < min(count, i + DEPTH):
-                pipe.submit(*pool[seeds[first + submitted] % 16])
+                key = seeds[(first + submitted) % len(seeds)] % 16
+                if from_host:
+                    hp, hl = host_pool[key]
+                    pipe.submit(hp.to(dev, non_blocking=True), hl.to(dev, non_blocking=True))
+                else:
+                    pipe.submit(*pool[key])
                 submitted += 1
-            out = pipe.result()
+            out = pipe.result(wait=False)         # (throughput loop: see PairStreams.result)
         return out
 
-    def fence():
+    def fence(pipe):
         pipe.drain()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    out = run_pairs(0, args.warmup)
-    fence()
-    ops.kpconv_profile_start()        # HIP events around every KPConv gather/aggregate launch from here on
-    for k in getattr(pipe, "front_stats", {}):
-        pipe.front_stats[k] = 0
-    for k in getattr(pipe, "stats", {}):
-        pipe.stats[k] = 0
-    t0 = time.perf_counter()
-    out = run_pairs(args.warmup, args.steps)
-    submit = time.perf_counter() - t0      # host time until the last forward was enqueued (GPU may still be busy)
-    fence()
-    elapsed = time.perf_counter() - t0
-    front_stats = dict(getattr(pipe, "front_stats", {}))
-    events = ops.kpconv_profile_stop()
-    assert out["feats_f"].shape[1] == cfg.final_feats_dim
+    def region(pipe, from_host=False):
+        """EXACTLY --steps steps from an empty engine to an empty engine; -> seconds (MAX over ranks), submit seconds."""
+        fence(pipe)
+        t0 = time.perf_counter()
+        out = run_pairs(pipe, args.steps, from_host)
+        submit = time.perf_counter() - t0      # host time until the last forward was enqueued (GPU may still be busy)
+        fence(pipe)
+        elapsed = time.perf_counter() - t0
+        assert out["feats_f"].shape[1] == cfg.final_feats_dim
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), submit
 
-    # the same kernels once more WITHOUT any concurrent stream: the roofline of the gather kernel in isolation
-    iso = None
+    # ---- headline: the reference's batch contract inside the engine too (full [N, limit] upsample tables) ----------
+    pipe = PairStreams(net, cfg, limits, dev, model_streams=WORKERS, front_threads=FRONTS, up_nearest=False)
+    run_pairs(pipe, args.warmup)
+    fence(pipe)
+    pipe.reset_stats()
+    ops.kpconv_profile_start()        # HIP events around every KPConv gather/aggregate launch from here on
+    regions = [region(pipe) for _ in range(R)]
+    events = ops.kpconv_profile_stop()
+    stats = pipe.stats_snapshot()
+    times = sorted(r[0] for r in regions)
+    elapsed = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
+    submit = sorted(r[1] for r in regions)[len(regions) // 2]
+
+    extras = {}
+    gemm_engine = gemm_iso = iso = None
+    if not args.no_extras:
+        # (a) the GEMM family inside the engine: one more region with start / stop events on every GEMM launch as well
+        ops.kpconv_profile_start(gemm=True)
+        t_g, _ = region(pipe)
+        gemm_engine = gemm_roofline(ops.kpconv_profile_stop(), args.steps)
+        if gemm_engine:
+            gemm_engine["pairs_per_s_of_this_region"] = round(args.steps * world / t_g, 1)
+        # (b) inputs in pinned host memory, uploaded inside the clock (SURVEY.md 8d's hand-over; PCIe-inclusive)
+        t_h, _ = region(pipe, from_host=True)
+        extras["pinned_host_inputs"] = {"value": round(args.steps * world / t_h, 3), "unit": "fragment-pairs/s",
+                                        "note": "one region; every pair's points + lengths (720 KB) copied from pinned host "
+                                                "memory inside the timed region; reported beside `value`, never as it"}
+    # the same kernels once more WITHOUT any concurrent stream: the kernels in isolation
     if rank == 0:
         from pcrcg_amd.pyramid import build_pyramid
         batch_iso = build_pyramid(*pool[seeds[0] % 16], cfg, limits)
         pipe.synchronize()
-        ops.kpconv_profile_start()
+        ops.kpconv_profile_start(gemm=True)
         with torch.no_grad():
             for _ in range(3):
                 net(batch_iso)
         torch.cuda.synchronize()
         iso = ops.kpconv_profile_stop()
-    if os.environ.get("PCRCG_PIPE_STATS") and rank == 0 and hasattr(pipe, "stats"):
-        n = max(pipe.stats["pairs"], 1)
-        print("pair engine, host ms per pair: " + ", ".join("%s %.3f" % (k[:-2], 1e3 * v / n) for k, v in pipe.stats.items()
+        gemm_iso = gemm_roofline(iso, 3)
+        iso = [e for e in iso if e[5] != 3]
+    if os.environ.get("PCRCG_PIPE_STATS") and rank == 0:
+        n = max(stats["pairs"], 1)
+        print("pair engine, host ms per pair: " + ", ".join("%s %.3f" % (k[:-2], 1e3 * v / n) for k, v in stats.items()
                                                             if k not in ("pairs", "builds"))
-              + "; %.2f pairs per build" % (n / max(pipe.stats.get("builds", n), 1)), file=sys.stderr, flush=True)
-    elif os.environ.get("PCRCG_PIPE_STATS") and rank == 0:
-        st = front_stats
-        n = max(st.get("pairs", 1), 1)
-        print("front-end worker per pair: advance (python + launches) %.3f ms, waiting for round trips %.3f ms, idle (no "
-              "request) %.3f ms; %d of %d resumes found their value already there" % (
-                  1e3 * st.get("advance_s", 0) / n, 1e3 * st.get("wait_s", 0) / n, 1e3 * st.get("idle_s", 0) / n,
-                  st.get("resumed_ready", 0), st.get("resumes", 0)), file=sys.stderr, flush=True)
+              + "; %.2f pairs per build" % (n / max(stats.get("builds", n), 1)), file=sys.stderr, flush=True)
     pipe.close()
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    if not args.no_extras:
+        # (c) the engine with ONE-column upsample tables (the nearest coarse point is all KPFCNN.forward reads of them,
+        # ref:models/blocks.py:77-87): not the batch contract, so not the headline
+        pipe1 = PairStreams(net, cfg, limits, dev, model_streams=WORKERS, front_threads=FRONTS, up_nearest=True)
+        run_pairs(pipe1, args.warmup)
+        t_u = sorted(region(pipe1)[0] for _ in range(min(R, 3)))
+        extras["one_column_upsample_tables"] = {"value": round(args.steps * world / t_u[len(t_u) // 2], 3),
+                                                "unit": "fragment-pairs/s", "regions": len(t_u)}
+        pipe1.close()
 
     if rank == 0:
-        # KPConv kernels bracketed by HIP events on their own stream (pcrcg_profile_kpconv): kind 0 =
-        # gather/aggregate kernel of the two-stage path, kind 1 = fused gather+aggregate+contraction kernel.
-        # Algorithmic bytes: SURVEY.md 8d no-reuse gather model of one KPConv call.
-        # (forwards are enqueued by several threads, so records of different pairs interleave: the output width
-        # of a launch is looked up by its input width, which is unique per KPConv in this architecture)
-        couts = [blk.KPConv.out_channels for blk in net.encoder_blocks]
-        cout_of = {blk.KPConv.in_channels: blk.KPConv.out_channels for blk in net.encoder_blocks}
-        assert all(cout_of[blk.KPConv.in_channels] == blk.KPConv.out_channels for blk in net.encoder_blocks)
-        gather = {"ms": 0.0, "bytes": 0, "n": 0}
-        fused = {"ms": 0.0, "bytes": 0, "flops": 0, "n": 0}
-        per_pair = len(couts)
-        for i, (ms, nq, h, cin, cout, kind) in enumerate(events):
-            co = cout if kind == 1 else cout_of[cin]
-            d = fused if kind == 1 else gather
-            d["ms"] += ms
-            d["bytes"] += kpconv_algorithmic_bytes(nq, h, cin, co, 2 if kind == 2 else 4)
-            d["n"] += 1
-            if kind == 1:
-                d["flops"] += 2 * nq * 15 * cin * (h + co)
+        gather, fused = kpconv_roofline(events, cout_of)
         k_bytes = gather["bytes"] + fused["bytes"]
         k_ms = gather["ms"] + fused["ms"]
+        n_launch = gather["n"] + fused["n"]
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         g_gbs = gather["bytes"] / (gather["ms"] * 1e-3) / 1e9 if gather["ms"] > 0 else 0.0
         f_gbs = fused["bytes"] / (fused["ms"] * 1e-3) / 1e9 if fused["ms"] > 0 else 0.0
         f_tf = fused["flops"] / (fused["ms"] * 1e-3) / 1e12 if fused["ms"] > 0 else 0.0
-        iso_ms = sum(e[0] for e in iso)
-        iso_bytes = sum(kpconv_algorithmic_bytes(nq, h, cin, cout_of[cin], 2 if kind == 2 else 4)
-                        for (_, nq, h, cin, _, kind) in iso)
+        ig, if_ = kpconv_roofline(iso, cout_of)
+        iso_ms, iso_bytes = ig["ms"] + if_["ms"], ig["bytes"] + if_["bytes"]
         iso_gbs = iso_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
         iso_rows = []                        # the last isolated forward, launch by launch
-        for i, (ms, nq, h, cin, _, kind) in enumerate(iso[-per_pair:]):
-            b = kpconv_algorithmic_bytes(nq, h, cin, cout_of[cin], 2 if kind == 2 else 4)
-            iso_rows.append({"nq": nq, "h": h, "cin": cin, "cout": cout_of[cin], "us": round(ms * 1e3, 1),
+        for (ms, nq, h, cin, cout, kind) in iso[-per_pair:]:
+            co = cout if kind == 1 else cout_of[cin]
+            b = kpconv_algorithmic_bytes(nq, h, cin, co, 2 if kind == 2 else 4)
+            iso_rows.append({"nq": nq, "h": h, "cin": cin, "cout": co, "kind": kind, "us": round(ms * 1e3, 1),
                              "GBs": round(b / (ms * 1e-3) / 1e9, 0) if ms > 0 else None})
         # `traffic` (HBM bytes per launch from PMC counters) cannot be collected by this process: rocprofv3 --pmc needs
         # its own passes.  The live line says null; the figure of the committed separate passes is quoted with its source.
         traffic, traffic_offline = None, None
-        pmc_path = os.path.join(REPO, "profiles", "r02_pmc_kpconv.json")
-        if os.path.exists(pmc_path):
-            traffic_offline = {"hbm_bytes_per_launch": json.load(open(pmc_path)).get("hbm_bytes_per_launch"),
-                               "source": "profiles/r02_pmc_kpconv.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                         "`bench.py --isolated-only`, corrected as MI355X_MICROARCH.md prescribes; NOT measured by this run"}
+        for name in ("r03_pmc_kpconv.json", "r02_pmc_kpconv.json"):
+            pmc_path = os.path.join(REPO, "profiles", name)
+            if os.path.exists(pmc_path):
+                traffic_offline = {"hbm_bytes_per_launch": json.load(open(pmc_path)).get("hbm_bytes_per_launch"),
+                                   "source": f"profiles/{name}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                             "`bench.py --isolated-only`, corrected as MI355X_MICROARCH.md prescribes; NOT measured by this run"}
+                break
+        from pcrcg_amd import _lib
+        lib_path, lib_sha = _lib.lib_identity()
+        ppb = stats["pairs"] / max(stats.get("builds", 1), 1)
+        tie = os.environ.get("PCRCG_TIE_ORDER", "auto")
         line = {
             "metric": ("fragment-pairs/s KPFCNN+GCN fwd, 30k-pt pairs" if RECIPE == "S30k"
                        else f"fragment-pairs/s KPFCNN+GCN fwd, {RECIPE} pairs (secondary workload)")
@@ -357,47 +417,56 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16 feature storage in the KPConv gathers, f32 weights / accumulation / outputs" if BF16 else "f32",
             "data": "synthetic",
-            "config": {"workload": WORKLOADS[RECIPE] + ", pyramid build + KPFCNN+GCN "
-                                   "forward, random-init full-width weights, 1 pair/GPU/step; "
-                                   + ("round-1 pipeline (front-end thread + 3 model streams); " if legacy else
-                                      "%d host threads build pyramids (pcrcg_pyramid_build, one call per pair) on one front-end "
-                                      "HIP stream, %d host threads enqueue the forwards (pcrcg_kpfcnn_forward) on one model "
-                                      "stream each; " % (FRONTS, WORKERS)) +
-                                   "the timed region starts and ends with an empty engine; neighbour tables in the "
-                                   "reference's own order inside groups of exactly equal distance (tie_order=%s); "
-                                   "GEMM arithmetic mode %d (1 = exact three-term bf16 split on the bf16 matrix cores, "
-                                   "fp32-class accuracy; 0 = fp32 MFMA)" % (os.environ.get("PCRCG_TIE_ORDER", "auto"),
-                                                                            _gemm_mode()),
-                       "tie_order": os.environ.get("PCRCG_TIE_ORDER", "auto"),
-                       "limits": limits, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
+            "repeats": {"regions": R, "steps_per_region": args.steps, "statistic": "median",
+                        "pairs_per_s": [round(args.steps * world / r[0], 1) for r in regions],
+                        "min": round(args.steps * world / max(times), 1), "max": round(args.steps * world / min(times), 1)},
+            "config": {"workload": WORKLOADS[RECIPE] + ", pyramid build + KPFCNN+GCN forward, random-init full-width weights, "
+                                   "1 pair/GPU/step, inputs resident in HBM; pair engine: %d front thread(s) build pyramids "
+                                   "(pcrcg_pyramid_build, %.2f pairs per call on average: two waiting pairs share one kernel "
+                                   "chain) on one front-end HIP stream, %d host threads enqueue the forwards "
+                                   "(pcrcg_kpfcnn_forward) on one model stream each; every table as the batch contract "
+                                   "defines it ([N, limit] upsample tables included); every timed region starts and ends "
+                                   "with an empty engine; neighbour tables in the reference's own order inside groups of "
+                                   "exactly equal distance (tie_order=%s); GEMM arithmetic mode %d (1 = exact three-term "
+                                   "bf16 split on the bf16 matrix cores, fp32-class accuracy; 0 = fp32 MFMA)"
+                                   % (FRONTS, ppb, WORKERS, tie, _gemm_mode()),
+                       "tie_order": tie, "up_nearest": 0, "pairs_per_pyramid_build": round(ppb, 2),
+                       "limits": limits, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
+                       "lib_path": os.path.relpath(lib_path, REPO), "lib_sha16": lib_sha},
+            "secondary": extras,
             "roofline": {"bound": "hbm", "kernel": "KPConv neighbour-gather kernels (k_kpconv_mfma / k_kpconv_c1 / "
-                                                     "k_kpconv_fused), %d launches/pair" % per_pair,
+                                                     "one-kernel KPConv), %d launches/pair" % per_pair,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_offline": traffic_offline,
-                         "avg_launch_us": round(k_ms * 1e3 / max(len(events), 1), 2),
-                         "algorithmic_bytes_per_pair": int(k_bytes / max(args.steps, 1)),
+                         "avg_launch_us": round(k_ms * 1e3 / max(n_launch, 1), 2),
+                         "algorithmic_bytes_per_pair": int(k_bytes / max(args.steps * R, 1)),
                          "note": "durations are the kernels' own start/stop events (hipExtLaunchKernel); achieved/frac "
-                                 "are measured inside the timed region, where several HIP streams share the GPU; `isolated` is the same 11 launches run alone right after it",
+                                 "are measured inside the timed regions, where several HIP streams share the GPU; `isolated` "
+                                 "is the same launches run alone right after them",
                          "isolated": {"achieved": round(iso_gbs, 1), "frac": round(iso_gbs / HBM_PEAK_GBS, 4),
                                       "avg_launch_us": round(iso_ms * 1e3 / max(len(iso), 1), 2),
                                       "per_launch": iso_rows},
-                         "gather_only_kernels": {"launches_per_pair": gather["n"] // max(args.steps, 1),
+                         "gather_only_kernels": {"launches_per_pair": gather["n"] // max(args.steps * R, 1),
                                                  "achieved_GBs": round(g_gbs, 1),
                                                  "frac": round(g_gbs / HBM_PEAK_GBS, 4)},
-                         "fused_kernels": {"launches_per_pair": fused["n"] // max(args.steps, 1),
+                         "fused_kernels": {"launches_per_pair": fused["n"] // max(args.steps * R, 1),
                                            "achieved_GBs": round(f_gbs, 1), "frac_hbm": round(f_gbs / HBM_PEAK_GBS, 4),
                                            "achieved_TFLOPs_f32_mfma": round(f_tf, 1),
-                                           "frac_mfma_f32_157TF": round(f_tf / 157.3, 4)}},
+                                           "frac_mfma_f32_157TF": round(f_tf / MFMA_F32_TF, 4)},
+                         "gemm": {"bound": "mfma", "kernel": "k_gemm_x6 family (every C = A * B^T product of the forward)",
+                                  "unit": "TFLOP/s (fp32-equivalent: 2*M*N*K per launch)",
+                                  "in_engine": gemm_engine, "isolated": gemm_iso,
+                                  "note": "in_engine: one extra region of the same engine with start/stop events on every "
+                                          "GEMM launch as well; isolated: three forwards alone on one stream"}},
         }
-        if hasattr(pipe, "stats") and pipe.stats.get("pairs"):
-            n = pipe.stats["pairs"]
-            line["host"] = {"note": "host_submit_ms_per_step is the main thread's time until the last pair is accepted; it blocks on "
-                                    "the engine's depth limit, so it tracks GPU throughput.  The engine threads' own times, ms "
-                                    "per pair over the whole run (warm-up included): inside pcrcg_pyramid_build (enqueue + its "
-                                    "four host round trips) / enqueueing the restore step + pcrcg_kpfcnn_forward",
-                            "front_thread_build_ms_per_pair": round(1e3 * pipe.stats["build_s"] / n, 3),
-                            "model_threads_enqueue_ms_per_pair": round(1e3 * pipe.stats["launch_s"] / n, 3),
-                            "pairs_per_pyramid_build": round(n / max(pipe.stats.get("builds", n), 1), 2)}
+        n = max(stats["pairs"], 1)
+        line["host"] = {"note": "host_submit_ms_per_step is the main thread's time until the last pair is accepted; it blocks on "
+                                "the engine's depth limit, so it tracks GPU throughput.  The engine threads' own times, ms "
+                                "per pair over the timed regions: inside pcrcg_pyramid_build (enqueue + its host round "
+                                "trips) / enqueueing the restore step + pcrcg_kpfcnn_forward",
+                        "front_thread_build_ms_per_pair": round(1e3 * stats["build_s"] / n, 3),
+                        "model_threads_enqueue_ms_per_pair": round(1e3 * stats["launch_s"] / n, 3),
+                        "pairs_per_pyramid_build": round(ppb, 2)}
         if BF16:
             line["variant"] = {"name": "bf16 feature storage", "max_abs_error_over_max_abs_vs_fp32_path": variant_error,
                                "note": "outside the 1e-4 parity bound of the fp32 path by construction; "

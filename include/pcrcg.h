@@ -211,6 +211,8 @@ int pcrcg_kpconv_x6(const float* q_pts, int nq, const float* s_pts, int ns, cons
  * are launched with HIP start / stop events (hipExtLaunchKernel) on their own stream, i.e. the kernel's own
  * execution time as rocprofv3 reports it, excluding the time its dispatch waited behind other streams; _read
  * waits for them and returns up to `cap` records (milliseconds, nq / h / cin of the launch, cout for kind 1).
+ * `enable` is a bit mask: 1 = the KPConv kernels (kinds 0, 1, 2 = bf16-storage gather), 2 = every GEMM of the
+ * split-bf16 family (kind 3: nq = M, h = N, cin = K, cout = bf16 matrix products per element, 6 or 3), 0 = off.
  * Safe to call from several host threads; off by default. */
 void pcrcg_profile_kpconv(int enable);
 int pcrcg_profile_kpconv_read(float* ms, int* nq, int* h, int* cin, int* cout, int* kind, int cap);

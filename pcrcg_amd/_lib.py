@@ -7,8 +7,16 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PCRCG_LIB: another build of the same ABI (scripts/knockout.py); the default is the in-tree library
-LIB_PATH = os.environ.get("PCRCG_LIB") or os.path.join(_HERE, "libpcrcg_hip.so")
+# Always the in-tree library.  (scripts/knockout.py, a measurement aid, assigns LIB_PATH before the first call to load
+# its instrumented build; no environment variable can redirect the product.)
+LIB_PATH = os.path.join(_HERE, "libpcrcg_hip.so")
+
+
+def lib_identity():
+    """(path, first 16 hex digits of the SHA-256) of the shared library that is loaded -- bench.py records both."""
+    import hashlib
+    with open(LIB_PATH, "rb") as f:
+        return LIB_PATH, hashlib.sha256(f.read()).hexdigest()[:16]
 
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 

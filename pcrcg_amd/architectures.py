@@ -147,7 +147,7 @@ class KPFCNN(nn.Module):
 
     def runner(self):
         """The (lazily created) descriptor cache of the C++ runner; creation is serialised because forwards may
-        be enqueued from several host threads (pcrcg_amd/pipeline.py)."""
+        be enqueued from several host threads (pcrcg_amd/pairstream.py)."""
         if self._runner is None:
             with _RUNNER_LOCK:
                 if self._runner is None:

@@ -77,7 +77,8 @@ int kpconv_aggregate_bf16(const float* q_pts, int nq, const float* s_pts, int ns
 // Optional start / stop events of a KPConv kernel (bench.py roofline); see pcrcg_profile_kpconv in
 // include/pcrcg.h.  The events are handed to hipExtLaunchKernelGGL, so they stamp the kernel's own begin and
 // end (what rocprofv3 reports), not the time its dispatch waited behind other streams.  a/b are NULL when
-// profiling is off (a plain launch).  kind 0 = gather/aggregate kernel, 1 = fused kernel.
+// profiling is off (a plain launch).  kind 0 = gather/aggregate kernel, 1 = fused kernel, 2 = bf16-storage gather kernel,
+// 3 = a GEMM of the k_gemm_x6 family (nq = M, h = N, cin = K, cout = bf16 products per element: 6, or 3 with a bf16 A).
 struct KpProfScope {
     hipStream_t st;
     hipEvent_t a, b;

@@ -395,6 +395,8 @@ int gemm_bf16a_bt_colstats(const void* a_bf16, int lda, const float* b, int ldb,
     PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 32 && k % 32 == 0 && lda >= k && lda % 8 == 0 && ldb >= k && ldc >= n);
     if (m == 0 || n == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(a_bf16 && b && c && (reinterpret_cast<uintptr_t>(a_bf16) & 15) == 0);
+    // the bf16-A kernel has no guarded A loads: every k-step must take the vector path, which also needs B aligned
+    PCRCG_CHECK_ARG(ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0);
     return gemm_x6_dispatch(static_cast<const float*>(a_bf16), lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats,
                             colstats_bytes, h_chunks, st, true, c_zeroed, 0, 0, colstats_sums);
 }

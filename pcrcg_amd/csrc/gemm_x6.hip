@@ -25,6 +25,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "pcrcg_train.h"
 
@@ -488,9 +490,10 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split,
-                       vec_a, vec_b, atomic_out, colp, colp_chunks, a_idx, a_idx_ld, a_ns, a_zero, a_sums, a_count, a_eps,
-                       a_slope);
+    KpProfScope prof(st, m, n, k, ATERMS == 1 ? 3 : 6, 3);     // bench.py's GEMM roofline: the kernel's own start / stop events
+    hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, st, prof.a, prof.b, 0, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
+                          k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks, a_idx, a_idx_ld, a_ns, a_zero, a_sums,
+                          a_count, a_eps, a_slope);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

@@ -41,15 +41,169 @@ __device__ __forceinline__ float knn_dist(float ax, float ay, float az, float sa
     return fmaxf(d, 1e-12f);                          // clamp :33
 }
 
+// ---- torch.topk's order among EXACTLY equal distances -------------------------------------------------------------
+// The reference takes `dist.topk(k+1, largest=False, sorted=True)` (ref:models/gcn.py:49).  With the ill-conditioned
+// distance above, equal fp32 values are common on large coordinates (K120k: ~1 % of the rows hold one among their k+2
+// smallest), and which of them survive the cut is decided by PyTorch's CPU kernel: (value, index) pairs through
+// std::partial_sort when (k+1)*64 <= n, else std::nth_element + std::sort of the first k (libstdc++; comparator on the
+// value alone).  Five such rows moved 4 % of the K120k pair's output rows by more than 1e-4.  A row whose k+2 smallest
+// distances are all different has ONE answer and comes from the rank selection below; a row that holds a tie replays
+// the library algorithms step by step (restated in oracle/topk_replay.py, pinned there against torch.topk itself).
+// The replay is written as sequential code that all 64 lanes of the row's wavefront execute redundantly on a
+// wavefront-private LDS array (identical writes to identical addresses); only the scan of __heap_select is spread
+// over the lanes.  Keys: (distance bits << 32) | index; distances are > 0, so the bit patterns order like the values.
+#define KNN_RB_MAX 704                     // regime B (nth_element) holds the whole row: n < 64 * (k + 1) <= 704
+#define KNN_K_MAX 10
+__device__ __forceinline__ bool kless(u64 x, u64 y) { return (x >> 32) < (y >> 32); }
+
+__device__ void rp_adjust_heap(u64* a, int hole, int len, u64 value) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (kless(a[child], a[child - 1])) --child;
+        a[hole] = a[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        a[hole] = a[child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;           // __push_heap
+    while (hole > top && kless(a[parent], value)) {
+        a[hole] = a[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a[hole] = value;
+}
+__device__ void rp_make_heap(u64* a, int len) {
+    if (len < 2) return;
+    for (int parent = (len - 2) / 2;; --parent) {
+        rp_adjust_heap(a, parent, len, a[parent]);
+        if (parent == 0) return;
+    }
+}
+__device__ void rp_sort_heap(u64* a, int len) {
+    while (len > 1) {
+        --len;
+        const u64 value = a[len];
+        a[len] = a[0];
+        rp_adjust_heap(a, 0, len, value);
+    }
+}
+__device__ void rp_insertion_sort(u64* a, int first, int last) {
+    for (int i = first + 1; i < last; ++i) {
+        const u64 v = a[i];
+        if (kless(v, a[first])) {
+            for (int j = i; j > first; --j) a[j] = a[j - 1];
+            a[first] = v;
+        } else {
+            int j = i;
+            while (kless(v, a[j - 1])) {
+                a[j] = a[j - 1];
+                --j;
+            }
+            a[j] = v;
+        }
+    }
+}
+__device__ int rp_partition_pivot(u64* a, int first, int last) {
+    const int mid = first + (last - first) / 2;
+    const int x = first + 1, y = mid, z = last - 1;
+    int pick;                               // __move_median_to_first
+    if (kless(a[x], a[y])) pick = kless(a[y], a[z]) ? y : (kless(a[x], a[z]) ? z : x);
+    else pick = kless(a[x], a[z]) ? x : (kless(a[y], a[z]) ? z : y);
+    u64 t = a[first];
+    a[first] = a[pick];
+    a[pick] = t;
+    int lo = first + 1, hi = last;
+    const u64 pivot = a[first];
+    for (;;) {                              // __unguarded_partition
+        while (kless(a[lo], pivot)) ++lo;
+        --hi;
+        while (kless(pivot, a[hi])) --hi;
+        if (!(lo < hi)) return lo;
+        t = a[lo];
+        a[lo] = a[hi];
+        a[hi] = t;
+        ++lo;
+    }
+}
+// one row: writes the k indices torch.topk(k+1 smallest, sorted)[1:] holds on the CPU.  `a`: KNN_RB_MAX keys of LDS
+// private to this wavefront.
+__device__ void knn_replay_row(const float* __restrict__ coords, int n, int i, int k, u64* a, int* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int K = k + 1;
+    const float ax = coords[3 * (long)i], ay = coords[3 * (long)i + 1], az = coords[3 * (long)i + 2];
+    const float sa = knn_sq(ax, ay, az);
+    auto key_of = [&](int j) -> u64 {
+        const float d = knn_dist(ax, ay, az, sa, coords[3 * (long)j], coords[3 * (long)j + 1], coords[3 * (long)j + 2]);
+        return ((u64)__float_as_uint(d) << 32) | (unsigned)j;
+    };
+    if (K * 64 <= n) {
+        // std::partial_sort = __heap_select + __sort_heap; the heap is a[0..K)
+        if (lane < K) a[lane] = key_of(lane);
+        rp_make_heap(a, K);
+        for (int base = K; base < n; base += 64) {
+            const int j = base + lane;
+            const u64 kj = j < n ? key_of(j) : ~0ull;
+            u64 m = __ballot(kless(kj, a[0]));
+            while (m) {                     // candidates in index order; the heap's top changes with every pop
+                const int l = __ffsll((long long)m) - 1;
+                const u64 value = __shfl(kj, l, 64);
+                rp_adjust_heap(a, 0, K, value);           // __pop_heap(first, middle, i): the old top leaves
+                m = __ballot(kless(kj, a[0])) & ~((2ull << l) - 1ull);
+            }
+        }
+        rp_sort_heap(a, K);
+    } else {
+        // std::nth_element(begin, begin + K - 1, end) + std::sort(begin, begin + K - 1)
+        for (int j = lane; j < n; j += 64) a[j] = key_of(j);
+        int first = 0, last = n;
+        const int nth = K - 1;
+        int depth = 2 * (31 - __clz(n));
+        bool done = false;
+        while (last - first > 3) {
+            if (depth == 0) {               // __heap_select(first, nth + 1, last) + iter_swap(first, nth)
+                u64* h = a + first;
+                const int hl = nth + 1 - first;
+                rp_make_heap(h, hl);
+                for (int j = nth + 1; j < last; ++j)
+                    if (kless(a[j], h[0])) {
+                        const u64 value = a[j];
+                        a[j] = h[0];
+                        rp_adjust_heap(h, 0, hl, value);
+                    }
+                const u64 t = a[first];
+                a[first] = a[nth];
+                a[nth] = t;
+                done = true;
+                break;
+            }
+            --depth;
+            const int cut = rp_partition_pivot(a, first, last);
+            if (cut <= nth) first = cut;
+            else last = cut;
+        }
+        if (!done) rp_insertion_sort(a, first, last);
+        rp_insertion_sort(a, 0, K - 1);     // std::sort of K - 1 <= 16 elements is its final insertion sort alone
+    }
+    if (lane >= 1 && lane < K) out[lane - 1] = (int)(a[lane] & 0xFFFFFFFFull);
+}
+
 __global__ void __launch_bounds__(256) k_knn(const float* __restrict__ coords, int n, int k, int* __restrict__ idx) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const float ax = coords[3 * (long)i], ay = coords[3 * (long)i + 1], az = coords[3 * (long)i + 2];
     const float sa = knn_sq(ax, ay, az);
+    __shared__ u64 s_q[4][KNN_RB_MAX];
     u64 last = 0;
     bool have_last = false;
-    for (int round = 0; round <= k; ++round) {
+    bool tie = false;
+    for (int round = 0; round <= k + 1; ++round) {      // one round past the cut: is the cut inside a tie group?
         u64 best = ~0ull;
         for (int j = lane; j < n; j += 64) {
             const float bx = coords[3 * (long)j], by = coords[3 * (long)j + 1], bz = coords[3 * (long)j + 2];
@@ -62,11 +216,14 @@ __global__ void __launch_bounds__(256) k_knn(const float* __restrict__ coords, i
             const u64 o = __shfl_xor(best, s, 64);
             best = o < best ? o : best;
         }
+        tie |= have_last && best != ~0ull && (best >> 32) == (last >> 32);
         last = best;
         have_last = true;
         // topk(k+1) sorted ascending, first dropped (:48-49)
-        if (round >= 1 && lane == 0) idx[(long)i * k + (round - 1)] = best == ~0ull ? i : (int)(best & 0xFFFFFFFFull);
+        if (round >= 1 && round <= k && lane == 0)
+            idx[(long)i * k + (round - 1)] = best == ~0ull ? i : (int)(best & 0xFFFFFFFFull);
     }
+    if (tie && n > k && k <= KNN_K_MAX) knn_replay_row(coords, n, i, k, s_q[threadIdx.x >> 6], idx + (long)i * k);
 }
 
 // The same selection with the candidate keys of a query kept in registers (n <= 64 * PER): the distances are formed
@@ -88,8 +245,10 @@ __global__ void __launch_bounds__(256) k_knn_reg(const float* __restrict__ coord
         float d = knn_dist(ax, ay, az, sa, bx, by, bz);
         key[t] = j < n ? (((u64)__float_as_uint(d) << 32) | (unsigned)j) : ~0ull;
     }
+    __shared__ u64 s_q[4][KNN_RB_MAX];
     u64 last = 0;
-    for (int round = 0; round <= k; ++round) {
+    bool tie = false;
+    for (int round = 0; round <= k + 1; ++round) {      // one round past the cut: is the cut inside a tie group?
         u64 best = ~0ull;
 #pragma unroll
         for (int t = 0; t < PER; ++t)
@@ -99,9 +258,12 @@ __global__ void __launch_bounds__(256) k_knn_reg(const float* __restrict__ coord
             const u64 o = __shfl_xor(best, s, 64);
             best = o < best ? o : best;
         }
+        tie |= round > 0 && best != ~0ull && (best >> 32) == (last >> 32);
         last = best;
-        if (round >= 1 && lane == 0) idx[(long)i * k + (round - 1)] = best == ~0ull ? i : (int)(best & 0xFFFFFFFFull);
+        if (round >= 1 && round <= k && lane == 0)
+            idx[(long)i * k + (round - 1)] = best == ~0ull ? i : (int)(best & 0xFFFFFFFFull);
     }
+    if (tie && n > k && k <= KNN_K_MAX) knn_replay_row(coords, n, i, k, s_q[threadIdx.x >> 6], idx + (long)i * k);
 }
 
 template <bool ATOMIC>      // ATOMIC: the chunk's sums are added into zeroed [2][c] accumulators instead of stored as partials

@@ -33,12 +33,13 @@ namespace pcrcg {
 
 // optional HIP-event timing of every KPConv launch (bench.py roofline)
 struct ProfRec { hipEvent_t a, b; int nq, h, cin, cout, kind; };
-static bool g_prof_on = false;
+static int g_prof_on = 0;         // bit 0: KPConv kernels (kinds 0-2), bit 1: the GEMM family (kind 3)
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;   // forwards may be enqueued from several host threads
 
 KpProfScope::KpProfScope(hipStream_t s, int nq_, int h_, int cin_, int cout_, int kind_)
-    : st(s), a(nullptr), b(nullptr), nq(nq_), h(h_), cin(cin_), cout(cout_), kind(kind_), on(g_prof_on) {
+    : st(s), a(nullptr), b(nullptr), nq(nq_), h(h_), cin(cin_), cout(cout_), kind(kind_),
+      on((g_prof_on & (kind_ == 3 ? 2 : 1)) != 0) {
     if (!on) return;
     (void)hipEventCreate(&a);
     (void)hipEventCreate(&b);
@@ -371,7 +372,7 @@ void pcrcg_profile_kpconv(int enable) {
     std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
-    g_prof_on = enable != 0;
+    g_prof_on = enable;
 }
 
 int pcrcg_profile_kpconv_read(float* ms, int* nq, int* h, int* cin, int* cout, int* kind, int cap) {

@@ -57,14 +57,16 @@ class _Workspaces:
 
 _ws = _Workspaces()
 
-def kpconv_profile_start():
-    """Bracket every KPConv gather/aggregate launch with HIP events (on the launching stream)."""
-    _lib.lib().pcrcg_profile_kpconv(1)
+def kpconv_profile_start(gemm=False):
+    """Bracket every KPConv gather/aggregate launch -- with gemm=True also every GEMM of the split-bf16 family -- with
+    HIP start / stop events (on the launching stream)."""
+    _lib.lib().pcrcg_profile_kpconv(3 if gemm else 1)
 
 
 def kpconv_profile_stop(cap=1 << 16):
     """-> list of (milliseconds, nq, h, cin, cout, kind) per KPConv kernel launch since
-    kpconv_profile_start(); kind 0 = gather/aggregate kernel (cout unknown: 0), 1 = fused kernel."""
+    kpconv_profile_start(); kind 0 = gather/aggregate kernel (cout unknown: 0), 1 = fused kernel, 2 = bf16-storage
+    gather kernel, 3 = GEMM (then the fields are M, N, K, bf16 products per element)."""
     import ctypes
     L = _lib.lib()
     ms = (ctypes.c_float * cap)()

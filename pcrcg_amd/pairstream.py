@@ -14,7 +14,7 @@ libpcrcg_hip.so that releases the GIL.
 
 One event per pair hands the finished tables from the front-end stream to a model stream; the arena holding them
 goes back to its front thread's ring once the forward has passed.  Pairs are independent, so nothing
-else crosses streams.  This replaces the generator-interleaving pipeline of pcrcg_amd/pipeline.py, whose front-end
+else crosses streams.  This replaced round 1's generator-interleaving pipeline, whose front-end
 worker spent 1.7 ms of interpreter time per pair.
 
     eng = PairStreams(net, config, limits, device)
@@ -54,7 +54,11 @@ class PairStreams:
     ARENAS = 4        # per front thread: pairs whose tables may be alive at once (built, forward not yet passed)
 
     def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=1, tie_order=None,
-                 pairs_per_build=2):
+                 pairs_per_build=2, up_nearest=False):
+        """up_nearest: the engine's internal pyramids carry ONE-column upsample tables (the nearest coarse point: the only
+        column KPFCNN.forward reads, ref:models/blocks.py:77-87) instead of the batch contract's [N, limit] tables:
+        ~1 % less front-end work, same outputs.  Off by default: the tables are then exactly what build_pyramid()
+        hands to any other consumer."""
         self.net, self.config, self.limits = net, config, neighborhood_limits
         self.device = torch.device(device if device is not None else "cuda")
         if not getattr(net, "use_runner", False):
@@ -75,8 +79,9 @@ class PairStreams:
         self.front = self.fronts[0]
         nf = max(1, int(front_threads))
         # every front thread owns a ring of builders (arena + pinned scratch each)
-        up1 = os.environ.get("PCRCG_UP_NEAREST", "1") != "0"       # one-column upsample tables (the forward reads column 0)
-        self._pyr = [[NativePyramid(config, neighborhood_limits, tie_order, up_nearest=up1) for _ in range(self.ARENAS)]
+        self.up_nearest = bool(up_nearest)
+        self._pyr = [[NativePyramid(config, neighborhood_limits, tie_order, up_nearest=self.up_nearest)
+                      for _ in range(self.ARENAS)]
                      for _ in range(nf)]
         # per arena: a one-slot queue holding the event after which it may be overwritten (None: never used); the
         # front thread TAKES it before building into the arena, the model thread puts the forward's event back
@@ -95,6 +100,7 @@ class PairStreams:
         self._lock = threading.Lock()
         self.stats = {"pairs": 0, "builds": 0, "front_idle_s": 0.0, "arena_wait_s": 0.0, "build_s": 0.0, "model_idle_s": 0.0,
                       "launch_s": 0.0}      # host seconds per stage, summed over the threads of the stage
+        self._stats_lock = threading.Lock()    # the stage threads all add to `stats`
         self._threads = []
         for f in range(nf):
             t = threading.Thread(target=self._serve_front, args=(f,), name=f"pcrcg-front-{f}", daemon=True)
@@ -104,6 +110,20 @@ class PairStreams:
             t = threading.Thread(target=self._serve_model, args=(m,), name=f"pcrcg-model-{m}", daemon=True)
             t.start()
             self._threads.append(t)
+
+    def _stat(self, **add):
+        with self._stats_lock:
+            for k, v in add.items():
+                self.stats[k] += v
+
+    def reset_stats(self):
+        with self._stats_lock:
+            for k in self.stats:
+                self.stats[k] = 0
+
+    def stats_snapshot(self):
+        with self._stats_lock:
+            return dict(self.stats)
 
     def _own_stream(self):
         import ctypes
@@ -132,10 +152,13 @@ class PairStreams:
                 items.pop()
                 if not items:
                     return
-            self.stats["front_idle_s"] += time.perf_counter() - t0
+            self._stat(front_idle_s=time.perf_counter() - t0)
             a = turn % self.ARENAS
             turn += 1
             k = len(items)
+            # hand-back accounting of the arena: `owed` tokens (one per forward that reads its current contents) are
+            # in its queue or still to come; `taken` of them have been consumed by this build so far
+            owed, taken, claimed = self._users[f][a], 0, False
             try:
                 with torch.cuda.stream(front), torch.no_grad():
                     for _, points, lengths, ready in items:
@@ -143,11 +166,13 @@ class PairStreams:
                         points.record_stream(front)
                         lengths.record_stream(front)
                     t0 = time.perf_counter()
-                    for _ in range(self._users[f][a]):            # blocks until those forwards have been enqueued ...
+                    while taken < owed:                           # blocks until those forwards have been enqueued ...
                         freed = self._free[f][a].get()
+                        taken += 1
                         if freed is not None:
                             front.wait_event(freed)               # ... and the stream waits until they have passed
                     self._users[f][a] = k
+                    claimed = True
                     pyr = self._pyr[f][a]
                     t1 = time.perf_counter()
                     if k == 1:
@@ -160,17 +185,25 @@ class PairStreams:
                         batches, arena, lens_h, slot = pyr.build(torch.cat([it[1] for it in items]),
                                                                  torch.cat([it[2] for it in items]), group=2)
                         deferred = None
-                    self.stats["arena_wait_s"] += t1 - t0
-                    self.stats["build_s"] += time.perf_counter() - t1
-                    self.stats["pairs"] += k
-                    self.stats["builds"] += 1
+                    self._stat(arena_wait_s=t1 - t0, build_s=time.perf_counter() - t1, pairs=k, builds=1)
                     built = torch.cuda.Event()
                     built.record(front)
                 for i, it in enumerate(items):
                     self._mid[it[0] % len(self.models)].put(it[0], (batches[i], arena, built, pyr, slot, deferred, f, a))
             except BaseException as e:                            # surfaced by result()
+                if claimed:
+                    # the arena was taken over for k forwards that will not happen: one token for each of them
+                    for _ in items:
+                        self._free[f][a].put(None)
+                else:
+                    # the previous contents' readers still owe `owed - taken` tokens; the next build waits for exactly
+                    # those (or, if none is left, for one free token)
+                    left = owed - taken
+                    if left == 0:
+                        self._free[f][a].put(None)
+                        left = 1
+                    self._users[f][a] = left
                 for it in items:
-                    self._free[f][a].put(None)
                     self._mid[it[0] % len(self.models)].put(it[0], e)
 
     def _serve_model(self, m):
@@ -182,7 +215,7 @@ class PairStreams:
             seq += len(self.models)
             if item is None:
                 return
-            self.stats["model_idle_s"] += time.perf_counter() - t0
+            self._stat(model_idle_s=time.perf_counter() - t0)
             try:
                 if isinstance(item, BaseException):
                     raise item
@@ -199,7 +232,7 @@ class PairStreams:
                     if deferred is not None:
                         pyr.restore(deferred, slot)
                     out = self.runner.launch(b, self.device)
-                    self.stats["launch_s"] += time.perf_counter() - t0
+                    self._stat(launch_s=time.perf_counter() - t0)
                     done = torch.cuda.Event()
                     done.record(stream)
                 self._free[f][a].put(done)
@@ -220,13 +253,15 @@ class PairStreams:
         ready.record(torch.cuda.current_stream(self.device))
         self._in.put((seq, points, lengths, ready))
 
-    def result(self, wait=False):
+    def result(self, wait=True):
         """Outputs of the oldest submitted pair, plus out["done_event"] (a torch.cuda.Event recorded behind their last
-        kernel).  The kernels are enqueued on a model stream, not necessarily finished: make the consuming stream wait
-        for out["done_event"] (wait=True does that for the caller's current stream), or call synchronize().
-        wait=False is the default on purpose: a wait queued on the caller's stream also delays the `ready` events that
-        later submit() calls record on it -- i.e. it would tie the start of pair k+depth's pyramid to the end of pair
-        k's forward (measured on the null stream: 240 instead of 340 pairs/s)."""
+        kernel).  The kernels run on a model stream.  wait=True (the default, the safe behaviour): the caller's current
+        stream waits for them, so any op or copy the caller enqueues next sees finished data.
+        wait=False: nothing is made to wait -- the tensors may still be being written; the caller orders its own
+        consumer behind out["done_event"] (or calls check() / synchronize()).  A throughput loop that keeps submitting
+        from the same stream wants this form (bench.py): a wait queued on the caller's stream also delays the `ready`
+        events that later submit() calls record on it, i.e. it ties the start of pair k+depth's pyramid to the end of
+        pair k's forward (measured on the null stream: 240 instead of 340 pairs/s)."""
         if self._returned >= self._submitted:
             raise RuntimeError("PairStreams.result(): nothing submitted")
         m = self._returned % len(self.models)
@@ -273,7 +308,7 @@ class PairStreams:
 
     def drain(self):
         while self._returned < self._submitted:
-            self.result()
+            self.result(wait=False)
         self.synchronize()
 
     def synchronize(self):

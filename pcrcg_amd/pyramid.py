@@ -72,12 +72,12 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
     defer_tie_check: the restore step reports "cannot happen on sane clouds" conditions (a KD-tree with more than
     128 pending branches on one query's path, ...) through a device status word.  By default it is read back here
     (one more host sync); with defer_tie_check=True it is returned as out["tie_status"] ([1] i32 device tensor or
-    None) and the CALLER must pass its value to check_tie_status() once the stream has finished (PairPipeline
+    None) and the CALLER must pass its value to check_tie_status() once the stream has finished (a pipelining caller
     does).
 
     The build needs four host round trips (three subsampled row counts, one for all table widths); this function
     waits for each of them.  pyramid_steps() is the same build as a generator that YIELDS at those points, so that a
-    caller can keep the stream busy with another pair's pyramid meanwhile (PairPipeline does)."""
+    caller can keep the stream busy with another pair's pyramid meanwhile (a pipelining caller does)."""
     if not points.is_cuda:
         raise RuntimeError("pcrcg_amd.build_pyramid: points must be on a HIP device (no CPU path)")
     mode = tie_order if tie_order is not None else os.environ.get("PCRCG_TIE_ORDER", "auto")
@@ -99,7 +99,7 @@ def pyramid_steps(points, lengths, config, neighborhood_limits, want_counts=Fals
     and returns the batch dict through StopIteration.value.
     defer_restore: do not launch the tie-order restore step (KD-forest + reorder) here; return it as
     out["restore"] = (callable -> status tensor or None, [tensors it touches]) for the consumer to run on ITS stream
-    before it reads the tables (PairPipeline runs it on the pair's model stream, which has slack, instead of the
+    before it reads the tables (a pipelining caller runs it on the pair's model stream, which has slack, instead of the
     front-end stream, which is the pipeline's bottleneck)."""
     config = as_config(config)
     if tie_order is None:

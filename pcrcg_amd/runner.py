@@ -115,6 +115,10 @@ class Runner:
         self.keep = []      # tensors the descriptor points into
         self.ws = {}
         self._lock = threading.Lock()   # descriptor() is called from one forward-worker thread per model stream
+        self._params = None             # the module tree's parameters, listed once (see _signature)
+        self._built = None              # event behind the re-packing kernels of the current descriptor
+        self._seen = set()              # launch streams that have been ordered behind _built
+        self._retired = []              # [(tensors of an older descriptor, events after which they may go)]
 
     # a copied / pickled model starts without a runner (KPFCNN.runner() re-creates it lazily)
     def __deepcopy__(self, memo):
@@ -124,8 +128,19 @@ class Runner:
         return (type(None), ())
 
     def _signature(self):
+        """Weight version: (storage address, in-place version counter) of every parameter.  Walking the module tree costs
+        ~1 ms of interpreter time, and every launch of every model thread asks -- so the parameter OBJECTS are listed
+        once; optimiser steps, load_state_dict and .to() all keep the objects and change what is compared here.
+        A caller that replaces a Parameter object calls invalidate()."""
+        if self._params is None:
+            self._params = list(self.model.parameters())
         return (bool(getattr(self.model, "feature_bf16", False)),) + tuple(
-            (p.data_ptr(), p._version) for p in self.model.parameters())
+            (p.data_ptr(), p._version) for p in self._params)
+
+    def invalidate(self):
+        """Forget the cached parameter list and descriptor (after replacing Parameter objects of the module)."""
+        with self._lock:
+            self._params, self.sig = None, None
 
     def _w(self, t):
         t = _dense(t)
@@ -232,8 +247,17 @@ class Runner:
             except BaseException:
                 self.keep = old_keep
                 raise
-            # the previous version's re-packed copies stay alive until forwards that may still use them are done
-            self._retired = old_keep
+            # the re-packing copies / split kernels above ran on the CURRENT stream; forwards are enqueued on other
+            # (non-blocking) streams: each of them waits for this event once (launch())
+            self._built = torch.cuda.Event()
+            self._built.record()
+            self._seen = set()
+            # the previous version's re-packed copies stay alive until every stream that launched forwards with them has
+            # passed the point it is at now
+            if old_keep:
+                evs = [torch.cuda.ExternalStream(st, device=torch.device("cuda", di)).record_event() for (di, st) in self.ws]
+                self._retired.append((old_keep, evs))
+            self._retired = [(k, evs) for (k, evs) in self._retired if not all(e.query() for e in evs)]
             self.desc, self.sig = d, sig
             return d
 
@@ -333,13 +357,17 @@ class Runner:
         if nbytes == 0:
             raise RuntimeError("pcrcg_kpfcnn_ws_bytes rejected the descriptors: "
                                + (L.pcrcg_last_error() or b"").decode())
-        stream = torch.cuda.current_stream().cuda_stream
-        key = (dev.index, stream)
+        cur = torch.cuda.current_stream()
+        stream = cur.cuda_stream
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
         with self._lock:
             ws = self.ws.get(key)
             if ws is None or ws.numel() < nbytes:
                 ws = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)
                 self.ws[key] = ws
+            if key not in self._seen and self._built is not None:
+                cur.wait_event(self._built)        # the descriptor's re-packed weights are complete before the first read
+                self._seen.add(key)
         _lib.check(L.pcrcg_kpfcnn_forward(ctypes.byref(desc), ctypes.byref(b), ctypes.byref(o), ws.data_ptr(),
                                           ws.numel(), stream), "pcrcg_kpfcnn_forward")
         return out

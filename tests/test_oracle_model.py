@@ -74,3 +74,17 @@ def test_image_feature_injection_vs_reference(golden_dir, batch):
         x = MR.inject_image_features(n, n_src, _image_list(g["inputs"], img_num, img_num < 3))
         assert torch.equal(x[::g["x_stride"]], g["x_rows"]), img_num
         assert int((x[:, :128] != 1).any(1).sum()) > (1500 if img_num > 1 else 1200)
+
+
+def test_topk_replay_is_torch_topk():
+    """oracle/topk_replay.py (libstdc++ partial_sort / nth_element + sort as PyTorch's CPU top-k kernel drives them)
+    against torch.topk itself on rows full of equal values, in both regimes (k * 64 <= n and above)."""
+    import numpy as np
+    from oracle.topk_replay import topk_smallest_indices
+    rng = np.random.RandomState(0)
+    for n in (12, 30, 100, 381, 703, 704, 705, 1000, 1936):
+        for levels in (2, 3, 5, 17, 1000):
+            for _ in range(3):
+                v = rng.randint(0, levels, n).astype(np.float32)
+                want = torch.from_numpy(v).topk(11, largest=False, sorted=True)[1].tolist()
+                assert topk_smallest_indices(v, 11) == want, (n, levels)

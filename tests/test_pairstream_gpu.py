@@ -159,7 +159,7 @@ def test_pair_engine_matches_sequential(cuda):
             ref.append(net(build_pyramid(pts, lens, cfg, limits)))
     torch.cuda.synchronize()
     for workers, fronts in ((1, 1), (3, 2)):
-        eng = PairStreams(net, cfg, limits, cuda, model_streams=workers, front_threads=fronts)
+        eng = PairStreams(net, cfg, limits, cuda, model_streams=workers, front_threads=fronts, up_nearest=(workers == 3))
         outs, submitted, total = [], 0, 3 * len(pairs)
         for i in range(total):
             while submitted < min(total, i + 5):

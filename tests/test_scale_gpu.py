@@ -132,9 +132,10 @@ def test_k120k_full_width_outputs_vs_reference(cuda, golden_dir):
     ns = int(batch["stack_lengths"][-1][0])
     for coords, want in ((batch["points"][-1][:ns], gold["knn_src"]), (batch["points"][-1][ns:], gold["knn_tgt"])):
         differ, cut_ties, exact = _check_knn(coords, want)
-        print("K120k kNN rows: %d of %d differ as sets (all among the %d rows whose cut splits a tie), %d identical in order"
+        print("K120k kNN rows: %d of %d differ as sets, %d rows whose cut splits a tie, %d identical in order"
               % (differ, len(want), cut_ties, exact))
-        assert differ <= cut_ties <= 0.01 * len(want)
+        # rows that hold a tie replay torch.topk's CPU selection (csrc/gnn.hip): the reference's rows, entry for entry
+        assert differ == 0 and exact == len(want) and cut_ties >= 1
     torch.manual_seed(0)
     np.random.seed(0)
     model = KPFCNN(cfg).to(cuda).eval()
