@@ -219,7 +219,7 @@ def main():
     # synthetic inputs; every step sees a different pair (16 distinct pairs per rank, cycled).  `pool`: resident in HBM
     # before the timed regions (the headline).  `host_pool`: the same pairs in pinned host memory, for the one extra
     # region that uploads every pair inside the clock (PCIe-inclusive figure, never `value`).
-    total = args.warmup + args.steps * (R + 3)
+    total = 2 * args.warmup + args.steps * (R + 6)
     seeds = pair_seeds_for_rank(total, rank, world)
     pool, host_pool = {}, {}
     for s in sorted(set(x % 16 for x in seeds)):
@@ -358,16 +358,16 @@ def main():
         print("pair engine, host ms per pair: " + ", ".join("%s %.3f" % (k[:-2], 1e3 * v / n) for k, v in stats.items()
                                                             if k not in ("pairs", "builds"))
               + "; %.2f pairs per build" % (n / max(stats.get("builds", n), 1)), file=sys.stderr, flush=True)
-    pipe.close()
     if not args.no_extras:
-        # (c) the engine with ONE-column upsample tables (the nearest coarse point is all KPFCNN.forward reads of them,
-        # ref:models/blocks.py:77-87): not the batch contract, so not the headline
-        pipe1 = PairStreams(net, cfg, limits, dev, model_streams=WORKERS, front_threads=FRONTS, up_nearest=True)
-        run_pairs(pipe1, args.warmup)
-        t_u = sorted(region(pipe1)[0] for _ in range(min(R, 3)))
+        # (c) the same engine with ONE-column upsample tables (the nearest coarse point is all KPFCNN.forward reads of
+        # them, ref:models/blocks.py:77-87): not the batch contract, so not the headline
+        fence(pipe)
+        pipe.set_up_nearest(True)
+        run_pairs(pipe, args.warmup)
+        t_u = sorted(region(pipe)[0] for _ in range(min(R, 3)))
         extras["one_column_upsample_tables"] = {"value": round(args.steps * world / t_u[len(t_u) // 2], 3),
                                                 "unit": "fragment-pairs/s", "regions": len(t_u)}
-        pipe1.close()
+    pipe.close()
 
     if rank == 0:
         gather, fused = kpconv_roofline(events, cout_of)

@@ -111,6 +111,17 @@ class PairStreams:
             t.start()
             self._threads.append(t)
 
+    def set_up_nearest(self, on):
+        """Switch the engine's internal upsample tables between the batch contract's [N, limit] form (off) and the
+        one-column form (see __init__); the engine must be drained."""
+        if self._returned < self._submitted:
+            raise RuntimeError("PairStreams.set_up_nearest(): pairs in flight -- drain() first")
+        self.synchronize()
+        self.up_nearest = bool(on)
+        for ring in self._pyr:
+            for pyr in ring:
+                pyr.cfg.up_nearest = int(self.up_nearest)
+
     def _stat(self, **add):
         with self._stats_lock:
             for k, v in add.items():
