@@ -164,6 +164,20 @@ def gemm_roofline(events, pairs):
             "frac_of_split_bf16_ceiling_%.0fTF" % (MFMA_BF16_TF / 6): round(tf / (MFMA_BF16_TF / 6), 4)}
 
 
+def gemm_by_shape(events, forwards):
+    """Per (M, N, K): launches per forward, average kernel microseconds, fp32-equivalent TFLOP/s."""
+    acc = {}
+    for e in events:
+        if e[5] == 3:
+            a = acc.setdefault((e[1], e[2], e[3], e[4]), [0, 0.0])
+            a[0] += 1
+            a[1] += e[0]
+    rows = [{"m": m, "n": n, "k": k, "products": pr, "per_forward": round(c / max(forwards, 1), 2), "avg_us": round(1e3 * ms / c, 1),
+             "us_per_forward": round(1e3 * ms / max(forwards, 1), 1), "TFLOPs": round(2.0 * m * n * k * c / (ms * 1e-3) / 1e12, 1)}
+            for (m, n, k, pr), (c, ms) in acc.items()]
+    return sorted(rows, key=lambda r: -r["us_per_forward"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,7 +280,7 @@ def main():
                           "kpconv_launches": g["n"] + f["n"], "kpconv_avg_launch_us": round(1e3 * ms / max(g["n"] + f["n"], 1), 2),
                           "kpconv_algorithmic_GBs": round(by / (ms * 1e-3) / 1e9, 1),
                           "kpconv_frac_of_hbm_peak": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                          "gemm": gemm_roofline(ev, args.steps)}), flush=True)
+                          "gemm": gemm_roofline(ev, args.steps), "gemm_by_shape": gemm_by_shape(ev, args.steps)}), flush=True)
         return
 
     # Pair engine (pcrcg_amd/pairstream.py): a front thread builds pyramids on the front-end stream, WORKERS threads with

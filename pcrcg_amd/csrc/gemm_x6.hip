@@ -141,7 +141,10 @@ constexpr int lds_bytes() { return 3 * (BM + BN) * ROWB; }
 // ATERMS = 3: A is fp32 and is split like B.  ATERMS = 1: A already IS bf16 in memory (the bf16 feature-storage
 // variant's wf, lda in bf16 elements): its tile is copied straight into plane 0 and only the three products a1*b3,
 // a1*b2, a1*b1 run -- exact in B, bf16-rounded in A by the storage format, fp32 accumulate.  K % 32 == 0 required.
-template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY, int ANORM = 0>
+// KNOCK (always 0 in the library; scripts/micro/x6_knock.hip instantiates other values to time the kernel with one of
+// its parts removed -- results wrong, timing meaningful): 1 no global loads inside the k-loop, 2 no split arithmetic,
+// 4 no LDS stores, 8 no MFMA, 16 no LDS operand reads, 32 no barriers.
+template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY, int ANORM = 0, int KNOCK = 0>
 __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                         int ldb, float* __restrict__ C, int ldc, int M, int N, int Kdim,
                                                         const float* __restrict__ row_scale,
@@ -289,7 +292,10 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     auto store_one = [&](unsigned char* base, int plane_bytes, int row, int kg, auto& src) {
         unsigned q1[4], q2[4], q3[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split2(src.get(2 * j), src.get(2 * j + 1), q1[j], q2[j], q3[j]);
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (KNOCK & 2) q1[j] = q2[j] = q3[j] = __float_as_uint(src.get(2 * j)) ^ __float_as_uint(src.get(2 * j + 1));
+            else split2(src.get(2 * j), src.get(2 * j + 1), q1[j], q2[j], q3[j]);
+        }
         const u32x4 p1 = {q1[0], q1[1], q1[2], q1[3]}, p2 = {q2[0], q2[1], q2[2], q2[3]},
                     p3 = {q3[0], q3[1], q3[2], q3[3]};
         unsigned char* d = base + row * ROWB + kg * 16;
@@ -322,15 +328,30 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < ATERMS; ++p)
-                    a[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                for (int p = 0; p < ATERMS; ++p) {
+                    if constexpr (KNOCK & 16) { u32x4 z = {(unsigned)lane, 1u, 2u, 3u}; asm volatile("" : "+v"(z)); a[i][p] = __builtin_bit_cast(bf16x8, z); }
+                    else a[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
                         As + p * A_PLANE + (wm * WM + i * 32 + l31) * ROWB + (c * 2 + half) * 16));
+                }
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    b[j][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                for (int p = 0; p < 3; ++p) {
+                    if constexpr (KNOCK & 16) { u32x4 z = {(unsigned)lane, 5u, 6u, 7u}; asm volatile("" : "+v"(z)); b[j][p] = __builtin_bit_cast(bf16x8, z); }
+                    else b[j][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
                         Bs + p * B_PLANE + (wn * WN + j * 32 + l31) * ROWB + (c * 2 + half) * 16));
+                }
+            if constexpr (KNOCK & 8) {              // operands stay live, no matrix instruction
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int p = 0; p < ATERMS; ++p) asm volatile("" ::"v"(a[i][p]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) asm volatile("" ::"v"(b[j][p]));
+                continue;
+            }
             // smallest terms first: a3b1 a2b2 a1b3 | a2b1 a1b2 | a1b1
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
@@ -350,7 +371,8 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     // Wait until only the other set's loads are in flight, then split this set into LDS.  `live` = 0 zeroes the tile
     // (the phantom second half of an odd tile count).
     auto consume = [&](Item<ALAY>* qa, Item<BLAY>* qb, bool live, int k0) {
-        vm_wait<TILE_LOADS>();
+        if constexpr (!(KNOCK & 1)) vm_wait<TILE_LOADS>();
+        else vm_wait<0>();
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) {
             if constexpr (ATERMS == 1) pin(qa[it].v[0]);
@@ -366,8 +388,30 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
         } else {
             normalise(qa, k0, false);
         }
-        __syncthreads();                                                  // previous tile fully read
-        store_tiles(qa, qb);                                              // registers -> LDS (split)
+        if constexpr (!(KNOCK & 32)) __syncthreads();                     // previous tile fully read
+        if constexpr (!(KNOCK & 4)) store_tiles(qa, qb);                  // registers -> LDS (split)
+        else {                                                            // (keep the split alive without the stores)
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) {
+                unsigned q1, q2, q3;
+                if constexpr (ATERMS == 3) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        split2(qa[it].get(2 * j), qa[it].get(2 * j + 1), q1, q2, q3);
+                        asm volatile("" ::"v"(q1), "v"(q2), "v"(q3));
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < B_ITERS; ++it) {
+                unsigned q1, q2, q3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    split2(qb[it].get(2 * j), qb[it].get(2 * j + 1), q1, q2, q3);
+                    asm volatile("" ::"v"(q1), "v"(q2), "v"(q3));
+                }
+            }
+        }
     };
     if (nfast > 0) {
         // ONE region without control-flow joins between a load and its wait: every join makes hipcc copy the
@@ -381,12 +425,12 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
         load_tiles(fast, min(k_begin + BK, k_last), ra[1], rb[1]);
         for (int s = 0; s < nfast; s += 2) {
             consume(ra[0], rb[0], true, k_begin + s * BK);
-            load_tiles(fast, min(k_begin + (s + 2) * BK, k_last), ra[0], rb[0]);   // tile s+2 into the freed set
-            __syncthreads();
+            if constexpr (!(KNOCK & 1)) load_tiles(fast, min(k_begin + (s + 2) * BK, k_last), ra[0], rb[0]);   // tile s+2 into the freed set
+            if constexpr (!(KNOCK & 32)) __syncthreads();
             multiply();
             consume(ra[1], rb[1], s + 1 < nfast, k_begin + (s + 1) * BK);
-            load_tiles(fast, min(k_begin + (s + 3) * BK, k_last), ra[1], rb[1]);
-            __syncthreads();
+            if constexpr (!(KNOCK & 1)) load_tiles(fast, min(k_begin + (s + 3) * BK, k_last), ra[1], rb[1]);
+            if constexpr (!(KNOCK & 32)) __syncthreads();
             multiply();
         }
         vm_wait<0>();                                                     // the two unused trailing prefetches
@@ -476,14 +520,14 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     }
 }
 
-template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY, int ANORM = 0>
+template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY, int ANORM = 0, int KNOCK = 0>
 int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n,
               int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b, int atomic_out,
               double* colp, int colp_chunks, const long long* a_idx = nullptr, int a_idx_ld = 0, int a_ns = 0,
               const float* a_zero = nullptr, const double* a_sums = nullptr, double a_count = 0.0, float a_eps = 0.f,
               float a_slope = 1.f) {
     const size_t lds = lds_bytes<BM, BN>() + (ANORM ? 2 * sizeof(float) * (size_t)(((k_per_split + BK - 1) / BK) * BK) : 0);
-    auto kern = k_gemm_x6<BM, BN, MINB, ATERMS, ALAY, BLAY, ANORM>;
+    auto kern = k_gemm_x6<BM, BN, MINB, ATERMS, ALAY, BLAY, ANORM, KNOCK>;
     static size_t configured = 0;
     if (lds > configured) {
         PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -33,23 +33,44 @@ def build():
         n = src.count(pat)
         src = src.replace(pat, 'ko("%s") ? PCRCG_OK : %s' % (tok, pat))
         print("%-8s %d call sites" % (tok, n))
+    # the KPConv contraction alone (the GEMM a one-kernel KPConv would absorb)
+    pat = "c.check(gemm_bt_colstats(wf.p, wf.ld, blk.kp_wt"
+    assert pat in src
+    src = src.replace(pat, 'c.check(ko("K_KPGEMM") ? PCRCG_OK : gemm_bt_colstats(wf.p, wf.ld, blk.kp_wt')
     tmp = os.path.join(CSRC, "build", "knock")
     os.makedirs(tmp, exist_ok=True)
     open(os.path.join(tmp, "runner_knock.hip"), "w").write(src)
-    objs = [os.path.join(CSRC, "build", f) for f in os.listdir(os.path.join(CSRC, "build")) if f.endswith(".o") and f != "runner.o"]
+    # GEMMs by row count: PCRCG_KNOCK_M="lo,hi" skips every split-bf16 product with lo <= M < hi
+    g = open(os.path.join(CSRC, "gemm_x6.hip")).read()
+    pat = "    // k-major operands (a_kmajor: A stored [K, M]; b_kmajor: B stored [K, N]) are read with 4-byte loads"
+    assert pat in g
+    g = g.replace(pat, '    { static const char* e = getenv("PCRCG_KNOCK_M"); int lo = 0, hi = 0;\n'
+                       '      if (e && sscanf(e, "%d,%d", &lo, &hi) == 2 && m >= lo && m < hi) return PCRCG_OK; }\n' + pat, 1)
+    open(os.path.join(tmp, "gemm_x6_knock.hip"), "w").write(g)
+    objs = [os.path.join(CSRC, "build", f) for f in os.listdir(os.path.join(CSRC, "build"))
+            if f.endswith(".o") and f not in ("runner.o", "gemm_x6.o")]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
-    subprocess.check_call(["hipcc", *flags, "-c", os.path.join(tmp, "runner_knock.hip"), "-o", os.path.join(tmp, "runner_knock.o")])
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, os.path.join(tmp, "runner_knock.o"), *objs])
+    mine = []
+    for name in ("runner_knock", "gemm_x6_knock"):
+        subprocess.check_call(["hipcc", *flags, "-c", os.path.join(tmp, name + ".hip"), "-o", os.path.join(tmp, name + ".o")])
+        mine.append(os.path.join(tmp, name + ".o"))
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *mine, *objs])
     print("built", LIB)
 
 
 def run():
     import json
-    toks = ["none"] + sorted({t for _, t in FAMILIES}) + ["none"]
+    toks = ["none"] + sorted({t for _, t in FAMILIES}) + ["K_KPGEMM", "M:0,1000", "M:1000,5000", "M:5000,20000", "M:20000,100000",
+                                                           "M:0,100000", "none"]
+    if len(sys.argv) > 2:
+        toks = sys.argv[2:]
     for t in toks:
         env = dict(os.environ, PCRCG_KNOCK=t)
+        env.pop("PCRCG_KNOCK_M", None)
+        if t.startswith("M:"):
+            env["PCRCG_KNOCK_M"] = t[2:]
         boot = ("import sys, runpy; sys.path.insert(0, %r); import pcrcg_amd._lib as L; L.LIB_PATH = %r; "
-                "sys.argv = ['bench.py', '--no-cpu-baseline', '--steps', '150']; runpy.run_path(%r, run_name='__main__')"
+                "sys.argv = ['bench.py', '--no-cpu-baseline', '--no-extras', '--steps', '100', '--repeats', '3']; runpy.run_path(%r, run_name='__main__')"
                 % (REPO, LIB, os.path.join(REPO, "bench.py")))
         out = subprocess.run([sys.executable, "-c", boot], env=env,
                              capture_output=True, text=True).stdout.strip().splitlines()
