@@ -181,33 +181,8 @@ int pcrcg_kpconv_aggregate_bf16(const float* q_pts, int nq, const float* s_pts, 
                                 int ld_idx, const float* x, int cin, const float* kp, float extent, void* x_bf16,
                                 void* wf_bf16, float* inv_n, void* ws, size_t ws_bytes, void* stream);
 
-/* The same operator in ONE kernel (gather + aggregate + contraction + 1/n scaling) for layers whose
- * [nq, 15*cin] intermediate would dominate HBM traffic: the aggregated tile of 16 queries stays in LDS
- * and is contracted on the matrix cores against wt, a K-contiguous copy of the layer's weights
- * (wt [cout, 15*cin] = weights.reshape(15*cin, cout)^T).  Supported when cin % 64 == 0 and
- * cout in {64, 128, 256} (pcrcg_kpconv_fused_supported); ws as for pcrcg_kpconv_aggregate. */
-int pcrcg_kpconv_fused_supported(int nq, int cin, int cout);
-int pcrcg_kpconv_fused(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h,
-                       int ld_idx, const float* x, int cin, const float* kp, float extent, const float* wt,
-                       int cout, float* out, int ld_out, void* ws, size_t ws_bytes, void* stream);
-
-/* The operator in one kernel WITHOUT the 61 KB tile: a workgroup aggregates 16 queries in registers (exact fp32 MFMA,
- * as pcrcg_kpconv_aggregate) and contracts them kernel point by kernel point through a 7 KB LDS slab on the bf16
- * matrix cores, with the exact three-term bf16 split of both operands (fp32-class accuracy, see pcrcg_gemm_set_mode);
- * `wf` never reaches HBM.  w_planes = pcrcg_split_bf16x3 of the K-contiguous weights wt [cout, 15*cin].
- * pcrcg_kpconv_x6_supported: cin in {64, 128}, cout in {64, 128, 256}, nq >= 2048 (layers whose weight set is small
- * against their activations; elsewhere the two-stage path is faster).  ws as for pcrcg_kpconv_aggregate.
- * pcrcg_split_bf16x3: fp32 [n, k] (row stride ld) -> three bf16 planes [3][n][k] with w = p0 + p1 + p2 exactly
- * (pcrcg_split_bf16x3_bytes(n, k) bytes); done once per weight version. */
-size_t pcrcg_split_bf16x3_bytes(int n, int k);
-int pcrcg_split_bf16x3(const float* w, int ld, int n, int k, void* planes, void* stream);
-int pcrcg_kpconv_x6_supported(int nq, int cin, int cout);
-int pcrcg_kpconv_x6(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h, int ld_idx,
-                    const float* x, int cin, const float* kp, float extent, const void* w_planes, int cout, float* out,
-                    int ld_out, void* ws, size_t ws_bytes, void* stream);
-
 /* Measurement aid for bench.py: when enabled, the gather/aggregate kernel of every
- * pcrcg_kpconv_aggregate call (kind 0) and the fused kernel of every pcrcg_kpconv_fused call (kind 1)
+ * pcrcg_kpconv_aggregate call (kind 0; kind 1 is reserved for a one-kernel KPConv)
  * are launched with HIP start / stop events (hipExtLaunchKernel) on their own stream, i.e. the kernel's own
  * execution time as rocprofv3 reports it, excluding the time its dispatch waited behind other streams; _read
  * waits for them and returns up to `cap` records (milliseconds, nq / h / cin of the launch, cout for kind 1).
@@ -399,7 +374,7 @@ typedef struct pcrcg_block {
     float extent;        /* KP_extent of the block's KPConv */
     const float* kp;     /* [15,3]  ...KPConv.kernel_points */
     const float* kp_w;   /* [15*cin, cout]  ...KPConv.weights */
-    const float* kp_wt;  /* [cout, 15*cin]  K-contiguous copy for pcrcg_kpconv_fused, or NULL */
+    const float* kp_wt;  /* [cout, 15*cin]  K-contiguous copy: the contraction then is a C = A * B^T product, or NULL */
     const float* kp_w_pad; /* [15*cin_pad, cout]: kp_w with the input channels zero-padded to cin_pad (a multiple of
                               4), or NULL.  Set when cin % 4 != 0 (PCR-CG's 129-channel first layer,
                               ref:models/architectures.py:195-514): the runner pads the features likewise, so the
@@ -410,7 +385,6 @@ typedef struct pcrcg_block {
     const float* shortcut; /* [out, in] or NULL (nn.Identity) */
     const float* mlp;    /* unary / last_unary: [out, in] with leading dimension mlp_ld (rows 16-B aligned) */
     int mlp_ld;
-    const void* kp_wsplit; /* pcrcg_split_bf16x3 planes of kp_wt (for pcrcg_kpconv_x6), or NULL */
     const float* mlp_skip; /* unary / last_unary that consumes cat([upsampled x, skip]) (model.dec_concat): a dense,
                               16-byte aligned copy of the weight's skip columns [out, skip_dim] (= mlp[:, in - skip_dim:]),
                               or NULL.  With it the runner never materialises the upsampled matrix or the concatenation:

@@ -19,6 +19,23 @@ size_t pcrcg_feature_argmax_ws_bytes(int n);
 int pcrcg_feature_argmax(const float* a, int lda, int n, const float* b, int ldb, int m, int c, int64_t* arg,
                          float* best, void* ws, size_t ws_bytes, void* stream);
 
+/* Ground-truth correspondences (replaces get_correspondences, ref:lib/benchmark_utils.py:121-134: an open3d KD-tree
+ * radius search per source point in a Python loop).  `grid` = pcrcg_cellgrid_build over the m target points as ONE
+ * cloud with a radius slightly above `radius` (the fp32 candidate search must not lose a pair that is inside in
+ * float64; pcrcg_amd/correspondences.py uses radius * (1 + 1e-4)).  trans: HOST pointer to the 4x4 row-major float64
+ * transform (open3d holds points and transform in float64; so does this kernel: p = R * src_i + t and every candidate
+ * distance are evaluated in float64, hit <=> |tgt_j - p| < radius).
+ *   _rows : per source point the hits ordered by (distance, target index), the first `keep` of them if keep > 0, into
+ *           stage [n, cols] (int32), their number into counts [n]; max_count (device int, zeroed by the caller) receives
+ *           the longest untruncated list: if it exceeds `cols` (or the 1024 hits a row can stage) the rows are incomplete
+ *           and the caller re-runs with more columns (or gives up).
+ *   _emit : out [sum(counts), 2] int64 = (source index, target index), source-major; offsets [n] = exclusive scan of
+ *           counts (int64). */
+int pcrcg_correspondences_rows(const float* src, int n, const double* trans, double radius, int keep, int m,
+                               const void* grid, int cols, int* stage, int* counts, int* max_count, void* stream);
+int pcrcg_correspondences_emit(const int* stage, int cols, const int* counts, const int64_t* offsets, int n, int64_t* out,
+                               void* stream);
+
 /* pcrcg_gemm_f32 with an optionally transposed A:  C = (Aop * Bop) * row_scale[m] + bias[n],
  * Aop = A ([M,K] row-major, lda >= K) or A^T (A stored [K,M] row-major, lda >= M) when trans_a.
  * The weight gradients dW = X^T * dY of nn.Linear / the 1x1 convolutions / the KPConv contraction

@@ -53,14 +53,6 @@ SIGNATURES = {
     "pcrcg_kpconv_aggregate_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                             c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                             c_void_p]),
-    "pcrcg_kpconv_fused_supported": (c_int, [c_int, c_int, c_int]),
-    "pcrcg_kpconv_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
-                                   c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
-    "pcrcg_split_bf16x3_bytes": (c_size_t, [c_int, c_int]),
-    "pcrcg_split_bf16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "pcrcg_kpconv_x6_supported": (c_int, [c_int, c_int, c_int]),
-    "pcrcg_kpconv_x6": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
-                                c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "pcrcg_profile_kpconv": (None, [c_int]),
     "pcrcg_profile_kpconv_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "pcrcg_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
@@ -135,6 +127,9 @@ SIGNATURES = {
     "pcrcg_edgeconv_backward_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_edgeconv_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_correspondences_rows": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_double, c_int, c_int, c_void_p, c_int, c_void_p,
+                                           c_void_p, c_void_p, c_void_p]),
+    "pcrcg_correspondences_emit": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "pcrcg_feature_argmax_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_feature_argmax": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),

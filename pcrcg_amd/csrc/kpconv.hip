@@ -349,8 +349,7 @@ float4* kpconv_pk_ptr(void* ws, size_t ws_bytes, int ns) {
     return cv.ok() ? pk : nullptr;
 }
 
-// pos / pk records of `x` (see k_row_positive) into the workspace layout of pcrcg_kpconv_ws_bytes; shared by the
-// two-stage path and the fused kernel (kpconv_x6.hip)
+// pos / pk records of `x` (see k_row_positive) into the workspace layout of pcrcg_kpconv_ws_bytes
 int kpconv_pack(const float* x, int ns, int cin, const float* s_pts, void* ws, size_t ws_bytes, hipStream_t st,
                 unsigned short* x_bf16) {
     Carver cv(ws, ws_bytes);

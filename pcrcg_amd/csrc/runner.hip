@@ -93,12 +93,6 @@ struct Ctx {
     void check(int r) { if (r != PCRCG_OK && rc == PCRCG_OK) rc = r; }
 };
 
-// The fused KPConv kernel (kpconv_fused.hip) is parity-tested but not used by the runner yet: measured
-// on MI355X (scripts/gpu_microbench.py kpconv) it ties or loses against the two-stage path (275 vs
-// 244 us on the 60k-query layers, 79 vs 97 us on the strided level-0 layer): with 61 KB of LDS per
-// 16-query workgroup only 8 wavefronts fit a CU and its dependent gathers stay latency-bound.
-constexpr bool kUseFusedKpconv = false;
-
 inline int pad4(int v) { return (v + 3) & ~3; }
 inline Mat cols(const Mat& m, int c0, int n) { Mat r = m; r.p = m.p ? m.p + c0 : nullptr; r.cols = n; return r; }
 inline Mat rows(const Mat& m, int r0, int n) { Mat r = m; r.p = m.p ? m.p + (long)r0 * m.ld : nullptr; r.rows = n; return r; }
@@ -231,28 +225,6 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
     const float* q = blk.strided ? b.points[l + 1] : b.points[l];
     const int nq = blk.strided ? b.n_points[l + 1] : b.n_points[l];
     const int ns = b.n_points[l];
-    // fine levels: one fused kernel, no [nq, 15*cin] intermediate (kpconv_fused.hip)
-    if (kUseFusedKpconv && blk.kp_wt && pcrcg_kpconv_fused_supported(nq, x.cols, y.cols)) {
-        const size_t m0 = c.mark();
-        const size_t wsb0 = pcrcg_kpconv_ws_bytes(ns);
-        void* ws0 = c.raw(wsb0);
-        if (c.live())
-            c.check(pcrcg_kpconv_fused(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, x.p, x.cols, blk.kp, blk.extent,
-                                       blk.kp_wt, y.cols, y.p, y.ld, ws0, wsb0, c.st));
-        c.release(m0);
-        return;
-    }
-    // fine levels with a small weight set: gather + aggregate + contraction in one kernel, `wf` never reaches HBM
-    if (blk.kp_wsplit && !blk.kp_w_pad && pcrcg_kpconv_x6_supported(nq, x.cols, y.cols)) {
-        const size_t m0 = c.mark();
-        const size_t wsb0 = pcrcg_kpconv_ws_bytes(ns);
-        void* ws0 = c.raw(wsb0);
-        if (c.live())
-            c.check(pcrcg_kpconv_x6(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, x.p, x.cols, blk.kp, blk.extent,
-                                    blk.kp_wsplit, y.cols, y.p, y.ld, ws0, wsb0, c.st));
-        c.release(m0);
-        return;
-    }
     const size_t m = c.mark();
     // channel counts that are not a multiple of 4 (the 129-channel PCR-CG input): zero-padded copy of the
     // features + zero-padded weights, so that the MFMA gather kernel applies (zeros change neither the sums nor

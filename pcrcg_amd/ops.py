@@ -357,30 +357,6 @@ def kpconv(q_pts, s_pts, idx, x, kernel_points, weights, extent):
     return gemm(wf, w2, row_scale=inv_n)
 
 
-def kpconv_fused(q_pts, s_pts, idx, x, kernel_points, weights, extent):
-    """KPConv.forward in one kernel (no [nq, 15*cin] intermediate); needs cin % 64 == 0 and
-    cout in {64, 128, 256}."""
-    L = _lib.lib()
-    q_pts = _dev(q_pts, _F32, "q_pts").contiguous()
-    s_pts = _dev(s_pts, _F32, "s_pts").contiguous()
-    idx, ld_idx = _rows(idx, _I64, "neighb_inds")
-    x = _dev(x, _F32, "x").contiguous()
-    kp = _dev(kernel_points, _F32, "kernel_points").contiguous()
-    nq, h = idx.shape
-    ns, cin = x.shape
-    cout = weights.shape[-1]
-    if not L.pcrcg_kpconv_fused_supported(nq, cin, cout):
-        raise RuntimeError(f"pcrcg_amd.kpconv_fused: unsupported widths {cin}->{cout}")
-    wt = _dev(weights, _F32, "weights").reshape(-1, cout).t().contiguous()
-    out = torch.empty((nq, cout), dtype=_F32, device=x.device)
-    nbytes = L.pcrcg_kpconv_ws_bytes(ns)
-    ws = _ws.get("kpconv", nbytes, x.device)
-    _lib.check(L.pcrcg_kpconv_fused(q_pts.data_ptr(), nq, s_pts.data_ptr(), ns, idx.data_ptr(), h, ld_idx,
-                                    x.data_ptr(), cin, kp.data_ptr(), float(extent), wt.data_ptr(), cout,
-                                    out.data_ptr(), cout, ws.data_ptr(), nbytes, _stream()), "pcrcg_kpconv_fused")
-    return out
-
-
 def inject_image_features(n_points, len_src, images, channels=128):
     """PCR-CG's image-feature injection (ref:models/architectures.py:195-514): -> x [n_points, channels + 1] f32 = ones
     with the 2-D features of the projected points written in.  `images`: list, IN THE REFERENCE'S WRITE ORDER (the last
@@ -406,29 +382,6 @@ def inject_image_features(n_points, len_src, images, channels=128):
                                                  int(len_src) if im.get("target") else 0, n_points, x.data_ptr(),
                                                  channels + 1, _stream()), "pcrcg_inject_image_features")
     return x
-
-
-def kpconv_x6(q_pts, s_pts, idx, x, kernel_points, weights, extent):
-    """KPConv.forward in one kernel without the [nq, 15*cin] intermediate (csrc/kpconv_x6.hip): register-resident
-    aggregation + slab-wise contraction on the bf16 matrix cores with the exact three-term split.  cin % 64 == 0,
-    cout in {64, 128, 256}.  (Parity-tested; the runner uses the two-stage path, which measures faster.)"""
-    L = _lib.lib()
-    q_pts, s_pts = _dev(q_pts, _F32, "q_pts").contiguous(), _dev(s_pts, _F32, "s_pts").contiguous()
-    idx, ld_idx = _rows(idx, _I64, "idx")
-    x = _dev(x, _F32, "x").contiguous()
-    kernel_points = _dev(kernel_points, _F32, "kernel_points").contiguous()
-    nq, ns, h, cin, cout = q_pts.shape[0], s_pts.shape[0], idx.shape[1], x.shape[1], weights.shape[2]
-    wt = _dev(weights, _F32, "weights").reshape(-1, cout).t().contiguous()           # [cout, 15*cin], K-contiguous
-    planes = torch.empty(int(L.pcrcg_split_bf16x3_bytes(cout, wt.shape[1])), dtype=torch.uint8, device=x.device)
-    _lib.check(L.pcrcg_split_bf16x3(wt.data_ptr(), wt.shape[1], cout, wt.shape[1], planes.data_ptr(), _stream()),
-               "pcrcg_split_bf16x3")
-    out = torch.empty((nq, cout), dtype=_F32, device=x.device)
-    nbytes = L.pcrcg_kpconv_ws_bytes(ns)
-    ws = _ws.get("kpconv", nbytes, x.device)
-    _lib.check(L.pcrcg_kpconv_x6(q_pts.data_ptr(), nq, s_pts.data_ptr(), ns, idx.data_ptr(), h, ld_idx, x.data_ptr(), cin,
-                                 kernel_points.data_ptr(), float(extent), planes.data_ptr(), cout, out.data_ptr(), cout,
-                                 ws.data_ptr(), nbytes, _stream()), "pcrcg_kpconv_x6")
-    return out
 
 
 def kpconv_bf16(q_pts, s_pts, idx, x, kernel_points, weights, extent, intermediates=False):

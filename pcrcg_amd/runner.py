@@ -29,7 +29,7 @@ class Block(ctypes.Structure):
                 ("in_dim", ctypes.c_int), ("out_dim", ctypes.c_int), ("mid_dim", ctypes.c_int),
                 ("extent", ctypes.c_float), ("kp", _fp), ("kp_w", _fp), ("kp_wt", _fp), ("kp_w_pad", _fp),
                 ("cin_pad", ctypes.c_int), ("unary1", _fp), ("unary2", _fp),
-                ("shortcut", _fp), ("mlp", _fp), ("mlp_ld", ctypes.c_int), ("kp_wsplit", _fp),
+                ("shortcut", _fp), ("mlp", _fp), ("mlp_ld", ctypes.c_int),
                 ("mlp_skip", _fp), ("mlp_skip_ld", ctypes.c_int), ("skip_dim", ctypes.c_int)]
 
 
@@ -164,16 +164,6 @@ class Runner:
             blk.kp_w_pad, blk.cin_pad = self._w(w), cp
         k = w.shape[0] * w.shape[1]
         blk.kp_wt = self._w(w.reshape(k, kp.out_channels).t()) if k % 4 == 0 else None
-        # exact three-term bf16 split of wt for the fused kernel (csrc/kpconv_x6.hip) on the layers it supports
-        blk.kp_wsplit = None
-        L = _lib.lib()
-        if blk.kp_wt and L.pcrcg_kpconv_x6_supported(1 << 20, cin, kp.out_channels):
-            wt = self.keep[-1]
-            planes = torch.empty(int(L.pcrcg_split_bf16x3_bytes(kp.out_channels, k)), dtype=torch.uint8, device=wt.device)
-            _lib.check(L.pcrcg_split_bf16x3(wt.data_ptr(), k, kp.out_channels, k, planes.data_ptr(),
-                                            torch.cuda.current_stream().cuda_stream), "pcrcg_split_bf16x3")
-            self.keep.append(planes)
-            blk.kp_wsplit = planes.data_ptr()
 
     def _fill_block(self, blk, mod):
         if isinstance(mod, SimpleBlock):

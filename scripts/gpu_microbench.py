@@ -95,18 +95,8 @@ def bench_kpconv():
         t = timeit(agg)
         t2 = timeit(lambda: ops.kpconv(q, s, idx, x, kp, w, 0.05 * 2 ** l))
         byt = nq * h * (cin * 4 + 20) + nq * cout * 4
-        t3 = float("nan")
-        if L.pcrcg_kpconv_fused_supported(nq, cin, cout):
-            wt = w.reshape(-1, cout).t().contiguous()
-            out = torch.empty((nq, cout), device=dev)
-
-            def fused():
-                L.pcrcg_kpconv_fused(q.data_ptr(), nq, s.data_ptr(), s.shape[0], idx.data_ptr(), h, idx.stride(0),
-                                     x.data_ptr(), cin, kp.data_ptr(), 0.05 * 2 ** l, wt.data_ptr(), cout,
-                                     out.data_ptr(), cout, ws.data_ptr(), nbytes, st)
-            t3 = timeit(fused)
         print(f"L{l} strided={int(strided)} Nq={nq:6d} H={h} Cin={cin:4d}: aggregate {t:7.1f} us = {byt / t / 1e3:7.1f} GB/s "
-              f"algorithmic | two-stage kpconv {t2:7.1f} us | fused {t3:7.1f} us")
+              f"algorithmic | two-stage kpconv {t2:7.1f} us")
 
 
 def bench_radius():

@@ -137,42 +137,6 @@ def test_kpconv_wide_channels_vs_oracle(cuda, mini):
     assert rel(y, MR.kpconv(s, s, wide[:, :17], x, kp, w, 0.2)) < TOL
 
 
-def test_kpconv_fused_vs_two_stage_and_oracle(cuda, mini):
-    batch, _ = mini
-    g = torch.Generator().manual_seed(12)
-    for l, strided, cin, cout in ((0, False, 64, 64), (0, True, 64, 64), (1, False, 128, 128), (1, True, 128, 64),
-                                  (2, False, 256, 256), (0, False, 64, 128)):
-        s = batch["points"][l]
-        q = batch["points"][l + 1] if strided else s
-        inds = batch["pools"][l] if strided else batch["neighbors"][l]
-        x = torch.randn(s.shape[0], cin, generator=g)
-        kp = (torch.rand(15, 3, generator=g) - 0.5) * 0.12 * 2 ** l
-        w = torch.randn(15, cin, cout, generator=g) * 0.1
-        args = (q.to(cuda), s.to(cuda), inds.to(cuda), x.to(cuda), kp.to(cuda), w.to(cuda), 0.05 * 2 ** l)
-        y = ops.kpconv_fused(*args)
-        assert rel(y, MR.kpconv(q, s, inds, x, kp, w, 0.05 * 2 ** l)) < TOL, (l, strided, cin, cout)
-        assert rel(y, ops.kpconv(*args)) < 1e-5
-
-
-def test_kpconv_x6_fused_vs_two_stage_and_oracle(cuda, mini):
-    """The slab-streaming fused kernel (csrc/kpconv_x6.hip): fp32-class agreement with the oracle although the
-    contraction runs on the bf16 matrix cores (exact three-term split of both operands)."""
-    batch, _ = mini
-    g = torch.Generator().manual_seed(13)
-    for l, strided, cin, cout in ((0, False, 64, 64), (0, True, 64, 128), (1, False, 128, 128), (1, True, 128, 256),
-                                  (2, False, 192, 64)):
-        s = batch["points"][l]
-        q = batch["points"][l + 1] if strided else s
-        inds = batch["pools"][l] if strided else batch["neighbors"][l]
-        x = torch.randn(s.shape[0], cin, generator=g)
-        kp = (torch.rand(15, 3, generator=g) - 0.5) * 0.12 * 2 ** l
-        w = torch.randn(15, cin, cout, generator=g) * 0.1
-        args = (q.to(cuda), s.to(cuda), inds.to(cuda), x.to(cuda), kp.to(cuda), w.to(cuda), 0.05 * 2 ** l)
-        y = ops.kpconv_x6(*args)
-        assert rel(y, MR.kpconv(q, s, inds, x, kp, w, 0.05 * 2 ** l)) < 1e-5, (l, strided, cin, cout)
-        assert rel(y, ops.kpconv(*args)) < 1e-5
-
-
 def test_pools_and_norm(cuda, mini):
     batch, _ = mini
     g = torch.Generator().manual_seed(4)

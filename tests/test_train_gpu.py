@@ -107,6 +107,37 @@ def test_get_correspondences_edge_cases(cuda):
     assert dense.shape == (100 * 100, 2) and torch.equal(dense[::100, 1], torch.arange(100, device=cuda))
     with pytest.raises(RuntimeError):
         get_correspondences(pts.cpu(), pts.cpu(), eye, 0.05)
+    many = torch.rand(700, 3, device=cuda)                                    # 700 hits per row (second, wider pass)
+    dense = get_correspondences(many, many, eye, 10.0, K=650)
+    assert dense.shape == (700 * 650, 2) and torch.equal(dense[::650, 1], torch.arange(700, device=cuda))
+    with pytest.raises(RuntimeError):                                         # beyond the 1024 hits a row can stage
+        get_correspondences(torch.rand(1100, 3, device=cuda), torch.rand(1100, 3, device=cuda), eye, 10.0)
+
+
+def test_get_correspondences_at_s30k_size(cuda):
+    """configs[2]'s pair: the rows of 400 sampled source points against the float64 brute force, and the whole call in a
+    few milliseconds (round 2's torch formulation took 527 ms)."""
+    import time
+    from oracle.correspondences import get_correspondences as oracle_corr
+    from pcrcg_amd import synthetic
+    from pcrcg_amd.correspondences import get_correspondences
+    src, tgt, rot, trans = synthetic.lomatch_pair("S30k", 1, 0.2)
+    s, t = torch.from_numpy(src).to(cuda), torch.from_numpy(tgt).to(cuda)
+    got = get_correspondences(s, t, _tsfm(rot, trans), 0.0375)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        got = get_correspondences(s, t, _tsfm(rot, trans), 0.0375)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    print("get_correspondences, S30k-LoMatch pair: %.2f ms, %d pairs" % (ms, got.shape[0]))
+    assert got.shape[0] > 10000 and ms < 20.0
+    rows = np.random.RandomState(0).permutation(len(src))[:400]
+    rows.sort()
+    want = oracle_corr(src[rows], tgt, _tsfm(rot, trans), 0.0375)
+    g = got.cpu().numpy()
+    sel = g[np.isin(g[:, 0], rows)]
+    assert np.array_equal(np.searchsorted(rows, sel[:, 0]), want[:, 0]) and np.array_equal(sel[:, 1], want[:, 1])
 
 
 def test_evaluate_pair_record_and_recall(cuda):
