@@ -189,6 +189,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary regions (GEMM events, one-column upsample tables, pinned-host inputs)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="S30k")
+    ap.add_argument("--model-streams", type=int, default=3, help="engine: host threads / HIP streams enqueueing forwards")
+    ap.add_argument("--front-threads", type=int, default=1, help="engine: host threads building pyramids")
+    ap.add_argument("--depth", type=int, default=6, help="pairs submitted ahead of the one being collected")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="A/B aid: no start/stop events on the KPConv launches of the timed regions (roofline comes out empty)")
     ap.add_argument("--isolated-only", action="store_true",
                     help="no engine: --steps forwards of one prepared pair on one stream, nothing else running (the "
                          "run rocprofv3 is pointed at for the kernels' isolated durations and PMC traffic)")
@@ -285,9 +290,7 @@ def main():
 
     # Pair engine (pcrcg_amd/pairstream.py): a front thread builds pyramids on the front-end stream, WORKERS threads with
     # one HIP stream each enqueue the forwards; pairs are submitted up to DEPTH ahead.
-    WORKERS = int(os.environ.get("PCRCG_MODEL_STREAMS", "3"))
-    FRONTS = int(os.environ.get("PCRCG_FRONT_THREADS", "1"))
-    DEPTH = int(os.environ.get("PCRCG_PIPE_DEPTH", "6"))
+    WORKERS, FRONTS, DEPTH = args.model_streams, args.front_threads, args.depth
     cursor = [0]
 
     def run_pairs(pipe, count, from_host=False):
@@ -332,7 +335,8 @@ def main():
     run_pairs(pipe, args.warmup)
     fence(pipe)
     pipe.reset_stats()
-    ops.kpconv_profile_start()        # HIP events around every KPConv gather/aggregate launch from here on
+    if not args.no_kernel_events:
+        ops.kpconv_profile_start()        # HIP events around every KPConv gather/aggregate launch from here on
     regions = [region(pipe) for _ in range(R)]
     events = ops.kpconv_profile_stop()
     stats = pipe.stats_snapshot()
@@ -367,7 +371,7 @@ def main():
         iso = ops.kpconv_profile_stop()
         gemm_iso = gemm_roofline(iso, 3)
         iso = [e for e in iso if e[5] != 3]
-    if os.environ.get("PCRCG_PIPE_STATS") and rank == 0:
+    if os.environ.get("PCRCG_PIPE_STATS") and rank == 0:       # (verbose host-side engine statistics on stderr)
         n = max(stats["pairs"], 1)
         print("pair engine, host ms per pair: " + ", ".join("%s %.3f" % (k[:-2], 1e3 * v / n) for k, v in stats.items()
                                                             if k not in ("pairs", "builds"))

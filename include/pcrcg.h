@@ -40,6 +40,16 @@ const char* pcrcg_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
 int pcrcg_abi_version(void);
 
+/* Tuning / A-B switches, for measurements only: "name=value,name=value" (NULL resets everything).  The same string is
+ * read once from the environment variable PCRCG_DEBUG at first use; nothing else in the library reads the environment
+ * except PCRCG_GEMM_MODE (pcrcg_gemm_set_mode).  Every switch defaults to the product behaviour:
+ *   zero_arena=1 stat_sums=1 stat_sums_rows=2^30 fuse_norm=1 fuse_pack=1 fuse_upsample=1   network runner fusions
+ *   radius_blocks=0 radius_eager_redo=0 pyr_wait=1 pyr_trace=0 kd_spin_limit=0            front end
+ *   att_tq=16                                                                              attention tile
+ *   gemm_log=0 x6_tile=-1 x6_splitk=0 x6_t1=200 x6_t2=1024 gemm_tile=-1 gemm_splitk=0 gemm_split_target=768   GEMM plans
+ * Returns PCRCG_EBADARG (and changes nothing) on an unknown name. */
+int pcrcg_debug_set(const char* spec);
+
 /* ------------------------------------------------------------------------------------------------
  * Front end: grid subsampling
  * Replaces cpp_wrappers.cpp_subsampling.grid_subsampling.subsample_batch(points, batches,

@@ -24,6 +24,7 @@ c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void
 SIGNATURES = {
     "pcrcg_last_error": (ctypes.c_char_p, []),
     "pcrcg_abi_version": (c_int, []),
+    "pcrcg_debug_set": (c_int, [ctypes.c_char_p]),
     "pcrcg_check_status": (c_int, [c_void_p, c_void_p]),
     "pcrcg_grid_subsample_ws_bytes": (c_size_t, [c_int, c_int]),
     "pcrcg_grid_subsample_batch": (c_int, [c_void_p, c_int, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p,

@@ -90,7 +90,8 @@ class KPFCNN(nn.Module):
                 out_dim = out_dim // 2
         self._eps_cache = None
         self._runner = None
-        self.use_runner = config.use_batch_norm and os.environ.get("PCRCG_PY_FORWARD", "0") != "1"
+        # the C++ runner enqueues the forward (one FFI call); set use_runner = False for the op-by-op mirror forward_ops
+        self.use_runner = bool(config.use_batch_norm)
 
     def regular_score(self, score):
         """ref:models/architectures.py:176-179."""

@@ -74,6 +74,29 @@ int kpconv_aggregate_bf16(const float* q_pts, int nq, const float* s_pts, int ns
                           const float* x, unsigned short* x_bf16, int cin, const float* kp, float extent,
                           unsigned short* wf_bf16, float* inv_n, void* ws, size_t ws_bytes, hipStream_t st);
 
+// Tuning / A-B switches of the library, in ONE place.  Every field defaults to the product behaviour; they are set by
+// pcrcg_debug_set("name=value,name=value") or, once at first use, from the environment variable PCRCG_DEBUG (same
+// syntax) -- include/pcrcg.h lists the names.  Nothing else in csrc/ reads the environment, except PCRCG_GEMM_MODE
+// (the documented arithmetic selector, pcrcg_gemm_set_mode).
+struct DebugOpts {
+    int zero_arena = 1;        // runner: split-K outputs from one pre-zeroed arena (0: each product clears its own C)
+    int stat_sums = 1;         // runner: InstanceNorm statistics as fp64 column sums added by the GEMM epilogues
+    int stat_sums_rows = 1 << 30;   //   ... only for outputs of up to that many rows (above: deterministic partials)
+    int fuse_norm = 1;         // runner: normalise-on-load inside the consuming product
+    int fuse_pack = 1;         // runner: the normalisation that feeds a KPConv also packs its support records
+    int fuse_upsample = 1;     // runner: nearest_upsample -> cat(skip) -> unary as two products into one output
+    int radius_blocks = 0;     // radius search grid (0: 512 workgroups)
+    int radius_eager_redo = 0; // pyramid builder: launch the >256-hit redo pass unconditionally
+    int pyr_wait = 1;          // pyramid builder host round trip: 0 stream sync, 1 event, 2 device-posted flag
+    int pyr_trace = 0;         // pyramid builder: host enqueue / wait microseconds at exit
+    int att_tq = 16;           // attention kernel: queries per workgroup (8 or 16)
+    int kd_spin_limit = 0;     // KD-forest task queue: spin bound (0: default)
+    int gemm_log = 0;          // print every GEMM's shape and grid
+    int x6_tile = -1, x6_splitk = 0, x6_t1 = 200, x6_t2 = 1024;          // split-bf16 GEMM plan overrides
+    int gemm_tile = -1, gemm_splitk = 0, gemm_split_target = 768;        // fp32-MFMA GEMM plan overrides
+};
+const DebugOpts& debug_opts();
+
 // Optional start / stop events of a KPConv kernel (bench.py roofline); see pcrcg_profile_kpconv in
 // include/pcrcg.h.  The events are handed to hipExtLaunchKernelGGL, so they stamp the kernel's own begin and
 // end (what rocprofv3 reports), not the time its dispatch waited behind other streams.  a/b are NULL when

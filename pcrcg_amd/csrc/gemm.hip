@@ -492,7 +492,7 @@ static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, i
         return (long)((m + tiles[t].bm - 1) / tiles[t].bm) * ((n + tiles[t].bn - 1) / tiles[t].bn);
     };
     int pick = -1;
-    if (const char* e = getenv("PCRCG_GEMM_TILE")) pick = atoi(e);          // tuning aid
+    pick = debug_opts().gemm_tile;                                           // tuning aid (-1: automatic)
     if (pick < 0 || pick > 3) pick = (n > 64 && ntiles(0) >= 1024) ? 0 : 3;
     if (trans_a) pick = 3;                                                   // only the 64x64 tile is built for A^T
     const int BM = tiles[pick].bm, BN = tiles[pick].bn;
@@ -500,11 +500,10 @@ static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, i
     constexpr int BK = 32;   // a 64-deep k-step (2 blocks/CU) measured 12 % slower on the path's shapes
     int splits = 1;
     const int ktiles = (k + BK - 1) / BK;
-    int split_target = 768;
-    if (const char* e = getenv("PCRCG_GEMM_SPLIT_TARGET")) split_target = atoi(e);   // tuning aid
+    const int split_target = debug_opts().gemm_split_target;
     const int max_splits = trans_a ? 256 : 32;   // A^T products reduce over the points: few tiles, very long K
     while ((long)gx * gy * splits < split_target && k / (2 * splits) >= 192 && splits < max_splits) splits *= 2;
-    if (const char* e = getenv("PCRCG_GEMM_SPLITK")) splits = atoi(e) > 0 ? atoi(e) : splits;   // tuning aid
+    if (debug_opts().gemm_splitk > 0) splits = debug_opts().gemm_splitk;     // tuning aid
     int k_per_split = ((ktiles + splits - 1) / splits) * BK;
     if (k_per_split < BK) k_per_split = BK;
     splits = k > 0 ? (k + k_per_split - 1) / k_per_split : 1;
@@ -515,7 +514,7 @@ static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, i
         else PCRCG_CHECK_HIP(hipMemset2DAsync(c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), m, st));
     }
     dim3 grid(gx, gy, splits);
-    static const bool log_shapes = getenv("PCRCG_GEMM_LOG") != nullptr;   // tuning aid
+    const bool log_shapes = debug_opts().gemm_log != 0;   // tuning aid
     if (log_shapes)
         fprintf(stderr, "pcrcg_gemm m=%d n=%d k=%d lda=%d ldb=%d ldc=%d tb=%d grid=%dx%dx%d rs=%d bias=%d stats=%d\n", m, n,
                 k, lda, ldb, ldc, trans_b, gx, gy, splits, row_scale != nullptr, bias != nullptr, colstats != nullptr);

@@ -555,7 +555,7 @@ static X6Plan x6_plan(int m, int n, int k, bool kmajor = false, bool reduce_rows
     static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     X6Plan p;
     p.pick = -1;
-    if (const char* e = getenv("PCRCG_X6_TILE")) p.pick = atoi(e);          // tuning aid
+    p.pick = debug_opts().x6_tile;                                           // tuning aid (-1: automatic)
     if (p.pick < 0 || p.pick > 3) p.pick = (n <= 64 && m >= 32768) ? 1 : 3;
     if (kmajor) p.pick = 3;                                   // the k-major operand forms are built for 64 x 64 only
     p.bm = tiles[p.pick][0];
@@ -565,11 +565,10 @@ static X6Plan x6_plan(int m, int n, int k, bool kmajor = false, bool reduce_rows
     int splits = 1;
     const int ktiles = (k + BK - 1) / BK;
     const int max_splits = reduce_rows ? 128 : 32;            // dW = X^T dY reduces over the points: few tiles, very long K
-    static const int t1 = getenv("PCRCG_X6_T1") ? atoi(getenv("PCRCG_X6_T1")) : 200;      // tuning aids
-    static const int t2 = getenv("PCRCG_X6_T2") ? atoi(getenv("PCRCG_X6_T2")) : 1024;
+    const int t1 = debug_opts().x6_t1, t2 = debug_opts().x6_t2;             // tuning aids
     while ((long)p.gx * p.gy * splits < t1 && k / (2 * splits) >= 256 && splits < max_splits) splits *= 2;
     while ((long)p.gx * p.gy * splits < t2 && k / splits > 1024 && splits < max_splits) splits *= 2;
-    if (const char* e = getenv("PCRCG_X6_SPLITK")) splits = atoi(e) > 0 ? atoi(e) : splits;   // tuning aid
+    if (debug_opts().x6_splitk > 0) splits = debug_opts().x6_splitk;        // tuning aid
     p.k_per_split = ((ktiles + splits - 1) / splits) * BK;
     if (p.k_per_split < BK) p.k_per_split = BK;
     p.splits = k > 0 ? (k + p.k_per_split - 1) / p.k_per_split : 1;
@@ -611,7 +610,7 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
         else PCRCG_CHECK_HIP(hipMemset2DAsync(c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), m, st));
     }
     dim3 grid(gx, gy, splits);
-    static const bool log_shapes = getenv("PCRCG_GEMM_LOG") != nullptr;   // tuning aid
+    const bool log_shapes = debug_opts().gemm_log != 0;   // tuning aid
     if (log_shapes)
         fprintf(stderr, "pcrcg_gemm_x6 m=%d n=%d k=%d lda=%d ldb=%d ldc=%d tile=%dx%d grid=%dx%dx%d rs=%d bias=%d stats=%d\n", m,
                 n, k, lda, ldb, ldc, BM, BN, gx, gy, splits, row_scale != nullptr, bias != nullptr, colstats != nullptr);

@@ -528,8 +528,8 @@ int pcrcg_attention(const float* q, int ldq, const float* k, int ldk, const floa
     } while (0)
     // d = 128: 16 queries x 16 lanes.  8 x 32 is faster alone (50 vs 62 us on 381 x 382 x 4 heads) but takes twice the
     // workgroups and re-reads K / V twice as often, and inside the four-stream engine that costs more than it gains
-    // (440 vs 446 pairs/s; 32 x 8 lanes: 89 us alone, 443) -- PCRCG_ATT_TQ=8 selects it for a lone forward.
-    static const int att_tq = getenv("PCRCG_ATT_TQ") ? atoi(getenv("PCRCG_ATT_TQ")) : 16;
+    // (440 vs 446 pairs/s; 32 x 8 lanes: 89 us alone, 443) -- DebugOpts::att_tq = 8 selects it for a lone forward.
+    const int att_tq = debug_opts().att_tq;
     if (d == 128 && att_tq == 8) ATT(128, 8);
     else if (d == 128) ATT(128, 16);
     else if (d == 64) ATT(64, 8);

@@ -27,7 +27,7 @@
 namespace pcrcg {
 namespace {
 
-// Host round trip, three ways (PCRCG_PYR_WAIT): 0 = async copy + hipStreamSynchronize, 1 = async copy + event (default:
+// Host round trip, three ways (DebugOpts::pyr_wait): 0 = async copy + hipStreamSynchronize, 1 = async copy + event (default:
 // waits for the caller's own work only, so several host threads can share one stream),
 // 2 = a one-wavefront kernel stores the words straight into the caller's pinned scratch (system-scope release of a
 // sequence tag last) and the host polls the tag -- no runtime call, no runtime lock held while waiting.
@@ -41,9 +41,9 @@ __global__ void k_post(int* __restrict__ h_dst, const int* __restrict__ src, int
     if (threadIdx.x == 0) __hip_atomic_store(h_dst, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// PCRCG_PYR_TRACE=1: host microseconds spent enqueueing vs waiting, per call, printed at exit (tuning aid)
+// DebugOpts::pyr_trace = 1: host microseconds spent enqueueing vs waiting, per call, printed at exit (tuning aid)
 struct Trace {
-    bool on = getenv("PCRCG_PYR_TRACE") != nullptr;
+    bool on = debug_opts().pyr_trace != 0;
     double enq = 0, wait = 0;
     long calls = 0, waits = 0;
     ~Trace() {
@@ -60,8 +60,7 @@ inline double now_us() {
 }
 
 int wait_mode() {
-    static const int m = [] { const char* e = getenv("PCRCG_PYR_WAIT"); return e ? atoi(e) : 1; }();
-    return m;
+    return debug_opts().pyr_wait;
 }
 
 // words src[0..n) (+ src2[0..n2)) -> h_scratch[1..]; returns when they are there
@@ -163,7 +162,7 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
     int* tie_status = A.take<int>(1);
     if (!A.ok()) return PCRCG_EWORKSPACE;
 
-    static const bool eager = getenv("PCRCG_RADIUS_EAGER_REDO") && atoi(getenv("PCRCG_RADIUS_EAGER_REDO")) != 0;   // A/B aid
+    const bool eager = debug_opts().radius_eager_redo != 0;   // A/B aid
     std::vector<TableRec> tables;
     tables.reserve(max_tables);
     if (!dry) {

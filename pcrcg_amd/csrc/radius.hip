@@ -579,7 +579,7 @@ int radius_query_pass(const float* q, int nq, const int* qlen, int ns, const int
     GridView g = grid_view(const_cast<void*>(grid), grid_bytes(ns, nb), ns, nb, &ok);
     const float r2 = radius * radius;  // neighbors.cpp:226
     int blocks = (nq + kQueryWaves - 1) / kQueryWaves;
-    static const int max_blocks_env = [] { const char* e = getenv("PCRCG_RADIUS_BLOCKS"); return e ? atoi(e) : 0; }();
+    const int max_blocks_env = debug_opts().radius_blocks;
     // 2 workgroups (8 wavefronts) per CU, wavefronts loop over the queries: inside the pipeline a smaller grid takes less
     // from the model streams (1024 workgroups: 455 pairs/s, 512: 464, 384: 453, 256: 398), and on voxelised data every
     // workgroup appends its tie rows with one atomic on one word (4096 workgroups: 264 us per 60k-row table)

@@ -79,8 +79,7 @@ struct Ctx {
     }
     // the output of a [rows, k] x [cols, k]^T product
     Mat gemm_out(int rows, int cols, int k) {
-        static const bool off = getenv("PCRCG_ZERO_ARENA") && atoi(getenv("PCRCG_ZERO_ARENA")) == 0;   // A/B aid
-        if (off || !gemm_bt_accumulates(rows, cols, k)) return mat(rows, cols);
+        if (!debug_opts().zero_arena || !gemm_bt_accumulates(rows, cols, k)) return mat(rows, cols);
         Mat m;
         m.rows = rows; m.cols = cols; m.ld = cols;
         m.p = static_cast<float*>(zraw((size_t)(rows > 0 ? rows : 1) * cols * sizeof(float)));
@@ -116,12 +115,10 @@ struct Stat {
 // from them itself: no partial buffers, no finishing launch (51 per S30k forward before).  With the per-wavefront
 // atomics of the first version the 60 000-row outputs (1 876 per address) measured slower than partials + finishing
 // kernel and kept those; with one per tile (938) the sums win everywhere: 470-473 vs 457-466 pairs/s.
-// (PCRCG_STAT_SUMS_ROWS: outputs above that many rows keep the deterministic partials.)
+// (DebugOpts::stat_sums_rows: outputs above that many rows keep the deterministic partials.)
 Stat stat_buffer(Ctx& c, int rows, int cols) {
     Stat s;
-    static const bool off = getenv("PCRCG_STAT_SUMS") && atoi(getenv("PCRCG_STAT_SUMS")) == 0;   // A/B aid
-    static const int max_rows = getenv("PCRCG_STAT_SUMS_ROWS") ? atoi(getenv("PCRCG_STAT_SUMS_ROWS")) : (1 << 30);   // tuning aid
-    if (!off && rows <= max_rows && gemm_colstats_sums_ok()) {
+    if (debug_opts().stat_sums && rows <= debug_opts().stat_sums_rows && gemm_colstats_sums_ok()) {
         s.sums = true;
         s.bytes = 2 * sizeof(double) * (size_t)cols;
         s.partials = c.zraw(s.bytes);
@@ -194,8 +191,7 @@ void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, co
 // x is the RAW output of the producing product and xs its column sums.  Returns false when that form does not apply
 // (the caller then normalises into a matrix of its own and calls linear()).
 bool norm_fuse_on() {
-    static const bool off = getenv("PCRCG_FUSE_NORM") && atoi(getenv("PCRCG_FUSE_NORM")) == 0;   // A/B aid
-    return !off && gemm_extra_ok();
+    return debug_opts().fuse_norm && gemm_extra_ok();
 }
 bool lazy_stats_ready(Ctx& c, const Mat& x, Stat* xs) {
     if (!xs || !xs->sums || x.ld % 4 != 0 || x.cols > 4096) return false;
@@ -273,9 +269,10 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
                                            wf.p, inv_n, ws, wsb, c.st));
         // contraction wf @ W: against the K-contiguous copy wt [cout, 15*cin] when the descriptor carries one
         // (C = A * B^T form: both operands k-contiguous, the form the split-bf16 GEMM is built for).
-        // (Measured and not adopted: aggregating + contracting 48 MB row chunks so that wf stays in L2 / Infinity
-        // Cache between the two kernels -- 3.50 vs 3.31 ms per forward, the extra launches cost more than the
-        // on-chip re-read saves.)
+        // (Measured and not adopted, rounds 2 and 3: aggregating + contracting row chunks so that wf stays in L2 /
+        // Infinity Cache between the two kernels -- isolated 3.50 vs 3.31 ms per forward with 48 MB chunks; inside the
+        // engine 416 / 446 / 459 / 462 pairs/s with 16 / 32 / 64 / 120 MB chunks against 460-464 unchunked: the extra
+        // launches cost more than the on-chip re-read saves.)
         if (blk.kp_wt)
             c.check(gemm_bt_colstats(wf.p, wf.ld, blk.kp_wt, wf.cols, y.p, y.ld, nq, y.cols, wf.cols, inv_n, nullptr,
                                      st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr, c.st,
@@ -312,8 +309,7 @@ Mat simple_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat
 // pass over u of its own (10 launches per S30k forward: +4 % pairs/s with them knocked out).  False: not applicable.
 bool norm_act_pack(Ctx& c, const Mat& t, float slope, const Mat& u, Stat* ts, const float* s_pts, void* kp_ws,
                    size_t kp_ws_bytes) {
-    static const bool off = getenv("PCRCG_FUSE_PACK") && atoi(getenv("PCRCG_FUSE_PACK")) == 0;   // A/B aid
-    if (off || c.bf16 || !instnorm_pack_ok(t.cols, t.ld, u.ld) || u.ld != u.cols) return false;
+    if (!debug_opts().fuse_pack || c.bf16 || !instnorm_pack_ok(t.cols, t.ld, u.ld) || u.ld != u.cols) return false;
     const size_t m = c.mark();
     float* stats = static_cast<float*>(c.raw(sizeof(float) * 2 * t.cols));
     const size_t wsb = pcrcg_instnorm_ws_bytes(t.cols);
@@ -538,7 +534,7 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
     }
     x = xc;
     // 4. decoder (:567-570)
-    static const bool fuse_off = getenv("PCRCG_FUSE_UPSAMPLE") && atoi(getenv("PCRCG_FUSE_UPSAMPLE")) == 0;   // A/B aid
+    const bool fuse_off = !debug_opts().fuse_upsample;
     // `x` may be LAZY between two decoder stages: the raw output of a unary's products whose InstanceNorm + LeakyReLU the
     // next stage's gathering product applies on load (xs = its column sums); materialise() applies it for anyone else
     Stat xs;

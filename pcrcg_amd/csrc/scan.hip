@@ -202,6 +202,57 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
     return PCRCG_OK;
 }
 
+// ---- the library's tuning / A-B switches (common.h: DebugOpts) ------------------------------------------------
+namespace {
+struct DebugName { const char* name; int DebugOpts::*field; };
+const DebugName kDebugNames[] = {
+    {"zero_arena", &DebugOpts::zero_arena}, {"stat_sums", &DebugOpts::stat_sums}, {"stat_sums_rows", &DebugOpts::stat_sums_rows},
+    {"fuse_norm", &DebugOpts::fuse_norm}, {"fuse_pack", &DebugOpts::fuse_pack}, {"fuse_upsample", &DebugOpts::fuse_upsample},
+    {"radius_blocks", &DebugOpts::radius_blocks}, {"radius_eager_redo", &DebugOpts::radius_eager_redo},
+    {"pyr_wait", &DebugOpts::pyr_wait}, {"pyr_trace", &DebugOpts::pyr_trace}, {"att_tq", &DebugOpts::att_tq},
+    {"kd_spin_limit", &DebugOpts::kd_spin_limit}, {"gemm_log", &DebugOpts::gemm_log}, {"x6_tile", &DebugOpts::x6_tile},
+    {"x6_splitk", &DebugOpts::x6_splitk}, {"x6_t1", &DebugOpts::x6_t1}, {"x6_t2", &DebugOpts::x6_t2},
+    {"gemm_tile", &DebugOpts::gemm_tile}, {"gemm_splitk", &DebugOpts::gemm_splitk},
+    {"gemm_split_target", &DebugOpts::gemm_split_target}};
+DebugOpts g_debug;
+bool g_debug_init = false;
+
+// "name=value,name=value" -> g_debug; false (and the error text) on an unknown name or a malformed item
+bool debug_parse(const char* spec) {
+    DebugOpts d = g_debug;
+    const char* p = spec;
+    while (p && *p) {
+        const char* end = strchr(p, ',');
+        const size_t len = end ? (size_t)(end - p) : strlen(p);
+        const char* eq = static_cast<const char*>(memchr(p, '=', len));
+        bool ok = false;
+        if (eq) {
+            for (const DebugName& n : kDebugNames)
+                if (strlen(n.name) == (size_t)(eq - p) && strncmp(n.name, p, (size_t)(eq - p)) == 0) {
+                    d.*(n.field) = atoi(eq + 1);
+                    ok = true;
+                }
+        }
+        if (!ok && len > 0) {
+            set_error("pcrcg_debug_set: unknown or malformed item '%.*s'", (int)len, p);
+            return false;
+        }
+        p = end ? end + 1 : nullptr;
+    }
+    g_debug = d;
+    return true;
+}
+}  // namespace
+
+const DebugOpts& debug_opts() {
+    if (!g_debug_init) {
+        g_debug_init = true;
+        if (const char* e = getenv("PCRCG_DEBUG"))
+            if (!debug_parse(e)) fprintf(stderr, "libpcrcg_hip: PCRCG_DEBUG ignored: %s\n", g_err);
+    }
+    return g_debug;
+}
+
 }  // namespace pcrcg
 
 extern "C" {
@@ -209,6 +260,12 @@ extern "C" {
 const char* pcrcg_last_error(void) { return pcrcg::g_err; }
 
 int pcrcg_abi_version(void) { return 1; }
+
+int pcrcg_debug_set(const char* spec) {
+    (void)pcrcg::debug_opts();                       // the environment first, then this call on top of it
+    if (!spec) { pcrcg::g_debug = pcrcg::DebugOpts(); return PCRCG_OK; }
+    return pcrcg::debug_parse(spec) ? PCRCG_OK : PCRCG_EBADARG;
+}
 
 int pcrcg_check_status(const int* status, void* stream) {
     PCRCG_CHECK_ARG(status != nullptr);

@@ -893,8 +893,8 @@ int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, void
         // one workgroup per ~1024 points can be busy at the deepest level of big nodes / the LDS subtrees
         int blocks = ns / (2 * kSubMax) + nb;
         if (blocks > kForestBlocks) blocks = kForestBlocks;
-        const char* env = getenv("PCRCG_KD_SPIN_LIMIT");      // debugging aid
-        hipLaunchKernelGGL(k_kd_forest, dim3(blocks), dim3(kBigThreads), 0, st, sup, v, env ? atoi(env) : kSpinLimitDefault);
+        const int spin = debug_opts().kd_spin_limit;          // debugging aid
+        hipLaunchKernelGGL(k_kd_forest, dim3(blocks), dim3(kBigThreads), 0, st, sup, v, spin > 0 ? spin : kSpinLimitDefault);
     }
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;

@@ -22,7 +22,6 @@ worker spent 1.7 ms of interpreter time per pair.
 
 The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): set GPU_MAX_HW_QUEUES=8
 before the first HIP call (bench.py does)."""
-import os
 import queue
 import threading
 import time
@@ -54,7 +53,7 @@ class PairStreams:
     ARENAS = 4        # per front thread: pairs whose tables may be alive at once (built, forward not yet passed)
 
     def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=1, tie_order=None,
-                 pairs_per_build=2, up_nearest=False):
+                 pairs_per_build=2, up_nearest=False, front_streams=1, front_priority=0):
         """up_nearest: the engine's internal pyramids carry ONE-column upsample tables (the nearest coarse point: the only
         column KPFCNN.forward reads, ref:models/blocks.py:77-87) instead of the batch contract's [N, limit] tables:
         ~1 % less front-end work, same outputs.  Off by default: the tables are then exactly what build_pyramid()
@@ -66,16 +65,11 @@ class PairStreams:
         self.runner = net.runner()
         with torch.cuda.device(self.device):
             self.runner.descriptor()           # built once, here, before any worker thread can race for it
-        nfs = int(os.environ.get("PCRCG_FRONT_STREAMS", "1"))
-        self._raw_streams = []
-        if os.environ.get("PCRCG_OWN_STREAMS", "0") == "1":       # experiment: streams created by the library
-            with torch.cuda.device(self.device):
-                self.fronts = [self._own_stream() for _ in range(max(1, nfs))]
-                self.models = [self._own_stream() for _ in range(max(1, int(model_streams)))]
-        else:
-            fp = int(os.environ.get("PCRCG_FRONT_PRIORITY", "0"))    # < 0: the front-end chain ahead of the forwards
-            self.fronts = [torch.cuda.Stream(device=self.device, priority=fp) for _ in range(max(1, nfs))]
-            self.models = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(model_streams)))]
+        # front_streams / front_priority (< 0: the front-end chain ahead of the forwards) exist for measurements: more
+        # than one front-end stream, and a prioritised one, both measured slower
+        self.fronts = [torch.cuda.Stream(device=self.device, priority=int(front_priority))
+                       for _ in range(max(1, int(front_streams)))]
+        self.models = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(model_streams)))]
         self.front = self.fronts[0]
         nf = max(1, int(front_threads))
         # every front thread owns a ring of builders (arena + pinned scratch each)
@@ -91,7 +85,7 @@ class PairStreams:
                 q.put(None)
         self._in = queue.Queue()               # one queue: a front thread takes up to `pairs_per_build` consecutive pairs
         self._take = threading.Lock()
-        self._per_build = max(1, int(os.environ.get("PCRCG_PAIRS_PER_BUILD", pairs_per_build)))
+        self._per_build = max(1, int(pairs_per_build))
         self._users = [[1] * self.ARENAS for _ in range(nf)]   # forwards that read the arena's current contents
         self._mid = [_Mailbox() for _ in self.models]
         self._out = [queue.Queue() for _ in self.models]
@@ -135,14 +129,6 @@ class PairStreams:
     def stats_snapshot(self):
         with self._stats_lock:
             return dict(self.stats)
-
-    def _own_stream(self):
-        import ctypes
-        from . import _lib
-        h = ctypes.c_void_p()
-        _lib.check(_lib.lib().pcrcg_stream_create(ctypes.byref(h), 0), "pcrcg_stream_create")
-        self._raw_streams.append(h.value)
-        return torch.cuda.ExternalStream(h.value, device=self.device)
 
     # ---- workers -------------------------------------------------------------------------------
     def _serve_front(self, f):

@@ -55,7 +55,7 @@ def check_tie_status(code):
 
 
 def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=False, tie_order=None,
-                  defer_tie_check=False):
+                  defer_tie_check=False, mirror=False):
     """points [N0,3] f32 and lengths [B] i32 on the device -> the reference's batch dict
     (ref:datasets/dataloader.py:363-380) restricted to the keys KPFCNN.forward reads, all on the
     device: points, neighbors, pools, upsamples (int64, shadow = support count), stack_lengths,
@@ -69,6 +69,8 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
       "reference"  the same through the KD-forest for every row (a cross-check of "auto");
       "index"      ascending index -- a defined order, NOT the reference's; no forest.
     None = the environment variable PCRCG_TIE_ORDER if set, else "auto".
+    mirror: build through the op-by-op Python mirror (pyramid_steps) instead of the C++ builder (same tables entry for
+    entry; want_counts / defer_tie_check / tie_order="reference" always take the mirror).
     defer_tie_check: the restore step reports "cannot happen on sane clouds" conditions (a KD-tree with more than
     128 pending branches on one query's path, ...) through a device status word.  By default it is read back here
     (one more host sync); with defer_tie_check=True it is returned as out["tie_status"] ([1] i32 device tensor or
@@ -81,8 +83,7 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
     if not points.is_cuda:
         raise RuntimeError("pcrcg_amd.build_pyramid: points must be on a HIP device (no CPU path)")
     mode = tie_order if tie_order is not None else os.environ.get("PCRCG_TIE_ORDER", "auto")
-    if (not want_counts and not defer_tie_check and mode in ("auto", "index")
-            and os.environ.get("PCRCG_PY_PYRAMID", "0") != "1"):
+    if not want_counts and not defer_tie_check and mode in ("auto", "index") and not mirror:
         return build_pyramid_native(points, lengths, config, neighborhood_limits, mode)
     steps = pyramid_steps(points, lengths, config, neighborhood_limits, want_counts, tie_order, defer_tie_check)
     try:

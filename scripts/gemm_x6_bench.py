@@ -72,9 +72,9 @@ for (m, n, k, c) in SHAPES:
             for sk in (1, 2, 4, 8):
                 if sk > 1 and k // sk < 128:
                     continue
-                os.environ["PCRCG_X6_TILE"], os.environ["PCRCG_X6_SPLITK"] = str(t), str(sk)
+                L.pcrcg_debug_set(("x6_tile=%d,x6_splitk=%d" % (t, sk)).encode())
                 best.append((timeit(lambda: ops.gemm(a, w.t(), out=out), reps=3), t, sk))
-        del os.environ["PCRCG_X6_TILE"], os.environ["PCRCG_X6_SPLITK"]
+        L.pcrcg_debug_set(b"x6_tile=-1,x6_splitk=0")
         best.sort()
         print("      sweep:", " ".join("t%d/k%d=%.1f" % (t, sk, u) for u, t, sk in best[:5]), flush=True)
     us = timeit(lambda: torch.matmul(a, w.t(), out=out))
