@@ -92,6 +92,39 @@ int pcrcg_edgeconv_backward(const float* ctr, const float* nbr, const int* idx, 
                             const float* dy, float slope, float* dctr, float* dnbr, void* ws, size_t ws_bytes,
                             void* stream);
 
+/* ---- the train step's network part in two calls (csrc/train_runner.hip) ---------------------------------------
+ * KPFCNN.forward with a tape, and its backward (ref:lib/trainer.py:216-265 runs ref:models/architectures.py:181-191,
+ * 516-610 under torch.autograd).  `model` as for pcrcg_kpfcnn_forward, with these differences in what the fields hold:
+ *   kp_w [15*cin, cout] is used as stored (kp_wt, kp_w_pad, mlp_skip are ignored; cin must be 1 or a multiple of 4);
+ *   gnn[].edge1 / edge2 are the packed [2*cout, cin] = [Wa - Wb ; Wb] form and the attention weights head-major,
+ *   exactly as the inference descriptor holds them.
+ * `grads` is a second pcrcg_model whose POINTER fields hold, for every weight of `model`, the buffer its gradient is
+ * ACCUMULATED into (same shape and leading dimension as the weight as handed over; NULL = frozen).  Its integer / float
+ * fields are ignored.  The caller maps the gradients of derived layouts (packed edge convolutions, permuted attention
+ * weights, padded decoder weights) back to its parameters.
+ *   _ws_bytes : sizes of the three regions of the workspace [values | gradients | backward scratch];
+ *   _forward  : enqueues the forward, returns device pointers to the three outputs (inside `ws`) and the tape;
+ *   _backward : d_* = gradients of the loss wrt the three outputs (device, dense; NULL = zero): clears the gradient
+ *               region, enqueues the whole backward; parameter gradients are accumulated into `grads`' buffers and
+ *               out->d_inv_temperature holds dL/d(1/temperature) (temperature = exp(epsilon) + 0.03 is the caller's);
+ *   _free     : releases the tape (host memory only).
+ * `ws` must stay untouched between _forward and _backward; both calls enqueue on `stream` and return without waiting. */
+typedef struct pcrcg_train_outputs {
+    float* feats_f;            /* [n_points, final_dim] */
+    float* scores_overlap;     /* [n_points] */
+    float* scores_saliency;    /* [n_points] */
+    float* d_inv_temperature;  /* [1], valid after _backward */
+    int n_points, final_dim;
+} pcrcg_train_outputs;
+int pcrcg_kpfcnn_train_ws_bytes(const pcrcg_model* model, const pcrcg_model* grads, const pcrcg_batch* batch,
+                                size_t* value_bytes, size_t* grad_bytes, size_t* scratch_bytes);
+int pcrcg_kpfcnn_train_forward(const pcrcg_model* model, const pcrcg_model* grads, const pcrcg_batch* batch, void* ws,
+                               size_t value_bytes, size_t grad_bytes, size_t scratch_bytes, pcrcg_train_outputs* out,
+                               void** tape, void* stream);
+int pcrcg_kpfcnn_train_backward(void* tape, const float* d_feats_f, const float* d_scores_overlap,
+                                const float* d_scores_saliency, void* stream);
+void pcrcg_kpfcnn_train_free(void* tape);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,6 +131,11 @@ SIGNATURES = {
     "pcrcg_correspondences_rows": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_double, c_int, c_int, c_void_p, c_int, c_void_p,
                                            c_void_p, c_void_p, c_void_p]),
     "pcrcg_correspondences_emit": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "pcrcg_kpfcnn_train_ws_bytes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcrcg_kpfcnn_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p,
+                                           c_void_p, c_void_p]),
+    "pcrcg_kpfcnn_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcrcg_kpfcnn_train_free": (None, [c_void_p]),
     "pcrcg_feature_argmax_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_feature_argmax": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),

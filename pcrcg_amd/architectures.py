@@ -156,6 +156,19 @@ class KPFCNN(nn.Module):
                     self._runner = Runner(self)
         return self._runner
 
+    def train_runner(self):
+        """The (lazily created) C++ train-step runner (pcrcg_amd/train_runner.py): forward with a tape + backward, one
+        library call each.  None when this configuration needs the op-by-op autograd path (pcrcg_amd/train_forward.py):
+        no InstanceNorm (use_batch_norm False) or the 129-channel image-feature input."""
+        if not self.use_runner or self.image_feature:
+            return None
+        if getattr(self, "_train_runner", None) is None:
+            with _RUNNER_LOCK:
+                if getattr(self, "_train_runner", None) is None:
+                    from .train_runner import TrainRunner
+                    self._train_runner = TrainRunner(self)
+        return self._train_runner
+
     def forward_ops(self, batch):
         """Op-by-op forward through pcrcg_amd.ops (one FFI call per kernel); same kernels, same results
         as the runner -- kept as the readable mirror of the reference's forward and for debugging."""

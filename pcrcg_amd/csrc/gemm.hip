@@ -382,6 +382,24 @@ int gemm_bt_extra(const float* a, int lda, const float* b, int ldb, float* c, in
     return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, nullptr, bias, colstats, colstats_bytes, h_chunks, st, false,
                             c_zeroed, 0, 0, colstats_sums, &ex);
 }
+// C (+)= (op(A) * op(B)) * row_scale[m] + bias[n] for the training runner (train_runner.hip): op = identity or transpose
+// as in pcrcg_gemm_f32_ex; accumulate adds the product onto C with fp32 atomics (gradients of tensors with several
+// consumers, parameter gradients of shared weights).  Split-bf16 arithmetic only.
+int gemm_general(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc, int m, int n,
+                 int k, const float* row_scale, const float* bias, bool accumulate, hipStream_t st) {
+    PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 0);
+    if (m == 0 || n == 0 || k == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(a && b && c && !(trans_a && trans_b));
+    PCRCG_CHECK_ARG((trans_a ? lda >= m : lda >= k) && ldc >= n && (trans_b ? ldb >= k : ldb >= n));
+    if (gemm_mode() != 1) {
+        set_error("gemm_general: the training runner needs the split-bf16 arithmetic (pcrcg_gemm_set_mode(1))");
+        return PCRCG_EBADARG;
+    }
+    GemmExtra ex;
+    ex.accumulate = accumulate;
+    return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, nullptr, 0, nullptr, st, false, false,
+                            trans_a ? 1 : 0, trans_b ? 0 : 1, false, accumulate ? &ex : nullptr);
+}
 int gemm_bt_colstats(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
                      hipStream_t st, bool c_zeroed, bool colstats_sums) {

@@ -594,8 +594,8 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
     const int k_per_split = plan.k_per_split;
     const bool accumulate = ex && ex->accumulate;
     const bool gather = ex && ex->a_idx;
-    if ((gather || accumulate) && (a_bf16 || a_kmajor || b_kmajor)) {
-        set_error("gemm_x6: gather / accumulate are built for k-contiguous fp32 operands");
+    if ((gather && (a_bf16 || a_kmajor || b_kmajor)) || (accumulate && a_bf16)) {
+        set_error("gemm_x6: gather is built for k-contiguous fp32 operands, accumulate for fp32 operands");
         return PCRCG_EBADARG;
     }
     if (gather && !ex->a_zero) { set_error("gemm_x6: gather needs a zero row"); return PCRCG_EBADARG; }

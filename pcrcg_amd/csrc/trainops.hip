@@ -587,3 +587,156 @@ extern "C" int pcrcg_kpconv_backward(const float* q_pts, int nq, const float* s_
     }
     return PCRCG_OK;
 }
+
+// ---- element-wise pieces of the C++ train step (train_runner.hip) --------------------------------------------------
+namespace pcrcg {
+namespace {
+__global__ void __launch_bounds__(256) k_add_lrelu(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                    float slope, float* __restrict__ y, int ldy, long total, int cols) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const long r = t / cols;
+    const int c = (int)(t - r * cols);
+    const float v = a[r * lda + c] + b[r * ldb + c];
+    y[r * ldy + c] = v >= 0.f ? v : v * slope;
+}
+// g = dy * (y > 0 ? 1 : slope), added to ga and gb (either may be NULL).  lrelu keeps the sign, so y > 0 <=> a + b > 0;
+// at exactly 0 torch's leaky_relu_backward takes the slope (x > 0 ? 1 : slope), and so does this.
+__global__ void __launch_bounds__(256) k_add_lrelu_bwd(const float* __restrict__ y, int ldy, const float* __restrict__ dy,
+                                                        int ld_dy, float slope, float* __restrict__ ga, int lga,
+                                                        float* __restrict__ gb, int lgb, long total, int cols) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const long r = t / cols;
+    const int c = (int)(t - r * cols);
+    const float g = dy[r * ld_dy + c] * (y[r * ldy + c] > 0.f ? 1.0f : slope);
+    if (ga) ga[r * lga + c] += g;
+    if (gb) gb[r * lgb + c] += g;
+}
+__global__ void __launch_bounds__(256) k_add2d(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst,
+                                                long total, int cols) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const long r = t / cols;
+    const int c = (int)(t - r * cols);
+    dst[r * ld_dst + c] += src[r * ld_src + c];
+}
+// db[c] += sum_r dy[r, c]: 64 columns x 4 row groups per workgroup (fp32 partial sums of a few hundred / thousand rows)
+__global__ void __launch_bounds__(256) k_bias_grad(const float* __restrict__ dy, int ld, int rows, int cols,
+                                                    float* __restrict__ db) {
+    __shared__ float s[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < cols)
+        for (int r = blockIdx.y * 4 + g; r < rows; r += 4 * gridDim.y) acc += dy[(long)r * ld + c];
+    s[g][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (g == 0 && c < cols) atomicAdd(&db[c], s[0][threadIdx.x & 63] + s[1][threadIdx.x & 63] + s[2][threadIdx.x & 63] +
+                                                 s[3][threadIdx.x & 63]);
+}
+// y = x / max(|x|, 1e-12) row-wise (F.normalize): dx += (dy - y * <y, dy>) / max(|x|, 1e-12); one wavefront per row
+__global__ void __launch_bounds__(256) k_l2norm_bwd(const float* __restrict__ x, int ldx, const float* __restrict__ dy,
+                                                     int ld_dy, float* __restrict__ dx, int ld_dx, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float ss = 0.f, sd = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = x[(long)r * ldx + c];
+        ss += v * v;
+        sd += v * dy[(long)r * ld_dy + c];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        ss += __shfl_xor(ss, d, 64);
+        sd += __shfl_xor(sd, d, 64);
+    }
+    const float nrm = sqrtf(ss);
+    if (nrm < 1e-12f) {                     // below the clamp the divisor is the constant eps: dx = dy / eps
+        for (int c = lane; c < cols; c += 64) dx[(long)r * ld_dx + c] += dy[(long)r * ld_dy + c] * 1e12f;
+        return;
+    }
+    const float inv = 1.0f / nrm, k = sd * inv * inv * inv;        // <x, dy> / |x|^3
+    for (int c = lane; c < cols; c += 64)
+        dx[(long)r * ld_dx + c] += dy[(long)r * ld_dy + c] * inv - x[(long)r * ldx + c] * k;
+}
+__global__ void __launch_bounds__(256) k_sigmoid_bwd(const float* __restrict__ s, const float* __restrict__ ds,
+                                                      float* __restrict__ dx, int ld_dx, int rows) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float v = s[r];
+    dx[(long)r * ld_dx] += ds[r] * v * (1.0f - v);
+}
+__global__ void __launch_bounds__(256) k_dot_acc(const float* __restrict__ a, const float* __restrict__ b, long n, float scale,
+                                                  float* __restrict__ out) {
+    __shared__ double s[256];
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += (double)a[i] * (double)b[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, (float)(s[0] * (double)scale));
+}
+inline unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
+}  // namespace
+
+int tr_scale_rows(const float* src, int ld_src, const float* s, float* dst, int rows, int cols, hipStream_t st) {
+    const long total = (long)rows * cols;
+    if (total > 0) hipLaunchKernelGGL(k_scale_rows, dim3(blocks_for(total)), dim3(256), 0, st, src, ld_src, s, dst, total, cols);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+int tr_add_lrelu(const float* a, int lda, const float* b, int ldb, float slope, float* y, int ldy, int rows, int cols,
+                 hipStream_t st) {
+    const long total = (long)rows * cols;
+    if (total > 0) hipLaunchKernelGGL(k_add_lrelu, dim3(blocks_for(total)), dim3(256), 0, st, a, lda, b, ldb, slope, y, ldy, total, cols);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+int tr_add_lrelu_bwd(const float* y, int ldy, const float* dy, int ld_dy, float slope, float* ga, int lga, float* gb, int lgb,
+                     int rows, int cols, hipStream_t st) {
+    const long total = (long)rows * cols;
+    if (total > 0)
+        hipLaunchKernelGGL(k_add_lrelu_bwd, dim3(blocks_for(total)), dim3(256), 0, st, y, ldy, dy, ld_dy, slope, ga, lga, gb, lgb,
+                           total, cols);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+int tr_add2d(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t st) {
+    const long total = (long)rows * cols;
+    if (total > 0) hipLaunchKernelGGL(k_add2d, dim3(blocks_for(total)), dim3(256), 0, st, src, ld_src, dst, ld_dst, total, cols);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+int tr_bias_grad(const float* dy, int ld, int rows, int cols, float* db, hipStream_t st) {
+    if (rows > 0 && cols > 0) {
+        int gy = (rows + 255) / 256;
+        if (gy > 64) gy = 64;
+        hipLaunchKernelGGL(k_bias_grad, dim3((cols + 63) / 64, gy), dim3(256), 0, st, dy, ld, rows, cols, db);
+    }
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+int tr_l2norm_bwd(const float* x, int ldx, const float* dy, int ld_dy, float* dx, int ld_dx, int rows, int cols, hipStream_t st) {
+    if (rows > 0) hipLaunchKernelGGL(k_l2norm_bwd, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, dy, ld_dy, dx, ld_dx, rows, cols);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+int tr_sigmoid_bwd(const float* s, const float* ds, float* dx, int ld_dx, int rows, hipStream_t st) {
+    if (rows > 0) hipLaunchKernelGGL(k_sigmoid_bwd, dim3((rows + 255) / 256), dim3(256), 0, st, s, ds, dx, ld_dx, rows);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+int tr_dot_acc(const float* a, const float* b, long n, float scale, float* out, hipStream_t st) {
+    if (n > 0) {
+        long blocks = (n + 255) / 256;
+        if (blocks > 256) blocks = 256;
+        hipLaunchKernelGGL(k_dot_acc, dim3((unsigned)blocks), dim3(256), 0, st, a, b, n, scale, out);
+    }
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+}  // namespace pcrcg

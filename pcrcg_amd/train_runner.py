@@ -1,0 +1,267 @@
+"""Python side of the C++ train-step runner (csrc/train_runner.hip; include/pcrcg_train.h: pcrcg_kpfcnn_train_*):
+KPFCNN.forward with a tape and its backward, each ONE call into libpcrcg_hip.so, wrapped as a single
+torch.autograd.Function so that `loss.backward()` works unchanged (ref:lib/trainer.py:216-265).
+
+What torch still does around it: the loss (pcrcg_amd/loss.py), a handful of tiny tensor ops per step that hand derived
+weight layouts to the library and fold their gradients back (the DGCNN edge convolutions' [Wa - Wb ; Wb] split, the
+head-major attention projections, two decoder weights with padded rows), and the optimiser.
+
+Parameter gradients are ACCUMULATED by the library straight into `p.grad` (pcrcg_amd/trainer.py makes those views of the
+flat all-reduce bucket); the autograd graph sees one differentiable input, `net.epsilon`, whose gradient it gets back
+-- so parameter hooks (the bucket's overlap of the exchange with backward) do not fire per parameter: the trainer
+reduces the bucket after the backward call, which is already complete when it returns."""
+import ctypes
+
+import torch
+
+from . import _lib
+from .blocks import LastUnaryBlock, NearestUpsampleBlock, ResnetBottleneckBlock, SimpleBlock, UnaryBlock
+from .gcn import AttentionalPropagation, SelfAttention
+from .runner import (BLK_LAST_UNARY, BLK_RESNETB, BLK_SIMPLE, BLK_UNARY, BLK_UPSAMPLE, MAX_BLOCKS, MAX_GNN, Model, Runner)
+
+
+class TrainOutputs(ctypes.Structure):
+    """pcrcg_train_outputs (include/pcrcg_train.h)."""
+    _fields_ = [("feats_f", ctypes.c_void_p), ("scores_overlap", ctypes.c_void_p), ("scores_saliency", ctypes.c_void_p),
+                ("d_inv_temperature", ctypes.c_void_p), ("n_points", ctypes.c_int), ("final_dim", ctypes.c_int)]
+
+
+def _grad(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+class TrainRunner:
+    def __init__(self, model):
+        self.model = model
+        self.ws = None
+        self._batch_helper = Runner(model)        # batch dict -> pcrcg_batch
+
+    # a copied / pickled model starts without a runner (KPFCNN.train_runner() re-creates it lazily)
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
+    # ---- descriptors ---------------------------------------------------------------------------------------------
+    def _pair(self, keep, value, grad):
+        """(value pointer, gradient pointer) of one weight; both tensors are kept alive."""
+        if value.dtype != torch.float32 or not value.is_cuda or not value.is_contiguous():
+            raise RuntimeError("pcrcg_amd.train_runner: weights must be contiguous float32 tensors on a HIP device")
+        keep.append(value)
+        keep.append(grad)
+        return value.data_ptr(), (grad.data_ptr() if grad is not None else None)
+
+    def _descriptors(self):
+        """-> (values Model, gradients Model, keep-alive list, fold-back closures run after the backward)."""
+        m = self.model
+        v, g = Model(), Model()
+        keep, fold = [], []
+        v.n_enc, v.n_dec, v.n_gnn = len(m.encoder_blocks), len(m.decoder_blocks), len(m.gnn.layers)
+        if v.n_enc > MAX_BLOCKS or v.n_dec > MAX_BLOCKS or v.n_gnn > MAX_GNN:
+            raise RuntimeError("pcrcg_amd.train_runner: architecture too deep for the descriptor")
+
+        def direct(dst_v, dst_g, name, param, view=None):
+            """A parameter used as stored (optionally through a reshaping VIEW of it and of its gradient)."""
+            val = param.data if view is None else view(param.data)
+            grd = _grad(param) if view is None else view(_grad(param))
+            pv, pg = self._pair(keep, val, grd)
+            setattr(dst_v, name, pv)
+            setattr(dst_g, name, pg)
+
+        def derived(dst_v, dst_g, name, value, fold_back):
+            """A re-packed copy of a parameter: its gradient lands in a zeroed buffer of the same shape and
+            fold_back(buffer) adds it to the parameter's gradient after the backward."""
+            value = value.contiguous()
+            buf = torch.zeros_like(value)
+            pv, pg = self._pair(keep, value, buf)
+            setattr(dst_v, name, pv)
+            setattr(dst_g, name, pg)
+            fold.append(lambda: fold_back(buf))
+
+        def kp_block(bv, bg, kp):
+            if kp.in_channels != 1 and kp.in_channels % 4 != 0:
+                raise RuntimeError("pcrcg_amd.train_runner: KPConv input widths must be 1 or a multiple of 4")
+            bv.extent = float(kp.KP_extent)
+            keep.append(kp.kernel_points.data)
+            bv.kp = kp.kernel_points.data.contiguous().data_ptr()
+            direct(bv, bg, "kp_w", kp.weights, lambda t: t.reshape(-1, t.shape[-1]))
+
+        for i, mod in enumerate(m.encoder_blocks):
+            bv, bg = v.enc[i], g.enc[i]
+            v.enc_skip[i] = int(i in m.encoder_skips)
+            if not getattr(mod, "use_bn", True):
+                raise RuntimeError("pcrcg_amd.train_runner: use_batch_norm=False is handled by the op-by-op path only")
+            if isinstance(mod, SimpleBlock):
+                bv.type, bv.layer, bv.strided = BLK_SIMPLE, mod.layer_ind, int("strided" in mod.block_name)
+                kp = mod.KPConv
+                bv.in_dim, bv.out_dim, bv.mid_dim = kp.in_channels, kp.out_channels, kp.out_channels
+                kp_block(bv, bg, kp)
+            elif isinstance(mod, ResnetBottleneckBlock):
+                bv.type, bv.layer, bv.strided = BLK_RESNETB, mod.layer_ind, int("strided" in mod.block_name)
+                kp = mod.KPConv
+                bv.in_dim, bv.out_dim, bv.mid_dim = mod.in_dim, mod.out_dim, kp.out_channels
+                kp_block(bv, bg, kp)
+                if isinstance(mod.unary1, UnaryBlock):
+                    direct(bv, bg, "unary1", mod.unary1.mlp.weight)
+                direct(bv, bg, "unary2", mod.unary2.mlp.weight)
+                if isinstance(mod.unary_shortcut, UnaryBlock):
+                    direct(bv, bg, "shortcut", mod.unary_shortcut.mlp.weight)
+            else:
+                raise RuntimeError(f"pcrcg_amd.train_runner: unsupported encoder block {type(mod).__name__}")
+        for j, mod in enumerate(m.decoder_blocks):
+            bv, bg = v.dec[j], g.dec[j]
+            v.dec_concat[j] = int(j in m.decoder_concats)
+            if isinstance(mod, (UnaryBlock, LastUnaryBlock)):
+                if not getattr(mod, "use_bn", True):
+                    raise RuntimeError("pcrcg_amd.train_runner: use_batch_norm=False is handled by the op-by-op path only")
+                bv.type = BLK_UNARY if isinstance(mod, UnaryBlock) else BLK_LAST_UNARY
+                bv.in_dim, bv.out_dim = mod.in_dim, mod.out_dim
+                w = mod.mlp.weight
+                k = w.shape[1]
+                if k % 4 == 0:
+                    direct(bv, bg, "mlp", w)
+                    bv.mlp_ld = k
+                else:                               # rows padded to 16 bytes (decoder widths 1538 and 769)
+                    kp4 = (k + 3) // 4 * 4
+                    padded = torch.zeros((w.shape[0], kp4), dtype=w.dtype, device=w.device)
+                    padded[:, :k].copy_(w.data)
+                    derived(bv, bg, "mlp", padded, lambda buf, w=w, k=k: _grad(w).add_(buf[:, :k]))
+                    bv.mlp_ld = kp4
+            elif isinstance(mod, NearestUpsampleBlock):
+                bv.type, bv.layer = BLK_UPSAMPLE, mod.layer_ind
+            else:
+                raise RuntimeError(f"pcrcg_amd.train_runner: unsupported decoder block {type(mod).__name__}")
+        heads = None
+        for i, layer in enumerate(m.gnn.layers):
+            lv, lg = v.gnn[i], g.gnn[i]
+            if isinstance(layer, SelfAttention):
+                lv.cross = 0
+                v.knn_k = layer.k
+
+                def packed(name, conv):
+                    w = conv.weight
+                    w2 = w.data.flatten(1)
+                    cin = w2.shape[1] // 2
+                    wa, wb = w2[:, :cin], w2[:, cin:]
+
+                    def back(buf, w=w, cin=cin):
+                        gw = _grad(w).flatten(1)
+                        cout = gw.shape[0]
+                        gw[:, :cin].add_(buf[:cout])                       # d(Wa - Wb) -> Wa
+                        gw[:, cin:].add_(buf[cout:] - buf[:cout])          # Wb sits in both terms
+                    derived(lv, lg, name, torch.cat([wa - wb, wb], 0), back)
+                packed("edge1", layer.conv1)
+                packed("edge2", layer.conv2)
+                direct(lv, lg, "conv3", layer.conv3.weight, lambda t: t.flatten(1))
+            elif isinstance(layer, AttentionalPropagation):
+                lv.cross = 1
+                att = layer.attn
+                h, d = att.num_heads, att.dim
+                heads = h
+                dev = att.merge.weight.device
+                perm = (torch.arange(h, device=dev)[:, None] + h * torch.arange(d, device=dev)[None, :]).reshape(-1)
+                for name, proj in zip("qkv", att.proj):
+                    derived(lv, lg, "w" + name, proj.weight.data.squeeze(-1)[perm],
+                            lambda buf, p=proj.weight: _grad(p).squeeze(-1).index_add_(0, perm, buf))
+                    derived(lv, lg, "b" + name, proj.bias.data[perm],
+                            lambda buf, p=proj.bias: _grad(p).index_add_(0, perm, buf))
+                derived(lv, lg, "wm", att.merge.weight.data.squeeze(-1)[:, perm],
+                        lambda buf, p=att.merge.weight: _grad(p).squeeze(-1).index_add_(1, perm, buf))
+                direct(lv, lg, "bm", att.merge.bias)
+                direct(lv, lg, "w0", layer.mlp[0].weight, lambda t: t.squeeze(-1))
+                direct(lv, lg, "b0", layer.mlp[0].bias)
+                direct(lv, lg, "w3", layer.mlp[3].weight, lambda t: t.squeeze(-1))
+                direct(lv, lg, "b3", layer.mlp[3].bias)
+            else:
+                raise RuntimeError(f"pcrcg_amd.train_runner: unsupported GNN layer {type(layer).__name__}")
+        v.heads = heads or 1
+        v.enc_out_dim, v.gnn_dim, v.final_dim = m.bottle.in_channels, m.bottle.out_channels, m.final_feats_dim
+        for name, conv in (("bottle", m.bottle), ("proj_gnn", m.proj_gnn), ("proj_score", m.proj_score)):
+            direct(v, g, name + "_w", conv.weight, lambda t: t.squeeze(-1))
+            direct(v, g, name + "_b", conv.bias)
+        v.temperature = float(torch.exp(m.epsilon.detach()).item()) + 0.03
+        # the gradient twin only needs its pointers; copy the integer layout so that validation sees the same model
+        for f in ("n_enc", "n_dec", "n_gnn", "enc_out_dim", "gnn_dim", "heads", "knn_k", "final_dim", "temperature"):
+            setattr(g, f, getattr(v, f))
+        return v, g, keep, fold
+
+    # ---- forward / backward --------------------------------------------------------------------------------------
+    def forward(self, batch):
+        """-> {'feats_f', 'scores_overlap', 'scores_saliency'} with a grad_fn (one autograd node for the whole network)."""
+        outs = _TrainNet.apply(self.model.epsilon, self, batch)
+        return {"feats_f": outs[0], "scores_overlap": outs[1], "scores_saliency": outs[2]}
+
+    def _forward(self, batch):
+        L = _lib.lib()
+        v, g, keep, fold = self._descriptors()
+        b, bkeep, dev = self._batch_helper.batch_struct(batch)
+        sizes = [ctypes.c_size_t() for _ in range(3)]
+        _lib.check(L.pcrcg_kpfcnn_train_ws_bytes(ctypes.byref(v), ctypes.byref(g), ctypes.byref(b), *[ctypes.byref(s) for s in sizes]),
+                   "pcrcg_kpfcnn_train_ws_bytes")
+        vb, gb, sb = (int(s.value) for s in sizes)
+        total = vb + gb + sb
+        if self.ws is None or self.ws.numel() < total or self.ws.device != dev:
+            self.ws = None
+            self.ws = torch.empty(int(total * 1.05), dtype=torch.uint8, device=dev)
+        ws = self.ws
+        out = TrainOutputs()
+        tape = ctypes.c_void_p()
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(L.pcrcg_kpfcnn_train_forward(ctypes.byref(v), ctypes.byref(g), ctypes.byref(b), ws.data_ptr(), vb, gb, sb,
+                                                ctypes.byref(out), ctypes.byref(tape), stream), "pcrcg_kpfcnn_train_forward")
+        base = ws.data_ptr()
+
+        def view(ptr, *shape):
+            n = 1
+            for s in shape:
+                n *= s
+            off = ptr - base
+            return ws[off:off + 4 * n].view(torch.float32).view(*shape)
+        n0, fd = out.n_points, out.final_dim
+        outs = (view(out.feats_f, n0, fd), view(out.scores_overlap, n0), view(out.scores_saliency, n0))
+        state = {"tape": tape, "keep": (keep, bkeep, v, g, b), "fold": fold, "d_inv_t": view(out.d_inv_temperature, 1),
+                 "inv_t": 1.0 / v.temperature, "ws": ws}
+        return outs, state
+
+    def _backward(self, state, d_f, d_so, d_ss):
+        L = _lib.lib()
+        tape = state["tape"]
+        if tape is None:
+            raise RuntimeError("pcrcg_amd.train_runner: backward called twice (the tape is released after the first)")
+
+        def ptr(t, shape):
+            if t is None:
+                return None
+            t = t.to(torch.float32).contiguous()
+            assert tuple(t.shape) == tuple(shape)
+            state.setdefault("dkeep", []).append(t)
+            return t.data_ptr()
+        n0, fd = state["shape"]
+        try:
+            _lib.check(L.pcrcg_kpfcnn_train_backward(tape, ptr(d_f, (n0, fd)), ptr(d_so, (n0,)), ptr(d_ss, (n0,)),
+                                                     torch.cuda.current_stream().cuda_stream), "pcrcg_kpfcnn_train_backward")
+        finally:
+            L.pcrcg_kpfcnn_train_free(tape)
+            state["tape"] = None
+        for f in state["fold"]:
+            f()
+        # temperature = exp(epsilon) + 0.03 and the library reports dL/d(1/temperature)
+        eps = self.model.epsilon.detach()
+        return state["d_inv_t"].reshape(()) * (-(state["inv_t"] ** 2)) * torch.exp(eps)
+
+
+class _TrainNet(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, epsilon, runner, batch):
+        outs, state = runner._forward(batch)
+        state["shape"] = tuple(outs[0].shape)
+        ctx.runner, ctx.state = runner, state
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_f, d_so, d_ss):
+        d_eps = ctx.runner._backward(ctx.state, d_f, d_so, d_ss)
+        return d_eps.reshape(ctx.runner.model.epsilon.shape), None, None

@@ -118,8 +118,9 @@ class GradientBucket:
 
 class Trainer:
     def __init__(self, model, desc_loss, lr=0.005, momentum=0.98, weight_decay=1e-6, scheduler_gamma=0.95,
-                 iter_size=1, process_group=None, overlap_chunks=4):
+                 iter_size=1, process_group=None, overlap_chunks=4, use_cpp_runner=True):
         self.model, self.desc_loss = model, desc_loss
+        self.use_cpp_runner = bool(use_cpp_runner)
         self.iter_size = iter_size
         self.bucket = GradientBucket(model.parameters(), process_group)
         if overlap_chunks and overlap_chunks > 1:
@@ -138,7 +139,14 @@ class Trainer:
         train = phase == "train"
         self.model.train(train)
         with torch.set_grad_enabled(train):
-            output = forward_train(self.model, inputs) if train else self.model(inputs)
+            if train:
+                # the network's forward + backward in C++ (one autograd node); the op-by-op autograd composition of
+                # pcrcg_amd/train_forward.py remains as its mirror (use_cpp_runner = False, or a configuration the runner
+                # does not cover)
+                tr = self.model.train_runner() if self.use_cpp_runner else None
+                output = tr.forward(inputs) if tr is not None else forward_train(self.model, inputs)
+            else:
+                output = self.model(inputs)
             len_src = int(inputs["stack_lengths_host"][0][0]) if "stack_lengths_host" in inputs \
                 else int(inputs["stack_lengths"][0][0])
             feats = output["feats_f"]

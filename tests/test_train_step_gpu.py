@@ -39,7 +39,18 @@ def _to(batch, dev):
     return out
 
 
-def test_full_model_gradients_match_oracle_autograd(cuda, golden_dir):
+def _train_forward(net, batch, path):
+    """path "cpp": the C++ tape runner (csrc/train_runner.hip, one autograd node); "python": the op-by-op autograd
+    composition of pcrcg_amd/train_forward.py, its mirror."""
+    if path == "cpp":
+        runner = net.train_runner()
+        assert runner is not None
+        return runner.forward(batch)
+    return forward_train(net, batch)
+
+
+@pytest.mark.parametrize("path", ["cpp", "python"])
+def test_full_model_gradients_match_oracle_autograd(cuda, golden_dir, path):
     """d(scalar)/d(every parameter) through encoder, GNN, saliency head and decoder."""
     gold = torch.load(os.path.join(golden_dir, "model_mini.pt"))
     col = torch.load(os.path.join(golden_dir, "collate_mini.pt"))
@@ -56,7 +67,7 @@ def test_full_model_gradients_match_oracle_autograd(cuda, golden_dir):
         return (out["feats_f"] * r1.to(dev)).sum() + (out["scores_overlap"] * r2.to(dev)).sum() \
             + (out["scores_saliency"] * r3.to(dev)).sum()
 
-    out = forward_train(net, batch)
+    out = _train_forward(net, batch, path)
     for k in gold["outputs"]:                                     # the forward values still match the reference
         assert rel(out[k], gold["outputs"][k]) < 1e-4, k
     scalar(out, cuda).backward()
@@ -130,7 +141,8 @@ def test_non_finite_gradients_skip_the_step(cuda):
     assert float(trainer.flat_grad.abs().sum()) == 0.0          # bucket cleared for the next pair
 
 
-def test_full_width_gradients_c1_vs_oracle(cuda):
+@pytest.mark.parametrize("path", ["cpp", "python"])
+def test_full_width_gradients_c1_vs_oracle(cuda, path):
     """The gradient check at the real channel widths (29.7 M parameters, Cin up to 2048 in the 1x1 convolutions,
     KPConv widths up to 512) on a C1 pair: exercises the multi-block gather variants, the split-K A^T products
     with K = number of points and the 1538 / 769-wide decoder GEMMs.  At this depth fp32 itself is the limit:
@@ -156,7 +168,7 @@ def test_full_width_gradients_c1_vs_oracle(cuda):
         return (out["feats_f"] * r1.to(dev).to(dt)).sum() + (out["scores_overlap"] * r2.to(dev).to(dt)).sum() \
             + (out["scores_saliency"] * r3.to(dev).to(dt)).sum()
 
-    out = forward_train(net, batch)
+    out = _train_forward(net, batch, path)
     scalar(out, cuda).backward()
     cpu_batch = {k: ([t.cpu() if isinstance(t, torch.Tensor) else t for t in v] if isinstance(v, list)
                      else (v.cpu() if isinstance(v, torch.Tensor) else v)) for k, v in batch.items()}
