@@ -1,5 +1,6 @@
 """GPU box: the train step by phase (differentiable forward, MetricLoss, backward, optimiser), each drained before the
-next is timed, host time to enqueue vs time to completion."""
+next is timed, host time to enqueue vs time to completion.  PATH_PY=1: the op-by-op autograd
+mirror instead of the C++ tape runner."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -28,7 +29,7 @@ N = 10
 for _ in range(N):
     net.train(True)
     t0 = time.perf_counter()
-    out = forward_train(net, inputs)
+    out = net.train_runner().forward(inputs) if os.environ.get("PATH_PY") != "1" else forward_train(net, inputs)
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     len_src = int(inputs["stack_lengths_host"][0][0])
     f = out["feats_f"]
