@@ -191,7 +191,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="S30k")
     ap.add_argument("--model-streams", type=int, default=3, help="engine: host threads / HIP streams enqueueing forwards")
     ap.add_argument("--front-threads", type=int, default=1, help="engine: host threads building pyramids")
-    ap.add_argument("--depth", type=int, default=6, help="pairs submitted ahead of the one being collected")
+    ap.add_argument("--depth", type=int, default=8, help="pairs submitted ahead of the one being collected")
+    ap.add_argument("--pairs-per-forward", type=int, default=2, choices=[1, 2],
+                    help="2: two pairs built together share one pcrcg_kpfcnn_forward_group call (weight products once for both)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="A/B aid: no start/stop events on the KPConv launches of the timed regions (roofline comes out empty)")
     ap.add_argument("--isolated-only", action="store_true",
@@ -331,7 +333,8 @@ def main():
         return float(t.item()), submit
 
     # ---- headline: the reference's batch contract inside the engine too (full [N, limit] upsample tables) ----------
-    pipe = PairStreams(net, cfg, limits, dev, model_streams=WORKERS, front_threads=FRONTS, up_nearest=False)
+    pipe = PairStreams(net, cfg, limits, dev, model_streams=WORKERS, front_threads=FRONTS, up_nearest=False,
+                       pairs_per_forward=args.pairs_per_forward)
     run_pairs(pipe, args.warmup)
     fence(pipe)
     pipe.reset_stats()
@@ -442,13 +445,16 @@ def main():
                                    "1 pair/GPU/step, inputs resident in HBM; pair engine: %d front thread(s) build pyramids "
                                    "(pcrcg_pyramid_build, %.2f pairs per call on average: two waiting pairs share one kernel "
                                    "chain) on one front-end HIP stream, %d host threads enqueue the forwards "
-                                   "(pcrcg_kpfcnn_forward) on one model stream each; every table as the batch contract "
+                                   "(pcrcg_kpfcnn_forward_group: %s) on one model stream each; every table as the batch contract "
                                    "defines it ([N, limit] upsample tables included); every timed region starts and ends "
                                    "with an empty engine; neighbour tables in the reference's own order inside groups of "
                                    "exactly equal distance (tie_order=%s); GEMM arithmetic mode %d (1 = exact three-term "
                                    "bf16 split on the bf16 matrix cores, fp32-class accuracy; 0 = fp32 MFMA)"
-                                   % (FRONTS, ppb, WORKERS, tie, _gemm_mode()),
+                                   % (FRONTS, ppb, WORKERS,
+                                      "the two pairs of a build in ONE call, every weight product once for both"
+                                      if args.pairs_per_forward == 2 else "one call per pair", tie, _gemm_mode()),
                        "tie_order": tie, "up_nearest": 0, "pairs_per_pyramid_build": round(ppb, 2),
+                       "pairs_per_forward_call": args.pairs_per_forward,
                        "limits": limits, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
                        "lib_path": os.path.relpath(lib_path, REPO), "lib_sha16": lib_sha},
             "secondary": extras,

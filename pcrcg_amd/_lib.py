@@ -98,6 +98,8 @@ SIGNATURES = {
     "pcrcg_sigmoid_scores": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     # struct-based entry points: pcrcg_amd/runner.py declares the ctypes.Structure mirrors
     "pcrcg_kpfcnn_ws_bytes": (c_size_t, [c_void_p, c_void_p]),
+    "pcrcg_kpfcnn_group_ws_bytes": (c_size_t, [c_void_p, c_void_p, c_int]),
+    "pcrcg_kpfcnn_forward_group": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "pcrcg_kpfcnn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pcrcg_pyramid_ws_bytes": (c_size_t, [c_int, c_int, c_void_p, ctypes.c_double]),
     "pcrcg_pyramid_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p,

@@ -63,6 +63,24 @@ struct GemmExtra {
     float a_eps = 1e-5f, a_slope = 1.0f;
 };
 
+// gemm_x6.hip: a SECOND product C1 = f(A1) * B^T that shares B (and the bias, the leading dimensions, n, k and every
+// GemmExtra setting except the per-product pointers below) with the first and runs in the SAME launch: the same layer
+// of a second fragment pair (runner.hip, pcrcg_kpfcnn_forward_group).  Small products fill the chip twice as well
+// and every product costs one launch per two pairs.
+struct GemmPair {
+    const float* a = nullptr;
+    float* c = nullptr;
+    int m = 0;
+    const float* row_scale = nullptr;
+    void* colstats = nullptr;           // statistics of C1, same form and size as the first product's
+    int* h_chunks = nullptr;
+    bool c_zeroed = false;
+    const long long* a_idx = nullptr;   // gather form: its own table and source row count (A1 = its source matrix)
+    int a_ns = 0;
+    const double* a_sums = nullptr;     // normalise-on-load form: its own column sums and row count
+    double a_count = 0.0;
+};
+
 // kpconv.hip: row-positive flags + packed (x, y, z, flag) support records into a pcrcg_kpconv_ws_bytes(ns) workspace
 // (x_bf16 != NULL: also the bf16 round-to-nearest-even copy of x, [ns, cin])
 int kpconv_pack(const float* x, int ns, int cin, const float* s_pts, void* ws, size_t ws_bytes, hipStream_t st,

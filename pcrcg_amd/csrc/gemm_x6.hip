@@ -41,6 +41,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 
+// kernel-side form of GemmPair (common.h): the second product's operands; pair_off = 0: a single product
+struct GemmPairArgs {
+    int pair_off = 0, m1 = 0;
+    const float* a1 = nullptr;
+    float* c1 = nullptr;
+    const float* rs1 = nullptr;
+    double* colp1 = nullptr;
+    int colp_chunks1 = 0;
+    const long long* a_idx1 = nullptr;
+    int a_ns1 = 0;
+    const double* a_sums1 = nullptr;
+    double a_count1 = 0.0;
+};
+
 // Register loads hidden from hipcc's s_waitcnt bookkeeping (guide 5.7, form ii).  hipcc merges the vmcnt state of
 // the two register sets of the k-loop conservatively and waits for BOTH at the top of every step (ISA checked),
 // i.e. it turns prefetch distance 2 into 1; with the loads in asm the waits below are counted by hand instead:
@@ -153,7 +167,7 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
                                                         int colp_chunks, const long long* __restrict__ a_idx,
                                                         int a_idx_ld, int a_ns, const float* __restrict__ a_zero,
                                                         const double* __restrict__ a_sums, double a_count, float a_eps,
-                                                        float a_slope) {
+                                                        float a_slope, GemmPairArgs pr) {
     constexpr int WAVES_M = 2, WAVES_N = 2;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -172,8 +186,29 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     const int lin = blockIdx.x + gx * blockIdx.y;
     const int xq = ntile >> 3, xr = ntile & 7, xcd = lin & 7, slot = lin >> 3;
     const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
-    const int tile_x = tile % gx, tile_y = tile / gx;
-    const int m0 = tile_y * BM, n0 = tile_x * BN;
+    const int tile_x = tile % gx;
+    int tile_y = tile / gx;
+    int m0 = tile_y * BM;
+    const int n0 = tile_x * BN;
+    // Two products that share B in ONE launch (GemmPair, common.h: the same layer of two fragment pairs): row tiles from
+    // pair_off on belong to the second product -- its own A, C, row scale, statistics and gather table; from here on the
+    // workgroup works on that product's matrices as if it had been launched alone.
+    if (pr.pair_off > 0) {
+        if (m0 >= pr.pair_off) {
+            m0 -= pr.pair_off;
+            tile_y = m0 / BM;
+            M = pr.m1;
+            A = pr.a1;
+            C = pr.c1;
+            row_scale = pr.rs1;
+            colp = pr.colp1;
+            colp_chunks = pr.colp_chunks1;
+            a_idx = pr.a_idx1;
+            a_ns = pr.a_ns1;
+            a_sums = pr.a_sums1;
+            a_count = pr.a_count1;
+        }
+    }
     const int k_begin = blockIdx.z * k_per_split;
     const int k_end = min(Kdim, k_begin + k_per_split);
 
@@ -525,7 +560,7 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
               int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b, int atomic_out,
               double* colp, int colp_chunks, const long long* a_idx = nullptr, int a_idx_ld = 0, int a_ns = 0,
               const float* a_zero = nullptr, const double* a_sums = nullptr, double a_count = 0.0, float a_eps = 0.f,
-              float a_slope = 1.f) {
+              float a_slope = 1.f, GemmPairArgs pr = GemmPairArgs()) {
     const size_t lds = lds_bytes<BM, BN>() + (ANORM ? 2 * sizeof(float) * (size_t)(((k_per_split + BK - 1) / BK) * BK) : 0);
     auto kern = k_gemm_x6<BM, BN, MINB, ATERMS, ALAY, BLAY, ANORM, KNOCK>;
     static size_t configured = 0;
@@ -537,7 +572,7 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
     KpProfScope prof(st, m, n, k, ATERMS == 1 ? 3 : 6, 3);     // bench.py's GEMM roofline: the kernel's own start / stop events
     hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, st, prof.a, prof.b, 0, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
                           k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks, a_idx, a_idx_ld, a_ns, a_zero, a_sums,
-                          a_count, a_eps, a_slope);
+                          a_count, a_eps, a_slope, pr);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -584,13 +619,17 @@ int gemm_x6_splits(int m, int n, int k) { return (m > 0 && n > 0) ? x6_plan(m, n
 int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
                      hipStream_t st, bool a_bf16, bool c_zeroed, int a_kmajor, int b_kmajor, bool colstats_sums,
-                     const GemmExtra* ex) {
+                     const GemmExtra* ex, const GemmPair* pair) {
     // k-major operands (a_kmajor: A stored [K, M]; b_kmajor: B stored [K, N]) are read with 4-byte loads: no alignment rule
     const int vec_a = (a_bf16 || a_kmajor) ? 1 : (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     const int vec_b = b_kmajor ? 1 : (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
     if (a_kmajor && !b_kmajor) { set_error("gemm_x6: A^T * B^T is not built"); return PCRCG_EBADARG; }
-    const X6Plan plan = x6_plan(m, n, k, a_kmajor || b_kmajor || (ex && ex->a_sums), a_kmajor != 0);
-    const int pick = plan.pick, BM = plan.bm, BN = plan.bn, gx = plan.gx, gy = plan.gy, splits = plan.splits;
+    // (a second product in the same launch: the plan of the larger one serves both)
+    const int m_plan = pair && pair->m > m ? pair->m : m;
+    const X6Plan plan = x6_plan(m_plan, n, k, a_kmajor || b_kmajor || (ex && ex->a_sums), a_kmajor != 0);
+    const int pick = plan.pick, BM = plan.bm, BN = plan.bn, gx = plan.gx, splits = plan.splits;
+    const int gy0 = (m + BM - 1) / BM, gy1 = pair ? (pair->m + BM - 1) / BM : 0, gy = gy0 + gy1;
+    if (pair && (a_kmajor || b_kmajor)) { set_error("gemm_x6: paired launches are built for the A * B^T form"); return PCRCG_EBADARG; }
     const int k_per_split = plan.k_per_split;
     const bool accumulate = ex && ex->accumulate;
     const bool gather = ex && ex->a_idx;
@@ -609,6 +648,10 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
         if (ldc == n) PCRCG_CHECK_HIP(hipMemsetAsync(c, 0, (size_t)m * n * sizeof(float), st));
         else PCRCG_CHECK_HIP(hipMemset2DAsync(c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), m, st));
     }
+    if (pair && splits > 1 && !pair->c_zeroed && !accumulate) {
+        if (ldc == n) PCRCG_CHECK_HIP(hipMemsetAsync(pair->c, 0, (size_t)pair->m * n * sizeof(float), st));
+        else PCRCG_CHECK_HIP(hipMemset2DAsync(pair->c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), pair->m, st));
+    }
     dim3 grid(gx, gy, splits);
     const bool log_shapes = debug_opts().gemm_log != 0;   // tuning aid
     if (log_shapes)
@@ -625,13 +668,38 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
             *h_chunks = -1;
         }
     } else if (colstats && h_chunks && !atomic_out) {
-        colp_chunks = gy * 2;   // WAVES_M
+        colp_chunks = gy0 * 2;   // WAVES_M
         if (carve_bytes(2 * (size_t)n * colp_chunks, sizeof(double)) <= colstats_bytes) {
             colp = static_cast<double*>(colstats);
             *h_chunks = colp_chunks;
         } else {
             colp_chunks = 0;
         }
+    }
+    GemmPairArgs pa;
+    if (pair) {
+        pa.pair_off = gy0 * BM;
+        pa.m1 = pair->m;
+        pa.a1 = pair->a;
+        pa.c1 = pair->c;
+        pa.rs1 = pair->row_scale;
+        pa.a_idx1 = pair->a_idx;
+        pa.a_ns1 = pair->a_ns;
+        pa.a_sums1 = pair->a_sums;
+        pa.a_count1 = pair->a_count;
+        if (pair->h_chunks) *pair->h_chunks = 0;
+        // the second product's statistics: the same form as the first one's, into its own buffer (same size rule)
+        if (colp && pair->colstats && pair->h_chunks) {
+            pa.colp1 = static_cast<double*>(pair->colstats);
+            pa.colp_chunks1 = colp_chunks < 0 ? -1 : gy1 * 2;
+            *pair->h_chunks = pa.colp_chunks1;
+            if (colp_chunks > 0 && carve_bytes(2 * (size_t)n * pa.colp_chunks1, sizeof(double)) > colstats_bytes) {
+                pa.colp1 = nullptr;
+                pa.colp_chunks1 = 0;
+                *pair->h_chunks = 0;
+            }
+        }
+        if (pair->m <= 0) { set_error("gemm_x6: empty second product"); return PCRCG_EBADARG; }
     }
     if (a_kmajor)   // dW = X^T * dY
         return launch_x6<64, 64, 3, 3, 1, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
@@ -643,17 +711,19 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
     do {                                                                                                                \
         if (a_bf16)                                                                                                     \
             return launch_x6<BMV, BNV, MINB, 1, 0, 0>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,           \
-                                                      k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks);            \
+                                                      k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks, nullptr, 0, \
+                                                      0, nullptr, nullptr, 0.0, 0.f, 1.f, pa);                                \
         return launch_x6<BMV, BNV, MINB, 3, 0, 0>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split,  \
                                                   vec_a, vec_b, atomic_out, colp, colp_chunks, gather ? ex->a_idx : nullptr,\
                                                   gather ? ex->a_idx_ld : 0, gather ? ex->a_ns : 0,                         \
-                                                  gather ? ex->a_zero : nullptr);                                           \
+                                                  gather ? ex->a_zero : nullptr, nullptr, 0.0, 0.f, 1.f, pa);               \
     } while (0)
     if (anorm)
         return launch_x6<64, 64, 4, 3, 0, 0, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
                                                 vec_b, atomic_out, colp, colp_chunks, gather ? ex->a_idx : nullptr,
                                                 gather ? ex->a_idx_ld : 0, gather ? ex->a_ns : 0,
-                                                gather ? ex->a_zero : nullptr, ex->a_sums, ex->a_count, ex->a_eps, ex->a_slope);
+                                                gather ? ex->a_zero : nullptr, ex->a_sums, ex->a_count, ex->a_eps, ex->a_slope,
+                                                pa);
     if (pick == 0) { GO(128, 128, 2); }
     if (pick == 1) { GO(128, 64, 2); }
     if (pick == 2) { GO(64, 128, 2); }

@@ -29,11 +29,26 @@ bool gemm_extra_ok();
 int gemm_bt_extra(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, hipStream_t st,
                   bool c_zeroed, const GemmExtra& ex, const float* bias = nullptr, void* colstats = nullptr,
                   size_t colstats_bytes = 0, int* h_chunks = nullptr, bool colstats_sums = false);
+bool gemm_pair_ok();
+int gemm_bt_colstats_pair(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
+                          const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
+                          hipStream_t st, bool c_zeroed, bool colstats_sums, const GemmPair* pair);
+int gemm_bt_extra_pair(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, hipStream_t st,
+                       bool c_zeroed, const GemmExtra& ex, const float* bias, void* colstats, size_t colstats_bytes,
+                       int* h_chunks, bool colstats_sums, const GemmPair* pair);
 namespace {
 
-struct Mat {          // row-major fp32 matrix view
-    float* p = nullptr;
-    int rows = 0, cols = 0, ld = 0;
+constexpr int GMAX = 2;   // fragment pairs one call can carry (pcrcg_kpfcnn_forward_group)
+
+// Row-major fp32 matrix view -- one per fragment pair of the call (same width and leading dimension, own rows).  With
+// two pairs every operator below runs its per-pair kernels twice and its weight products ONCE for both pairs (GemmPair):
+// the pairs never mix (InstanceNorm statistics, neighbour tables, kNN and attention stay per pair -- SURVEY.md 8e), but a
+// coarse-level product that fills a fifth of the chip for one pair fills twice that for two at the same duration, and
+// every product costs one launch per two pairs.
+struct Mat {
+    float* p[GMAX] = {nullptr, nullptr};
+    int rows[GMAX] = {0, 0};
+    int cols = 0, ld = 0;
     bool zeroed = false;   // lives in the zero arena and has not been written yet
 };
 
@@ -43,6 +58,7 @@ struct Ctx {
     hipStream_t st = nullptr;
     bool dry = false;
     bool bf16 = false;      // pcrcg_model.feature_bf16
+    int G = 1;              // pairs of this call
     int rc = PCRCG_OK;
 
     void* raw(size_t bytes) {
@@ -56,10 +72,13 @@ struct Ctx {
         }
         return p;
     }
-    Mat mat(int rows, int cols, int ld = 0) {
+    Mat mat(const int* rows, int cols, int ld = 0) {
         Mat m;
-        m.rows = rows; m.cols = cols; m.ld = ld ? ld : cols;
-        m.p = static_cast<float*>(raw((size_t)(rows > 0 ? rows : 1) * m.ld * sizeof(float)));
+        m.cols = cols; m.ld = ld ? ld : cols;
+        for (int g = 0; g < G; ++g) {
+            m.rows[g] = rows[g];
+            m.p[g] = static_cast<float*>(raw((size_t)(rows[g] > 0 ? rows[g] : 1) * m.ld * sizeof(float)));
+        }
         return m;
     }
     // Zero arena: the front part of the workspace, cleared by ONE memset at the start of the forward and handed out
@@ -77,12 +96,16 @@ struct Ctx {
         }
         return p;
     }
-    // the output of a [rows, k] x [cols, k]^T product
-    Mat gemm_out(int rows, int cols, int k) {
-        if (!debug_opts().zero_arena || !gemm_bt_accumulates(rows, cols, k)) return mat(rows, cols);
+    int max_rows(const int* rows) const { int m = rows[0]; for (int g = 1; g < G; ++g) m = rows[g] > m ? rows[g] : m; return m; }
+    // the output of a [rows, k] x [cols, k]^T product (the plan of the pair with most rows decides for all)
+    Mat gemm_out(const int* rows, int cols, int k) {
+        if (!debug_opts().zero_arena || !gemm_bt_accumulates(max_rows(rows), cols, k)) return mat(rows, cols);
         Mat m;
-        m.rows = rows; m.cols = cols; m.ld = cols;
-        m.p = static_cast<float*>(zraw((size_t)(rows > 0 ? rows : 1) * cols * sizeof(float)));
+        m.cols = cols; m.ld = cols;
+        for (int g = 0; g < G; ++g) {
+            m.rows[g] = rows[g];
+            m.p[g] = static_cast<float*>(zraw((size_t)(rows[g] > 0 ? rows[g] : 1) * cols * sizeof(float)));
+        }
         m.zeroed = true;
         return m;
     }
@@ -90,23 +113,33 @@ struct Ctx {
     void release(size_t m) { off = m; }
     bool live() const { return !dry && rc == PCRCG_OK; }
     void check(int r) { if (r != PCRCG_OK && rc == PCRCG_OK) rc = r; }
+    // two pairs in one launch: only with the split-bf16 arithmetic (PCRCG_GEMM_MODE=0 runs the products pair by pair)
+    bool paired() const { return G == 2 && gemm_pair_ok(); }
 };
 
 inline int pad4(int v) { return (v + 3) & ~3; }
-inline Mat cols(const Mat& m, int c0, int n) { Mat r = m; r.p = m.p ? m.p + c0 : nullptr; r.cols = n; return r; }
-inline Mat rows(const Mat& m, int r0, int n) { Mat r = m; r.p = m.p ? m.p + (long)r0 * m.ld : nullptr; r.rows = n; return r; }
+inline Mat cols(const Mat& m, int c0, int n) {
+    Mat r = m;
+    for (int g = 0; g < GMAX; ++g) r.p[g] = m.p[g] ? m.p[g] + c0 : nullptr;
+    r.cols = n;
+    return r;
+}
+// rows [r0[g], r0[g] + n[g]) of every pair's matrix
+inline Mat rows(const Mat& m, const int* r0, const int* n) {
+    Mat r = m;
+    for (int g = 0; g < GMAX; ++g) {
+        r.p[g] = m.p[g] ? m.p[g] + (long)r0[g] * m.ld : nullptr;
+        r.rows[g] = n[g];
+    }
+    return r;
+}
 
-struct Stat;
-// y = x @ w^T (+ bias); w is [out, in] with leading dimension ldw; optionally leaves the column
-// partials of y for the InstanceNorm that follows
-void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, const Mat& y, Stat* st = nullptr);
-
-// A GEMM output together with the InstanceNorm column partials its epilogue may have produced.
+// A GEMM output together with the InstanceNorm column partials its epilogue may have produced (per pair).
 struct Stat {
-    void* partials = nullptr;   // [2][cols][chunks] fp64 partials, valid when chunks > 0; or, when `sums`, zeroed
-                                // [2][cols] fp64 accumulators that hold the column sums when chunks == -1
+    void* partials[GMAX] = {nullptr, nullptr};   // [2][cols][chunks] fp64 partials, valid when chunks > 0; or, when `sums`,
+                                                 // zeroed [2][cols] fp64 accumulators that hold the column sums when chunks == -1
     size_t bytes = 0;
-    int chunks = 0;
+    int chunks[GMAX] = {0, 0};
     bool sums = false;
 };
 
@@ -116,16 +149,17 @@ struct Stat {
 // atomics of the first version the 60 000-row outputs (1 876 per address) measured slower than partials + finishing
 // kernel and kept those; with one per tile (938) the sums win everywhere: 470-473 vs 457-466 pairs/s.
 // (DebugOpts::stat_sums_rows: outputs above that many rows keep the deterministic partials.)
-Stat stat_buffer(Ctx& c, int rows, int cols) {
+Stat stat_buffer(Ctx& c, const int* rows, int cols) {
     Stat s;
-    if (debug_opts().stat_sums && rows <= debug_opts().stat_sums_rows && gemm_colstats_sums_ok()) {
+    const int mr = c.max_rows(rows);
+    if (debug_opts().stat_sums && mr <= debug_opts().stat_sums_rows && gemm_colstats_sums_ok()) {
         s.sums = true;
         s.bytes = 2 * sizeof(double) * (size_t)cols;
-        s.partials = c.zraw(s.bytes);
+        for (int g = 0; g < c.G; ++g) s.partials[g] = c.zraw(s.bytes);
         return s;
     }
-    s.bytes = pcrcg_gemm_colstats_bytes(rows, cols);
-    s.partials = c.raw(s.bytes);
+    s.bytes = pcrcg_gemm_colstats_bytes(mr, cols);
+    for (int g = 0; g < c.G; ++g) s.partials[g] = c.raw(s.bytes);
     return s;
 }
 
@@ -136,32 +170,42 @@ inline bool sums_apply_ok(const Mat& x, const Mat& y, const Mat* res) {
            (!res || res->ld % 4 == 0);
 }
 
-// (mean, rstd) of x: from the producing GEMM's partials when it left some, else by a pass over x
-void col_stats(Ctx& c, const Mat& x, const Stat* s, float* stats, void* ws, size_t wsb) {
-    if (s && s->chunks == -1)      // column sums: the finishing kernel reads them as one chunk per column
-        c.check(pcrcg_instnorm_stats_from_partials(s->partials, 1, x.cols, (double)x.rows, 1e-5f, stats, c.st));
-    else if (s && s->chunks > 0)
-        c.check(pcrcg_instnorm_stats_from_partials(s->partials, s->chunks, x.cols, (double)x.rows, 1e-5f, stats, c.st));
+// (mean, rstd) of pair g's x: from the producing GEMM's partials when it left some, else by a pass over x
+void col_stats(Ctx& c, const Mat& x, int g, const Stat* s, float* stats, void* ws, size_t wsb) {
+    if (s && s->chunks[g] == -1)      // column sums: the finishing kernel reads them as one chunk per column
+        c.check(pcrcg_instnorm_stats_from_partials(s->partials[g], 1, x.cols, (double)x.rows[g], 1e-5f, stats, c.st));
+    else if (s && s->chunks[g] > 0)
+        c.check(pcrcg_instnorm_stats_from_partials(s->partials[g], s->chunks[g], x.cols, (double)x.rows[g], 1e-5f, stats, c.st));
     else
-        c.check(pcrcg_instnorm_stats(x.p, x.rows, x.cols, x.ld, 1e-5f, stats, ws, wsb, c.st));
+        c.check(pcrcg_instnorm_stats(x.p[g], x.rows[g], x.cols, x.ld, 1e-5f, stats, ws, wsb, c.st));
+}
+
+// sums-mode statistics the producing product could not leave (a split-K product): one pass into the same accumulators
+void fill_sums(Ctx& c, const Mat& x, Stat* xs) {
+    if (!c.live() || !xs || !xs->sums) return;
+    for (int g = 0; g < c.G; ++g)
+        if (xs->chunks[g] == 0) {
+            c.check(pcrcg_instnorm_colsums(x.p[g], x.rows[g], x.cols, x.ld, xs->partials[g], c.st));
+            xs->chunks[g] = -1;
+        }
+}
+inline bool all_sums(const Ctx& c, const Stat* s) {
+    if (!s) return false;
+    for (int g = 0; g < c.G; ++g)
+        if (s->chunks[g] != -1) return false;
+    return true;
 }
 
 // y = lrelu(IN(x) [+ IN(res) | + res], slope)
 void norm_act(Ctx& c, const Mat& x, float slope, const Mat& y, Stat* xs = nullptr, const Mat* res = nullptr,
               bool norm_res = false, Stat* rs = nullptr) {
-    // sums-mode statistics the producing GEMM could not leave (a split-K product): one pass into the same accumulators
-    if (c.live() && xs && xs->sums && xs->chunks == 0) {
-        c.check(pcrcg_instnorm_colsums(x.p, x.rows, x.cols, x.ld, xs->partials, c.st));
-        xs->chunks = -1;
-    }
-    if (c.live() && res && norm_res && rs && rs->sums && rs->chunks == 0) {
-        c.check(pcrcg_instnorm_colsums(res->p, res->rows, res->cols, res->ld, rs->partials, c.st));
-        rs->chunks = -1;
-    }
-    if (c.live() && xs && xs->chunks == -1 && (!res || !norm_res || (rs && rs->chunks == -1)) && sums_apply_ok(x, y, res)) {
-        c.check(pcrcg_instnorm_apply_sums(x.p, x.rows, x.cols, x.ld, xs->partials, (double)x.rows, 1e-5f, res ? res->p : nullptr,
-                                          res ? res->ld : 0, (res && norm_res) ? rs->partials : nullptr, slope, y.p, y.ld,
-                                          c.st));
+    fill_sums(c, x, xs);
+    if (res && norm_res) fill_sums(c, *res, rs);
+    if (c.live() && all_sums(c, xs) && (!res || !norm_res || all_sums(c, rs)) && sums_apply_ok(x, y, res)) {
+        for (int g = 0; g < c.G; ++g)
+            c.check(pcrcg_instnorm_apply_sums(x.p[g], x.rows[g], x.cols, x.ld, xs->partials[g], (double)x.rows[g], 1e-5f,
+                                              res ? res->p[g] : nullptr, res ? res->ld : 0,
+                                              (res && norm_res) ? rs->partials[g] : nullptr, slope, y.p[g], y.ld, c.st));
         return;
     }
     const size_t m = c.mark();
@@ -169,104 +213,181 @@ void norm_act(Ctx& c, const Mat& x, float slope, const Mat& y, Stat* xs = nullpt
     float* rstats = (res && norm_res) ? static_cast<float*>(c.raw(sizeof(float) * 2 * x.cols)) : nullptr;
     const size_t wsb = pcrcg_instnorm_ws_bytes(x.cols);
     void* ws = c.raw(wsb);
-    if (c.live()) {
-        col_stats(c, x, xs, stats, ws, wsb);
-        if (rstats) col_stats(c, *res, rs, rstats, ws, wsb);
-        c.check(pcrcg_instnorm_apply(x.p, x.rows, x.cols, x.ld, stats, res ? res->p : nullptr, res ? res->ld : 0,
-                                     rstats, slope, y.p, y.ld, c.st));
-    }
+    if (c.live())
+        for (int g = 0; g < c.G; ++g) {
+            col_stats(c, x, g, xs, stats, ws, wsb);
+            if (rstats) col_stats(c, *res, g, rs, rstats, ws, wsb);
+            c.check(pcrcg_instnorm_apply(x.p[g], x.rows[g], x.cols, x.ld, stats, res ? res->p[g] : nullptr, res ? res->ld : 0,
+                                         rstats, slope, y.p[g], y.ld, c.st));
+        }
     c.release(m);
 }
 
-void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, const Mat& y, Stat* st) {
-    if (!c.live()) return;
-    c.check(gemm_bt_colstats(x.p, x.ld, w, ldw, y.p, y.ld, x.rows, y.cols, x.cols, nullptr, bias,
-                             st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr, c.st, y.zeroed,
-                             st && st->sums));
+// the second pair's side of a product
+GemmPair pair_of(const Mat& x, const Mat& y, Stat* st, const float* const* row_scale = nullptr) {
+    GemmPair p;
+    p.a = x.p[1];
+    p.c = y.p[1];
+    p.m = x.rows[1];
+    p.row_scale = row_scale ? row_scale[1] : nullptr;
+    p.colstats = st ? st->partials[1] : nullptr;
+    p.h_chunks = st ? &st->chunks[1] : nullptr;
+    p.c_zeroed = y.zeroed;
+    return p;
 }
 
-// packed_ws != NULL: a pcrcg_kpconv_ws_bytes(ns) workspace whose support records the producer of x has already filled
-// (norm_act_pack): the aggregate kernel starts without the row-positive pass
+// y = x @ w^T (+ bias); w is [out, in] with leading dimension ldw; optionally leaves the column statistics of y for the
+// InstanceNorm that follows.  row_scale: per-pair row factors (KPConv's 1 / neighbour count)
+void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, const Mat& y, Stat* st = nullptr,
+            const float* const* row_scale = nullptr) {
+    if (!c.live()) return;
+    if (c.paired()) {
+        GemmPair p = pair_of(x, y, st, row_scale);
+        c.check(gemm_bt_colstats_pair(x.p[0], x.ld, w, ldw, y.p[0], y.ld, x.rows[0], y.cols, x.cols, row_scale ? row_scale[0] : nullptr,
+                                      bias, st ? st->partials[0] : nullptr, st ? st->bytes : 0, st ? &st->chunks[0] : nullptr, c.st,
+                                      y.zeroed, st && st->sums, &p));
+        return;
+    }
+    for (int g = 0; g < c.G; ++g)
+        c.check(gemm_bt_colstats(x.p[g], x.ld, w, ldw, y.p[g], y.ld, x.rows[g], y.cols, x.cols, row_scale ? row_scale[g] : nullptr,
+                                 bias, st ? st->partials[g] : nullptr, st ? st->bytes : 0, st ? &st->chunks[g] : nullptr, c.st,
+                                 y.zeroed, st && st->sums));
+}
+
+// C (+)= f(A)[rows] @ w^T: the GemmExtra forms, for all pairs.  idx / ns: per-pair gather table (first column) and source
+// row count, sums: per-pair column sums of the raw A (normalise-on-load), or NULL
+void linear_extra(Ctx& c, const Mat& a, const float* w, int ldw, const float* bias, const Mat& y, int out_rows_of_table,
+                  const pcrcg_table* const* tabs, const float* zero_row, Stat* a_sums, float a_slope, bool accumulate,
+                  bool c_zeroed, Stat* st = nullptr) {
+    if (!c.live()) return;
+    (void)out_rows_of_table;
+    auto extra = [&](int g) {
+        GemmExtra ex;
+        if (a_sums) {
+            ex.a_sums = static_cast<const double*>(a_sums->partials[g]);
+            ex.a_count = (double)a.rows[g];
+            ex.a_slope = a_slope;
+        }
+        if (tabs) {
+            ex.a_idx = reinterpret_cast<const long long*>(tabs[g]->idx);
+            ex.a_idx_ld = tabs[g]->ld;
+            ex.a_ns = a.rows[g];
+            ex.a_zero = zero_row;
+        }
+        ex.accumulate = accumulate;
+        return ex;
+    };
+    auto m_of = [&](int g) { return tabs ? tabs[g]->rows : a.rows[g]; };
+    if (c.paired() && (!tabs || tabs[0]->ld == tabs[1]->ld)) {
+        GemmExtra ex = extra(0);
+        GemmPair p;
+        p.a = a.p[1];
+        p.c = y.p[1];
+        p.m = m_of(1);
+        p.colstats = st ? st->partials[1] : nullptr;
+        p.h_chunks = st ? &st->chunks[1] : nullptr;
+        p.c_zeroed = c_zeroed;
+        if (tabs) { p.a_idx = reinterpret_cast<const long long*>(tabs[1]->idx); p.a_ns = a.rows[1]; }
+        if (a_sums) { p.a_sums = static_cast<const double*>(a_sums->partials[1]); p.a_count = (double)a.rows[1]; }
+        c.check(gemm_bt_extra_pair(a.p[0], a.ld, w, ldw, y.p[0], y.ld, m_of(0), y.cols, a.cols, c.st, c_zeroed, ex, bias,
+                                   st ? st->partials[0] : nullptr, st ? st->bytes : 0, st ? &st->chunks[0] : nullptr,
+                                   st && st->sums, &p));
+        return;
+    }
+    for (int g = 0; g < c.G; ++g) {
+        GemmExtra ex = extra(g);
+        c.check(gemm_bt_extra(a.p[g], a.ld, w, ldw, y.p[g], y.ld, m_of(g), y.cols, a.cols, c.st, c_zeroed, ex, bias,
+                              st ? st->partials[g] : nullptr, st ? st->bytes : 0, st ? &st->chunks[g] : nullptr, st && st->sums));
+    }
+}
+
 // y = lrelu(IN(x), slope) @ w^T (+ bias) with the normalisation done inside the product's A loads (GemmExtra::a_sums):
 // x is the RAW output of the producing product and xs its column sums.  Returns false when that form does not apply
 // (the caller then normalises into a matrix of its own and calls linear()).
-bool norm_fuse_on() {
-    return debug_opts().fuse_norm && gemm_extra_ok();
-}
+bool norm_fuse_on() { return debug_opts().fuse_norm && gemm_extra_ok(); }
 bool lazy_stats_ready(Ctx& c, const Mat& x, Stat* xs) {
     if (!xs || !xs->sums || x.ld % 4 != 0 || x.cols > 4096) return false;
-    if (c.live() && xs->chunks == 0) {               // nobody left the sums yet (split-K or accumulated output): one pass
-        c.check(pcrcg_instnorm_colsums(x.p, x.rows, x.cols, x.ld, xs->partials, c.st));
-        xs->chunks = -1;
-    }
+    fill_sums(c, x, xs);              // nobody left the sums yet (split-K or accumulated output): one pass
     return true;
 }
 bool linear_norm(Ctx& c, const Mat& x, Stat* xs, float slope, const float* w, int ldw, const float* bias, const Mat& y,
                  Stat* st = nullptr) {
     if (!norm_fuse_on() || !lazy_stats_ready(c, x, xs)) return false;
-    if (!c.live()) return true;
-    GemmExtra ex;
-    ex.a_sums = static_cast<const double*>(xs->partials);
-    ex.a_count = (double)x.rows;
-    ex.a_slope = slope;
-    c.check(gemm_bt_extra(x.p, x.ld, w, ldw, y.p, y.ld, x.rows, y.cols, x.cols, c.st, y.zeroed, ex, bias,
-                          st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr, st && st->sums));
+    linear_extra(c, x, w, ldw, bias, y, 0, nullptr, nullptr, xs, slope, false, y.zeroed, st);
     return true;
 }
 
-void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, const Mat& y, Stat* st = nullptr,
-            void* packed_ws = nullptr) {
+struct Batches { const pcrcg_batch* b[GMAX]; };
+
+void kpconv(Ctx& c, const Batches& B, const pcrcg_block& blk, const Mat& x, const Mat& y, Stat* st = nullptr,
+            void* const* packed_ws = nullptr) {
     const int l = blk.layer;
-    const pcrcg_table& t = blk.strided ? b.pools[l] : b.neighbors[l];
-    const float* q = blk.strided ? b.points[l + 1] : b.points[l];
-    const int nq = blk.strided ? b.n_points[l + 1] : b.n_points[l];
-    const int ns = b.n_points[l];
     const size_t m = c.mark();
     // channel counts that are not a multiple of 4 (the 129-channel PCR-CG input): zero-padded copy of the
     // features + zero-padded weights, so that the MFMA gather kernel applies (zeros change neither the sums nor
     // the neighbour count of the normaliser)
-    const float* xp = x.p;
+    Mat xin = x;
     const float* w = blk.kp_w;
     int cin = x.cols;
     if (blk.kp_w_pad && blk.cin_pad > x.cols) {
         cin = blk.cin_pad;
-        Mat pad = c.mat(x.rows, cin);
-        if (c.live()) {
-            c.check(hipMemsetAsync(pad.p, 0, sizeof(float) * (size_t)x.rows * cin, c.st) == hipSuccess ? PCRCG_OK
-                                                                                                       : PCRCG_ELAUNCH);
-            c.check(pcrcg_copy2d(x.p, x.ld, pad.p, cin, x.rows, x.cols, c.st));
-        }
-        xp = pad.p;
+        xin = c.mat(x.rows, cin);
+        if (c.live())
+            for (int g = 0; g < c.G; ++g) {
+                c.check(hipMemsetAsync(xin.p[g], 0, sizeof(float) * (size_t)x.rows[g] * cin, c.st) == hipSuccess ? PCRCG_OK
+                                                                                                                   : PCRCG_ELAUNCH);
+                c.check(pcrcg_copy2d(x.p[g], x.ld, xin.p[g], cin, x.rows[g], x.cols, c.st));
+            }
         w = blk.kp_w_pad;
     }
-    float* inv_n = static_cast<float*>(c.raw(sizeof(float) * (nq > 0 ? nq : 1)));
-    const size_t wsb = pcrcg_kpconv_ws_bytes(ns);
-    void* ws = packed_ws ? packed_ws : c.raw(wsb);
+    int nq[GMAX], ns[GMAX];
+    const float* q[GMAX];
+    const pcrcg_table* tab[GMAX];
+    float* inv_n[GMAX];
+    void* ws[GMAX];
+    size_t wsb[GMAX];
+    for (int g = 0; g < c.G; ++g) {
+        const pcrcg_batch& b = *B.b[g];
+        tab[g] = blk.strided ? &b.pools[l] : &b.neighbors[l];
+        q[g] = blk.strided ? b.points[l + 1] : b.points[l];
+        nq[g] = blk.strided ? b.n_points[l + 1] : b.n_points[l];
+        ns[g] = b.n_points[l];
+        inv_n[g] = static_cast<float*>(c.raw(sizeof(float) * (nq[g] > 0 ? nq[g] : 1)));
+        wsb[g] = pcrcg_kpconv_ws_bytes(ns[g]);
+        ws[g] = (packed_ws && packed_ws[g]) ? packed_ws[g] : c.raw(wsb[g]);
+    }
+    const int kk = PCRCG_KPOINTS * cin;
     // bf16 feature storage (pcrcg_model.feature_bf16): the gathers read a bf16 copy of x and wf is bf16 in HBM -- half
     // the bytes of the two streams that bound the encoder; the contraction takes wf as the (single-term) bf16 operand
     // against the exact three-term split of the fp32 weights, fp32 accumulate and fp32 output.
     if (c.bf16 && blk.kp_wt && cin % 32 == 0) {
-        const int kk = PCRCG_KPOINTS * cin;
-        void* xb = c.raw(sizeof(unsigned short) * (size_t)(ns > 0 ? ns : 1) * cin);
-        void* wfb = c.raw(sizeof(unsigned short) * (size_t)(nq > 0 ? nq : 1) * kk);
-        if (c.live()) {
-            c.check(pcrcg_kpconv_aggregate_bf16(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, xp, cin, blk.kp, blk.extent,
-                                                xb, wfb, inv_n, ws, wsb, c.st));
-            c.check(gemm_bf16a_bt_colstats(wfb, kk, blk.kp_wt, kk, y.p, y.ld, nq, y.cols, kk, inv_n, nullptr,
-                                           st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr,
-                                           c.st, y.zeroed, st && st->sums));
+        for (int g = 0; g < c.G; ++g) {
+            const pcrcg_batch& b = *B.b[g];
+            void* xb = c.raw(sizeof(unsigned short) * (size_t)(ns[g] > 0 ? ns[g] : 1) * cin);
+            void* wfb = c.raw(sizeof(unsigned short) * (size_t)(nq[g] > 0 ? nq[g] : 1) * kk);
+            if (c.live()) {
+                c.check(pcrcg_kpconv_aggregate_bf16(q[g], nq[g], b.points[l], ns[g], tab[g]->idx, tab[g]->cols, tab[g]->ld, xin.p[g],
+                                                    cin, blk.kp, blk.extent, xb, wfb, inv_n[g], ws[g], wsb[g], c.st));
+                c.check(gemm_bf16a_bt_colstats(wfb, kk, blk.kp_wt, kk, y.p[g], y.ld, nq[g], y.cols, kk, inv_n[g], nullptr,
+                                               st ? st->partials[g] : nullptr, st ? st->bytes : 0, st ? &st->chunks[g] : nullptr,
+                                               c.st, y.zeroed, st && st->sums));
+            }
         }
         c.release(m);
         return;
     }
-    Mat wf = c.mat(nq, PCRCG_KPOINTS * cin);
+    Mat wf = c.mat(nq, kk);
     if (c.live()) {
-        if (packed_ws && xp == x.p)
-            c.check(kpconv_aggregate_rows(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, xp, cin, blk.kp, blk.extent, wf.p, inv_n,
-                                          ws, wsb, c.st, /*pack=*/false, /*stream_out=*/true));
-        else
-            c.check(pcrcg_kpconv_aggregate(q, nq, b.points[l], ns, t.idx, t.cols, t.ld, xp, cin, blk.kp, blk.extent,
-                                           wf.p, inv_n, ws, wsb, c.st));
+        for (int g = 0; g < c.G; ++g) {
+            const pcrcg_batch& b = *B.b[g];
+            if (packed_ws && packed_ws[g] && xin.p[g] == x.p[g])
+                c.check(kpconv_aggregate_rows(q[g], nq[g], b.points[l], ns[g], tab[g]->idx, tab[g]->cols, tab[g]->ld, xin.p[g], cin,
+                                              blk.kp, blk.extent, wf.p[g], inv_n[g], ws[g], wsb[g], c.st, /*pack=*/false,
+                                              /*stream_out=*/true));
+            else
+                c.check(pcrcg_kpconv_aggregate(q[g], nq[g], b.points[l], ns[g], tab[g]->idx, tab[g]->cols, tab[g]->ld, xin.p[g], cin,
+                                               blk.kp, blk.extent, wf.p[g], inv_n[g], ws[g], wsb[g], c.st));
+        }
         // contraction wf @ W: against the K-contiguous copy wt [cout, 15*cin] when the descriptor carries one
         // (C = A * B^T form: both operands k-contiguous, the form the split-bf16 GEMM is built for).
         // (Measured and not adopted, rounds 2 and 3: aggregating + contracting row chunks so that wf stays in L2 /
@@ -274,13 +395,12 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
         // engine 416 / 446 / 459 / 462 pairs/s with 16 / 32 / 64 / 120 MB chunks against 460-464 unchunked: the extra
         // launches cost more than the on-chip re-read saves.)
         if (blk.kp_wt)
-            c.check(gemm_bt_colstats(wf.p, wf.ld, blk.kp_wt, wf.cols, y.p, y.ld, nq, y.cols, wf.cols, inv_n, nullptr,
-                                     st ? st->partials : nullptr, st ? st->bytes : 0, st ? &st->chunks : nullptr, c.st,
-                                     y.zeroed, st && st->sums));
+            linear(c, wf, blk.kp_wt, kk, nullptr, y, st, inv_n);
         else   // (descriptor without the K-contiguous weight copy: the plain entry point knows only the partials layout)
-            c.check(pcrcg_gemm_f32_colstats(wf.p, wf.ld, w, y.cols, 0, y.p, y.ld, nq, y.cols, wf.cols, inv_n, nullptr,
-                                            (st && !st->sums) ? st->partials : nullptr, (st && !st->sums) ? st->bytes : 0,
-                                            (st && !st->sums) ? &st->chunks : nullptr, c.st));
+            for (int g = 0; g < c.G; ++g)
+                c.check(pcrcg_gemm_f32_colstats(wf.p[g], wf.ld, w, y.cols, 0, y.p[g], y.ld, nq[g], y.cols, kk, inv_n[g], nullptr,
+                                                (st && !st->sums) ? st->partials[g] : nullptr, (st && !st->sums) ? st->bytes : 0,
+                                                (st && !st->sums) ? &st->chunks[g] : nullptr, c.st));
     }
     c.release(m);
 }
@@ -288,17 +408,20 @@ void kpconv(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x, 
 // input channels of the block's KPConv as the gather kernel sees them (padded to a multiple of 4)
 int kp_cin(const pcrcg_block& blk, const Mat& x) { return (blk.kp_w_pad && blk.cin_pad > x.cols) ? blk.cin_pad : x.cols; }
 
-int out_rows(const pcrcg_batch& b, const pcrcg_block& blk) {
-    return blk.strided ? b.n_points[blk.layer + 1] : b.n_points[blk.layer];
+void out_rows(const Ctx& c, const Batches& B, const pcrcg_block& blk, int* rows) {
+    for (int g = 0; g < GMAX; ++g)
+        rows[g] = g < c.G ? (blk.strided ? B.b[g]->n_points[blk.layer + 1] : B.b[g]->n_points[blk.layer]) : 0;
 }
 
 // SimpleBlock.forward (ref:models/blocks.py:578-590)
-Mat simple_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& x) {
-    Mat y = c.mat(out_rows(b, blk), blk.mid_dim);
+Mat simple_block(Ctx& c, const Batches& B, const pcrcg_block& blk, const Mat& x) {
+    int nq[GMAX];
+    out_rows(c, B, blk, nq);
+    Mat y = c.mat(nq, blk.mid_dim);
     const size_t m = c.mark();
-    Mat t = c.gemm_out(y.rows, y.cols, PCRCG_KPOINTS * kp_cin(blk, x));
-    Stat ts = stat_buffer(c, t.rows, t.cols);
-    kpconv(c, b, blk, x, t, &ts);
+    Mat t = c.gemm_out(nq, y.cols, PCRCG_KPOINTS * kp_cin(blk, x));
+    Stat ts = stat_buffer(c, nq, t.cols);
+    kpconv(c, B, blk, x, t, &ts);
     norm_act(c, t, 0.1f, y, &ts);
     c.release(m);
     return y;
@@ -307,56 +430,60 @@ Mat simple_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat
 // u = lrelu(IN(t), slope) for a u that is the input of the block's KPConv: the normalisation kernel leaves the KPConv's
 // support records (coordinates + "feature row sums to a positive value" flag) in kp_ws as it goes, so the KPConv needs no
 // pass over u of its own (10 launches per S30k forward: +4 % pairs/s with them knocked out).  False: not applicable.
-bool norm_act_pack(Ctx& c, const Mat& t, float slope, const Mat& u, Stat* ts, const float* s_pts, void* kp_ws,
-                   size_t kp_ws_bytes) {
+bool norm_act_pack(Ctx& c, const Batches& B, int layer, const Mat& t, float slope, const Mat& u, Stat* ts, void* const* kp_ws,
+                   const size_t* kp_ws_bytes) {
     if (!debug_opts().fuse_pack || c.bf16 || !instnorm_pack_ok(t.cols, t.ld, u.ld) || u.ld != u.cols) return false;
     const size_t m = c.mark();
     float* stats = static_cast<float*>(c.raw(sizeof(float) * 2 * t.cols));
     const size_t wsb = pcrcg_instnorm_ws_bytes(t.cols);
     void* ws = c.raw(wsb);
-    if (c.live()) {
-        if (ts && ts->sums && ts->chunks == 0) {        // a split-K product left nothing: one pass into the accumulators
-            c.check(pcrcg_instnorm_colsums(t.p, t.rows, t.cols, t.ld, ts->partials, c.st));
-            ts->chunks = -1;
+    fill_sums(c, t, ts);              // a split-K product left nothing: one pass into the accumulators
+    if (c.live())
+        for (int g = 0; g < c.G; ++g) {
+            const float* s_pts = B.b[g]->points[layer];
+            float4* pk = kpconv_pk_ptr(kp_ws[g], kp_ws_bytes[g], t.rows[g]);
+            if (!pk) c.check(PCRCG_EWORKSPACE);
+            else if (ts && ts->chunks[g] == -1)
+                c.check(instnorm_apply_pack(t.p[g], t.rows[g], t.cols, t.ld, nullptr, static_cast<const double*>(ts->partials[g]),
+                                            (double)t.rows[g], 1e-5f, slope, u.p[g], u.ld, s_pts, pk, c.st));
+            else {
+                col_stats(c, t, g, ts, stats, ws, wsb);
+                c.check(instnorm_apply_pack(t.p[g], t.rows[g], t.cols, t.ld, stats, nullptr, 0.0, 1e-5f, slope, u.p[g], u.ld, s_pts,
+                                            pk, c.st));
+            }
         }
-        float4* pk = kpconv_pk_ptr(kp_ws, kp_ws_bytes, t.rows);
-        if (!pk) c.check(PCRCG_EWORKSPACE);
-        else if (ts && ts->chunks == -1)
-            c.check(instnorm_apply_pack(t.p, t.rows, t.cols, t.ld, nullptr, static_cast<const double*>(ts->partials),
-                                        (double)t.rows, 1e-5f, slope, u.p, u.ld, s_pts, pk, c.st));
-        else {
-            col_stats(c, t, ts, stats, ws, wsb);
-            c.check(instnorm_apply_pack(t.p, t.rows, t.cols, t.ld, stats, nullptr, 0.0, 1e-5f, slope, u.p, u.ld, s_pts, pk, c.st));
-        }
-    }
     c.release(m);
     return true;
 }
 
 // ResnetBottleneckBlock.forward (ref:models/blocks.py:650-678)
-Mat resnet_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat& feats) {
-    const int nq = out_rows(b, blk);
+Mat resnet_block(Ctx& c, const Batches& B, const pcrcg_block& blk, const Mat& feats) {
+    int nq[GMAX];
+    out_rows(c, B, blk, nq);
     Mat y = c.mat(nq, blk.out_dim);
     const size_t m = c.mark();
     Mat x = feats;
-    void* kp_ws = nullptr;
-    size_t kp_wsb = 0;
+    void* kp_ws[GMAX] = {nullptr, nullptr};
+    size_t kp_wsb[GMAX] = {0, 0};
+    bool packed = false;
     if (blk.unary1) {
         Mat t = c.gemm_out(feats.rows, blk.mid_dim, feats.cols), u = c.mat(feats.rows, blk.mid_dim);
         Stat ts = stat_buffer(c, t.rows, t.cols);
         linear(c, feats, blk.unary1, feats.cols, nullptr, t, &ts);
         // u feeds the KPConv whose supports are this block's input rows: pack its support records on the way
         if (blk.mid_dim % 4 == 0 && !(blk.kp_w_pad && blk.cin_pad > blk.mid_dim)) {
-            kp_wsb = pcrcg_kpconv_ws_bytes(feats.rows);
-            kp_ws = c.raw(kp_wsb);
-            if (!norm_act_pack(c, t, 0.1f, u, &ts, b.points[blk.layer], kp_ws, kp_wsb)) kp_ws = nullptr;
+            for (int g = 0; g < c.G; ++g) {
+                kp_wsb[g] = pcrcg_kpconv_ws_bytes(feats.rows[g]);
+                kp_ws[g] = c.raw(kp_wsb[g]);
+            }
+            packed = norm_act_pack(c, B, blk.layer, t, 0.1f, u, &ts, kp_ws, kp_wsb);
         }
-        if (!kp_ws) norm_act(c, t, 0.1f, u, &ts);
+        if (!packed) norm_act(c, t, 0.1f, u, &ts);
         x = u;
     }
     Mat k = c.gemm_out(nq, blk.mid_dim, PCRCG_KPOINTS * kp_cin(blk, x)), kn = c.mat(nq, blk.mid_dim);
     Stat ks = stat_buffer(c, nq, blk.mid_dim);
-    kpconv(c, b, blk, x, k, &ks, kp_ws);
+    kpconv(c, B, blk, x, k, &ks, packed ? kp_ws : nullptr);
     Mat u2 = c.gemm_out(nq, blk.out_dim, blk.mid_dim);
     Stat u2s = stat_buffer(c, nq, blk.out_dim);
     // lrelu(IN(k)) is read by unary2 alone: its product normalises k on load when k's statistics are column sums
@@ -366,10 +493,12 @@ Mat resnet_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat
     }
     Mat sc = feats;
     if (blk.strided) {   // max_pool shortcut (:672-673)
-        const pcrcg_table& t = b.pools[blk.layer];
         sc = c.mat(nq, feats.cols);
         if (c.live())
-            c.check(pcrcg_gather_max(feats.p, feats.rows, feats.cols, t.idx, nq, t.cols, t.ld, sc.p, c.st));
+            for (int g = 0; g < c.G; ++g) {
+                const pcrcg_table& t = B.b[g]->pools[blk.layer];
+                c.check(pcrcg_gather_max(feats.p[g], feats.rows[g], feats.cols, t.idx, nq[g], t.cols, t.ld, sc.p[g], c.st));
+            }
     }
     if (blk.shortcut) {
         Mat s2 = c.gemm_out(nq, blk.out_dim, sc.cols);
@@ -385,49 +514,61 @@ Mat resnet_block(Ctx& c, const pcrcg_batch& b, const pcrcg_block& blk, const Mat
 
 // x_out = lrelu(IN2d(max_j e), 0.2) for e[i,j,:] = cn[i, :cw] + cn[idx[i,j], cw:2cw]: reduction + normalisation
 // (max commutes with the monotone normalise + LeakyReLU); statistics as fp64 sums when the widths allow, else as pairs
-void edge_norm(Ctx& c, const Mat& cn, int cw, const int* idx, int n, int k, const Mat& emax, const Mat& out, void* sums,
-               float* stats, void* ws, size_t wsb) {
-    if (sums && sums_apply_ok(emax, out, nullptr)) {
-        c.check(pcrcg_edgeconv_reduce_sums(cn.p, cn.ld, cn.p + cw, cn.ld, idx, n, k, cw, emax.p, emax.ld, sums, c.st));
-        c.check(pcrcg_instnorm_apply_sums(emax.p, n, cw, emax.ld, sums, (double)n * (double)k, 1e-5f, nullptr, 0, nullptr, 0.2f,
-                                          out.p, out.ld, c.st));
+void edge_norm(Ctx& c, const float* cn, int ld_cn, int cw, const int* idx, int n, int k, float* emax, int ld_emax, float* out,
+               int ld_out, void* sums, bool sums_ok, float* stats, void* ws, size_t wsb) {
+    if (sums && sums_ok) {
+        c.check(pcrcg_edgeconv_reduce_sums(cn, ld_cn, cn + cw, ld_cn, idx, n, k, cw, emax, ld_emax, sums, c.st));
+        c.check(pcrcg_instnorm_apply_sums(emax, n, cw, ld_emax, sums, (double)n * (double)k, 1e-5f, nullptr, 0, nullptr, 0.2f, out,
+                                          ld_out, c.st));
         return;
     }
-    c.check(pcrcg_edgeconv_reduce(cn.p, cn.ld, cn.p + cw, cn.ld, idx, n, k, cw, 1e-5f, emax.p, emax.ld, stats, ws, wsb, c.st));
-    c.check(pcrcg_instnorm_apply(emax.p, n, cw, emax.ld, stats, nullptr, 0, nullptr, 0.2f, out.p, out.ld, c.st));
+    c.check(pcrcg_edgeconv_reduce(cn, ld_cn, cn + cw, ld_cn, idx, n, k, cw, 1e-5f, emax, ld_emax, stats, ws, wsb, c.st));
+    c.check(pcrcg_instnorm_apply(emax, n, cw, ld_emax, stats, nullptr, 0, nullptr, 0.2f, out, ld_out, c.st));
 }
 
-// SelfAttention.forward (ref:models/gcn.py:110-134) on row-major [n, ch]
-Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, const float* coords, const Mat& f) {
-    const int n = f.rows, ch = f.cols;
-    Mat y = c.mat(n, ch);
+// SelfAttention.forward (ref:models/gcn.py:110-134) on row-major [n, ch]: one cloud of every pair
+Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, const float* const* coords, const Mat& f) {
+    const int ch = f.cols;
+    Mat y = c.mat(f.rows, ch);
     const size_t m = c.mark();
-    const int k = mdl.knn_k < n - 1 ? mdl.knn_k : n - 1;
-    int* idx = static_cast<int*>(c.raw(sizeof(int) * (size_t)n * (k > 0 ? k : 1)));
-    Mat cat = c.mat(n, 4 * ch);
+    int kq[GMAX];
+    int* idx[GMAX];
+    for (int g = 0; g < c.G; ++g) {
+        const int n = f.rows[g];
+        kq[g] = mdl.knn_k < n - 1 ? mdl.knn_k : n - 1;
+        idx[g] = static_cast<int*>(c.raw(sizeof(int) * (size_t)n * (kq[g] > 0 ? kq[g] : 1)));
+    }
+    Mat cat = c.mat(f.rows, 4 * ch);
     const size_t wsb = pcrcg_edgeconv_ws_bytes(2 * ch);
     void* ws = c.raw(wsb);
     float* stats = static_cast<float*>(c.raw(sizeof(float) * 4 * ch));
-    Mat cn1 = c.gemm_out(n, 2 * ch, ch), e1 = c.mat(n, ch), cn2 = c.gemm_out(n, 4 * ch, ch), e2 = c.mat(n, 2 * ch);
-    Mat x3 = c.gemm_out(n, ch, 4 * ch);
-    Stat x3s = stat_buffer(c, n, ch);
+    Mat cn1 = c.gemm_out(f.rows, 2 * ch, ch), e1 = c.mat(f.rows, ch), cn2 = c.gemm_out(f.rows, 4 * ch, ch), e2 = c.mat(f.rows, 2 * ch);
+    Mat x3 = c.gemm_out(f.rows, ch, 4 * ch);
+    Stat x3s = stat_buffer(c, f.rows, ch);
     // InstanceNorm2d statistics of the two edge convolutions as fp64 sums (zero arena) when that form applies
-    void* sums1 = gemm_colstats_sums_ok() ? c.zraw(2 * sizeof(double) * (size_t)ch) : nullptr;
-    void* sums2 = gemm_colstats_sums_ok() ? c.zraw(2 * sizeof(double) * (size_t)(2 * ch)) : nullptr;
+    void *sums1[GMAX], *sums2[GMAX];
+    for (int g = 0; g < c.G; ++g) {
+        sums1[g] = gemm_colstats_sums_ok() ? c.zraw(2 * sizeof(double) * (size_t)ch) : nullptr;
+        sums2[g] = gemm_colstats_sums_ok() ? c.zraw(2 * sizeof(double) * (size_t)(2 * ch)) : nullptr;
+    }
+    Mat cat1 = cols(cat, ch, ch), cat2 = cols(cat, 2 * ch, 2 * ch);
+    const bool ok1 = sums_apply_ok(e1, cat1, nullptr), ok2 = sums_apply_ok(e2, cat2, nullptr);
     if (c.live()) {
-        c.check(pcrcg_knn(coords, n, k, idx, c.st));
-        c.check(pcrcg_copy2d(f.p, f.ld, cat.p, cat.ld, n, ch, c.st));                                    // x0
+        for (int g = 0; g < c.G; ++g) {
+            c.check(pcrcg_knn(coords[g], f.rows[g], kq[g], idx[g], c.st));
+            c.check(pcrcg_copy2d(f.p[g], f.ld, cat.p[g], cat.ld, f.rows[g], ch, c.st));                     // x0
+        }
         // x1 = max_k lrelu(IN2d(conv1(cat(f_i, f_j - f_i))))  (:121-125)
-        c.check(gemm_bt_colstats(f.p, f.ld, g.edge1, ch, cn1.p, cn1.ld, n, 2 * ch, ch, nullptr, nullptr, nullptr, 0, nullptr,
-                                 c.st, cn1.zeroed));
-        edge_norm(c, cn1, ch, idx, n, k, e1, cols(cat, ch, ch), sums1, stats, ws, wsb);
+        linear(c, f, gl.edge1, ch, nullptr, cn1);
+        for (int g = 0; g < c.G; ++g)
+            edge_norm(c, cn1.p[g], cn1.ld, ch, idx[g], f.rows[g], kq[g], e1.p[g], e1.ld, cat1.p[g], cat.ld, sums1[g], ok1, stats, ws, wsb);
         // x2 from x1 with conv2 (:127-129)
-        c.check(gemm_bt_colstats(cat.p + ch, cat.ld, g.edge2, ch, cn2.p, cn2.ld, n, 4 * ch, ch, nullptr, nullptr, nullptr, 0,
-                                 nullptr, c.st, cn2.zeroed));
-        edge_norm(c, cn2, 2 * ch, idx, n, k, e2, cols(cat, 2 * ch, 2 * ch), sums2, stats, ws, wsb);
+        linear(c, cat1, gl.edge2, ch, nullptr, cn2);
+        for (int g = 0; g < c.G; ++g)
+            edge_norm(c, cn2.p[g], cn2.ld, 2 * ch, idx[g], f.rows[g], kq[g], e2.p[g], e2.ld, cat2.p[g], cat.ld, sums2[g], ok2, stats, ws,
+                      wsb);
         // x3 = lrelu(IN(conv3(cat(x0,x1,x2))))  (:131-132)
-        c.check(gemm_bt_colstats(cat.p, cat.ld, g.conv3, 4 * ch, x3.p, x3.ld, n, ch, 4 * ch, nullptr, nullptr, x3s.partials,
-                                 x3s.bytes, &x3s.chunks, c.st, x3.zeroed, x3s.sums));
+        linear(c, cat, gl.conv3, 4 * ch, nullptr, x3, &x3s);
     }
     norm_act(c, x3, 0.2f, y, &x3s);
     c.release(m);
@@ -435,66 +576,85 @@ Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, con
 }
 
 // x + AttentionalPropagation(x, src)  (ref:models/gcn.py:151-185, 213-214)
-Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& g, const Mat& x, const Mat& src) {
-    const int n = x.rows, ms = src.rows, ch = x.cols, h = mdl.heads, d = ch / h;
-    Mat y = c.mat(n, ch);
+Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, const Mat& x, const Mat& src) {
+    const int ch = x.cols, h = mdl.heads, d = ch / h;
+    Mat y = c.mat(x.rows, ch);
     const size_t m = c.mark();
-    Mat q = c.gemm_out(n, ch, ch), kk = c.gemm_out(ms, ch, ch), v = c.gemm_out(ms, ch, ch), msg = c.mat(n, ch);
-    Mat sc = c.mat(n, ms);
-    Mat cat = c.mat(n, 2 * ch), h0 = c.gemm_out(n, 2 * ch, 2 * ch), h1 = c.mat(n, 2 * ch), delta = c.gemm_out(n, ch, 2 * ch);
-    linear(c, x, g.wq, ch, g.bq, q);
-    linear(c, src, g.wk, ch, g.bk, kk);
-    linear(c, src, g.wv, ch, g.bv, v);
-    if (c.live() && pcrcg_attention_supported(d) && (long)n * ms <= 1000000) {
-        // all heads in one launch (heads are contiguous column blocks after the weight permutation); a latency win on
-        // the few hundred coarse points of an indoor pair (49 vs 138 us of kernels + 11 launches less per call,
-        // scripts/attention_bench.py) -- beyond ~1000 x 1000 the GEMM path below is faster (1900 x 1900: 228 vs 640 us)
-        c.check(pcrcg_attention(q.p, q.ld, kk.p, kk.ld, v.p, v.ld, msg.p, msg.ld, n, ms, h, d, 1.0f / sqrtf((float)d),
-                                c.st));
-        c.check(pcrcg_copy2d(x.p, x.ld, cat.p, cat.ld, n, ch, c.st));
-    } else if (c.live()) {
-        for (int i = 0; i < h; ++i) {
-            c.check(pcrcg_gemm_f32(q.p + i * d, q.ld, kk.p + i * d, kk.ld, 1, sc.p, sc.ld, n, ms, d, nullptr, nullptr,
-                                   c.st));
-            c.check(pcrcg_softmax_rows(sc.p, n, ms, sc.ld, 1.0f / sqrtf((float)d), c.st));
-            c.check(pcrcg_gemm_f32(sc.p, sc.ld, v.p + i * d, v.ld, 0, msg.p + i * d, msg.ld, n, d, ms, nullptr, nullptr,
-                                   c.st));
+    Mat q = c.gemm_out(x.rows, ch, ch), kk = c.gemm_out(src.rows, ch, ch), v = c.gemm_out(src.rows, ch, ch), msg = c.mat(x.rows, ch);
+    int sc_rows[GMAX] = {0, 0};
+    for (int g = 0; g < c.G; ++g) sc_rows[g] = x.rows[g];
+    int ms_max = 0;
+    for (int g = 0; g < c.G; ++g) ms_max = src.rows[g] > ms_max ? src.rows[g] : ms_max;
+    Mat sc = c.mat(sc_rows, ms_max);
+    int r2[GMAX];
+    for (int g = 0; g < GMAX; ++g) r2[g] = x.rows[g];
+    Mat cat = c.mat(r2, 2 * ch), h0 = c.gemm_out(r2, 2 * ch, 2 * ch), h1 = c.mat(r2, 2 * ch), delta = c.gemm_out(r2, ch, 2 * ch);
+    linear(c, x, gl.wq, ch, gl.bq, q);
+    linear(c, src, gl.wk, ch, gl.bk, kk);
+    linear(c, src, gl.wv, ch, gl.bv, v);
+    if (c.live())
+        for (int g = 0; g < c.G; ++g) {
+            const int n = x.rows[g], ms = src.rows[g];
+            if (pcrcg_attention_supported(d) && (long)n * ms <= 1000000) {
+                // all heads in one launch (heads are contiguous column blocks after the weight permutation); a latency win on
+                // the few hundred coarse points of an indoor pair (49 vs 138 us of kernels + 11 launches less per call,
+                // scripts/attention_bench.py) -- beyond ~1000 x 1000 the GEMM path below is faster (1900 x 1900: 228 vs 640 us)
+                c.check(pcrcg_attention(q.p[g], q.ld, kk.p[g], kk.ld, v.p[g], v.ld, msg.p[g], msg.ld, n, ms, h, d,
+                                        1.0f / sqrtf((float)d), c.st));
+            } else {
+                for (int i = 0; i < h; ++i) {
+                    c.check(pcrcg_gemm_f32(q.p[g] + i * d, q.ld, kk.p[g] + i * d, kk.ld, 1, sc.p[g], ms, n, ms, d, nullptr, nullptr,
+                                           c.st));
+                    c.check(pcrcg_softmax_rows(sc.p[g], n, ms, ms, 1.0f / sqrtf((float)d), c.st));
+                    c.check(pcrcg_gemm_f32(sc.p[g], ms, v.p[g] + i * d, v.ld, 0, msg.p[g] + i * d, msg.ld, n, d, ms, nullptr, nullptr,
+                                           c.st));
+                }
+            }
+            c.check(pcrcg_copy2d(x.p[g], x.ld, cat.p[g], cat.ld, n, ch, c.st));
         }
-        c.check(pcrcg_copy2d(x.p, x.ld, cat.p, cat.ld, n, ch, c.st));
-    }
-    linear(c, msg, g.wm, ch, g.bm, cols(cat, ch, ch));       // merge, written next to x: cat([x, message])
-    Stat h0s = stat_buffer(c, n, 2 * ch);
-    linear(c, cat, g.w0, 2 * ch, g.b0, h0, &h0s);
-    if (!linear_norm(c, h0, &h0s, 0.0f, g.w3, 2 * ch, g.b3, delta)) {      // InstanceNorm1d + ReLU, inside w3's A loads
+    linear(c, msg, gl.wm, ch, gl.bm, cols(cat, ch, ch));       // merge, written next to x: cat([x, message])
+    Stat h0s = stat_buffer(c, r2, 2 * ch);
+    linear(c, cat, gl.w0, 2 * ch, gl.b0, h0, &h0s);
+    if (!linear_norm(c, h0, &h0s, 0.0f, gl.w3, 2 * ch, gl.b3, delta)) {      // InstanceNorm1d + ReLU, inside w3's A loads
         norm_act(c, h0, 0.0f, h1, &h0s);
-        linear(c, h1, g.w3, 2 * ch, g.b3, delta);
+        linear(c, h1, gl.w3, 2 * ch, gl.b3, delta);
     }
-    if (c.live()) c.check(pcrcg_add(x.p, delta.p, y.p, (long)n * ch, c.st));
+    if (c.live())
+        for (int g = 0; g < c.G; ++g) c.check(pcrcg_add(x.p[g], delta.p[g], y.p[g], (long)x.rows[g] * ch, c.st));
     c.release(m);
     return y;
 }
 
-void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_outputs& out) {
-    const int L = b.n_levels;
+void forward(Ctx& c, const pcrcg_model& mdl, const Batches& B, const pcrcg_outputs* out) {
+    const int L = B.b[0]->n_levels;
     c.bf16 = mdl.feature_bf16 != 0;
     Mat x;
-    x.p = const_cast<float*>(b.features);
-    x.rows = b.n_points[0];
-    x.cols = x.ld = b.feat_dim;
+    for (int g = 0; g < c.G; ++g) {
+        x.p[g] = const_cast<float*>(B.b[g]->features);
+        x.rows[g] = B.b[g]->n_points[0];
+    }
+    x.cols = x.ld = B.b[0]->feat_dim;
     std::vector<Mat> skips;
     // 1. encoder (:519-524)
     for (int i = 0; i < mdl.n_enc; ++i) {
         if (mdl.enc_skip[i]) skips.push_back(x);
         const pcrcg_block& blk = mdl.enc[i];
-        x = blk.type == PCRCG_BLK_SIMPLE ? simple_block(c, b, blk, x) : resnet_block(c, b, blk, x);
+        x = blk.type == PCRCG_BLK_SIMPLE ? simple_block(c, B, blk, x) : resnet_block(c, B, blk, x);
     }
     // 2. bottleneck (:527-528) and 3. GNN (:532-536)
-    const int nc = b.n_points[L - 1], ns = b.len_src_c, nt = nc - ns, g = mdl.gnn_dim;
-    Mat fc = c.gemm_out(nc, g, mdl.enc_out_dim);
+    const int gd = mdl.gnn_dim;
+    int nc[GMAX] = {0, 0}, ns[GMAX] = {0, 0}, nt[GMAX] = {0, 0}, zero[GMAX] = {0, 0};
+    const float *c0[GMAX], *c1[GMAX];
+    for (int g = 0; g < c.G; ++g) {
+        nc[g] = B.b[g]->n_points[L - 1];
+        ns[g] = B.b[g]->len_src_c;
+        nt[g] = nc[g] - ns[g];
+        c0[g] = B.b[g]->points[L - 1];
+        c1[g] = B.b[g]->points[L - 1] + 3 * (long)ns[g];
+    }
+    Mat fc = c.gemm_out(nc, gd, mdl.enc_out_dim);
     linear(c, x, mdl.bottle_w, mdl.enc_out_dim, mdl.bottle_b, fc);
-    Mat d0 = rows(fc, 0, ns), d1 = rows(fc, ns, nt);
-    const float* c0 = b.points[L - 1];
-    const float* c1 = b.points[L - 1] + 3 * (long)ns;
+    Mat d0 = rows(fc, zero, ns), d1 = rows(fc, ns, nt);
     for (int i = 0; i < mdl.n_gnn; ++i) {
         const pcrcg_gnn_layer& gl = mdl.gnn[i];
         if (gl.cross) {
@@ -506,30 +666,38 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
         }
     }
     // coarse features [score | saliency | proj_gnn feats] (:538-565), rows 16-byte aligned
-    const int wc = g + 2;
+    const int wc = gd + 2;
     Mat xc = c.mat(nc, wc, pad4(wc));
     {
         const size_t m = c.mark();
-        Mat gcat = c.mat(nc, g), fn = c.mat(nc, g), pst = c.mat(ns, nt), pts = c.mat(nt, ns);
-        if (c.live()) {
-            c.check(pcrcg_copy2d(d0.p, d0.ld, gcat.p, gcat.ld, ns, g, c.st));
-            c.check(pcrcg_copy2d(d1.p, d1.ld, gcat.p + (long)ns * gcat.ld, gcat.ld, nt, g, c.st));
-        }
-        Mat feats = cols(xc, 2, g), score = cols(xc, 0, 1), sal = cols(xc, 1, 1);
-        linear(c, gcat, mdl.proj_gnn_w, g, mdl.proj_gnn_b, feats);           // :538
-        linear(c, feats, mdl.proj_score_w, g, mdl.proj_score_b, score);      // :539
-        if (c.live()) {
-            c.check(pcrcg_l2norm_rows(feats.p, feats.ld, fn.p, fn.ld, nc, g, c.st));   // :541
-            const float inv_t = 1.0f / mdl.temperature;
-            const float* fs = fn.p;
-            const float* ft = fn.p + (long)ns * fn.ld;
-            // s1 = softmax(inner/T) @ tgt_scores, s2 = softmax(inner^T/T) @ src_scores  (:562-563); the softmax and
-            // the product with the score column are one pass over each inner-product matrix
-            c.check(pcrcg_gemm_f32(fs, fn.ld, ft, fn.ld, 1, pst.p, pst.ld, ns, nt, g, nullptr, nullptr, c.st));
-            c.check(pcrcg_softmax_matvec(pst.p, ns, nt, pst.ld, inv_t, score.p + (long)ns * xc.ld, xc.ld, sal.p, xc.ld, c.st));
-            c.check(pcrcg_gemm_f32(ft, fn.ld, fs, fn.ld, 1, pts.p, pts.ld, nt, ns, g, nullptr, nullptr, c.st));
-            c.check(pcrcg_softmax_matvec(pts.p, nt, ns, pts.ld, inv_t, score.p, xc.ld, sal.p + (long)ns * xc.ld, xc.ld, c.st));
-        }
+        Mat gcat = c.mat(nc, gd), fn = c.mat(nc, gd);
+        int st_rows[GMAX], ts_rows[GMAX];
+        int nt_max = 0, ns_max = 0;
+        for (int g = 0; g < GMAX; ++g) { st_rows[g] = ns[g]; ts_rows[g] = nt[g]; nt_max = nt[g] > nt_max ? nt[g] : nt_max; ns_max = ns[g] > ns_max ? ns[g] : ns_max; }
+        Mat pst = c.mat(st_rows, nt_max), pts = c.mat(ts_rows, ns_max);
+        if (c.live())
+            for (int g = 0; g < c.G; ++g) {
+                c.check(pcrcg_copy2d(d0.p[g], d0.ld, gcat.p[g], gcat.ld, ns[g], gd, c.st));
+                c.check(pcrcg_copy2d(d1.p[g], d1.ld, gcat.p[g] + (long)ns[g] * gcat.ld, gcat.ld, nt[g], gd, c.st));
+            }
+        Mat feats = cols(xc, 2, gd), score = cols(xc, 0, 1), sal = cols(xc, 1, 1);
+        linear(c, gcat, mdl.proj_gnn_w, gd, mdl.proj_gnn_b, feats);           // :538
+        linear(c, feats, mdl.proj_score_w, gd, mdl.proj_score_b, score);      // :539
+        if (c.live())
+            for (int g = 0; g < c.G; ++g) {
+                c.check(pcrcg_l2norm_rows(feats.p[g], feats.ld, fn.p[g], fn.ld, nc[g], gd, c.st));   // :541
+                const float inv_t = 1.0f / mdl.temperature;
+                const float* fs = fn.p[g];
+                const float* ft = fn.p[g] + (long)ns[g] * fn.ld;
+                // s1 = softmax(inner/T) @ tgt_scores, s2 = softmax(inner^T/T) @ src_scores  (:562-563); the softmax and
+                // the product with the score column are one pass over each inner-product matrix
+                c.check(pcrcg_gemm_f32(fs, fn.ld, ft, fn.ld, 1, pst.p[g], nt[g], ns[g], nt[g], gd, nullptr, nullptr, c.st));
+                c.check(pcrcg_softmax_matvec(pst.p[g], ns[g], nt[g], nt[g], inv_t, score.p[g] + (long)ns[g] * xc.ld, xc.ld, sal.p[g],
+                                             xc.ld, c.st));
+                c.check(pcrcg_gemm_f32(ft, fn.ld, fs, fn.ld, 1, pts.p[g], ns[g], nt[g], ns[g], gd, nullptr, nullptr, c.st));
+                c.check(pcrcg_softmax_matvec(pts.p[g], nt[g], ns[g], ns[g], inv_t, score.p[g], xc.ld, sal.p[g] + (long)ns[g] * xc.ld,
+                                             xc.ld, c.st));
+            }
         c.release(m);
     }
     x = xc;
@@ -549,7 +717,9 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
     for (int j = 0; j < mdl.n_dec; ++j) {
         const pcrcg_block& blk = mdl.dec[j];
         if (blk.type == PCRCG_BLK_UPSAMPLE) {
-            const pcrcg_table& t = b.upsamples[blk.layer - 1];
+            const pcrcg_table* tabs[GMAX];
+            int trows[GMAX] = {0, 0};
+            for (int g = 0; g < c.G; ++g) { tabs[g] = &B.b[g]->upsamples[blk.layer - 1]; trows[g] = tabs[g]->rows; }
             const bool concat = j + 1 < mdl.n_dec && mdl.dec_concat[j + 1];
             const int cs = concat ? skips.back().cols : 0;
             const pcrcg_block* next = j + 1 < mdl.n_dec ? &mdl.dec[j + 1] : nullptr;
@@ -562,26 +732,12 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
                 skips.back().ld % 4 == 0) {
                 const Mat& sk = skips.back();
                 const bool last = next->type == PCRCG_BLK_LAST_UNARY;
-                Mat tt = c.mat(t.rows, next->out_dim, pad4(next->out_dim));    // rows 16-byte aligned: it may be gathered next
+                Mat tt = c.mat(trows, next->out_dim, pad4(next->out_dim));    // rows 16-byte aligned: it may be gathered next
                 float* zero_row = static_cast<float*>(c.zraw(sizeof(float) * (size_t)(x.cols + 8)));
                 if (lazy && !(norm_fuse_on() && lazy_stats_ready(c, x, &xs))) materialise();
-                if (c.live()) {
-                    GemmExtra g1, g2;
-                    if (lazy) {                              // the producer's normalisation, applied to the gathered rows
-                        g1.a_sums = static_cast<const double*>(xs.partials);
-                        g1.a_count = (double)x.rows;
-                        g1.a_slope = 0.1f;
-                    }
-                    g1.a_idx = reinterpret_cast<const long long*>(t.idx);
-                    g1.a_idx_ld = t.ld;
-                    g1.a_ns = x.rows;
-                    g1.a_zero = zero_row;
-                    g2.accumulate = true;
-                    c.check(gemm_bt_extra(x.p, x.ld, next->mlp, next->mlp_ld, tt.p, tt.ld, t.rows, next->out_dim, x.cols, c.st,
-                                          false, g1));
-                    c.check(gemm_bt_extra(sk.p, sk.ld, next->mlp_skip, next->mlp_skip_ld, tt.p, tt.ld, t.rows, next->out_dim,
-                                          cs, c.st, true, g2));
-                }
+                // the producer's normalisation (when lazy) applied to the gathered rows; then the skip part on top
+                linear_extra(c, x, next->mlp, next->mlp_ld, nullptr, tt, 0, tabs, zero_row, lazy ? &xs : nullptr, 0.1f, false, false);
+                linear_extra(c, sk, next->mlp_skip, next->mlp_skip_ld, nullptr, tt, 0, nullptr, nullptr, nullptr, 1.0f, true, true);
                 skips.pop_back();
                 lazy = false;
                 x = tt;
@@ -593,19 +749,21 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
                 continue;
             }
             materialise();
-            Mat y = c.mat(t.rows, x.cols + cs, pad4(x.cols + cs));
+            Mat y = c.mat(trows, x.cols + cs, pad4(x.cols + cs));
             Mat xd = x;
             if (x.ld != x.cols) {   // gather_first reads dense rows
                 xd = c.mat(x.rows, x.cols);
-                if (c.live()) c.check(pcrcg_copy2d(x.p, x.ld, xd.p, xd.ld, x.rows, x.cols, c.st));
+                if (c.live())
+                    for (int g = 0; g < c.G; ++g) c.check(pcrcg_copy2d(x.p[g], x.ld, xd.p[g], xd.ld, x.rows[g], x.cols, c.st));
             }
-            if (c.live()) {
-                c.check(pcrcg_gather_first(xd.p, xd.rows, xd.cols, t.idx, t.rows, t.ld, y.p, y.ld, c.st));
-                if (concat) {
-                    const Mat& s = skips.back();
-                    c.check(pcrcg_copy2d(s.p, s.ld, y.p + x.cols, y.ld, s.rows, s.cols, c.st));
+            if (c.live())
+                for (int g = 0; g < c.G; ++g) {
+                    c.check(pcrcg_gather_first(xd.p[g], xd.rows[g], xd.cols, tabs[g]->idx, tabs[g]->rows, tabs[g]->ld, y.p[g], y.ld, c.st));
+                    if (concat) {
+                        const Mat& s = skips.back();
+                        c.check(pcrcg_copy2d(s.p[g], s.ld, y.p[g] + x.cols, y.ld, s.rows[g], s.cols, c.st));
+                    }
                 }
-            }
             if (concat) skips.pop_back();
             x = y;
         } else if (blk.type == PCRCG_BLK_UNARY) {
@@ -626,9 +784,11 @@ void forward(Ctx& c, const pcrcg_model& mdl, const pcrcg_batch& b, const pcrcg_o
     // heads (:571-582)
     if (c.live()) {
         const int fd = mdl.final_dim;
-        c.check(pcrcg_l2norm_rows(x.p, x.ld, out.feats_f, fd, x.rows, fd, c.st));
-        c.check(pcrcg_sigmoid_scores(x.p + fd, x.ld, out.scores_overlap, x.rows, c.st));
-        c.check(pcrcg_sigmoid_scores(x.p + fd + 1, x.ld, out.scores_saliency, x.rows, c.st));
+        for (int g = 0; g < c.G; ++g) {
+            c.check(pcrcg_l2norm_rows(x.p[g], x.ld, out[g].feats_f, fd, x.rows[g], fd, c.st));
+            c.check(pcrcg_sigmoid_scores(x.p[g] + fd, x.ld, out[g].scores_overlap, x.rows[g], c.st));
+            c.check(pcrcg_sigmoid_scores(x.p[g] + fd + 1, x.ld, out[g].scores_saliency, x.rows[g], c.st));
+        }
     }
 }
 
@@ -643,6 +803,15 @@ int validate(const pcrcg_model* m, const pcrcg_batch* b) {
     return PCRCG_OK;
 }
 
+int validate_group(const pcrcg_model* m, const pcrcg_batch* b, int n) {
+    PCRCG_CHECK_ARG(b && n >= 1 && n <= GMAX);
+    for (int g = 0; g < n; ++g) {
+        PCRCG_PROPAGATE(validate(m, b + g));
+        PCRCG_CHECK_ARG(b[g].n_levels == b[0].n_levels && b[g].feat_dim == b[0].feat_dim);
+    }
+    return PCRCG_OK;
+}
+
 }  // namespace
 }  // namespace pcrcg
 
@@ -650,36 +819,49 @@ using namespace pcrcg;
 
 extern "C" {
 
-size_t pcrcg_kpfcnn_ws_bytes(const pcrcg_model* model, const pcrcg_batch* batch) {
-    if (validate(model, batch) != PCRCG_OK) return 0;
+size_t pcrcg_kpfcnn_group_ws_bytes(const pcrcg_model* model, const pcrcg_batch* batches, int n) {
+    if (validate_group(model, batches, n) != PCRCG_OK) return 0;
     Ctx c;
     c.dry = true;
-    pcrcg_outputs none = {nullptr, nullptr, nullptr};
-    forward(c, *model, *batch, none);
+    c.G = n;
+    Batches B = {{batches, n > 1 ? batches + 1 : nullptr}};
+    forward(c, *model, B, nullptr);
     return c.peak + c.zoff + 4096;
 }
 
-int pcrcg_kpfcnn_forward(const pcrcg_model* model, const pcrcg_batch* batch, const pcrcg_outputs* out, void* ws,
-                         size_t ws_bytes, void* stream) {
-    PCRCG_PROPAGATE(validate(model, batch));
-    PCRCG_CHECK_ARG(out && out->feats_f && out->scores_overlap && out->scores_saliency && ws);
-    // pass 1 (no launches): how much of the workspace the zero arena takes for this batch
+size_t pcrcg_kpfcnn_ws_bytes(const pcrcg_model* model, const pcrcg_batch* batch) {
+    return pcrcg_kpfcnn_group_ws_bytes(model, batch, 1);
+}
+
+int pcrcg_kpfcnn_forward_group(const pcrcg_model* model, const pcrcg_batch* batches, const pcrcg_outputs* outs, int n, void* ws,
+                               size_t ws_bytes, void* stream) {
+    PCRCG_PROPAGATE(validate_group(model, batches, n));
+    PCRCG_CHECK_ARG(outs && ws);
+    for (int g = 0; g < n; ++g) PCRCG_CHECK_ARG(outs[g].feats_f && outs[g].scores_overlap && outs[g].scores_saliency);
+    Batches B = {{batches, n > 1 ? batches + 1 : nullptr}};
+    // pass 1 (no launches): how much of the workspace the zero arena takes for these batches
     Ctx d;
     d.dry = true;
-    pcrcg_outputs none = {nullptr, nullptr, nullptr};
-    forward(d, *model, *batch, none);
+    d.G = n;
+    forward(d, *model, B, nullptr);
     if (d.zoff + d.peak > ws_bytes) {
         set_error("pcrcg_kpfcnn_forward: workspace too small (%zu needed, %zu given)", d.zoff + d.peak, ws_bytes);
         return PCRCG_EWORKSPACE;
     }
     Ctx c;
+    c.G = n;
     c.zbase = static_cast<char*>(ws);
     c.zcap = d.zoff;
     c.base = c.zbase + d.zoff;
     c.cap = ws_bytes - d.zoff;
     c.st = as_stream(stream);
     if (d.zoff > 0) PCRCG_CHECK_HIP(hipMemsetAsync(ws, 0, d.zoff, c.st));
-    forward(c, *model, *batch, *out);
+    forward(c, *model, B, outs);
     return c.rc;
+}
+
+int pcrcg_kpfcnn_forward(const pcrcg_model* model, const pcrcg_batch* batch, const pcrcg_outputs* out, void* ws,
+                         size_t ws_bytes, void* stream) {
+    return pcrcg_kpfcnn_forward_group(model, batch, out, 1, ws, ws_bytes, stream);
 }
 }

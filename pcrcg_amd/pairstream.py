@@ -53,8 +53,11 @@ class PairStreams:
     ARENAS = 4        # per front thread: pairs whose tables may be alive at once (built, forward not yet passed)
 
     def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=1, tie_order=None,
-                 pairs_per_build=2, up_nearest=False, front_streams=1, front_priority=0):
-        """up_nearest: the engine's internal pyramids carry ONE-column upsample tables (the nearest coarse point: the only
+                 pairs_per_build=2, up_nearest=False, front_streams=1, front_priority=0, pairs_per_forward=2):
+        """pairs_per_forward = 2: two pairs that were built together also go through the network together -- one
+        pcrcg_kpfcnn_forward_group call on one model stream, in which every product with a weight matrix runs once for
+        both pairs (the pairs never mix; outputs equal separate forwards up to summation order).  1: one call per pair.
+        up_nearest: the engine's internal pyramids carry ONE-column upsample tables (the nearest coarse point: the only
         column KPFCNN.forward reads, ref:models/blocks.py:77-87) instead of the batch contract's [N, limit] tables:
         ~1 % less front-end work, same outputs.  Off by default: the tables are then exactly what build_pyramid()
         hands to any other consumer."""
@@ -87,8 +90,10 @@ class PairStreams:
         self._take = threading.Lock()
         self._per_build = max(1, int(pairs_per_build))
         self._users = [[1] * self.ARENAS for _ in range(nf)]   # forwards that read the arena's current contents
-        self._mid = [_Mailbox() for _ in self.models]
-        self._out = [queue.Queue() for _ in self.models]
+        self._per_forward = 2 if int(pairs_per_forward) >= 2 else 1
+        self._mid = [_Mailbox() for _ in self.models]     # jobs (one or two pairs) by job index: thread m serves m, m + M, ...
+        self._jobs = 0                                     # job indices are handed out under self._take, with the pairs
+        self._results = _Mailbox()                         # (outputs, done event) or an exception, by submission index
         self._submitted = self._returned = 0
         self._pending = []                     # (status tensor, slot, event) of pairs whose tie status is unread
         self._lock = threading.Lock()
@@ -144,11 +149,16 @@ class PairStreams:
                         items.append(self._in.get_nowait())
                     except queue.Empty:
                         break
-            if items[-1] is None:
-                self._in.put(None)             # pass the shutdown token on to the other front threads
-                items.pop()
-                if not items:
-                    return
+                if items[-1] is None:
+                    self._in.put(None)         # pass the shutdown token on to the other front threads
+                    items.pop()
+                # the pairs' forward jobs, in submission order: one job for two pairs built together, else one per pair
+                grouped = len(items) == 2 and self._per_forward == 2
+                njobs = (1 if grouped else len(items))
+                job0 = self._jobs
+                self._jobs += njobs
+            if not items:
+                return
             self._stat(front_idle_s=time.perf_counter() - t0)
             a = turn % self.ARENAS
             turn += 1
@@ -185,8 +195,13 @@ class PairStreams:
                     self._stat(arena_wait_s=t1 - t0, build_s=time.perf_counter() - t1, pairs=k, builds=1)
                     built = torch.cuda.Event()
                     built.record(front)
-                for i, it in enumerate(items):
-                    self._mid[it[0] % len(self.models)].put(it[0], (batches[i], arena, built, pyr, slot, deferred, f, a))
+                if grouped:
+                    self._mid[job0 % len(self.models)].put(job0, ([it[0] for it in items], batches, arena, built, pyr, slot,
+                                                                   deferred, f, a))
+                else:
+                    for i, it in enumerate(items):
+                        self._mid[(job0 + i) % len(self.models)].put(job0 + i, ([it[0]], batches[i], arena, built, pyr, slot,
+                                                                                  deferred, f, a))
             except BaseException as e:                            # surfaced by result()
                 if claimed:
                     # the arena was taken over for k forwards that will not happen: one token for each of them
@@ -200,26 +215,28 @@ class PairStreams:
                         self._free[f][a].put(None)
                         left = 1
                     self._users[f][a] = left
-                for it in items:
-                    self._mid[it[0] % len(self.models)].put(it[0], e)
+                if grouped:
+                    self._mid[job0 % len(self.models)].put(job0, ([it[0] for it in items], e))
+                else:
+                    for i, it in enumerate(items):
+                        self._mid[(job0 + i) % len(self.models)].put(job0 + i, ([it[0]], e))
 
     def _serve_model(self, m):
         torch.cuda.set_device(self.device)
-        stream, seq = self.models[m], m
+        stream, job = self.models[m], m
         while True:
             t0 = time.perf_counter()
-            item = self._mid[m].get(seq)
-            seq += len(self.models)
+            item = self._mid[m].get(job)
+            job += len(self.models)
             if item is None:
                 return
             self._stat(model_idle_s=time.perf_counter() - t0)
-            try:
-                if isinstance(item, BaseException):
-                    raise item
-                b, arena, built, pyr, slot, deferred, f, a = item
-            except BaseException as e:
-                self._out[m].put(e)
+            seqs = item[0]
+            if isinstance(item[1], BaseException):
+                for q in seqs:
+                    self._results.put(q, item[1])
                 continue
+            _, b, arena, built, pyr, slot, deferred, f, a = item
             try:
                 with torch.cuda.stream(stream), torch.no_grad():
                     stream.wait_event(built)
@@ -228,18 +245,24 @@ class PairStreams:
                     # stream: that stream's serial kernel chain is the pipeline's bottleneck, the model streams have slack
                     if deferred is not None:
                         pyr.restore(deferred, slot)
-                    out = self.runner.launch(b, self.device)
+                    if len(seqs) == 2:
+                        outs = self.runner.launch_group(b, 2, self.device)     # both pairs in ONE call
+                    else:
+                        outs = [self.runner.launch(b, self.device)]
                     self._stat(launch_s=time.perf_counter() - t0)
                     done = torch.cuda.Event()
                     done.record(stream)
-                self._free[f][a].put(done)
-                out["_tie_status"] = (pyr.status, slot)
-                with self._lock:
-                    self._pending.append((pyr.status, slot, done))
-                self._out[m].put((out, done))
+                for q, out in zip(seqs, outs):
+                    self._free[f][a].put(done)                 # one token per pair that read the arena
+                    out["_tie_status"] = (pyr.status, slot)
+                    with self._lock:
+                        self._pending.append((pyr.status, slot, done))
+                    out["_keep"] = (b, arena)
+                    self._results.put(q, (out, done))
             except BaseException as e:
-                self._free[f][a].put(None)
-                self._out[m].put(e)
+                for q in seqs:
+                    self._free[f][a].put(None)
+                    self._results.put(q, e)
 
     # ---- caller --------------------------------------------------------------------------------
     def submit(self, points, lengths):
@@ -261,9 +284,8 @@ class PairStreams:
         pair k's forward (measured on the null stream: 240 instead of 340 pairs/s)."""
         if self._returned >= self._submitted:
             raise RuntimeError("PairStreams.result(): nothing submitted")
-        m = self._returned % len(self.models)
+        item = self._results.get(self._returned)
         self._returned += 1
-        item = self._out[m].get()
         if isinstance(item, BaseException):
             raise item
         out, done = item
@@ -315,7 +337,7 @@ class PairStreams:
 
     def close(self):
         self._in.put(None)
-        for mb in self._mid:
+        for mb in self._mid + [self._results]:
             mb.put(None, None)
         for t in self._threads:
             t.join(timeout=10)

@@ -333,6 +333,39 @@ class Runner:
         b, keep, dev = self.batch_struct(batch)
         return self.launch(b, dev)
 
+    def launch_group(self, batches, n, dev):
+        """Enqueue ONE forward call for the n (1 or 2) pcrcg_batch structs of the ctypes array `batches` (as
+        NativePyramid.build(group=2) returns them) on the current stream -> list of n output dicts.  Weight products run
+        once for both pairs (pcrcg_kpfcnn_forward_group)."""
+        L = _bind()
+        desc = self.descriptor()
+        outs, o = [], (Outputs * n)()
+        for g in range(n):
+            n0 = batches[g].n_points[0]
+            out = {"feats_f": torch.empty((n0, desc.final_dim), dtype=torch.float32, device=dev),
+                   "scores_overlap": torch.empty(n0, dtype=torch.float32, device=dev),
+                   "scores_saliency": torch.empty(n0, dtype=torch.float32, device=dev)}
+            o[g].feats_f, o[g].scores_overlap, o[g].scores_saliency = (out["feats_f"].data_ptr(), out["scores_overlap"].data_ptr(),
+                                                                      out["scores_saliency"].data_ptr())
+            outs.append(out)
+        nbytes = L.pcrcg_kpfcnn_group_ws_bytes(ctypes.byref(desc), batches, n)
+        if nbytes == 0:
+            raise RuntimeError("pcrcg_kpfcnn_group_ws_bytes rejected the descriptors: " + (L.pcrcg_last_error() or b"").decode())
+        cur = torch.cuda.current_stream()
+        stream = cur.cuda_stream
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+        with self._lock:
+            ws = self.ws.get(key)
+            if ws is None or ws.numel() < nbytes:
+                ws = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)
+                self.ws[key] = ws
+            if key not in self._seen and self._built is not None:
+                cur.wait_event(self._built)
+                self._seen.add(key)
+        _lib.check(L.pcrcg_kpfcnn_forward_group(ctypes.byref(desc), batches, o, n, ws.data_ptr(), ws.numel(), stream),
+                   "pcrcg_kpfcnn_forward_group")
+        return outs
+
     def launch(self, b, dev):
         """Enqueue the forward for a pcrcg_batch (from batch_struct, or filled by pcrcg_pyramid_build) on the
         current stream; the caller keeps whatever `b` points into alive until the stream has passed."""

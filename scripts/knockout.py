@@ -28,7 +28,11 @@ FAMILIES = [("pcrcg_copy2d(", "K_COPY"), ("pcrcg_gather_max(", "K_GMAX"), ("pcrc
 def build():
     src = open(os.path.join(CSRC, "runner.hip")).read()
     src = src.replace("namespace pcrcg {\n// gemm.hip", '#include <cstring>\nstatic bool ko(const char* name) { static const char* e = '
-                      'getenv("PCRCG_KNOCK"); return e && strstr(e, name); }\nnamespace pcrcg {\n// gemm.hip', 1)
+                      'getenv("PCRCG_KNOCK"); return e && strstr(e, name); }\nthread_local int pcrcg_knock_forward_count = 0;\n'
+                      'namespace pcrcg {\n// gemm.hip', 1)
+    pat = "    PCRCG_PROPAGATE(validate(model, batch));\n    PCRCG_CHECK_ARG(out && out->feats_f"
+    assert pat in src
+    src = src.replace(pat, "    ++pcrcg_knock_forward_count;\n" + pat, 1)
     for pat, tok in FAMILIES:
         n = src.count(pat)
         src = src.replace(pat, 'ko("%s") ? PCRCG_OK : %s' % (tok, pat))
@@ -44,8 +48,13 @@ def build():
     g = open(os.path.join(CSRC, "gemm_x6.hip")).read()
     pat = "    // k-major operands (a_kmajor: A stored [K, M]; b_kmajor: B stored [K, N]) are read with 4-byte loads"
     assert pat in g
-    g = g.replace(pat, '    { static const char* e = getenv("PCRCG_KNOCK_M"); int lo = 0, hi = 0;\n'
-                       '      if (e && sscanf(e, "%d,%d", &lo, &hi) == 2 && m >= lo && m < hi) return PCRCG_OK; }\n' + pat, 1)
+    # PCRCG_KNOCK_M="lo,hi" skips the products with lo <= M < hi; "lo,hi,2" skips them in every SECOND forward of a host
+    # thread only: what launching them once for two stacked pairs could buy at most
+    g = g.replace(pat, '    { static const char* e = getenv("PCRCG_KNOCK_M"); int lo = 0, hi = 0, every = 1;\n'
+                       '      if (e && sscanf(e, "%d,%d,%d", &lo, &hi, &every) >= 2 && m >= lo && m < hi &&\n'
+                       '          (every <= 1 || (pcrcg_knock_forward_count % every) == 1)) return PCRCG_OK; }\n' + pat, 1)
+    g = g.replace("namespace pcrcg {\nnamespace {\n\ntypedef float f32x16", "extern thread_local int pcrcg_knock_forward_count;\nnamespace pcrcg {\nnamespace {\n\ntypedef float f32x16", 1)
+    assert "pcrcg_knock_forward_count;" in g
     open(os.path.join(tmp, "gemm_x6_knock.hip"), "w").write(g)
     objs = [os.path.join(CSRC, "build", f) for f in os.listdir(os.path.join(CSRC, "build"))
             if f.endswith(".o") and f not in ("runner.o", "gemm_x6.o")]
