@@ -138,7 +138,12 @@ class KPFCNN(nn.Module):
             batch = dict(batch)
             batch["features"] = self.image_features(batch, backbone2d)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # training: the differentiable composition of the same kernels (pcrcg_amd/train_forward.py)
+            # training: forward with a tape + backward in C++ (pcrcg_amd/train_runner.py, one autograd node whose backward
+            # accumulates every parameter's gradient into p.grad); configurations it does not cover take the op-by-op
+            # autograd composition of the same kernels (pcrcg_amd/train_forward.py)
+            tr = self.train_runner()
+            if tr is not None:
+                return tr.forward(batch)
             from .train_forward import forward_train
             return forward_train(self, batch)
         if self.use_runner:
