@@ -192,8 +192,10 @@ def main():
     ap.add_argument("--model-streams", type=int, default=3, help="engine: host threads / HIP streams enqueueing forwards")
     ap.add_argument("--front-threads", type=int, default=1, help="engine: host threads building pyramids")
     ap.add_argument("--depth", type=int, default=8, help="pairs submitted ahead of the one being collected")
-    ap.add_argument("--pairs-per-forward", type=int, default=2, choices=[1, 2],
-                    help="2: two pairs built together share one pcrcg_kpfcnn_forward_group call (weight products once for both)")
+    ap.add_argument("--pairs-per-forward", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="pairs built together that share one pcrcg_kpfcnn_forward_group call (weight products once for all)")
+    ap.add_argument("--pairs-per-build", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="pairs one front-end kernel chain (pcrcg_pyramid_build call) carries")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="A/B aid: no start/stop events on the KPConv launches of the timed regions (roofline comes out empty)")
     ap.add_argument("--isolated-only", action="store_true",
@@ -334,7 +336,7 @@ def main():
 
     # ---- headline: the reference's batch contract inside the engine too (full [N, limit] upsample tables) ----------
     pipe = PairStreams(net, cfg, limits, dev, model_streams=WORKERS, front_threads=FRONTS, up_nearest=False,
-                       pairs_per_forward=args.pairs_per_forward)
+                       pairs_per_forward=args.pairs_per_forward, pairs_per_build=args.pairs_per_build)
     # engine priming (untimed, before the W warm-up steps): every model stream's first call allocates its workspace
     # and every front-end arena its tables; a handful of pairs per stream gets that out of the way
     run_pairs(pipe, 4 * WORKERS * args.pairs_per_forward)
@@ -455,8 +457,9 @@ def main():
                                    "exactly equal distance (tie_order=%s); GEMM arithmetic mode %d (1 = exact three-term "
                                    "bf16 split on the bf16 matrix cores, fp32-class accuracy; 0 = fp32 MFMA)"
                                    % (FRONTS, ppb, WORKERS,
-                                      "the two pairs of a build in ONE call, every weight product once for both"
-                                      if args.pairs_per_forward == 2 else "one call per pair", tie, _gemm_mode()),
+                                      "up to %d pairs of a build in ONE call, every weight product once for all of them"
+                                      % args.pairs_per_forward if args.pairs_per_forward >= 2 else "one call per pair",
+                                      tie, _gemm_mode()),
                        "tie_order": tie, "up_nearest": 0, "pairs_per_pyramid_build": round(ppb, 2),
                        "pairs_per_forward_call": args.pairs_per_forward,
                        "limits": limits, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",

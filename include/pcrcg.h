@@ -461,12 +461,12 @@ size_t pcrcg_kpfcnn_ws_bytes(const pcrcg_model* model, const pcrcg_batch* batch)
 int pcrcg_kpfcnn_forward(const pcrcg_model* model, const pcrcg_batch* batch, const pcrcg_outputs* out, void* ws,
                          size_t ws_bytes, void* stream);
 
-/* The same forward for n (1 or 2) INDEPENDENT fragment pairs in one call: batches[n], outs[n] (e.g. the batches one
- * pcrcg_pyramid_build call with cfg.group = 2 returns).  Pairs never mix -- InstanceNorm statistics, neighbour tables,
+/* The same forward for n (1 to 4) INDEPENDENT fragment pairs in one call: batches[n], outs[n] (e.g. the batches one
+ * pcrcg_pyramid_build call with cfg.group = 2 returns for 2n clouds).  Pairs never mix -- InstanceNorm statistics, neighbour tables,
  * the GNN's kNN and attention stay per pair (ref:datasets/dataloader.py:207 asserts one pair per batch;
  * ref:models/blocks.py:456-463 normalises over the batch's stacked points), so the outputs are those of n separate
- * pcrcg_kpfcnn_forward calls up to fp32 summation order -- but every product with a weight matrix runs ONCE for both
- * pairs (two row ranges sharing the weight operand in one launch): the coarse-level products, which fill a fraction of
+ * pcrcg_kpfcnn_forward calls up to fp32 summation order -- but every product with a weight matrix runs ONCE for all
+ * pairs (their row ranges sharing the weight operand in one launch): the coarse-level products, which fill a fraction of
  * the chip for one pair, fill twice that at the same duration, and a pair costs half the GEMM launches.
  * Per-pair kernels (gathers, normalisation, kNN, attention) are enqueued once per pair.  With the fp32-MFMA arithmetic
  * (pcrcg_gemm_set_mode(0)) the products run pair by pair as well. */

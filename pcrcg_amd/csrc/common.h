@@ -80,6 +80,10 @@ struct GemmPair {
     const double* a_sums = nullptr;     // normalise-on-load form: its own column sums and row count
     double a_count = 0.0;
 };
+struct GemmGroup {                      // up to 3 further products in the launch (4 fragment pairs per call)
+    int n = 0;
+    GemmPair p[3];
+};
 
 // kpconv.hip: row-positive flags + packed (x, y, z, flag) support records into a pcrcg_kpconv_ws_bytes(ns) workspace
 // (x_bf16 != NULL: also the bf16 round-to-nearest-even copy of x, [ns, cin])

@@ -337,7 +337,7 @@ namespace pcrcg {
 int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
                      hipStream_t st, bool a_bf16, bool c_zeroed, int a_kmajor = 0, int b_kmajor = 0,
-                     bool colstats_sums = false, const GemmExtra* ex = nullptr, const GemmPair* pair = nullptr);   // gemm_x6.hip
+                     bool colstats_sums = false, const GemmExtra* ex = nullptr, const GemmGroup* grp = nullptr);   // gemm_x6.hip
 int gemm_x6_splits(int m, int n, int k);
 }
 
@@ -386,23 +386,23 @@ int gemm_bt_extra(const float* a, int lda, const float* b, int ldb, float* c, in
 bool gemm_pair_ok() { return gemm_mode() == 1; }
 int gemm_bt_colstats_pair(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                           const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
-                          hipStream_t st, bool c_zeroed, bool colstats_sums, const GemmPair* pair) {
-    if (!pair)
+                          hipStream_t st, bool c_zeroed, bool colstats_sums, const GemmGroup* pair) {
+    if (!pair || pair->n == 0)
         return gemm_dispatch(a, lda, 0, b, ldb, 1, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks, st,
                              c_zeroed, colstats_sums);
     if (h_chunks) *h_chunks = 0;
-    PCRCG_CHECK_ARG(m >= 1 && n >= 1 && k >= 1 && lda >= k && ldb >= k && ldc >= n && pair->m >= 1);
-    PCRCG_CHECK_ARG(a && b && c && pair->a && pair->c && gemm_mode() == 1);
+    PCRCG_CHECK_ARG(m >= 1 && n >= 1 && k >= 1 && lda >= k && ldb >= k && ldc >= n);
+    PCRCG_CHECK_ARG(a && b && c && gemm_mode() == 1);
     return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, colstats, colstats_bytes, h_chunks, st, false,
                             c_zeroed, 0, 0, colstats_sums, nullptr, pair);
 }
 int gemm_bt_extra_pair(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, hipStream_t st,
                        bool c_zeroed, const GemmExtra& ex, const float* bias, void* colstats, size_t colstats_bytes,
-                       int* h_chunks, bool colstats_sums, const GemmPair* pair) {
+                       int* h_chunks, bool colstats_sums, const GemmGroup* pair) {
     if (h_chunks) *h_chunks = 0;
     PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 1 && lda >= k && ldb >= k && ldc >= n);
     if (m == 0 || n == 0) return PCRCG_OK;
-    PCRCG_CHECK_ARG(a && b && c && gemm_mode() == 1 && (!pair || (pair->a && pair->c && pair->m >= 1)));
+    PCRCG_CHECK_ARG(a && b && c && gemm_mode() == 1);
     return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, nullptr, bias, colstats, colstats_bytes, h_chunks, st, false,
                             c_zeroed, 0, 0, colstats_sums, &ex, pair);
 }

@@ -41,18 +41,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 
-// kernel-side form of GemmPair (common.h): the second product's operands; pair_off = 0: a single product
+// kernel-side form of GemmGroup (common.h): the operands of up to 3 further products; extra = 0: a single product.
+// Product e's row tiles start at row off[e] of the launch's tile space.
+constexpr int kGroupExtra = 3;
 struct GemmPairArgs {
-    int pair_off = 0, m1 = 0;
-    const float* a1 = nullptr;
-    float* c1 = nullptr;
-    const float* rs1 = nullptr;
-    double* colp1 = nullptr;
-    int colp_chunks1 = 0;
-    const long long* a_idx1 = nullptr;
-    int a_ns1 = 0;
-    const double* a_sums1 = nullptr;
-    double a_count1 = 0.0;
+    int extra = 0;
+    int off[kGroupExtra] = {0, 0, 0}, m[kGroupExtra] = {0, 0, 0};
+    const float* a[kGroupExtra] = {nullptr, nullptr, nullptr};
+    float* c[kGroupExtra] = {nullptr, nullptr, nullptr};
+    const float* rs[kGroupExtra] = {nullptr, nullptr, nullptr};
+    double* colp[kGroupExtra] = {nullptr, nullptr, nullptr};
+    int colp_chunks[kGroupExtra] = {0, 0, 0};
+    const long long* a_idx[kGroupExtra] = {nullptr, nullptr, nullptr};
+    int a_ns[kGroupExtra] = {0, 0, 0};
+    const double* a_sums[kGroupExtra] = {nullptr, nullptr, nullptr};
+    double a_count[kGroupExtra] = {0.0, 0.0, 0.0};
 };
 
 // Register loads hidden from hipcc's s_waitcnt bookkeeping (guide 5.7, form ii).  hipcc merges the vmcnt state of
@@ -190,24 +193,25 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     int tile_y = tile / gx;
     int m0 = tile_y * BM;
     const int n0 = tile_x * BN;
-    // Two products that share B in ONE launch (GemmPair, common.h: the same layer of two fragment pairs): row tiles from
-    // pair_off on belong to the second product -- its own A, C, row scale, statistics and gather table; from here on the
-    // workgroup works on that product's matrices as if it had been launched alone.
-    if (pr.pair_off > 0) {
-        if (m0 >= pr.pair_off) {
-            m0 -= pr.pair_off;
-            tile_y = m0 / BM;
-            M = pr.m1;
-            A = pr.a1;
-            C = pr.c1;
-            row_scale = pr.rs1;
-            colp = pr.colp1;
-            colp_chunks = pr.colp_chunks1;
-            a_idx = pr.a_idx1;
-            a_ns = pr.a_ns1;
-            a_sums = pr.a_sums1;
-            a_count = pr.a_count1;
-        }
+    // Several products that share B in ONE launch (GemmGroup, common.h: the same layer of several fragment pairs): row
+    // tiles from off[e] on belong to product e + 1 -- its own A, C, row scale, statistics and gather table; from here on
+    // the workgroup works on that product's matrices as if it had been launched alone.
+    if (pr.extra > 0 && m0 >= pr.off[0]) {
+        int e = 0;
+        if (pr.extra > 1 && m0 >= pr.off[1]) e = 1;
+        if (pr.extra > 2 && m0 >= pr.off[2]) e = 2;
+        m0 -= pr.off[e];
+        tile_y = m0 / BM;
+        M = pr.m[e];
+        A = pr.a[e];
+        C = pr.c[e];
+        row_scale = pr.rs[e];
+        colp = pr.colp[e];
+        colp_chunks = pr.colp_chunks[e];
+        a_idx = pr.a_idx[e];
+        a_ns = pr.a_ns[e];
+        a_sums = pr.a_sums[e];
+        a_count = pr.a_count[e];
     }
     const int k_begin = blockIdx.z * k_per_split;
     const int k_end = min(Kdim, k_begin + k_per_split);
@@ -619,17 +623,25 @@ int gemm_x6_splits(int m, int n, int k) { return (m > 0 && n > 0) ? x6_plan(m, n
 int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
                      hipStream_t st, bool a_bf16, bool c_zeroed, int a_kmajor, int b_kmajor, bool colstats_sums,
-                     const GemmExtra* ex, const GemmPair* pair) {
+                     const GemmExtra* ex, const GemmGroup* grp) {
     // k-major operands (a_kmajor: A stored [K, M]; b_kmajor: B stored [K, N]) are read with 4-byte loads: no alignment rule
     const int vec_a = (a_bf16 || a_kmajor) ? 1 : (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     const int vec_b = b_kmajor ? 1 : (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
     if (a_kmajor && !b_kmajor) { set_error("gemm_x6: A^T * B^T is not built"); return PCRCG_EBADARG; }
-    // (a second product in the same launch: the plan of the larger one serves both)
-    const int m_plan = pair && pair->m > m ? pair->m : m;
+    // (further products in the same launch: the plan of the largest one serves all)
+    int m_plan = m;
+    const int n_extra = grp ? grp->n : 0;
+    if (n_extra < 0 || n_extra > kGroupExtra) { set_error("gemm_x6: at most %d further products per launch", kGroupExtra); return PCRCG_EBADARG; }
+    for (int e = 0; e < n_extra; ++e) {
+        if (grp->p[e].m <= 0 || !grp->p[e].a || !grp->p[e].c) { set_error("gemm_x6: empty product in a group"); return PCRCG_EBADARG; }
+        m_plan = grp->p[e].m > m_plan ? grp->p[e].m : m_plan;
+    }
     const X6Plan plan = x6_plan(m_plan, n, k, a_kmajor || b_kmajor || (ex && ex->a_sums), a_kmajor != 0);
     const int pick = plan.pick, BM = plan.bm, BN = plan.bn, gx = plan.gx, splits = plan.splits;
-    const int gy0 = (m + BM - 1) / BM, gy1 = pair ? (pair->m + BM - 1) / BM : 0, gy = gy0 + gy1;
-    if (pair && (a_kmajor || b_kmajor)) { set_error("gemm_x6: paired launches are built for the A * B^T form"); return PCRCG_EBADARG; }
+    const int gy0 = (m + BM - 1) / BM;
+    int gy = gy0, gye[kGroupExtra] = {0, 0, 0};
+    for (int e = 0; e < n_extra; ++e) { gye[e] = (grp->p[e].m + BM - 1) / BM; gy += gye[e]; }
+    if (n_extra && (a_kmajor || b_kmajor)) { set_error("gemm_x6: grouped launches are built for the A * B^T form"); return PCRCG_EBADARG; }
     const int k_per_split = plan.k_per_split;
     const bool accumulate = ex && ex->accumulate;
     const bool gather = ex && ex->a_idx;
@@ -648,10 +660,11 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
         if (ldc == n) PCRCG_CHECK_HIP(hipMemsetAsync(c, 0, (size_t)m * n * sizeof(float), st));
         else PCRCG_CHECK_HIP(hipMemset2DAsync(c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), m, st));
     }
-    if (pair && splits > 1 && !pair->c_zeroed && !accumulate) {
-        if (ldc == n) PCRCG_CHECK_HIP(hipMemsetAsync(pair->c, 0, (size_t)pair->m * n * sizeof(float), st));
-        else PCRCG_CHECK_HIP(hipMemset2DAsync(pair->c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), pair->m, st));
-    }
+    for (int e = 0; e < n_extra; ++e)
+        if (splits > 1 && !grp->p[e].c_zeroed && !accumulate) {
+            if (ldc == n) PCRCG_CHECK_HIP(hipMemsetAsync(grp->p[e].c, 0, (size_t)grp->p[e].m * n * sizeof(float), st));
+            else PCRCG_CHECK_HIP(hipMemset2DAsync(grp->p[e].c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), grp->p[e].m, st));
+        }
     dim3 grid(gx, gy, splits);
     const bool log_shapes = debug_opts().gemm_log != 0;   // tuning aid
     if (log_shapes)
@@ -677,29 +690,32 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
         }
     }
     GemmPairArgs pa;
-    if (pair) {
-        pa.pair_off = gy0 * BM;
-        pa.m1 = pair->m;
-        pa.a1 = pair->a;
-        pa.c1 = pair->c;
-        pa.rs1 = pair->row_scale;
-        pa.a_idx1 = pair->a_idx;
-        pa.a_ns1 = pair->a_ns;
-        pa.a_sums1 = pair->a_sums;
-        pa.a_count1 = pair->a_count;
-        if (pair->h_chunks) *pair->h_chunks = 0;
-        // the second product's statistics: the same form as the first one's, into its own buffer (same size rule)
-        if (colp && pair->colstats && pair->h_chunks) {
-            pa.colp1 = static_cast<double*>(pair->colstats);
-            pa.colp_chunks1 = colp_chunks < 0 ? -1 : gy1 * 2;
-            *pair->h_chunks = pa.colp_chunks1;
-            if (colp_chunks > 0 && carve_bytes(2 * (size_t)n * pa.colp_chunks1, sizeof(double)) > colstats_bytes) {
-                pa.colp1 = nullptr;
-                pa.colp_chunks1 = 0;
-                *pair->h_chunks = 0;
+    pa.extra = n_extra;
+    int row_off = gy0 * BM;
+    for (int e = 0; e < n_extra; ++e) {
+        const GemmPair& q = grp->p[e];
+        pa.off[e] = row_off;
+        row_off += gye[e] * BM;
+        pa.m[e] = q.m;
+        pa.a[e] = q.a;
+        pa.c[e] = q.c;
+        pa.rs[e] = q.row_scale;
+        pa.a_idx[e] = q.a_idx;
+        pa.a_ns[e] = q.a_ns;
+        pa.a_sums[e] = q.a_sums;
+        pa.a_count[e] = q.a_count;
+        if (q.h_chunks) *q.h_chunks = 0;
+        // the product's statistics: the same form as the first one's, into its own buffer (same size rule)
+        if (colp && q.colstats && q.h_chunks) {
+            pa.colp[e] = static_cast<double*>(q.colstats);
+            pa.colp_chunks[e] = colp_chunks < 0 ? -1 : gye[e] * 2;
+            *q.h_chunks = pa.colp_chunks[e];
+            if (colp_chunks > 0 && carve_bytes(2 * (size_t)n * pa.colp_chunks[e], sizeof(double)) > colstats_bytes) {
+                pa.colp[e] = nullptr;
+                pa.colp_chunks[e] = 0;
+                *q.h_chunks = 0;
             }
         }
-        if (pair->m <= 0) { set_error("gemm_x6: empty second product"); return PCRCG_EBADARG; }
     }
     if (a_kmajor)   // dW = X^T * dY
         return launch_x6<64, 64, 3, 3, 1, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,

@@ -32,22 +32,22 @@ int gemm_bt_extra(const float* a, int lda, const float* b, int ldb, float* c, in
 bool gemm_pair_ok();
 int gemm_bt_colstats_pair(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                           const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
-                          hipStream_t st, bool c_zeroed, bool colstats_sums, const GemmPair* pair);
+                          hipStream_t st, bool c_zeroed, bool colstats_sums, const GemmGroup* grp);
 int gemm_bt_extra_pair(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, hipStream_t st,
                        bool c_zeroed, const GemmExtra& ex, const float* bias, void* colstats, size_t colstats_bytes,
-                       int* h_chunks, bool colstats_sums, const GemmPair* pair);
+                       int* h_chunks, bool colstats_sums, const GemmGroup* grp);
 namespace {
 
-constexpr int GMAX = 2;   // fragment pairs one call can carry (pcrcg_kpfcnn_forward_group)
+constexpr int GMAX = 4;   // fragment pairs one call can carry (pcrcg_kpfcnn_forward_group)
 
 // Row-major fp32 matrix view -- one per fragment pair of the call (same width and leading dimension, own rows).  With
-// two pairs every operator below runs its per-pair kernels twice and its weight products ONCE for both pairs (GemmPair):
+// several pairs every operator below runs its per-pair kernels once per pair and its weight products ONCE for all pairs (GemmGroup):
 // the pairs never mix (InstanceNorm statistics, neighbour tables, kNN and attention stay per pair -- SURVEY.md 8e), but a
 // coarse-level product that fills a fifth of the chip for one pair fills twice that for two at the same duration, and
 // every product costs one launch per two pairs.
 struct Mat {
-    float* p[GMAX] = {nullptr, nullptr};
-    int rows[GMAX] = {0, 0};
+    float* p[GMAX] = {};
+    int rows[GMAX] = {};
     int cols = 0, ld = 0;
     bool zeroed = false;   // lives in the zero arena and has not been written yet
 };
@@ -113,8 +113,8 @@ struct Ctx {
     void release(size_t m) { off = m; }
     bool live() const { return !dry && rc == PCRCG_OK; }
     void check(int r) { if (r != PCRCG_OK && rc == PCRCG_OK) rc = r; }
-    // two pairs in one launch: only with the split-bf16 arithmetic (PCRCG_GEMM_MODE=0 runs the products pair by pair)
-    bool paired() const { return G == 2 && gemm_pair_ok(); }
+    // several pairs in one launch: only with the split-bf16 arithmetic (PCRCG_GEMM_MODE=0 runs the products pair by pair)
+    bool paired() const { return G >= 2 && gemm_pair_ok(); }
 };
 
 inline int pad4(int v) { return (v + 3) & ~3; }
@@ -136,10 +136,10 @@ inline Mat rows(const Mat& m, const int* r0, const int* n) {
 
 // A GEMM output together with the InstanceNorm column partials its epilogue may have produced (per pair).
 struct Stat {
-    void* partials[GMAX] = {nullptr, nullptr};   // [2][cols][chunks] fp64 partials, valid when chunks > 0; or, when `sums`,
+    void* partials[GMAX] = {};                // [2][cols][chunks] fp64 partials, valid when chunks > 0; or, when `sums`,
                                                  // zeroed [2][cols] fp64 accumulators that hold the column sums when chunks == -1
     size_t bytes = 0;
-    int chunks[GMAX] = {0, 0};
+    int chunks[GMAX] = {};
     bool sums = false;
 };
 
@@ -223,17 +223,21 @@ void norm_act(Ctx& c, const Mat& x, float slope, const Mat& y, Stat* xs = nullpt
     c.release(m);
 }
 
-// the second pair's side of a product
-GemmPair pair_of(const Mat& x, const Mat& y, Stat* st, const float* const* row_scale = nullptr) {
-    GemmPair p;
-    p.a = x.p[1];
-    p.c = y.p[1];
-    p.m = x.rows[1];
-    p.row_scale = row_scale ? row_scale[1] : nullptr;
-    p.colstats = st ? st->partials[1] : nullptr;
-    p.h_chunks = st ? &st->chunks[1] : nullptr;
-    p.c_zeroed = y.zeroed;
-    return p;
+// the further pairs' sides of a product
+GemmGroup group_of(const Ctx& c, const Mat& x, const Mat& y, Stat* st, const float* const* row_scale = nullptr) {
+    GemmGroup grp;
+    grp.n = c.G - 1;
+    for (int g = 1; g < c.G; ++g) {
+        GemmPair& p = grp.p[g - 1];
+        p.a = x.p[g];
+        p.c = y.p[g];
+        p.m = x.rows[g];
+        p.row_scale = row_scale ? row_scale[g] : nullptr;
+        p.colstats = st ? st->partials[g] : nullptr;
+        p.h_chunks = st ? &st->chunks[g] : nullptr;
+        p.c_zeroed = y.zeroed;
+    }
+    return grp;
 }
 
 // y = x @ w^T (+ bias); w is [out, in] with leading dimension ldw; optionally leaves the column statistics of y for the
@@ -242,7 +246,7 @@ void linear(Ctx& c, const Mat& x, const float* w, int ldw, const float* bias, co
             const float* const* row_scale = nullptr) {
     if (!c.live()) return;
     if (c.paired()) {
-        GemmPair p = pair_of(x, y, st, row_scale);
+        GemmGroup p = group_of(c, x, y, st, row_scale);
         c.check(gemm_bt_colstats_pair(x.p[0], x.ld, w, ldw, y.p[0], y.ld, x.rows[0], y.cols, x.cols, row_scale ? row_scale[0] : nullptr,
                                       bias, st ? st->partials[0] : nullptr, st ? st->bytes : 0, st ? &st->chunks[0] : nullptr, c.st,
                                       y.zeroed, st && st->sums, &p));
@@ -278,17 +282,23 @@ void linear_extra(Ctx& c, const Mat& a, const float* w, int ldw, const float* bi
         return ex;
     };
     auto m_of = [&](int g) { return tabs ? tabs[g]->rows : a.rows[g]; };
-    if (c.paired() && (!tabs || tabs[0]->ld == tabs[1]->ld)) {
+    bool same_ld = true;
+    for (int g = 1; g < c.G && tabs; ++g) same_ld = same_ld && tabs[g]->ld == tabs[0]->ld;
+    if (c.paired() && same_ld) {
         GemmExtra ex = extra(0);
-        GemmPair p;
-        p.a = a.p[1];
-        p.c = y.p[1];
-        p.m = m_of(1);
-        p.colstats = st ? st->partials[1] : nullptr;
-        p.h_chunks = st ? &st->chunks[1] : nullptr;
-        p.c_zeroed = c_zeroed;
-        if (tabs) { p.a_idx = reinterpret_cast<const long long*>(tabs[1]->idx); p.a_ns = a.rows[1]; }
-        if (a_sums) { p.a_sums = static_cast<const double*>(a_sums->partials[1]); p.a_count = (double)a.rows[1]; }
+        GemmGroup p;
+        p.n = c.G - 1;
+        for (int g = 1; g < c.G; ++g) {
+            GemmPair& q = p.p[g - 1];
+            q.a = a.p[g];
+            q.c = y.p[g];
+            q.m = m_of(g);
+            q.colstats = st ? st->partials[g] : nullptr;
+            q.h_chunks = st ? &st->chunks[g] : nullptr;
+            q.c_zeroed = c_zeroed;
+            if (tabs) { q.a_idx = reinterpret_cast<const long long*>(tabs[g]->idx); q.a_ns = a.rows[g]; }
+            if (a_sums) { q.a_sums = static_cast<const double*>(a_sums->partials[g]); q.a_count = (double)a.rows[g]; }
+        }
         c.check(gemm_bt_extra_pair(a.p[0], a.ld, w, ldw, y.p[0], y.ld, m_of(0), y.cols, a.cols, c.st, c_zeroed, ex, bias,
                                    st ? st->partials[0] : nullptr, st ? st->bytes : 0, st ? &st->chunks[0] : nullptr,
                                    st && st->sums, &p));
@@ -463,8 +473,8 @@ Mat resnet_block(Ctx& c, const Batches& B, const pcrcg_block& blk, const Mat& fe
     Mat y = c.mat(nq, blk.out_dim);
     const size_t m = c.mark();
     Mat x = feats;
-    void* kp_ws[GMAX] = {nullptr, nullptr};
-    size_t kp_wsb[GMAX] = {0, 0};
+    void* kp_ws[GMAX] = {};
+    size_t kp_wsb[GMAX] = {};
     bool packed = false;
     if (blk.unary1) {
         Mat t = c.gemm_out(feats.rows, blk.mid_dim, feats.cols), u = c.mat(feats.rows, blk.mid_dim);
@@ -581,7 +591,7 @@ Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, c
     Mat y = c.mat(x.rows, ch);
     const size_t m = c.mark();
     Mat q = c.gemm_out(x.rows, ch, ch), kk = c.gemm_out(src.rows, ch, ch), v = c.gemm_out(src.rows, ch, ch), msg = c.mat(x.rows, ch);
-    int sc_rows[GMAX] = {0, 0};
+    int sc_rows[GMAX] = {};
     for (int g = 0; g < c.G; ++g) sc_rows[g] = x.rows[g];
     int ms_max = 0;
     for (int g = 0; g < c.G; ++g) ms_max = src.rows[g] > ms_max ? src.rows[g] : ms_max;
@@ -643,7 +653,7 @@ void forward(Ctx& c, const pcrcg_model& mdl, const Batches& B, const pcrcg_outpu
     }
     // 2. bottleneck (:527-528) and 3. GNN (:532-536)
     const int gd = mdl.gnn_dim;
-    int nc[GMAX] = {0, 0}, ns[GMAX] = {0, 0}, nt[GMAX] = {0, 0}, zero[GMAX] = {0, 0};
+    int nc[GMAX] = {}, ns[GMAX] = {}, nt[GMAX] = {}, zero[GMAX] = {};
     const float *c0[GMAX], *c1[GMAX];
     for (int g = 0; g < c.G; ++g) {
         nc[g] = B.b[g]->n_points[L - 1];
@@ -718,7 +728,7 @@ void forward(Ctx& c, const pcrcg_model& mdl, const Batches& B, const pcrcg_outpu
         const pcrcg_block& blk = mdl.dec[j];
         if (blk.type == PCRCG_BLK_UPSAMPLE) {
             const pcrcg_table* tabs[GMAX];
-            int trows[GMAX] = {0, 0};
+            int trows[GMAX] = {};
             for (int g = 0; g < c.G; ++g) { tabs[g] = &B.b[g]->upsamples[blk.layer - 1]; trows[g] = tabs[g]->rows; }
             const bool concat = j + 1 < mdl.n_dec && mdl.dec_concat[j + 1];
             const int cs = concat ? skips.back().cols : 0;
@@ -824,7 +834,8 @@ size_t pcrcg_kpfcnn_group_ws_bytes(const pcrcg_model* model, const pcrcg_batch* 
     Ctx c;
     c.dry = true;
     c.G = n;
-    Batches B = {{batches, n > 1 ? batches + 1 : nullptr}};
+    Batches B;
+    for (int g = 0; g < GMAX; ++g) B.b[g] = g < n ? batches + g : nullptr;
     forward(c, *model, B, nullptr);
     return c.peak + c.zoff + 4096;
 }
@@ -838,7 +849,8 @@ int pcrcg_kpfcnn_forward_group(const pcrcg_model* model, const pcrcg_batch* batc
     PCRCG_PROPAGATE(validate_group(model, batches, n));
     PCRCG_CHECK_ARG(outs && ws);
     for (int g = 0; g < n; ++g) PCRCG_CHECK_ARG(outs[g].feats_f && outs[g].scores_overlap && outs[g].scores_saliency);
-    Batches B = {{batches, n > 1 ? batches + 1 : nullptr}};
+    Batches B;
+    for (int g = 0; g < GMAX; ++g) B.b[g] = g < n ? batches + g : nullptr;
     // pass 1 (no launches): how much of the workspace the zero arena takes for these batches
     Ctx d;
     d.dry = true;

@@ -54,9 +54,10 @@ class PairStreams:
 
     def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=1, tie_order=None,
                  pairs_per_build=2, up_nearest=False, front_streams=1, front_priority=0, pairs_per_forward=2):
-        """pairs_per_forward = 2: two pairs that were built together also go through the network together -- one
-        pcrcg_kpfcnn_forward_group call on one model stream, in which every product with a weight matrix runs once for
-        both pairs (the pairs never mix; outputs equal separate forwards up to summation order).  1: one call per pair.
+        """pairs_per_forward = 2 .. 4: pairs that were built together also go through the network together, up to that
+        many per pcrcg_kpfcnn_forward_group call on one model stream, in which every product with a weight matrix runs
+        once for all of them (the pairs never mix; outputs equal separate forwards up to summation order).  1: one call
+        per pair.  pairs_per_build (1 .. 4): pairs one front-end kernel chain carries.
         up_nearest: the engine's internal pyramids carry ONE-column upsample tables (the nearest coarse point: the only
         column KPFCNN.forward reads, ref:models/blocks.py:77-87) instead of the batch contract's [N, limit] tables:
         ~1 % less front-end work, same outputs.  Off by default: the tables are then exactly what build_pyramid()
@@ -88,9 +89,9 @@ class PairStreams:
                 q.put(None)
         self._in = queue.Queue()               # one queue: a front thread takes up to `pairs_per_build` consecutive pairs
         self._take = threading.Lock()
-        self._per_build = max(1, int(pairs_per_build))
+        self._per_build = min(4, max(1, int(pairs_per_build)))
         self._users = [[1] * self.ARENAS for _ in range(nf)]   # forwards that read the arena's current contents
-        self._per_forward = 2 if int(pairs_per_forward) >= 2 else 1
+        self._per_forward = min(4, max(1, int(pairs_per_forward)))
         self._mid = [_Mailbox() for _ in self.models]     # jobs (one or two pairs) by job index: thread m serves m, m + M, ...
         self._jobs = 0                                     # job indices are handed out under self._take, with the pairs
         self._results = _Mailbox()                         # (outputs, done event) or an exception, by submission index
@@ -152,11 +153,14 @@ class PairStreams:
                 if items[-1] is None:
                     self._in.put(None)         # pass the shutdown token on to the other front threads
                     items.pop()
-                # the pairs' forward jobs, in submission order: one job for two pairs built together, else one per pair
-                grouped = len(items) == 2 and self._per_forward == 2
-                njobs = (1 if grouped else len(items))
+                # the pairs' forward jobs, in submission order: consecutive pairs of this build, up to per_forward each
+                sizes = []
+                left = len(items)
+                while left > 0:
+                    sizes.append(min(self._per_forward, left))
+                    left -= sizes[-1]
                 job0 = self._jobs
-                self._jobs += njobs
+                self._jobs += len(sizes)
             if not items:
                 return
             self._stat(front_idle_s=time.perf_counter() - t0)
@@ -195,13 +199,12 @@ class PairStreams:
                     self._stat(arena_wait_s=t1 - t0, build_s=time.perf_counter() - t1, pairs=k, builds=1)
                     built = torch.cuda.Event()
                     built.record(front)
-                if grouped:
-                    self._mid[job0 % len(self.models)].put(job0, ([it[0] for it in items], batches, arena, built, pyr, slot,
-                                                                   deferred, f, a))
-                else:
-                    for i, it in enumerate(items):
-                        self._mid[(job0 + i) % len(self.models)].put(job0 + i, ([it[0]], batches[i], arena, built, pyr, slot,
-                                                                                  deferred, f, a))
+                start = 0
+                for j, n in enumerate(sizes):
+                    seqs = [it[0] for it in items[start:start + n]]
+                    self._mid[(job0 + j) % len(self.models)].put(job0 + j, (seqs, (batches, start, n), arena, built, pyr, slot,
+                                                                             deferred, f, a))
+                    start += n
             except BaseException as e:                            # surfaced by result()
                 if claimed:
                     # the arena was taken over for k forwards that will not happen: one token for each of them
@@ -215,11 +218,10 @@ class PairStreams:
                         self._free[f][a].put(None)
                         left = 1
                     self._users[f][a] = left
-                if grouped:
-                    self._mid[job0 % len(self.models)].put(job0, ([it[0] for it in items], e))
-                else:
-                    for i, it in enumerate(items):
-                        self._mid[(job0 + i) % len(self.models)].put(job0 + i, ([it[0]], e))
+                start = 0
+                for j, n in enumerate(sizes):
+                    self._mid[(job0 + j) % len(self.models)].put(job0 + j, ([it[0] for it in items[start:start + n]], e))
+                    start += n
 
     def _serve_model(self, m):
         torch.cuda.set_device(self.device)
@@ -245,10 +247,11 @@ class PairStreams:
                     # stream: that stream's serial kernel chain is the pipeline's bottleneck, the model streams have slack
                     if deferred is not None:
                         pyr.restore(deferred, slot)
-                    if len(seqs) == 2:
-                        outs = self.runner.launch_group(b, 2, self.device)     # both pairs in ONE call
+                    batches, start, n = b
+                    if n >= 2:
+                        outs = self.runner.launch_group(batches, n, self.device, start)     # these pairs in ONE call
                     else:
-                        outs = [self.runner.launch(b, self.device)]
+                        outs = [self.runner.launch(batches[start], self.device)]
                     self._stat(launch_s=time.perf_counter() - t0)
                     done = torch.cuda.Event()
                     done.record(stream)

@@ -333,22 +333,23 @@ class Runner:
         b, keep, dev = self.batch_struct(batch)
         return self.launch(b, dev)
 
-    def launch_group(self, batches, n, dev):
-        """Enqueue ONE forward call for the n (1 or 2) pcrcg_batch structs of the ctypes array `batches` (as
-        NativePyramid.build(group=2) returns them) on the current stream -> list of n output dicts.  Weight products run
-        once for both pairs (pcrcg_kpfcnn_forward_group)."""
+    def launch_group(self, batches, n, dev, start=0):
+        """Enqueue ONE forward call for n (1 to 4) consecutive pcrcg_batch structs of the ctypes array `batches`, from
+        element `start` (as NativePyramid.build(group=2) returns them) on the current stream -> list of n output dicts.
+        Weight products run once for all pairs (pcrcg_kpfcnn_forward_group)."""
         L = _bind()
         desc = self.descriptor()
         outs, o = [], (Outputs * n)()
+        first = ctypes.byref(batches[start])
         for g in range(n):
-            n0 = batches[g].n_points[0]
+            n0 = batches[start + g].n_points[0]
             out = {"feats_f": torch.empty((n0, desc.final_dim), dtype=torch.float32, device=dev),
                    "scores_overlap": torch.empty(n0, dtype=torch.float32, device=dev),
                    "scores_saliency": torch.empty(n0, dtype=torch.float32, device=dev)}
             o[g].feats_f, o[g].scores_overlap, o[g].scores_saliency = (out["feats_f"].data_ptr(), out["scores_overlap"].data_ptr(),
                                                                       out["scores_saliency"].data_ptr())
             outs.append(out)
-        nbytes = L.pcrcg_kpfcnn_group_ws_bytes(ctypes.byref(desc), batches, n)
+        nbytes = L.pcrcg_kpfcnn_group_ws_bytes(ctypes.byref(desc), first, n)
         if nbytes == 0:
             raise RuntimeError("pcrcg_kpfcnn_group_ws_bytes rejected the descriptors: " + (L.pcrcg_last_error() or b"").decode())
         cur = torch.cuda.current_stream()
@@ -362,7 +363,7 @@ class Runner:
             if key not in self._seen and self._built is not None:
                 cur.wait_event(self._built)
                 self._seen.add(key)
-        _lib.check(L.pcrcg_kpfcnn_forward_group(ctypes.byref(desc), batches, o, n, ws.data_ptr(), ws.numel(), stream),
+        _lib.check(L.pcrcg_kpfcnn_forward_group(ctypes.byref(desc), first, o, n, ws.data_ptr(), ws.numel(), stream),
                    "pcrcg_kpfcnn_forward_group")
         return outs
 

@@ -20,17 +20,18 @@ CSRC = os.path.join(REPO, "pcrcg_amd", "csrc")
 LIB = os.path.join(REPO, "pcrcg_amd", "libpcrcg_hip_knock.so")
 FAMILIES = [("pcrcg_copy2d(", "K_COPY"), ("pcrcg_gather_max(", "K_GMAX"), ("pcrcg_instnorm_colsums(", "K_CSUM"),
             ("pcrcg_instnorm_stats_from_partials(", "K_CFIN"), ("pcrcg_instnorm_apply_sums(", "K_APPLY"),
-            ("pcrcg_instnorm_apply(", "K_APPLY"), ("instnorm_apply_pack(t.p", "K_PACK"), ("pcrcg_attention(q.p", "K_ATT"),
-            ("pcrcg_edgeconv_reduce_sums(", "K_EDGE"), ("kpconv_aggregate_rows(q, nq", "K_GATH"),
-            ("pcrcg_kpconv_aggregate(q, nq", "K_GATH")]
+            ("pcrcg_instnorm_apply(", "K_APPLY"), ("instnorm_apply_pack(t.p[g]", "K_PACK"), ("pcrcg_attention(q.p[g]", "K_ATT"),
+            ("pcrcg_edgeconv_reduce_sums(", "K_EDGE"), ("kpconv_aggregate_rows(q[g], nq[g]", "K_GATH"),
+            ("pcrcg_kpconv_aggregate(q[g], nq[g]", "K_GATH"), ("pcrcg_knn(coords[g]", "K_KNN")]
 
 
 def build():
     src = open(os.path.join(CSRC, "runner.hip")).read()
-    src = src.replace("namespace pcrcg {\n// gemm.hip", '#include <cstring>\nstatic bool ko(const char* name) { static const char* e = '
-                      'getenv("PCRCG_KNOCK"); return e && strstr(e, name); }\nthread_local int pcrcg_knock_forward_count = 0;\n'
+    src = src.replace("namespace pcrcg {\n// gemm.hip", '#include <cstring>\nthread_local int pcrcg_knock_forward_count = 0;\nstatic bool ko(const char* name) { static const char* e = '
+                      'getenv("PCRCG_KNOCK"); static const int every = getenv("PCRCG_KNOCK_EVERY") ? atoi(getenv("PCRCG_KNOCK_EVERY")) : 1; '
+                      'return e && strstr(e, name) && (every <= 1 || (pcrcg_knock_forward_count % every) == 1); }\n'
                       'namespace pcrcg {\n// gemm.hip', 1)
-    pat = "    PCRCG_PROPAGATE(validate(model, batch));\n    PCRCG_CHECK_ARG(out && out->feats_f"
+    pat = "    PCRCG_PROPAGATE(validate_group(model, batches, n));\n    PCRCG_CHECK_ARG(outs && ws);"
     assert pat in src
     src = src.replace(pat, "    ++pcrcg_knock_forward_count;\n" + pat, 1)
     for pat, tok in FAMILIES:
@@ -38,9 +39,9 @@ def build():
         src = src.replace(pat, 'ko("%s") ? PCRCG_OK : %s' % (tok, pat))
         print("%-8s %d call sites" % (tok, n))
     # the KPConv contraction alone (the GEMM a one-kernel KPConv would absorb)
-    pat = "c.check(gemm_bt_colstats(wf.p, wf.ld, blk.kp_wt"
+    pat = "            linear(c, wf, blk.kp_wt, kk, nullptr, y, st, inv_n);"
     assert pat in src
-    src = src.replace(pat, 'c.check(ko("K_KPGEMM") ? PCRCG_OK : gemm_bt_colstats(wf.p, wf.ld, blk.kp_wt')
+    src = src.replace(pat, '            if (!ko("K_KPGEMM")) linear(c, wf, blk.kp_wt, kk, nullptr, y, st, inv_n);')
     tmp = os.path.join(CSRC, "build", "knock")
     os.makedirs(tmp, exist_ok=True)
     open(os.path.join(tmp, "runner_knock.hip"), "w").write(src)
@@ -76,8 +77,11 @@ def run():
     for t in toks:
         env = dict(os.environ, PCRCG_KNOCK=t)
         env.pop("PCRCG_KNOCK_M", None)
+        env.pop("PCRCG_KNOCK_EVERY", None)
         if t.startswith("M:"):
             env["PCRCG_KNOCK_M"] = t[2:]
+        if t.endswith("/2"):                       # "K_EDGE,K_ATT/2": the families, in every second forward call only
+            env["PCRCG_KNOCK"], env["PCRCG_KNOCK_EVERY"] = t[:-2], "2"
         boot = ("import sys, runpy; sys.path.insert(0, %r); import pcrcg_amd._lib as L; L.LIB_PATH = %r; "
                 "sys.argv = ['bench.py', '--no-cpu-baseline', '--no-extras', '--steps', '100', '--repeats', '3']; runpy.run_path(%r, run_name='__main__')"
                 % (REPO, LIB, os.path.join(REPO, "bench.py")))
