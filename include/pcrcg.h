@@ -251,7 +251,12 @@ int pcrcg_gemm_f32_fused(const float* a, int lda, const int64_t* idx, int ld_idx
  *      below 2^-23 relative per product, i.e. fp32-class accuracy (measured against float64 it is no
  *      worse than mode 0), at 16/6 of the fp32 matrix rate.
  * Process-wide; also read once from the environment variable PCRCG_GEMM_MODE.  Interface: fp32 in,
- * fp32 out in both modes. */
+ * fp32 out in both modes.
+ * Non-finite operands: mode 1 turns an operand value of +-inf into NaN in every output it touches (the split's residual
+ * is inf - inf), where mode 0 / an fp32 GEMM would produce +-inf or, against a zero, NaN as well; NaN operands give NaN in
+ * both modes.  Finite operands are unaffected, however large (the three terms are exact for every finite fp32 value,
+ * subnormal terms included).  The train step's non-finite check (pcrcg_amd/trainer.py: the reference's
+ * validate_gradient) treats inf and NaN alike, so the skip decision does not depend on the mode. */
 void pcrcg_gemm_set_mode(int mode);
 int pcrcg_gemm_get_mode(void);
 

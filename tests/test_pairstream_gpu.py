@@ -158,8 +158,11 @@ def test_pair_engine_matches_sequential(cuda):
         for pts, lens in pairs:
             ref.append(net(build_pyramid(pts, lens, cfg, limits)))
     torch.cuda.synchronize()
-    for workers, fronts in ((1, 1), (3, 2)):
-        eng = PairStreams(net, cfg, limits, cuda, model_streams=workers, front_threads=fronts, up_nearest=(workers == 3))
+    # (model streams, front threads, pairs per build, pairs per forward call): one call per pair, the default two pairs
+    # per call, and builds / calls of up to four pairs
+    for workers, fronts, per_build, per_fwd in ((1, 1, 2, 1), (3, 2, 2, 2), (2, 1, 4, 4), (2, 1, 3, 2)):
+        eng = PairStreams(net, cfg, limits, cuda, model_streams=workers, front_threads=fronts, up_nearest=(workers == 3),
+                          pairs_per_build=per_build, pairs_per_forward=per_fwd)
         outs, submitted, total = [], 0, 3 * len(pairs)
         for i in range(total):
             while submitted < min(total, i + 5):
