@@ -47,6 +47,7 @@ MFMA_BF16_TF = 2500.0  # dense bf16 matrix peak; the exact three-term split spen
 RECIPE = "S30k"       # the workload BASELINE.json's metric is quoted on (configs[1]); --workload picks a secondary one
 WORKLOADS = {
     "S30k": "S30k: 2x30000-pt shell pairs (3DMatch-shaped), indoor hyper-parameters",
+    "C1": "C1 (secondary, configs[0]'s size): 2x5000-pt shell pairs, indoor hyper-parameters",
     "U30k": "U30k (secondary): 2x30000 uniform-random points in a 1.07 m cube, indoor hyper-parameters",
     "K120k": "K120k (secondary, configs[4]): 2x120000-pt KITTI-shaped slabs, KITTI hyper-parameters",
     "T30k": "T30k (secondary): the S30k pairs snapped to a 1/256 m lattice (voxelised-scan-like: most rows hold exactly "

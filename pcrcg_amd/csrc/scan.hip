@@ -259,7 +259,7 @@ extern "C" {
 
 const char* pcrcg_last_error(void) { return pcrcg::g_err; }
 
-int pcrcg_abi_version(void) { return 1; }
+int pcrcg_abi_version(void) { return 2; }   // 2 (round 3): forward groups, train-step runner, correspondences, debug switches; one-kernel KPConv entries removed
 
 int pcrcg_debug_set(const char* spec) {
     (void)pcrcg::debug_opts();                       // the environment first, then this call on top of it
