@@ -26,6 +26,27 @@ class TrainOutputs(ctypes.Structure):
                 ("d_inv_temperature", ctypes.c_void_p), ("n_points", ctypes.c_int), ("final_dim", ctypes.c_int)]
 
 
+class _Tape:
+    """Owner of one C++ tape: frees it exactly once (after the backward, or when the autograd node is dropped without
+    one) and tells the runner that its cached workspace is free again."""
+
+    def __init__(self, handle, runner, ws):
+        self.handle, self.runner, self.ws = handle, runner, ws
+
+    def release(self):
+        if self.handle is not None:
+            _lib.lib().pcrcg_kpfcnn_train_free(self.handle)
+            self.handle = None
+            if self.runner._lent is self.ws:
+                self.runner._lent = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 def _grad(p):
     if p.grad is None:
         p.grad = torch.zeros_like(p)
@@ -35,7 +56,8 @@ def _grad(p):
 class TrainRunner:
     def __init__(self, model):
         self.model = model
-        self.ws = None
+        self.ws = None                            # cached workspace (values | gradients | scratch of one step)
+        self._lent = None                         # ... while a tape that lives in it is outstanding
         self._batch_helper = Runner(model)        # batch dict -> pcrcg_batch
 
     # a copied / pickled model starts without a runner (KPFCNN.train_runner() re-creates it lazily)
@@ -190,7 +212,10 @@ class TrainRunner:
 
     # ---- forward / backward --------------------------------------------------------------------------------------
     def forward(self, batch):
-        """-> {'feats_f', 'scores_overlap', 'scores_saliency'} with a grad_fn (one autograd node for the whole network)."""
+        """-> {'feats_f', 'scores_overlap', 'scores_saliency'} with a grad_fn (one autograd node for the whole network).
+        The three tensors are views into the step's workspace, which the NEXT training forward reuses once this one's
+        backward has run: clone what must outlive the step.  (A forward issued while an earlier one still awaits its
+        backward gets a workspace of its own.)"""
         outs = _TrainNet.apply(self.model.epsilon, self, batch)
         return {"feats_f": outs[0], "scores_overlap": outs[1], "scores_saliency": outs[2]}
 
@@ -203,10 +228,13 @@ class TrainRunner:
                    "pcrcg_kpfcnn_train_ws_bytes")
         vb, gb, sb = (int(s.value) for s in sizes)
         total = vb + gb + sb
-        if self.ws is None or self.ws.numel() < total or self.ws.device != dev:
-            self.ws = None
-            self.ws = torch.empty(int(total * 1.05), dtype=torch.uint8, device=dev)
-        ws = self.ws
+        if self._lent is not None:                # an earlier tape still lives in the cached workspace
+            ws = torch.empty(int(total), dtype=torch.uint8, device=dev)
+        else:
+            if self.ws is None or self.ws.numel() < total or self.ws.device != dev:
+                self.ws = None
+                self.ws = torch.empty(int(total * 1.05), dtype=torch.uint8, device=dev)
+            ws = self._lent = self.ws
         out = TrainOutputs()
         tape = ctypes.c_void_p()
         stream = torch.cuda.current_stream().cuda_stream
@@ -222,14 +250,14 @@ class TrainRunner:
             return ws[off:off + 4 * n].view(torch.float32).view(*shape)
         n0, fd = out.n_points, out.final_dim
         outs = (view(out.feats_f, n0, fd), view(out.scores_overlap, n0), view(out.scores_saliency, n0))
-        state = {"tape": tape, "keep": (keep, bkeep, v, g, b), "fold": fold, "d_inv_t": view(out.d_inv_temperature, 1),
-                 "inv_t": 1.0 / v.temperature, "ws": ws}
+        state = {"tape": _Tape(tape, self, ws), "keep": (keep, bkeep, v, g, b), "fold": fold,
+                 "d_inv_t": view(out.d_inv_temperature, 1), "inv_t": 1.0 / v.temperature, "ws": ws}
         return outs, state
 
     def _backward(self, state, d_f, d_so, d_ss):
         L = _lib.lib()
         tape = state["tape"]
-        if tape is None:
+        if tape.handle is None:
             raise RuntimeError("pcrcg_amd.train_runner: backward called twice (the tape is released after the first)")
 
         def ptr(t, shape):
@@ -241,11 +269,10 @@ class TrainRunner:
             return t.data_ptr()
         n0, fd = state["shape"]
         try:
-            _lib.check(L.pcrcg_kpfcnn_train_backward(tape, ptr(d_f, (n0, fd)), ptr(d_so, (n0,)), ptr(d_ss, (n0,)),
+            _lib.check(L.pcrcg_kpfcnn_train_backward(tape.handle, ptr(d_f, (n0, fd)), ptr(d_so, (n0,)), ptr(d_ss, (n0,)),
                                                      torch.cuda.current_stream().cuda_stream), "pcrcg_kpfcnn_train_backward")
         finally:
-            L.pcrcg_kpfcnn_train_free(tape)
-            state["tape"] = None
+            tape.release()
         for f in state["fold"]:
             f()
         # temperature = exp(epsilon) + 0.03 and the library reports dL/d(1/temperature)

@@ -90,6 +90,49 @@ def test_full_model_gradients_match_oracle_autograd(cuda, golden_dir, path):
     assert np.median(list(worst.values())) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
 
 
+def test_two_outstanding_tapes_and_a_dropped_one(cuda, golden_dir):
+    """The C++ runner's workspace discipline: a forward issued while an earlier one still awaits its backward gets its own
+    workspace (both backwards are right: the gradients add up to twice one backward's), a forward that is dropped without a
+    backward frees its tape, and a second backward through one node raises."""
+    gold = torch.load(os.path.join(golden_dir, "model_mini.pt"))
+    col = torch.load(os.path.join(golden_dir, "collate_mini.pt"))
+    cfg = indoor_config(**{k: v for k, v in gold["config"].items() if k in ("first_feats_dim", "gnn_feats_dim")})
+    net = KPFCNN(cfg)
+    net.load_state_dict(gold["state_dict"])
+    net = net.to(cuda).train()
+    batch = _to(col["batch"], cuda)
+    runner = net.train_runner()
+
+    def scalar(out):
+        return out["feats_f"].sum() + (out["scores_overlap"] * 2.0).sum() + out["scores_saliency"].sum()
+
+    scalar(runner.forward(batch)).backward()
+    once = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    for p in net.parameters():
+        p.grad = None
+    o1 = runner.forward(batch)
+    o2 = runner.forward(batch)                    # o1's tape is outstanding: a workspace of its own
+    assert o1["feats_f"].data_ptr() != o2["feats_f"].data_ptr()
+    v1 = o1["feats_f"].clone()
+    scalar(o2).backward()
+    assert torch.equal(o1["feats_f"], v1)         # ... so o1's values are untouched
+    scalar(o1).backward()
+    for n, p in net.named_parameters():
+        if n in once:
+            ref = 2.0 * once[n]
+            assert float((p.grad - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, n
+    dropped = runner.forward(batch)
+    del dropped                                   # no backward: the tape goes with the autograd node
+    import gc
+    gc.collect()
+    assert runner._lent is None
+    out = runner.forward(batch)
+    loss = scalar(out)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError):
+        loss.backward()
+
+
 def _lomatch_inputs(cfg, dev, seed=2):
     src, tgt, rot, trans = synthetic.lomatch_pair("mini", seed, overlap=0.3)
     tsfm = np.eye(4)
