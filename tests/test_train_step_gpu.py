@@ -117,10 +117,13 @@ def test_two_outstanding_tapes_and_a_dropped_one(cuda, golden_dir):
     scalar(o2).backward()
     assert torch.equal(o1["feats_f"], v1)         # ... so o1's values are untouched
     scalar(o1).backward()
+    # (parameters whose true gradient is zero -- biases in front of an InstanceNorm -- hold rounding noise on both sides:
+    # the bar is relative to the largest gradient of the model)
+    floor = 1e-4 * max(float(g.abs().max()) for g in once.values())
     for n, p in net.named_parameters():
         if n in once:
             ref = 2.0 * once[n]
-            assert float((p.grad - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, n
+            assert float((p.grad - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + floor, n
     dropped = runner.forward(batch)
     del dropped                                   # no backward: the tape goes with the autograd node
     import gc
