@@ -36,6 +36,21 @@ int pcrcg_correspondences_rows(const float* src, int n, const double* trans, dou
 int pcrcg_correspondences_emit(const int* stage, int cols, const int* counts, const int64_t* offsets, int n, int64_t* out,
                                void* stream);
 
+/* MetricLoss's dense parts with their gradients (ref:lib/loss.py:71-135; csrc/lossops.hip).
+ * pcrcg_circle_loss: n <= 512 matched descriptor pairs a, b [n, c] (c <= 64) and their coordinate distances
+ *   coords_dist [n, n]: out2[0] = get_circle_loss (:71-104, NaN when no row or no column holds both a positive and a
+ *   negative, as the reference's mean over nothing), out2[1] = get_recall (:106-116); da, db [n, c] dense (both or neither)
+ *   receive d circle_loss / d a, d b.  One launch.
+ * pcrcg_weighted_bce: get_weighted_bce_loss (:118-135) over n predictions in (0, 1) and labels gt: out3 = (loss,
+ *   precision, recall) with sklearn's binary definition (0/0 -> 0); grad [n] (may be NULL) = d loss / d prediction as
+ *   torch's binary_cross_entropy backward defines it.  ws: pcrcg_weighted_bce_ws_bytes(). */
+int pcrcg_circle_loss(const float* a, int lda, const float* b, int ldb, const float* coords_dist, int ldc, int n, int c,
+                      float pos_radius, float safe_radius, float pos_optimal, float neg_optimal, float pos_margin,
+                      float neg_margin, float log_scale, float* out2, float* da, float* db, void* stream);
+size_t pcrcg_weighted_bce_ws_bytes(void);
+int pcrcg_weighted_bce(const float* prediction, const float* gt, int n, float* out3, float* grad, void* ws, size_t ws_bytes,
+                       void* stream);
+
 /* pcrcg_gemm_f32 with an optionally transposed A:  C = (Aop * Bop) * row_scale[m] + bias[n],
  * Aop = A ([M,K] row-major, lda >= K) or A^T (A stored [K,M] row-major, lda >= M) when trans_a.
  * The weight gradients dW = X^T * dY of nn.Linear / the 1x1 convolutions / the KPConv contraction

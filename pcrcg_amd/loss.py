@@ -12,8 +12,10 @@ What differs from the reference, on purpose:
     (no host round trip inside the step);
   * `set(...)` of the correspondence columns (:159-160) becomes torch.unique -- the set's iteration order is
     irrelevant to every output (all consumers are order-invariant sums or means).
-The remaining small dense math (<= max_points^2 matrices, BCE over N points) is plain torch on the device
-and differentiable by autograd; the descriptors / scores it is fed come from the HIP path."""
+The dense math -- the circle loss with the feature-match recall on the <= max_points^2 matrices, the class-weighted
+BCE over N points -- runs in two fused HIP kernels with their gradients (csrc/lossops.hip, round 3: ~130 small torch ops
+per step before) when the tensors are on the device; the torch formulation below stays as their mirror (`fused=False`,
+and on the CPU).  The data-dependent selections around them (overlap region, max_points draw) are plain torch."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -32,11 +34,59 @@ def square_distance(src, dst, normalised=False):
     return torch.clamp(dist, min=1e-12, max=None)
 
 
+class _CircleLoss(torch.autograd.Function):
+    """get_circle_loss + get_recall in one launch (pcrcg_circle_loss), gradients wrt both descriptor sets included."""
+
+    @staticmethod
+    def forward(ctx, src_feats, tgt_feats, coords_dist, cfg):
+        from . import _lib
+        a, b, cd = src_feats.detach().float().contiguous(), tgt_feats.detach().float().contiguous(), coords_dist.float().contiguous()
+        n, c = a.shape
+        out = torch.empty(2, dtype=torch.float32, device=a.device)
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        _lib.check(_lib.lib().pcrcg_circle_loss(a.data_ptr(), c, b.data_ptr(), c, cd.data_ptr(), n, n, c, *cfg, out.data_ptr(),
+                                                da.data_ptr(), db.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "pcrcg_circle_loss")
+        ctx.save_for_backward(da, db)
+        ctx.mark_non_differentiable(out[1])
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_recall):
+        da, db = ctx.saved_tensors
+        return g_loss * da, g_loss * db, None, None
+
+
+class _WeightedBCE(torch.autograd.Function):
+    """get_weighted_bce_loss in three launches (pcrcg_weighted_bce), gradient wrt the prediction included."""
+
+    @staticmethod
+    def forward(ctx, prediction, gt):
+        from . import _lib
+        L = _lib.lib()
+        p, g = prediction.detach().float().contiguous(), gt.float().contiguous()
+        n = p.shape[0]
+        out = torch.empty(3, dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p)
+        ws = torch.empty(int(L.pcrcg_weighted_bce_ws_bytes()), dtype=torch.uint8, device=p.device)
+        _lib.check(L.pcrcg_weighted_bce(p.data_ptr(), g.data_ptr(), n, out.data_ptr(), grad.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        torch.cuda.current_stream().cuda_stream), "pcrcg_weighted_bce")
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(out[1], out[2])
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_p, g_r):
+        (grad,) = ctx.saved_tensors
+        return g_loss * grad, None
+
+
 class MetricLoss(torch.nn.Module):
     """Circle loss + overlap / saliency weighted BCE + feature-match recall (ref:lib/loss.py:46-70)."""
 
-    def __init__(self, configs, log_scale=16, pos_optimal=0.1, neg_optimal=1.4):
+    def __init__(self, configs, log_scale=16, pos_optimal=0.1, neg_optimal=1.4, fused=True):
         super().__init__()
+        self.fused = bool(fused)          # the dense parts in the fused HIP kernels when the tensors are on the device
         # NB the yaml's `log_scale` is NOT read by the reference either (ref:main.py:100, SURVEY appendix C)
         self.log_scale, self.pos_optimal, self.neg_optimal = log_scale, pos_optimal, neg_optimal
         self.image_feature = configs.get("image_feature", False)
@@ -83,6 +133,8 @@ class MetricLoss(torch.nn.Module):
 
     def get_weighted_bce_loss(self, prediction, gt):
         """ref:lib/loss.py:118-135 -> (loss, precision, recall)."""
+        if self.fused and prediction.is_cuda and prediction.dim() == 1 and prediction.numel() >= 1:
+            return _WeightedBCE.apply(prediction, gt)
         class_loss = F.binary_cross_entropy(prediction, gt, reduction="none")
         w_negative = gt.sum() / gt.size(0)
         w_positive = 1 - w_negative
@@ -157,8 +209,14 @@ class MetricLoss(torch.nn.Module):
         src_pcd, tgt_pcd = src_pcd[src_sel], tgt_pcd[tgt_sel]
         src_feats, tgt_feats = src_feats[src_sel], tgt_feats[tgt_sel]
         coords_dist = torch.sqrt(square_distance(src_pcd[None], tgt_pcd[None]).squeeze(0))
-        feats_dist = torch.sqrt(square_distance(src_feats[None], tgt_feats[None], normalised=True)).squeeze(0)
 
+        n_sel = src_feats.shape[0]
+        if self.fused and src_feats.is_cuda and 1 <= n_sel <= 512 and src_feats.shape[1] <= 64:
+            cfg = (float(self.pos_radius), float(self.safe_radius), float(self.pos_optimal), float(self.neg_optimal),
+                   float(self.pos_margin), float(self.neg_margin), float(self.log_scale))
+            stats["circle_loss"], stats["recall"] = _CircleLoss.apply(src_feats, tgt_feats, coords_dist, cfg)
+            return stats
+        feats_dist = torch.sqrt(square_distance(src_feats[None], tgt_feats[None], normalised=True)).squeeze(0)
         stats["circle_loss"] = self.get_circle_loss(coords_dist, feats_dist)
         stats["recall"] = self.get_recall(coords_dist, feats_dist)
         return stats

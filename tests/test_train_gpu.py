@@ -57,6 +57,30 @@ def test_metric_loss_forward_matches_reference(cuda, golden_dir, case):
         assert abs(got - float(want)) <= 1e-4 * max(1.0, abs(float(want))), (k, got, float(want))
 
 
+@pytest.mark.parametrize("case", ["capped", "all"])
+def test_fused_loss_kernels_equal_the_torch_mirror(cuda, golden_dir, case):
+    """csrc/lossops.hip (circle loss + recall, weighted BCE, with gradients) against the torch formulation of the same
+    MetricLoss (fused=False), values and gradients wrt descriptors and scores."""
+    gold = torch.load(os.path.join(golden_dir, "loss_mini.pt"), weights_only=False)
+    cs = gold["cases"][case]
+    res = {}
+    for fused in (True, False):
+        loss = MetricLoss(Config(gold["config"]), fused=fused)
+        inputs = {k: v.to(cuda) for k, v in cs["inputs"].items()}
+        for k in ("src_feats", "tgt_feats", "scores_overlap", "scores_saliency"):
+            inputs[k] = inputs[k].clone().requires_grad_(True)
+        np.random.seed(cs["numpy_seed"])
+        stats = loss(inputs)
+        (stats["circle_loss"] + stats["overlap_loss"] + stats["saliency_loss"]).backward()
+        res[fused] = ({k: float(v) for k, v in stats.items()},
+                      {k: inputs[k].grad.clone() for k in ("src_feats", "tgt_feats", "scores_overlap", "scores_saliency")})
+    for k, want in res[False][0].items():
+        assert abs(res[True][0][k] - want) <= 1e-5 * max(1.0, abs(want)), (k, res[True][0][k], want)
+    for k, want in res[False][1].items():
+        got = res[True][1][k]
+        assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-9, k
+
+
 def test_metric_loss_is_differentiable(cuda, golden_dir):
     gold = torch.load(os.path.join(golden_dir, "loss_mini.pt"), weights_only=False)
     cs = gold["cases"]["all"]
