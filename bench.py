@@ -55,12 +55,25 @@ WORKLOADS = {
 }
 
 
+def _morton_order(p):
+    q = ((p - p.min(0)) / max(float((p.max(0) - p.min(0)).max()), 1e-9) * 1023).astype(np.int64)
+    code = np.zeros(len(p), np.int64)
+    for b in range(10):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return np.argsort(code, kind="stable")
+
+
 def make_pair(recipe, seed):
     if recipe == "U30k":
-        return synthetic.uniform_pair(30000, 1.07, seed)
-    if recipe == "K120k":
-        return synthetic.slab_pair(120000, seed)
-    return synthetic.pair(recipe, seed)
+        pr = synthetic.uniform_pair(30000, 1.07, seed)
+    elif recipe == "K120k":
+        pr = synthetic.slab_pair(120000, seed)
+    else:
+        pr = synthetic.pair(recipe, seed)
+    if os.environ.get("PCRCG_BENCH_INPUT_ORDER") == "morton":      # experiment: spatially coherent point order
+        pr = tuple(np.ascontiguousarray(c[_morton_order(c)]) for c in pr)
+    return pr
 
 
 def _gemm_mode():

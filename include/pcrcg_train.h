@@ -40,13 +40,16 @@ int pcrcg_correspondences_emit(const int* stage, int cols, const int* counts, co
  * pcrcg_circle_loss: n <= 512 matched descriptor pairs a, b [n, c] (c <= 64) and their coordinate distances
  *   coords_dist [n, n]: out2[0] = get_circle_loss (:71-104, NaN when no row or no column holds both a positive and a
  *   negative, as the reference's mean over nothing), out2[1] = get_recall (:106-116); da, db [n, c] dense (both or neither)
- *   receive d circle_loss / d a, d b.  One launch.
+ *   receive d circle_loss / d a, d b.  a, b 16-byte aligned (lda, ldb multiples of 4 when c is); ws:
+ *   pcrcg_circle_loss_ws_bytes(n).  Two launches of 2n workgroups.
  * pcrcg_weighted_bce: get_weighted_bce_loss (:118-135) over n predictions in (0, 1) and labels gt: out3 = (loss,
  *   precision, recall) with sklearn's binary definition (0/0 -> 0); grad [n] (may be NULL) = d loss / d prediction as
  *   torch's binary_cross_entropy backward defines it.  ws: pcrcg_weighted_bce_ws_bytes(). */
 int pcrcg_circle_loss(const float* a, int lda, const float* b, int ldb, const float* coords_dist, int ldc, int n, int c,
                       float pos_radius, float safe_radius, float pos_optimal, float neg_optimal, float pos_margin,
-                      float neg_margin, float log_scale, float* out2, float* da, float* db, void* stream);
+                      float neg_margin, float log_scale, float* out2, float* da, float* db, void* ws, size_t ws_bytes,
+                      void* stream);
+size_t pcrcg_circle_loss_ws_bytes(int n);
 size_t pcrcg_weighted_bce_ws_bytes(void);
 int pcrcg_weighted_bce(const float* prediction, const float* gt, int n, float* out3, float* grad, void* ws, size_t ws_bytes,
                        void* stream);

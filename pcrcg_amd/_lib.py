@@ -139,7 +139,9 @@ SIGNATURES = {
     "pcrcg_kpfcnn_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcrcg_kpfcnn_train_free": (None, [c_void_p]),
     "pcrcg_circle_loss": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float,
-                                  c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                  c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                  c_void_p]),
+    "pcrcg_circle_loss_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_weighted_bce_ws_bytes": (c_size_t, []),
     "pcrcg_weighted_bce": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pcrcg_feature_argmax_ws_bytes": (c_size_t, [c_int]),

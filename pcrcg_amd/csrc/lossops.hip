@@ -10,9 +10,11 @@
 //   pw = max(0, fd - 1e5 * !pos - pos_optimal), nw = max(0, neg_optimal - (fd + 1e5 * !neg))     (constants for autograd)
 //   row i: softplus(logsumexp_j(ls (fd - pos_margin) pw) + logsumexp_j(ls (neg_margin - fd) nw)) / ls, same per column;
 //   loss = (mean over rows holding a pos and a neg + mean over such columns) / 2
-// and recall (:106-116) = share of rows holding a positive whose nearest descriptor is one.  One workgroup: thread i < n
-// owns row i, thread n + j column j (online logsumexp, 2n <= 1024 threads); the second phase turns the row / column
-// terms into d loss / d a_i and d loss / d b_j the same way.
+// and recall (:106-116) = share of rows holding a positive whose nearest descriptor is one.  Two launches of 2n
+// workgroups, one per LINE (row i = line i, column j = line n + j): k_circle_lines reduces each line (one wave, online
+// logsumexp merged across lanes); k_circle_grads counts the selected lines, writes loss and recall (workgroup 0) and turns
+// the line terms into d loss / d a_i resp. d loss / d b_j.  The n x n matrices are never stored: a line's <a_i, b_j>
+// are recomputed where needed (n * c multiply-adds per line, the descriptors stay in L2).
 #include "common.h"
 #include "pcrcg_train.h"
 
@@ -21,103 +23,155 @@ namespace {
 
 struct CircleCfg { float pos_radius, safe_radius, pos_optimal, neg_optimal, pos_margin, neg_margin, log_scale; };
 
-__device__ __forceinline__ float fdist(const float* __restrict__ x, const float* __restrict__ y, int c) {
+__device__ __forceinline__ float dotc(const float* __restrict__ x, const float* __restrict__ y, int c) {
     float s = 0.f;
-    for (int k = 0; k < c; ++k) s += x[k] * y[k];
-    return sqrtf(fmaxf(-2.0f * s + 2.0f, 1e-12f));
+    if ((c & 3) == 0) {
+        for (int k = 0; k < c; k += 4) {
+            const float4 u = *reinterpret_cast<const float4*>(x + k), v = *reinterpret_cast<const float4*>(y + k);
+            s += u.x * v.x; s += u.y * v.y; s += u.z * v.z; s += u.w * v.w;
+        }
+    } else {
+        for (int k = 0; k < c; ++k) s += x[k] * y[k];
+    }
+    return s;
 }
 __device__ __forceinline__ void lse_push(float z, float& mx, float& sum) {      // online logsumexp
     if (z > mx) { sum = sum * expf(mx - z) + 1.0f; mx = z; }
     else sum += expf(z - mx);
 }
+__device__ __forceinline__ void lse_merge(float& mx, float& sum, float m2, float s2) {
+    const float m = fmaxf(mx, m2);
+    if (m == -INFINITY) return;                                // two empty lanes
+    sum = sum * expf(mx - m) + s2 * expf(m2 - m);
+    mx = m;
+}
 
-// LDS: per line (row or column): lse_pos, lse_neg, coefficient g (d loss / d softplus-argument, 0 when the line is not
-// selected); out[0] = loss, out[1] = recall
-__global__ void __launch_bounds__(1024) k_circle_loss(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
-                                                       const float* __restrict__ cd, int ldc, int n, int c, CircleCfg cfg,
-                                                       float* __restrict__ out, float* __restrict__ da, float* __restrict__ db) {
-    extern __shared__ float sm[];
-    float* lse_p = sm;                 // [2n]: rows then columns
-    float* lse_n = sm + 2 * n;
-    float* coef = sm + 4 * n;
-    float* red = sm + 6 * n;           // [4]: selected rows, selected columns, rows with a positive, recalled rows
-    __shared__ float s_loss[2];
-    const int t = threadIdx.x;
-    if (t < 4) red[t] = 0.f;
-    if (t < 2) s_loss[t] = 0.f;
-    __syncthreads();
-    const bool is_row = t < n, is_col = t >= n && t < 2 * n;
-    const int me = is_row ? t : t - n;
+// per-line record in the workspace, 8 floats: lse_pos, lse_neg, sigmoid(z) / ls, line loss, selected, has a positive,
+// recalled, -
+constexpr int kLineRec = 8;
+
+__global__ void __launch_bounds__(64) k_circle_lines(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                      const float* __restrict__ cd, int ldc, int n, int c, CircleCfg cfg,
+                                                      float* __restrict__ lines) {
+    const int line = blockIdx.x, lane = threadIdx.x;
+    const bool is_row = line < n;
+    const int me = is_row ? line : line - n;
+    const float* mine = is_row ? a + (long)me * lda : b + (long)me * ldb;
     const float ls = cfg.log_scale;
-    float line_loss = 0.f;
-    bool sel = false;
-    if (is_row || is_col) {
-        const float* mine = is_row ? a + (long)me * lda : b + (long)me * ldb;
-        float mp = -INFINITY, sp = 0.f, mn = -INFINITY, sn = 0.f, best = INFINITY;
-        int npos = 0, nneg = 0, arg = 0;
-        for (int o = 0; o < n; ++o) {
-            const float* other = is_row ? b + (long)o * ldb : a + (long)o * lda;
-            const float d = is_row ? cd[(long)me * ldc + o] : cd[(long)o * ldc + me];
-            const float fd = fdist(mine, other, c);
-            const bool pos = d < cfg.pos_radius, neg = d > cfg.safe_radius;
-            npos += pos;
-            nneg += neg;
-            const float pw = fmaxf(0.f, fd - (pos ? 0.f : 1e5f) - cfg.pos_optimal);
-            const float nw = fmaxf(0.f, cfg.neg_optimal - (fd + (neg ? 0.f : 1e5f)));
-            lse_push(ls * (fd - cfg.pos_margin) * pw, mp, sp);
-            lse_push(ls * (cfg.neg_margin - fd) * nw, mn, sn);
-            if (fd < best) { best = fd; arg = o; }          // torch.min: first index attaining the minimum
+    float mp = -INFINITY, sp = 0.f, mn = -INFINITY, sn = 0.f, best = INFINITY;
+    int npos = 0, nneg = 0, arg = 0x7fffffff;
+    for (int o = lane; o < n; o += 64) {
+        const float* other = is_row ? b + (long)o * ldb : a + (long)o * lda;
+        const float d = is_row ? cd[(long)me * ldc + o] : cd[(long)o * ldc + me];
+        const float fd = sqrtf(fmaxf(-2.0f * dotc(mine, other, c) + 2.0f, 1e-12f));
+        const bool pos = d < cfg.pos_radius, neg = d > cfg.safe_radius;
+        npos += pos;
+        nneg += neg;
+        const float pw = fmaxf(0.f, fd - (pos ? 0.f : 1e5f) - cfg.pos_optimal);
+        const float nw = fmaxf(0.f, cfg.neg_optimal - (fd + (neg ? 0.f : 1e5f)));
+        lse_push(ls * (fd - cfg.pos_margin) * pw, mp, sp);
+        lse_push(ls * (cfg.neg_margin - fd) * nw, mn, sn);
+        if (fd < best) { best = fd; arg = o; }                 // torch.min: the first index attaining the minimum
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        lse_merge(mp, sp, __shfl_xor(mp, off), __shfl_xor(sp, off));
+        lse_merge(mn, sn, __shfl_xor(mn, off), __shfl_xor(sn, off));
+        npos += __shfl_xor(npos, off);
+        nneg += __shfl_xor(nneg, off);
+        const float b2 = __shfl_xor(best, off);
+        const int a2 = __shfl_xor(arg, off);
+        if (b2 < best || (b2 == best && a2 < arg)) { best = b2; arg = a2; }
+    }
+    if (lane == 0) {
+        const float lp = mp + logf(sp), ln = mn + logf(sn), z = lp + ln;
+        const bool sel = npos > 0 && nneg > 0;
+        float* r = lines + (long)line * kLineRec;
+        r[0] = lp;
+        r[1] = ln;
+        r[2] = sel ? 1.0f / (1.0f + expf(-z)) / ls : 0.f;                       // d line loss / d z
+        r[3] = sel ? (z > 20.f ? z : log1pf(expf(z))) / ls : 0.f;                // F.softplus (threshold 20)
+        r[4] = sel ? 1.f : 0.f;
+        r[5] = is_row && npos > 0 ? 1.f : 0.f;
+        r[6] = is_row && npos > 0 && cd[(long)me * ldc + arg] < cfg.pos_radius ? 1.f : 0.f;      // recall (:106-116)
+        r[7] = 0.f;
+    }
+}
+
+// d loss / d fd_ij = g_row_i * (P_row_ij ls pw - N_row_ij ls nw) + g_col_j * (same with the column terms),
+// P = exp(z_pos - lse_pos) etc., g = sigmoid(z) / ls * 0.5 / (selected lines of that kind);
+// d fd / d <a_i, b_j> = -1 / fd (0 where the clamp is active)
+__global__ void __launch_bounds__(256) k_circle_grads(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                       const float* __restrict__ cd, int ldc, int n, int c, CircleCfg cfg,
+                                                       const float* __restrict__ lines, float* __restrict__ out,
+                                                       float* __restrict__ da, float* __restrict__ db) {
+    __shared__ float red[6];                  // selected rows, selected columns, row loss, column loss, rows with a positive, recalled
+    __shared__ float gs[512];
+    __shared__ float part[256];
+    const int line = blockIdx.x, t = threadIdx.x;
+    if (t < 6) red[t] = 0.f;
+    __syncthreads();
+    {
+        float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int l = t; l < 2 * n; l += 256) {
+            const float* r = lines + (long)l * kLineRec;
+            const int col = l >= n;
+            v[col] += r[4];
+            v[2 + col] += r[3];
+            v[4] += r[5];
+            v[5] += r[6];
         }
-        const float lp = mp + logf(sp), ln = mn + logf(sn);
-        lse_p[t] = lp;
-        lse_n[t] = ln;
-        sel = npos > 0 && nneg > 0;
-        const float z = lp + ln;
-        line_loss = (z > 20.f ? z : log1pf(expf(z))) / ls;   // F.softplus (threshold 20)
-        coef[t] = sel ? 1.0f / (1.0f + expf(-z)) / ls : 0.f;
-        if (sel) atomicAdd(&red[is_row ? 0 : 1], 1.0f);
-        if (is_row && npos > 0) {                            // recall (:106-116)
-            atomicAdd(&red[2], 1.0f);
-            if (cd[(long)me * ldc + arg] < cfg.pos_radius) atomicAdd(&red[3], 1.0f);
+        for (int q = 0; q < 6; ++q) {
+            float x = v[q];
+            for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+            if ((t & 63) == 0) atomicAdd(&red[q], x);
         }
     }
     __syncthreads();
     const float nrow = red[0], ncol = red[1];
-    if (sel) atomicAdd(&s_loss[is_row ? 0 : 1], line_loss / (is_row ? nrow : ncol));
-    // d loss / d z of a selected line: mean over the selected lines, half weight for rows and columns each
-    if (is_row || is_col) coef[t] = sel ? coef[t] * 0.5f / (is_row ? nrow : ncol) : 0.f;
-    __syncthreads();
-    if (t == 0) {
-        out[0] = 0.5f * (s_loss[0] + s_loss[1]);             // (an empty selection gives nan in the reference: mean of nothing)
-        if (nrow == 0.f || ncol == 0.f) out[0] = NAN;
-        out[1] = red[3] / (red[2] + 1e-12f);
+    if (line == 0 && t == 0) {
+        // (an empty selection gives nan in the reference: mean of nothing)
+        out[0] = nrow == 0.f || ncol == 0.f ? NAN : 0.5f * (red[2] / nrow + red[3] / ncol);
+        out[1] = red[5] / (red[4] + 1e-12f);
     }
-    // gradients: d loss / d fd_ij = g_row_i * (P_row_ij ls pw - N_row_ij ls nw) + g_col_j * (same with the column terms),
-    // P = exp(z_pos - lse_pos) etc.; d fd / d <a_i, b_j> = -1 / fd (0 where the clamp is active)
-    if ((is_row || is_col) && da && db) {
-        const float* mine = is_row ? a + (long)me * lda : b + (long)me * ldb;
-        float acc[64];
-        for (int k = 0; k < c; ++k) acc[k] = 0.f;
-        for (int o = 0; o < n; ++o) {
-            const float* other = is_row ? b + (long)o * ldb : a + (long)o * lda;
-            const float d = is_row ? cd[(long)me * ldc + o] : cd[(long)o * ldc + me];
-            float s = 0.f;
-            for (int k = 0; k < c; ++k) s += mine[k] * other[k];
-            const float q = -2.0f * s + 2.0f;
-            if (q <= 1e-12f) continue;                       // clamped: no gradient
+    if (!da) return;
+    const bool is_row = line < n;
+    const int me = is_row ? line : line - n;
+    const float* mine = is_row ? a + (long)me * lda : b + (long)me * ldb;
+    const float ls = cfg.log_scale;
+    const float* rm = lines + (long)line * kLineRec;
+    const float lp_m = rm[0], ln_m = rm[1], g_m = rm[4] != 0.f ? rm[2] * 0.5f / (is_row ? nrow : ncol) : 0.f;
+    const float inv_other = 0.5f / (is_row ? ncol : nrow);
+    for (int o = t; o < n; o += 256) {
+        const float* other = is_row ? b + (long)o * ldb : a + (long)o * lda;
+        const float d = is_row ? cd[(long)me * ldc + o] : cd[(long)o * ldc + me];
+        const float q = -2.0f * dotc(mine, other, c) + 2.0f;
+        float g = 0.f;
+        if (q > 1e-12f) {                                      // clamped entries pass no gradient
             const float fd = sqrtf(q);
             const bool pos = d < cfg.pos_radius, neg = d > cfg.safe_radius;
             const float pw = fmaxf(0.f, fd - (pos ? 0.f : 1e5f) - cfg.pos_optimal);
             const float nw = fmaxf(0.f, cfg.neg_optimal - (fd + (neg ? 0.f : 1e5f)));
             const float zp = ls * (fd - cfg.pos_margin) * pw, zn = ls * (cfg.neg_margin - fd) * nw;
-            const int ro = is_row ? t : o, co = is_row ? n + o : t;       // the row line and the column line of this entry
-            const float g = coef[ro] * (expf(zp - lse_p[ro]) * ls * pw - expf(zn - lse_n[ro]) * ls * nw) +
-                            coef[co] * (expf(zp - lse_p[co]) * ls * pw - expf(zn - lse_n[co]) * ls * nw);
-            const float gs = -g / fd;                        // d loss / d <a_i, b_j>
-            for (int k = 0; k < c; ++k) acc[k] += gs * other[k];
+            const float* ro = lines + (long)(is_row ? n + o : o) * kLineRec;      // the crossing line of this entry
+            const float g_o = ro[4] != 0.f ? ro[2] * inv_other : 0.f;
+            const float gfd = g_m * (expf(zp - lp_m) * ls * pw - expf(zn - ln_m) * ls * nw) +
+                              g_o * (expf(zp - ro[0]) * ls * pw - expf(zn - ro[1]) * ls * nw);
+            g = -gfd / fd;                                     // d loss / d <a_i, b_j>
         }
-        float* dst = is_row ? da + (long)me * c : db + (long)me * c;
-        for (int k = 0; k < c; ++k) dst[k] = acc[k];
+        gs[o] = g;
+    }
+    __syncthreads();
+    // d mine[k] = sum_o gs[o] other[o][k]: thread (part, k) over every parts-th o, then across the parts
+    const int parts = 256 / c, k = t % c, pt = t / c;
+    float acc = 0.f;
+    if (pt < parts)
+        for (int o = pt; o < n; o += parts) acc += gs[o] * (is_row ? b[(long)o * ldb + k] : a[(long)o * lda + k]);
+    part[t] = acc;
+    __syncthreads();
+    if (t < c) {
+        float s = 0.f;
+        for (int q = 0; q < parts; ++q) s += part[q * c + t];
+        (is_row ? da : db)[(long)me * c + t] = s;
     }
 }
 
@@ -178,14 +232,21 @@ using namespace pcrcg;
 
 extern "C" {
 
+size_t pcrcg_circle_loss_ws_bytes(int n) { return sizeof(float) * kLineRec * 2 * (size_t)(n > 0 ? n : 0); }
+
 int pcrcg_circle_loss(const float* a, int lda, const float* b, int ldb, const float* coords_dist, int ldc, int n, int c,
                       float pos_radius, float safe_radius, float pos_optimal, float neg_optimal, float pos_margin,
-                      float neg_margin, float log_scale, float* out2, float* da, float* db, void* stream) {
+                      float neg_margin, float log_scale, float* out2, float* da, float* db, void* ws, size_t ws_bytes,
+                      void* stream) {
     PCRCG_CHECK_ARG(n >= 1 && n <= 512 && c >= 1 && c <= 64 && lda >= c && ldb >= c && ldc >= n);
-    PCRCG_CHECK_ARG(a && b && coords_dist && out2 && (!da == !db));
+    PCRCG_CHECK_ARG(a && b && coords_dist && out2 && (!da == !db) && ws && ws_bytes >= pcrcg_circle_loss_ws_bytes(n));
+    PCRCG_CHECK_ARG(((uintptr_t)a | (uintptr_t)b) % 16 == 0 && (c % 4 != 0 || (lda % 4 == 0 && ldb % 4 == 0)));
     CircleCfg cfg = {pos_radius, safe_radius, pos_optimal, neg_optimal, pos_margin, neg_margin, log_scale};
-    hipLaunchKernelGGL(k_circle_loss, dim3(1), dim3(1024), sizeof(float) * (6 * (size_t)n + 8), as_stream(stream), a, lda, b, ldb,
-                       coords_dist, ldc, n, c, cfg, out2, da, db);
+    hipStream_t st = as_stream(stream);
+    float* lines = static_cast<float*>(ws);
+    hipLaunchKernelGGL(k_circle_lines, dim3(2 * n), dim3(64), 0, st, a, lda, b, ldb, coords_dist, ldc, n, c, cfg, lines);
+    hipLaunchKernelGGL(k_circle_grads, dim3(da ? 2 * n : 1), dim3(256), 0, st, a, lda, b, ldb, coords_dist, ldc, n, c, cfg, lines,
+                       out2, da, db);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

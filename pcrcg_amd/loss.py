@@ -44,9 +44,10 @@ class _CircleLoss(torch.autograd.Function):
         n, c = a.shape
         out = torch.empty(2, dtype=torch.float32, device=a.device)
         da, db = torch.empty_like(a), torch.empty_like(b)
+        ws = torch.empty(16 * n, dtype=torch.float32, device=a.device)          # pcrcg_circle_loss_ws_bytes(n)
         _lib.check(_lib.lib().pcrcg_circle_loss(a.data_ptr(), c, b.data_ptr(), c, cd.data_ptr(), n, n, c, *cfg, out.data_ptr(),
-                                                da.data_ptr(), db.data_ptr(), torch.cuda.current_stream().cuda_stream),
-                   "pcrcg_circle_loss")
+                                                da.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                                torch.cuda.current_stream().cuda_stream), "pcrcg_circle_loss")
         ctx.save_for_backward(da, db)
         ctx.mark_non_differentiable(out[1])
         return out[0], out[1]
