@@ -155,6 +155,35 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigne
 template <int BM, int BN>
 constexpr int lds_bytes() { return 3 * (BM + BN) * ROWB; }
 
+// How a launch's tiles are laid over the eight XCDs (see the kernel).  Each XCD takes T / 8 consecutive tiles of the
+// order (split, row tile, column tile) [0] or (split, column tile, row tile) [1]; the estimate below counts what the
+// eight private L2s fetch between them under either -- an A block (row tile x split) and a B block (column tile x split)
+// once per XCD that touches it, again per pass when the blocks revisited between passes exceed what an L2 keeps -- and
+// picks the cheaper.  Tall products (many row tiles per XCD) keep order 0: A streams once, B's few blocks stay cached.
+// Short, wide ones (the coarse levels: 381 .. 763 rows against 512 .. 2048 output columns) take order 1: every XCD then
+// owns a few column tiles of the weights instead of reading all of them (measured before: fetch = A + 8 B).
+struct TileMap { int gx, gy, gs, order; };
+static int x6_tile_order(int gx, int gy, int gs, int bm, int bn, int k_per_split) {
+    const int forced = debug_opts().x6_order;
+    if (forced >= 0 && forced <= 2) return forced;
+    const double a_blk = 4.0 * bm * k_per_split, b_blk = 4.0 * bn * k_per_split, keep = 2.0e6;   // bytes; L2 = 4 MB per XCD
+    const double total = (double)gx * gy * gs, q = total / 8.0;                                     // tiles per XCD
+    const double per_split = (double)gx * gy;
+    const double splits_touched = q >= per_split ? q / per_split : 1.0;
+    const double in_split = q >= per_split ? per_split : q;                                         // tiles per XCD inside one split
+    // order 0: in_split tiles = rows of gx column tiles
+    double rows0 = in_split / gx; if (rows0 < 1.0) rows0 = 1.0;
+    const double cols0 = in_split < gx ? in_split : gx;
+    const double b0 = cols0 * b_blk, a0 = rows0 * a_blk;
+    const double cost0 = splits_touched * (a0 + (b0 <= keep ? b0 : b0 * rows0));
+    // order 1: in_split tiles = columns of gy row tiles
+    double cols1 = in_split / gy; if (cols1 < 1.0) cols1 = 1.0;
+    const double rows1 = in_split < gy ? in_split : gy;
+    const double a1 = rows1 * a_blk, b1 = cols1 * b_blk;
+    const double cost1 = splits_touched * (b1 + (a1 <= keep ? a1 : a1 * cols1));
+    return cost1 < 0.9 * cost0 ? 1 : 0;
+}
+
 // ATERMS = 3: A is fp32 and is split like B.  ATERMS = 1: A already IS bf16 in memory (the bf16 feature-storage
 // variant's wf, lda in bf16 elements): its tile is copied straight into plane 0 and only the three products a1*b3,
 // a1*b2, a1*b1 run -- exact in B, bf16-rounded in A by the storage format, fp32 accumulate.  K % 32 == 0 required.
@@ -170,7 +199,7 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
                                                         int colp_chunks, const long long* __restrict__ a_idx,
                                                         int a_idx_ld, int a_ns, const float* __restrict__ a_zero,
                                                         const double* __restrict__ a_sums, double a_count, float a_eps,
-                                                        float a_slope, GemmPairArgs pr) {
+                                                        float a_slope, GemmPairArgs pr, TileMap tm) {
     constexpr int WAVES_M = 2, WAVES_N = 2;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -184,13 +213,28 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    // XCD-aware tile order (as k_gemm_f32): each XCD walks a contiguous range of tiles, n fastest
-    const int gx = gridDim.x, ntile = gridDim.x * gridDim.y;
-    const int lin = blockIdx.x + gx * blockIdx.y;
+    // XCD-aware tile order over the WHOLE launch (1-D grid of gx * gy * gs workgroups; the dispatcher hands workgroup L
+    // to XCD L % 8): each XCD walks a contiguous range of the (split, row tile, column tile) space, in the order
+    // x6_tile_order() picked -- so that the operand blocks an XCD touches are few and their re-use happens inside its own
+    // L2 (the eight L2s are private: what two XCDs both read is fetched twice)
+    const int gx = tm.gx;
+    int ntile = tm.gx * tm.gy * tm.gs, lin = blockIdx.x, base = 0;
+    if (tm.order == 2) {            // measurement aid (x6_order=2): the round-2 map, every split's tiles spread over all XCDs
+        ntile = tm.gx * tm.gy;
+        base = lin / ntile * ntile;
+        lin -= base;
+    }
     const int xq = ntile >> 3, xr = ntile & 7, xcd = lin & 7, slot = lin >> 3;
-    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
-    const int tile_x = tile % gx;
-    int tile_y = tile / gx;
+    const int tile = base + (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+    int tile_x, tile_y;
+    const int split = tile / (tm.gx * tm.gy), in_split = tile % (tm.gx * tm.gy);
+    if (tm.order != 1) {            // split, row tile, column tile (fastest)
+        tile_x = in_split % gx;
+        tile_y = in_split / gx;
+    } else {                        // split, column tile, row tile (fastest)
+        tile_y = in_split % tm.gy;
+        tile_x = in_split / tm.gy;
+    }
     int m0 = tile_y * BM;
     const int n0 = tile_x * BN;
     // Several products that share B in ONE launch (GemmGroup, common.h: the same layer of several fragment pairs): row
@@ -213,7 +257,7 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
         a_sums = pr.a_sums[e];
         a_count = pr.a_count[e];
     }
-    const int k_begin = blockIdx.z * k_per_split;
+    const int k_begin = split * k_per_split;
     const int k_end = min(Kdim, k_begin + k_per_split);
 
     f32x16 acc[TM][TN];
@@ -485,7 +529,7 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     }
 
     // epilogue (as k_gemm_f32): C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool first_split = blockIdx.z == 0;
+    const bool first_split = split == 0;
     float rs[TM][16], bv[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -565,6 +609,12 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
               double* colp, int colp_chunks, const long long* a_idx = nullptr, int a_idx_ld = 0, int a_ns = 0,
               const float* a_zero = nullptr, const double* a_sums = nullptr, double a_count = 0.0, float a_eps = 0.f,
               float a_slope = 1.f, GemmPairArgs pr = GemmPairArgs()) {
+    // grid = (column tiles, row tiles, splits) as the caller counts them; launched 1-D (see the kernel's tile order)
+    TileMap tm;
+    tm.gx = (int)grid.x;
+    tm.gy = (int)grid.y;
+    tm.gs = (int)grid.z;
+    tm.order = x6_tile_order(tm.gx, tm.gy, tm.gs, BM, BN, k_per_split);
     const size_t lds = lds_bytes<BM, BN>() + (ANORM ? 2 * sizeof(float) * (size_t)(((k_per_split + BK - 1) / BK) * BK) : 0);
     auto kern = k_gemm_x6<BM, BN, MINB, ATERMS, ALAY, BLAY, ANORM, KNOCK>;
     static size_t configured = 0;
@@ -574,9 +624,9 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
         configured = lds;
     }
     KpProfScope prof(st, m, n, k, ATERMS == 1 ? 3 : 6, 3);     // bench.py's GEMM roofline: the kernel's own start / stop events
-    hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, st, prof.a, prof.b, 0, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,
-                          k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks, a_idx, a_idx_ld, a_ns, a_zero, a_sums,
-                          a_count, a_eps, a_slope, pr);
+    hipExtLaunchKernelGGL(kern, dim3(tm.gx * tm.gy * tm.gs), dim3(256), lds, st, prof.a, prof.b, 0, a, lda, b, ldb, c, ldc, m, n,
+                          k, row_scale, bias, k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks, a_idx, a_idx_ld, a_ns,
+                          a_zero, a_sums, a_count, a_eps, a_slope, pr, tm);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
