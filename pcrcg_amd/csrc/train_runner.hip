@@ -21,6 +21,7 @@
 // the values and every parameter gradient against torch autograd of the CPU oracle.
 #include <cmath>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -65,8 +66,54 @@ struct Region {
     }
 };
 
+// The backward's second stream (one per device, created at first use and kept): weight gradients are off the critical
+// path -- nothing in the backward reads them -- so their products (dW = dY^T X, dW_kp = wf^T dY: 1/3 of the backward's GEMM
+// time) run beside the activation-gradient chain instead of inside it.  Fork = an event on the main stream the side stream
+// waits for (what the product reads is complete by then: gradients of an operator's output are final when its backward
+// starts, forward values never change); join = one event at the end of the backward.
+struct SideStream {
+    hipStream_t st = nullptr;
+    std::vector<hipEvent_t> ev;
+    hipEvent_t joined = nullptr;
+    unsigned next = 0;
+};
+static SideStream* side_stream() {
+    static std::mutex mu;
+    static SideStream* per_device[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!per_device[dev]) {
+        SideStream* s = new SideStream();
+        if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) { delete s; return nullptr; }
+        s->ev.resize(64);
+        bool ok = hipEventCreateWithFlags(&s->joined, hipEventDisableTiming) == hipSuccess;
+        for (auto& e : s->ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { delete s; return nullptr; }       // (a failed creation leaks a few handles once; the backward then runs on one stream)
+        per_device[dev] = s;
+    }
+    return per_device[dev];
+}
+
 struct Tape {
     Region val, grad, scratch;
+    SideStream* side = nullptr;         // set by the backward when the second stream is in use
+    bool forked = false;
+    // the stream for work nothing later in the backward depends on (see SideStream); the main stream without one
+    hipStream_t off_path() {
+        if (!side) return st;
+        hipEvent_t e = side->ev[side->next++ % side->ev.size()];
+        if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(side->st, e, 0) != hipSuccess) return st;
+        forked = true;
+        return side->st;
+    }
+    void join() {
+        if (!forked) return;
+        forked = false;
+        if (hipEventRecord(side->joined, side->st) != hipSuccess || hipStreamWaitEvent(st, side->joined, 0) != hipSuccess) {
+            (void)hipStreamSynchronize(side->st);
+        }
+    }
     bool dry = true;
     int rc = PCRCG_OK;
     hipStream_t st = nullptr;
@@ -137,9 +184,12 @@ TT linear(Tape& t, const TT& x, Wt w, int ldw, Wt bias, int out, TT* into = null
     t.record([x, y, w, ldw, bias, out](Tape& b) {
         if (x.g)     // dx += dy @ W
             b.check(gemm_general(y.g, y.ld, 0, w.p, ldw, 0, x.g, x.ld, x.rows, x.cols, out, nullptr, nullptr, true, b.st));
-        if (w.g)     // dW += dy^T @ x
-            b.check(gemm_general(y.g, y.ld, 1, x.p, x.ld, 0, w.g, ldw, out, x.cols, x.rows, nullptr, nullptr, true, b.st));
-        if (bias.g) b.check(tr_bias_grad(y.g, y.ld, y.rows, out, bias.g, b.st));
+        if (w.g || bias.g) {
+            hipStream_t side = b.off_path();
+            if (w.g)     // dW += dy^T @ x
+                b.check(gemm_general(y.g, y.ld, 1, x.p, x.ld, 0, w.g, ldw, out, x.cols, x.rows, nullptr, nullptr, true, side));
+            if (bias.g) b.check(tr_bias_grad(y.g, y.ld, y.rows, out, bias.g, side));
+        }
     });
     return y;
 }
@@ -222,15 +272,15 @@ TT kpconv(Tape& t, const pcrcg_batch& b, const pcrcg_block& blk, Wt w, const TT&
                                        inv_n, ws, wsb, t.st));
         t.check(gemm_general(wf, kc, 0, w.p, cout, 0, y.p, y.ld, nq, cout, kc, inv_n, nullptr, false, t.st));
     }
-    t.need_scratch(fbytes(nq, kc) + fbytes(nq, cout));
+    t.need_scratch(fbytes(nq, kc));
+    float* dys = static_cast<float*>(t.value_bytes(fbytes(nq, cout)));          // dy / n: read by the off-path dW product
     const float* s_pts = b.points[l];
     const float* kp = blk.kp;
     const float extent = blk.extent;
     t.record([=](Tape& bk) {
-        float* dys = bk.tmp((size_t)(nq > 0 ? nq : 1) * cout + 64);
         bk.check(tr_scale_rows(y.g, y.ld, inv_n, dys, nq, cout, bk.st));          // dy / n
         if (w.g)                                                                  // dW += wf^T @ (dy / n)
-            bk.check(gemm_general(wf, kc, 1, dys, cout, 0, w.g, cout, kc, cout, nq, nullptr, nullptr, true, bk.st));
+            bk.check(gemm_general(wf, kc, 1, dys, cout, 0, w.g, cout, kc, cout, nq, nullptr, nullptr, true, bk.off_path()));
         if (x.g) {                                                                // d wf = (dy / n) @ W^T, scattered through w
             float* d_wf = bk.tmp((size_t)(nq > 0 ? nq : 1) * kc + 64);
             bk.check(gemm_general(dys, cout, 0, w.p, cout, 1, d_wf, kc, nq, kc, cout, nullptr, nullptr, false, bk.st));
@@ -528,6 +578,8 @@ int pcrcg_kpfcnn_train_backward(void* tape, const float* d_feats_f, const float*
     Tape& t = *static_cast<Tape*>(tape);
     t.st = as_stream(stream);
     t.rc = PCRCG_OK;
+    t.side = debug_opts().train_side_stream ? side_stream() : nullptr;
+    t.forked = false;
     PCRCG_CHECK_HIP(hipMemsetAsync(t.grad.base, 0, t.grad.off, t.st));
     // heads: the gradients of the three outputs into the gradient of x_final
     const TT& x = t.x_final;
@@ -539,6 +591,7 @@ int pcrcg_kpfcnn_train_backward(void* tape, const float* d_feats_f, const float*
         t.scratch.off = 0;
         t.bw[i](t);
     }
+    t.join();                 // the weight gradients are complete when the main stream passes this point
     return t.rc;
 }
 

@@ -151,21 +151,48 @@ class MetricLoss(torch.nn.Module):
         recall = torch.where(n_true > 0, tp / n_true.clamp(min=1), zero)
         return w_class_loss, precision, recall
 
-    def forward(self, inputs):
+    def prepare(self, inputs):
+        """The part of forward() that reads no network output (ref:lib/loss.py:139-203,227-235: the moved source cloud,
+        which points lie in the overlap, the overlap labels, the <= max_points correspondences drawn with the HOST numpy
+        generator exactly as the reference does -- same draws for the same np.random state -- and their coordinate
+        distances).  forward() calls it itself; a trainer may call it on a second stream while the network's forward runs
+        (its data-dependent shapes cost host round trips that then wait for a few small kernels, not for the forward) and
+        hand the result to forward(inputs, prepared=...).  Call order = draw order: one prepare() per forward()."""
+        rot, trans = inputs["rot"], inputs["trans"]
+        src_pcd, tgt_pcd = inputs["src_pcd_raw"], inputs["tgt_pcd_raw"]
+        dev = src_pcd.device
+        correspondence = inputs["correspondences"].to(dev).long()
+        p = dict()
+        src_pcd = (torch.matmul(rot, src_pcd.transpose(0, 1)) + trans).transpose(0, 1)
+        p["src_idx"] = src_idx = torch.unique(correspondence[:, 0])
+        p["tgt_idx"] = tgt_idx = torch.unique(correspondence[:, 1])
+        # overlap labels: a point is "in the overlap" iff it appears in a correspondence (:193-203)
+        src_gt = torch.zeros(src_pcd.size(0), device=dev)
+        src_gt[src_idx] = 1.
+        tgt_gt = torch.zeros(tgt_pcd.size(0), device=dev)
+        tgt_gt[tgt_idx] = 1.
+        p["overlap_labels"] = torch.cat((src_gt, tgt_gt))
+        p["src_pcd_sel"], p["tgt_pcd_sel"] = src_pcd[src_idx], tgt_pcd[tgt_idx]
+        # correspondences closer than pos_radius, capped to max_points (:227-233)
+        c_dist = torch.norm(src_pcd[correspondence[:, 0]] - tgt_pcd[correspondence[:, 1]], dim=1)
+        correspondence = correspondence[c_dist < self.pos_radius - 0.001]
+        if correspondence.size(0) > self.max_points:
+            choice = np.random.permutation(correspondence.size(0))[:self.max_points]
+            correspondence = correspondence[torch.from_numpy(choice).to(dev)]
+        p["src_sel"], p["tgt_sel"] = correspondence[:, 0], correspondence[:, 1]
+        p["coords_dist"] = torch.sqrt(square_distance(src_pcd[p["src_sel"]][None], tgt_pcd[p["tgt_sel"]][None]).squeeze(0))
+        return p
+
+    def forward(self, inputs, prepared=None):
         """ref:lib/loss.py:139-252.  inputs: rot [3,3], trans [3,1], src_feats [N,C], tgt_feats [M,C],
         src_pcd_raw [N,3], tgt_pcd_raw [M,3], correspondences [K,2] int64, scores_overlap / scores_saliency
-        [N+M] -- all on one device."""
-        rot, trans = inputs["rot"], inputs["trans"]
+        [N+M] -- all on one device.  prepared: the result of prepare(inputs), when the caller ran it ahead."""
         src_feats, tgt_feats = inputs["src_feats"], inputs["tgt_feats"]
-        src_pcd, tgt_pcd = inputs["src_pcd_raw"], inputs["tgt_pcd_raw"]
-        correspondence = inputs["correspondences"].to(src_pcd.device).long()
         scores_overlap, scores_saliency = inputs["scores_overlap"], inputs["scores_saliency"]
-        dev = src_pcd.device
+        p = prepared if prepared is not None else self.prepare(inputs)
+        src_idx, tgt_idx = p["src_idx"], p["tgt_idx"]
+        n_src = inputs["src_pcd_raw"].size(0)
         stats = dict()
-
-        src_pcd = (torch.matmul(rot, src_pcd.transpose(0, 1)) + trans).transpose(0, 1)
-        src_idx = torch.unique(correspondence[:, 0])
-        tgt_idx = torch.unique(correspondence[:, 1])
 
         if self.node_overlap:
             loss, a, b = self.get_weighted_bce_loss(inputs["node_overlap_score_pred"], inputs["node_overlap_gt"])
@@ -175,19 +202,14 @@ class MetricLoss(torch.nn.Module):
             t = F.mse_loss(inputs["trans_pred"], inputs["trans_gt"], reduction="sum")
             stats["pose_loss"] = q + t
 
-        # overlap BCE: a point is "in the overlap" iff it appears in a correspondence (:193-203)
-        src_gt = torch.zeros(src_pcd.size(0), device=dev)
-        src_gt[src_idx] = 1.
-        tgt_gt = torch.zeros(tgt_pcd.size(0), device=dev)
-        tgt_gt[tgt_idx] = 1.
-        gt_labels = torch.cat((src_gt, tgt_gt))
-        class_loss, cls_precision, cls_recall = self.get_weighted_bce_loss(scores_overlap, gt_labels)
+        # overlap BCE (:193-203)
+        class_loss, cls_precision, cls_recall = self.get_weighted_bce_loss(scores_overlap, p["overlap_labels"])
         stats["overlap_loss"], stats["overlap_recall"], stats["overlap_precision"] = class_loss, cls_recall, cls_precision
 
         # saliency BCE, supervised in the overlap region only (:205-225): a point is matchable iff its nearest
         # descriptor on the other side lies within matchability_radius
-        src_feats_sel, src_pcd_sel = src_feats[src_idx], src_pcd[src_idx]
-        tgt_feats_sel, tgt_pcd_sel = tgt_feats[tgt_idx], tgt_pcd[tgt_idx]
+        src_feats_sel, src_pcd_sel = src_feats[src_idx], p["src_pcd_sel"]
+        tgt_feats_sel, tgt_pcd_sel = tgt_feats[tgt_idx], p["tgt_pcd_sel"]
         with torch.no_grad():
             idx12 = ops.feature_argmax(src_feats_sel.detach().float(), tgt_feats_sel.detach().float())
             idx21 = ops.feature_argmax(tgt_feats_sel.detach().float(), src_feats_sel.detach().float())
@@ -195,22 +217,13 @@ class MetricLoss(torch.nn.Module):
         distance_2 = torch.norm(tgt_pcd_sel - src_pcd_sel[idx21], p=2, dim=1)
         gt_labels = torch.cat(((distance_1 < self.matchability_radius).float(),
                                (distance_2 < self.matchability_radius).float()))
-        saliency = torch.cat((scores_saliency[:src_pcd.size(0)][src_idx], scores_saliency[src_pcd.size(0):][tgt_idx]))
+        saliency = torch.cat((scores_saliency[:n_src][src_idx], scores_saliency[n_src:][tgt_idx]))
         class_loss, cls_precision, cls_recall = self.get_weighted_bce_loss(saliency, gt_labels)
         stats["saliency_loss"], stats["saliency_recall"], stats["saliency_precision"] = class_loss, cls_recall, cls_precision
 
-        # correspondences closer than pos_radius, capped to max_points with the HOST numpy generator exactly as
-        # the reference does (:227-233): same draws for the same np.random state
-        c_dist = torch.norm(src_pcd[correspondence[:, 0]] - tgt_pcd[correspondence[:, 1]], dim=1)
-        correspondence = correspondence[c_dist < self.pos_radius - 0.001]
-        if correspondence.size(0) > self.max_points:
-            choice = np.random.permutation(correspondence.size(0))[:self.max_points]
-            correspondence = correspondence[torch.from_numpy(choice).to(dev)]
-        src_sel, tgt_sel = correspondence[:, 0], correspondence[:, 1]
-        src_pcd, tgt_pcd = src_pcd[src_sel], tgt_pcd[tgt_sel]
-        src_feats, tgt_feats = src_feats[src_sel], tgt_feats[tgt_sel]
-        coords_dist = torch.sqrt(square_distance(src_pcd[None], tgt_pcd[None]).squeeze(0))
-
+        # circle loss + feature-match recall on the drawn correspondences (:227-252)
+        src_feats, tgt_feats = src_feats[p["src_sel"]], tgt_feats[p["tgt_sel"]]
+        coords_dist = p["coords_dist"]
         n_sel = src_feats.shape[0]
         if self.fused and src_feats.is_cuda and 1 <= n_sel <= 512 and src_feats.shape[1] <= 64:
             cfg = (float(self.pos_radius), float(self.safe_radius), float(self.pos_optimal), float(self.neg_optimal),

@@ -139,6 +139,7 @@ class Trainer:
         train = phase == "train"
         self.model.train(train)
         with torch.set_grad_enabled(train):
+            ahead = self._prepare_ahead(inputs)
             if train:
                 # the network's forward + backward in C++ (one autograd node); the op-by-op autograd composition of
                 # pcrcg_amd/train_forward.py remains as its mirror (use_cpp_runner = False, or a configuration the runner
@@ -147,6 +148,7 @@ class Trainer:
                 output = tr.forward(inputs) if tr is not None else forward_train(self.model, inputs)
             else:
                 output = self.model(inputs)
+            prepared = ahead() if ahead is not None else None
             len_src = int(inputs["stack_lengths_host"][0][0]) if "stack_lengths_host" in inputs \
                 else int(inputs["stack_lengths"][0][0])
             feats = output["feats_f"]
@@ -157,13 +159,40 @@ class Trainer:
                 "src_pcd_raw": inputs["src_pcd_raw"], "tgt_pcd_raw": inputs["tgt_pcd_raw"],
                 "correspondences": inputs["correspondences"],
             }
-            res = self.desc_loss(loss_input)
+            res = self.desc_loss(loss_input, prepared=prepared) if prepared is not None else self.desc_loss(loss_input)
             if train:
                 c_loss = sum(res[k] for k in res if k in LOSS_KEYS)
                 self.bucket.arm((self._iter + 1) % self.iter_size == 0)   # exchange overlaps the step's last backward
                 c_loss.backward()               # accumulates into the flat bucket (iter_size > 1 sums pairs)
                 res["total_loss"] = c_loss
         return {k: float(v.detach()) if isinstance(v, torch.Tensor) else float(v) for k, v in res.items()}
+
+    def _prepare_ahead(self, inputs):
+        """The loss's geometry-only part (MetricLoss.prepare: which points overlap, the max_points draw, the coordinate
+        distances) on a second stream, beside the network's forward: its data-dependent shapes cost host round trips, which
+        then wait for a handful of small kernels instead of for the forward.  -> a callable that runs it (after the
+        forward has been enqueued) and returns its result, made safe to use on the current stream; None when the loss
+        has no prepare() or the inputs are not on a GPU."""
+        if not hasattr(self.desc_loss, "prepare") or not inputs["src_pcd_raw"].is_cuda:
+            return None
+        main = torch.cuda.current_stream()
+        if getattr(self, "_prep_stream", None) is None:
+            self._prep_stream = torch.cuda.Stream()
+        side = self._prep_stream
+        ready = torch.cuda.Event()
+        ready.record(main)                      # the inputs are complete here; the forward is enqueued after this point
+
+        def run():
+            with torch.cuda.stream(side), torch.no_grad():
+                side.wait_event(ready)
+                prepared = self.desc_loss.prepare({k: inputs[k] for k in ("rot", "trans", "src_pcd_raw", "tgt_pcd_raw",
+                                                                         "correspondences")})
+            main.wait_stream(side)
+            for v in prepared.values():
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    v.record_stream(main)
+            return prepared
+        return run
 
     # ---- optimisation block -------------------------------------------------------------------------
     def gradient_valid(self):

@@ -72,7 +72,7 @@ def test_fused_loss_kernels_equal_the_torch_mirror(cuda, golden_dir, case):
         np.random.seed(cs["numpy_seed"])
         stats = loss(inputs)
         (stats["circle_loss"] + stats["overlap_loss"] + stats["saliency_loss"]).backward()
-        res[fused] = ({k: float(v) for k, v in stats.items()},
+        res[fused] = ({k: float(v.detach()) for k, v in stats.items()},
                       {k: inputs[k].grad.clone() for k in ("src_feats", "tgt_feats", "scores_overlap", "scores_saliency")})
     for k, want in res[False][0].items():
         assert abs(res[True][0][k] - want) <= 1e-5 * max(1.0, abs(want)), (k, res[True][0][k], want)
