@@ -473,7 +473,16 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
         }
         if constexpr (!(KNOCK & 32)) __syncthreads();                     // previous tile fully read
         if constexpr (!(KNOCK & 4)) store_tiles(qa, qb);                  // registers -> LDS (split)
-        else {                                                            // (keep the split alive without the stores)
+        else if constexpr (KNOCK & 2) {                                   // neither split nor stores: the loaded registers stay live
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(qa[it].get(j)));
+#pragma unroll
+            for (int it = 0; it < B_ITERS; ++it)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(qb[it].get(j)));
+        } else {                                                          // (keep the split alive without the stores)
 #pragma unroll
             for (int it = 0; it < A_ITERS; ++it) {
                 unsigned q1, q2, q3;

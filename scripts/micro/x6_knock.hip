@@ -9,6 +9,7 @@
 
 namespace pcrcg {
 void set_error(const char*, ...) {}
+const DebugOpts& debug_opts() { static DebugOpts d; return d; }
 KpProfScope::KpProfScope(hipStream_t s, int, int, int, int, int) : st(s), a(nullptr), b(nullptr), on(false) {}
 KpProfScope::~KpProfScope() {}
 }  // namespace pcrcg
@@ -36,12 +37,13 @@ float run(const float* a, const float* b, float* c, int m, int n, int k, int spl
 template <int BM, int BN, int MINB>
 void sweep(const char* tag, const float* a, const float* b, float* c, int m, int n, int k, int splits) {
     printf("%-8s %6dx%4dx%5d split %d | full %6.1f | -loads %6.1f | -split %6.1f | -ldsW %6.1f | -mfma %6.1f | -ldsR %6.1f | -bar %6.1f | "
-           "-loads-split-ldsW %6.1f | only loads(-split-ldsW-mfma-ldsR) %6.1f | -ldsR-mfma %6.1f\n", tag, m, n, k, splits,
+           "-loads-split-ldsW %6.1f | only loads(-split-ldsW-mfma-ldsR) %6.1f | -ldsR-mfma %6.1f | loads+split(-ldsW-mfma-ldsR) %6.1f | only loads, no barriers %6.1f\n", tag, m, n, k, splits,
            run<BM, BN, MINB, 0>(a, b, c, m, n, k, splits), run<BM, BN, MINB, 1>(a, b, c, m, n, k, splits),
            run<BM, BN, MINB, 2>(a, b, c, m, n, k, splits), run<BM, BN, MINB, 4>(a, b, c, m, n, k, splits),
            run<BM, BN, MINB, 8>(a, b, c, m, n, k, splits), run<BM, BN, MINB, 16>(a, b, c, m, n, k, splits),
            run<BM, BN, MINB, 32>(a, b, c, m, n, k, splits), run<BM, BN, MINB, 7>(a, b, c, m, n, k, splits),
-           run<BM, BN, MINB, 30>(a, b, c, m, n, k, splits), run<BM, BN, MINB, 24>(a, b, c, m, n, k, splits));
+           run<BM, BN, MINB, 30>(a, b, c, m, n, k, splits), run<BM, BN, MINB, 24>(a, b, c, m, n, k, splits),
+           run<BM, BN, MINB, 28>(a, b, c, m, n, k, splits), run<BM, BN, MINB, 62>(a, b, c, m, n, k, splits));
     fflush(stdout);
 }
 
@@ -60,7 +62,6 @@ int main() {
         hipMemset(c, 0, sizeof(float) * (size_t)m * n);
         sweep<64, 64, 4>("64x64", a, b, c, m, n, k, s[3]);
         sweep<128, 64, 2>("128x64", a, b, c, m, n, k, s[3]);
-        sweep<128, 128, 2>("128x128", a, b, c, m, n, k, s[3] * 2);
         hipFree(a);
         hipFree(b);
         hipFree(c);
