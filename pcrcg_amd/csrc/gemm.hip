@@ -338,7 +338,7 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
                      hipStream_t st, bool a_bf16, bool c_zeroed, int a_kmajor = 0, int b_kmajor = 0,
                      bool colstats_sums = false, const GemmExtra* ex = nullptr, const GemmGroup* grp = nullptr);   // gemm_x6.hip
-int gemm_x6_splits(int m, int n, int k);
+int gemm_x6_splits(int m, int n, int k, long m_total = 0);
 }
 
 using namespace pcrcg;
@@ -365,7 +365,8 @@ static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, i
 namespace pcrcg {
 // For the network runner (runner.hip): does a C = A * B^T product of this shape accumulate split-K partial sums into C
 // (so that a C taken from the runner's pre-zeroed arena saves the product's own memset)?  Only the default arithmetic.
-bool gemm_bt_accumulates(int m, int n, int k) { return gemm_mode() == 1 && gemm_x6_splits(m, n, k) > 1; }
+// (m: rows of the largest product of a grouped launch, m_total: of all of them -- the plan looks at both)
+bool gemm_bt_accumulates(int m, int n, int k, long m_total) { return gemm_mode() == 1 && gemm_x6_splits(m, n, k, m_total) > 1; }
 // pcrcg_gemm_f32_colstats (trans_b = 1) / pcrcg_gemm_bf16a_f32_colstats with the promise that C is all zeros.
 // colstats_sums: `colstats` is a ZEROED [2][n] fp64 accumulator; when the product writes every element once, its epilogue
 // adds the column sums / sums of squares there with atomics and reports *h_chunks = -1 (else 0: nothing was added).

@@ -154,6 +154,8 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigne
 
 template <int BM, int BN>
 constexpr int lds_bytes() { return 3 * (BM + BN) * ROWB; }
+template <int BM, int BN>
+constexpr int x6_threads() { return (BM == 128 && BN == 128) ? 512 : 256; }
 
 // How a launch's tiles are laid over the eight XCDs (see the kernel).  Each XCD takes T / 8 consecutive tiles of the
 // order (split, row tile, column tile) [0] or (split, column tile, row tile) [1]; the estimate below counts what the
@@ -191,7 +193,7 @@ static int x6_tile_order(int gx, int gy, int gs, int bm, int bn, int k_per_split
 // its parts removed -- results wrong, timing meaningful): 1 no global loads inside the k-loop, 2 no split arithmetic,
 // 4 no LDS stores, 8 no MFMA, 16 no LDS operand reads, 32 no barriers.
 template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY, int ANORM = 0, int KNOCK = 0>
-__global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__ A, int lda, const float* __restrict__ B,
+__global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                         int ldb, float* __restrict__ C, int ldc, int M, int N, int Kdim,
                                                         const float* __restrict__ row_scale,
                                                         const float* __restrict__ bias, int k_per_split, int vec_a,
@@ -200,11 +202,14 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
                                                         int a_idx_ld, int a_ns, const float* __restrict__ a_zero,
                                                         const double* __restrict__ a_sums, double a_count, float a_eps,
                                                         float a_slope, GemmPairArgs pr, TileMap tm) {
-    constexpr int WAVES_M = 2, WAVES_N = 2;
+    // 256 threads = 2 x 2 wavefronts; the 128 x 128 tile runs 512 threads = 2 x 4 wavefronts (64 x 32 each): the same
+    // registers per thread and wavefronts per CU as the 64 x 64 tile at half its L1 fills per flop
+    constexpr int NT = x6_threads<BM, BN>();
+    constexpr int WAVES_M = 2, WAVES_N = NT / 128;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_ITERS = BM * 4 / 256;    // (row, 8-k group) items per thread
-    constexpr int B_ITERS = BN * 4 / 256;
+    constexpr int A_ITERS = BM * 4 / NT;    // (row, 8-k group) items per thread
+    constexpr int B_ITERS = BN * 4 / NT;
     constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;
     static_assert(A_ITERS >= 1 && B_ITERS >= 1, "tile too small");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -277,7 +282,7 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     if constexpr (ALAY == 0 && ATERMS == 3) {
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) {
-            const int gr = m0 + ((tid + it * 256) >> 2);
+            const int gr = m0 + ((tid + it * NT) >> 2);
             const int r = min(gr, M - 1);
             arok[it] = gr < M;
             azero[it] = false;
@@ -298,7 +303,7 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
     float* const s_mean = reinterpret_cast<float*>(smem + 3 * (A_PLANE + B_PLANE));
     float* const s_rstd = s_mean + (ANORM ? ((k_per_split + BK - 1) / BK) * BK : 0);
     if constexpr (ANORM) {
-        for (int kk = tid; kk < k_end - k_begin; kk += 256) {
+        for (int kk = tid; kk < k_end - k_begin; kk += NT) {
             const double mu = a_sums[k_begin + kk] / a_count;
             double var = a_sums[(long)Kdim + k_begin + kk] / a_count - mu * mu;
             if (var < 0.0) var = 0.0;
@@ -311,7 +316,7 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
         if constexpr (ANORM && ALAY == 0 && ATERMS == 3) {
 #pragma unroll
             for (int it = 0; it < A_ITERS; ++it) {
-                const int kb = k0 - k_begin + ((tid + it * 256) & 3) * 8;
+                const int kb = k0 - k_begin + ((tid + it * NT) & 3) * 8;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int kk = guard ? min(kb + j, k_end - k_begin - 1) : kb + j;
@@ -340,36 +345,36 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
 #pragma unroll
             for (int it = 0; it < A_ITERS; ++it) {
                 if constexpr (ATERMS == 1) {
-                    const int e = tid + it * 256;
+                    const int e = tid + it * NT;
                     gload16(qa[it].v[0], reinterpret_cast<const float*>(Ah + (long)min(m0 + (e >> 2), M - 1) * lda + k0 + (e & 3) * 8));
                 } else if constexpr (ALAY == 0) {
-                    const float* p = arow[it] + k0 + ((tid + it * 256) & 3) * 8;
+                    const float* p = arow[it] + k0 + ((tid + it * NT) & 3) * 8;
                     gload16(qa[it].v[0], p);
                     gload16(qa[it].v[1], p + 4);
                 } else {
-                    item_load_fast<ALAY, BM>(qa[it], A, lda, m0, M, k0, tid + it * 256);
+                    item_load_fast<ALAY, BM>(qa[it], A, lda, m0, M, k0, tid + it * NT);
                 }
             }
 #pragma unroll
-            for (int it = 0; it < B_ITERS; ++it) item_load_fast<BLAY, BN>(qb[it], B, ldb, n0, N, k0, tid + it * 256);
+            for (int it = 0; it < B_ITERS; ++it) item_load_fast<BLAY, BN>(qb[it], B, ldb, n0, N, k0, tid + it * NT);
         } else {
             if constexpr (ATERMS != 1) {      // (the bf16-A form is dispatched only for aligned operands and K % 32 == 0)
 #pragma unroll
                 for (int it = 0; it < A_ITERS; ++it) {
                     if constexpr (ALAY == 0) {
-                        const int gk = k0 + ((tid + it * 256) & 3) * 8, ke = k_end - 1;
+                        const int gk = k0 + ((tid + it * NT) & 3) * 8, ke = k_end - 1;
                         float v[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] = arow[it][min(gk + j, ke)];          // always a valid address
 #pragma unroll
                         for (int j = 0; j < 8; ++j) qa[it].set(j, (arok[it] && gk + j < k_end) ? v[j] : 0.f);
                     } else {
-                        item_load_edge<ALAY, BM>(qa[it], A, lda, m0, M, k0, k_end, tid + it * 256);
+                        item_load_edge<ALAY, BM>(qa[it], A, lda, m0, M, k0, k_end, tid + it * NT);
                     }
                 }
             }
 #pragma unroll
-            for (int it = 0; it < B_ITERS; ++it) item_load_edge<BLAY, BN>(qb[it], B, ldb, n0, N, k0, k_end, tid + it * 256);
+            for (int it = 0; it < B_ITERS; ++it) item_load_edge<BLAY, BN>(qb[it], B, ldb, n0, N, k0, k_end, tid + it * NT);
         }
     };
     auto store_one = [&](unsigned char* base, int plane_bytes, int row, int kg, auto& src) {
@@ -390,14 +395,14 @@ __global__ void __launch_bounds__(256, MINB) k_gemm_x6(const float* __restrict__
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) {
             int row, kg;
-            item_pos<ALAY, BM>(tid + it * 256, row, kg);
+            item_pos<ALAY, BM>(tid + it * NT, row, kg);
             if constexpr (ATERMS == 1) *reinterpret_cast<f32x4*>(As + row * ROWB + kg * 16) = qa[it].v[0];
             else store_one(As, A_PLANE, row, kg, qa[it]);
         }
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
             int row, kg;
-            item_pos<BLAY, BN>(tid + it * 256, row, kg);
+            item_pos<BLAY, BN>(tid + it * NT, row, kg);
             store_one(Bs, B_PLANE, row, kg, qb[it]);
         }
     };
@@ -633,7 +638,7 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
         configured = lds;
     }
     KpProfScope prof(st, m, n, k, ATERMS == 1 ? 3 : 6, 3);     // bench.py's GEMM roofline: the kernel's own start / stop events
-    hipExtLaunchKernelGGL(kern, dim3(tm.gx * tm.gy * tm.gs), dim3(256), lds, st, prof.a, prof.b, 0, a, lda, b, ldb, c, ldc, m, n,
+    hipExtLaunchKernelGGL(kern, dim3(tm.gx * tm.gy * tm.gs), dim3(x6_threads<BM, BN>()), lds, st, prof.a, prof.b, 0, a, lda, b, ldb, c, ldc, m, n,
                           k, row_scale, bias, k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks, a_idx, a_idx_ld, a_ns,
                           a_zero, a_sums, a_count, a_eps, a_slope, pr, tm);
     PCRCG_CHECK_LAUNCH();
@@ -649,13 +654,10 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
 // dominates; each split costs atomic traffic (and a memset unless the caller hands over a zeroed C), so never
 // below 256 k per split.
 struct X6Plan { int pick, bm, bn, gx, gy, splits, k_per_split; };
-static X6Plan x6_plan(int m, int n, int k, bool kmajor = false, bool reduce_rows = false) {
+static X6Plan x6_plan_for(int pick, int m, int n, int k, bool reduce_rows) {
     static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     X6Plan p;
-    p.pick = -1;
-    p.pick = debug_opts().x6_tile;                                           // tuning aid (-1: automatic)
-    if (p.pick < 0 || p.pick > 3) p.pick = (n <= 64 && m >= 32768) ? 1 : 3;
-    if (kmajor) p.pick = 3;                                   // the k-major operand forms are built for 64 x 64 only
+    p.pick = pick;
     p.bm = tiles[p.pick][0];
     p.bn = tiles[p.pick][1];
     p.gx = (n + p.bn - 1) / p.bn;
@@ -673,9 +675,26 @@ static X6Plan x6_plan(int m, int n, int k, bool kmajor = false, bool reduce_rows
     if (p.splits < 1) p.splits = 1;
     return p;
 }
+// m: rows of the (largest) product; m_total: rows of the whole launch (the products of a group share the plan)
+static X6Plan x6_plan(int m, int n, int k, bool kmajor = false, bool reduce_rows = false, long m_total = 0) {
+    int pick = debug_opts().x6_tile;                                         // tuning aid (-1: automatic)
+    if (kmajor) return x6_plan_for(3, m, n, k, reduce_rows);  // the k-major operand forms are built for 64 x 64 only
+    if (pick >= 0 && pick <= 3) return x6_plan_for(pick, m, n, k, reduce_rows);
+    // x6_big=1 (off by default): 128 x 128 on eight wavefronts halves the L1 fills per flop (profiles/
+    // r03_gemm_load_skeleton.txt) and wins 5-10 % in a back-to-back loop where its tiles still fill the chip (15456x128x1920
+    // 58.5 vs 63.0 us, 3934x256x3840 57.1 vs 63.6, 60000x256x128 39.7 vs 41.8; 15456x128x512 with 121 tiles 28.0 vs 22.4)
+    // -- but inside a forward it gains nothing (GEMM time per forward 1.86 vs 1.82 ms) and inside the four-stream engine it
+    // loses (442 vs 454 pairs/s, same box): two 512-thread workgroups hold a CU that four small ones share more gracefully
+    if (n >= 128 && debug_opts().x6_big) {
+        const X6Plan big = x6_plan_for(0, m, n, k, reduce_rows);
+        const long rows = m_total > m ? m_total : m;
+        if ((long)big.gx * ((rows + 127) / 128) * big.splits >= 240) return big;
+    }
+    return x6_plan_for((n <= 64 && m >= 32768) ? 1 : 3, m, n, k, reduce_rows);
+}
 
 // the split-K factor gemm_x6_dispatch uses for an [m, n, k] product (> 1: it accumulates into a zeroed C)
-int gemm_x6_splits(int m, int n, int k) { return (m > 0 && n > 0) ? x6_plan(m, n, k).splits : 1; }
+int gemm_x6_splits(int m, int n, int k, long m_total) { return (m > 0 && n > 0) ? x6_plan(m, n, k, false, false, m_total).splits : 1; }
 
 // Called by gemm_dispatch (gemm.hip) for C = A * B^T products when the split-bf16 mode is on.  c_zeroed: C is
 // already all zeros (the runner's zero arena), so a split-K product needs no memset of its own.
@@ -695,7 +714,9 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
         if (grp->p[e].m <= 0 || !grp->p[e].a || !grp->p[e].c) { set_error("gemm_x6: empty product in a group"); return PCRCG_EBADARG; }
         m_plan = grp->p[e].m > m_plan ? grp->p[e].m : m_plan;
     }
-    const X6Plan plan = x6_plan(m_plan, n, k, a_kmajor || b_kmajor || (ex && ex->a_sums), a_kmajor != 0);
+    long m_total = m;
+    for (int e = 0; e < n_extra; ++e) m_total += grp->p[e].m;
+    const X6Plan plan = x6_plan(m_plan, n, k, a_kmajor || b_kmajor || (ex && ex->a_sums), a_kmajor != 0, m_total);
     const int pick = plan.pick, BM = plan.bm, BN = plan.bn, gx = plan.gx, splits = plan.splits;
     const int gy0 = (m + BM - 1) / BM;
     int gy = gy0, gye[kGroupExtra] = {0, 0, 0};

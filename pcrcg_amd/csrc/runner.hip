@@ -17,7 +17,7 @@
 
 namespace pcrcg {
 // gemm.hip
-bool gemm_bt_accumulates(int m, int n, int k);
+bool gemm_bt_accumulates(int m, int n, int k, long m_total = 0);
 int gemm_bt_colstats(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
                      hipStream_t st, bool c_zeroed, bool colstats_sums = false);
@@ -99,7 +99,9 @@ struct Ctx {
     int max_rows(const int* rows) const { int m = rows[0]; for (int g = 1; g < G; ++g) m = rows[g] > m ? rows[g] : m; return m; }
     // the output of a [rows, k] x [cols, k]^T product (the plan of the pair with most rows decides for all)
     Mat gemm_out(const int* rows, int cols, int k) {
-        if (!debug_opts().zero_arena || !gemm_bt_accumulates(max_rows(rows), cols, k)) return mat(rows, cols);
+        long total = 0;
+        for (int g = 0; g < G; ++g) total += rows[g];
+        if (!debug_opts().zero_arena || !gemm_bt_accumulates(max_rows(rows), cols, k, total)) return mat(rows, cols);
         Mat m;
         m.cols = cols; m.ld = cols;
         for (int g = 0; g < G; ++g) {

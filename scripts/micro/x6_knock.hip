@@ -62,6 +62,8 @@ int main() {
         hipMemset(c, 0, sizeof(float) * (size_t)m * n);
         sweep<64, 64, 4>("64x64", a, b, c, m, n, k, s[3]);
         sweep<128, 64, 2>("128x64", a, b, c, m, n, k, s[3]);
+        if (n >= 128) sweep<128, 128, 2>("128x128", a, b, c, m, n, k, s[3]);
+        if (n >= 128) sweep<128, 128, 2>("128x128", a, b, c, m, n, k, s[3] * 2);
         hipFree(a);
         hipFree(b);
         hipFree(c);
