@@ -44,6 +44,7 @@ from pcrcg_amd.sharding import pair_seeds_for_rank  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_TF = 157.3    # dense fp32 matrix peak (MI355X_MICROARCH.md)
 MFMA_BF16_TF = 2500.0  # dense bf16 matrix peak; the exact three-term split spends 6 bf16 products per fp32 product
+INPUT_ORDER = "generator"   # --input-order: "morton" sorts every synthetic cloud along a Z-order curve (never the headline)
 RECIPE = "S30k"       # the workload BASELINE.json's metric is quoted on (configs[1]); --workload picks a secondary one
 WORKLOADS = {
     "S30k": "S30k: 2x30000-pt shell pairs (3DMatch-shaped), indoor hyper-parameters",
@@ -71,7 +72,7 @@ def make_pair(recipe, seed):
         pr = synthetic.slab_pair(120000, seed)
     else:
         pr = synthetic.pair(recipe, seed)
-    if os.environ.get("PCRCG_BENCH_INPUT_ORDER") == "morton":      # experiment: spatially coherent point order
+    if INPUT_ORDER == "morton":      # experiment (--input-order morton): spatially coherent point order, DESIGN.md 5
         pr = tuple(np.ascontiguousarray(c[_morton_order(c)]) for c in pr)
     return pr
 
@@ -203,6 +204,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary regions (GEMM events, one-column upsample tables, pinned-host inputs)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="S30k")
+    ap.add_argument("--input-order", choices=["generator", "morton"], default="generator",
+                    help="experiment: Morton-sort each synthetic cloud (spatially coherent indices); recorded in config")
     ap.add_argument("--model-streams", type=int, default=3, help="engine: host threads / HIP streams enqueueing forwards")
     ap.add_argument("--front-threads", type=int, default=1, help="engine: host threads building pyramids")
     ap.add_argument("--depth", type=int, default=8, help="pairs submitted ahead of the one being collected")
@@ -219,8 +222,9 @@ def main():
                     help="bf16: the bf16 feature-storage VARIANT (pcrcg_model.feature_bf16) -- a separate line with its "
                          "measured error against the fp32 path; never the headline")
     args = ap.parse_args()
-    global RECIPE
+    global RECIPE, INPUT_ORDER
     RECIPE = args.workload
+    INPUT_ORDER = args.input_order
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -461,7 +465,8 @@ def main():
             "repeats": {"regions": R, "steps_per_region": args.steps, "statistic": "median",
                         "pairs_per_s": [round(args.steps * world / r[0], 1) for r in regions],
                         "min": round(args.steps * world / max(times), 1), "max": round(args.steps * world / min(times), 1)},
-            "config": {"workload": WORKLOADS[RECIPE] + ", pyramid build + KPFCNN+GCN forward, random-init full-width weights, "
+            "config": {"workload": WORKLOADS[RECIPE] + ("" if INPUT_ORDER == "generator" else " [clouds Morton-sorted: an "
+                                                        "experiment, not the headline workload]") + ", pyramid build + KPFCNN+GCN forward, random-init full-width weights, "
                                    "1 pair/GPU/step, inputs resident in HBM; pair engine: %d front thread(s) build pyramids "
                                    "(pcrcg_pyramid_build, %.2f pairs per call on average: two waiting pairs share one kernel "
                                    "chain) on one front-end HIP stream, %d host threads enqueue the forwards "
