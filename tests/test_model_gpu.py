@@ -56,6 +56,32 @@ def test_gemm_vs_torch(cuda, m, n, k):
     assert rel(out, ref2) < 2e-6 * max(1, k) ** 0.5
 
 
+def _debug(spec):
+    from pcrcg_amd import _lib
+    _lib.check(_lib.lib().pcrcg_debug_set(spec.encode()), "pcrcg_debug_set")
+
+
+@pytest.mark.parametrize("m,n,k", [(763, 512, 7680), (381, 2048, 512), (3934, 256, 3840), (15456, 128, 1920), (60000, 256, 128),
+                                   (1000, 130, 70)])
+def test_gemm_tile_maps_and_big_tile_agree(cuda, m, n, k):
+    """The XCD tile map's two orders, the round-2 map (x6_order = 0 / 1 / 2) and the 128 x 128 eight-wavefront tile (x6_big)
+    are schedules of the same product: every one of them within the fp32 bar of float64, and of each other."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    b = torch.randn(k, n, generator=g) * 0.05
+    ref = (a.double() @ b.double()).float()
+    outs = {}
+    try:
+        for spec in ("x6_order=-1,x6_big=0", "x6_order=0", "x6_order=1", "x6_order=2", "x6_order=-1,x6_big=1"):
+            _debug(spec)
+            outs[spec] = ops.gemm(a.to(cuda), b.to(cuda)).cpu()
+    finally:
+        _debug("x6_order=-1,x6_big=0")
+    for spec, out in outs.items():
+        assert rel(out, ref) < 2e-6 * k ** 0.5, spec
+        assert rel(out, outs["x6_order=0"]) < 2e-6, spec
+
+
 @pytest.mark.parametrize("m,ns,n,k1,k2", [(3934, 763, 257, 514, 1024), (60000, 15456, 34, 128, 256), (100, 7, 5, 6, 12),
                                          (15456, 3934, 128, 257, 512)])
 def test_gemm_gather_and_accumulate(cuda, m, ns, n, k1, k2):

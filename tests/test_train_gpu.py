@@ -81,6 +81,26 @@ def test_fused_loss_kernels_equal_the_torch_mirror(cuda, golden_dir, case):
         assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-9, k
 
 
+def test_prepared_loss_equals_the_loss(cuda, golden_dir):
+    """MetricLoss.prepare() (the geometry-only part, which a trainer runs beside the network's forward) handed to forward()
+    gives the same statistics as forward() alone, and consumes the host generator identically."""
+    gold = torch.load(os.path.join(golden_dir, "loss_mini.pt"), weights_only=False)
+    for case, cs in gold["cases"].items():
+        loss = MetricLoss(Config(gold["config"]))
+        inputs = {k: v.to(cuda) for k, v in cs["inputs"].items()}
+        np.random.seed(cs["numpy_seed"])
+        plain = {k: float(v) for k, v in loss(inputs).items()}
+        after_plain = np.random.rand()
+        np.random.seed(cs["numpy_seed"])
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            prepared = loss.prepare(inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        ahead = {k: float(v) for k, v in loss(inputs, prepared=prepared).items()}
+        assert np.random.rand() == after_plain, case
+        assert ahead == plain, case
+
+
 def test_metric_loss_is_differentiable(cuda, golden_dir):
     gold = torch.load(os.path.join(golden_dir, "loss_mini.pt"), weights_only=False)
     cs = gold["cases"]["all"]

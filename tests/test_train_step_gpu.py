@@ -90,6 +90,35 @@ def test_full_model_gradients_match_oracle_autograd(cuda, golden_dir, path):
     assert np.median(list(worst.values())) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
 
 
+def test_weight_gradients_on_the_second_stream_equal_one_stream(cuda, golden_dir):
+    """train_side_stream (default on): the backward's weight-gradient products run on a second stream; same gradients as
+    with everything on one stream, and complete when backward() returns to the caller's stream."""
+    from pcrcg_amd import _lib
+    gold = torch.load(os.path.join(golden_dir, "model_mini.pt"))
+    col = torch.load(os.path.join(golden_dir, "collate_mini.pt"))
+    cfg = indoor_config(**{k: v for k, v in gold["config"].items() if k in ("first_feats_dim", "gnn_feats_dim")})
+    net = KPFCNN(cfg)
+    net.load_state_dict(gold["state_dict"])
+    net = net.to(cuda).train()
+    batch = _to(col["batch"], cuda)
+    runner = net.train_runner()
+    grads = {}
+    try:
+        for side in (1, 0, 1):
+            _lib.check(_lib.lib().pcrcg_debug_set(f"train_side_stream={side}".encode()), "pcrcg_debug_set")
+            for p in net.parameters():
+                p.grad = None
+            out = runner.forward(batch)
+            (out["feats_f"].sum() + (out["scores_overlap"] * 2.0).sum() + out["scores_saliency"].sum()).backward()
+            # read on the caller's stream right away: the join inside backward orders the side stream before this
+            grads[side] = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    finally:
+        _lib.check(_lib.lib().pcrcg_debug_set(b"train_side_stream=1"), "pcrcg_debug_set")
+    floor = 1e-5 * max(float(g.abs().max()) for g in grads[0].values())
+    for n, ref in grads[0].items():
+        assert float((grads[1][n] - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + floor, n
+
+
 def test_two_outstanding_tapes_and_a_dropped_one(cuda, golden_dir):
     """The C++ runner's workspace discipline: a forward issued while an earlier one still awaits its backward gets its own
     workspace (both backwards are right: the gradients add up to twice one backward's), a forward that is dropped without a
