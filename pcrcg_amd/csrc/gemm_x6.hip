@@ -637,7 +637,9 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
-    KpProfScope prof(st, m, n, k, ATERMS == 1 ? 3 : 6, 3);     // bench.py's GEMM roofline: the kernel's own start / stop events
+    int m_all = m;                                             // a grouped launch's products all count
+    for (int e = 0; e < pr.extra; ++e) m_all += pr.m[e];
+    KpProfScope prof(st, m_all, n, k, ATERMS == 1 ? 3 : 6, 3);  // bench.py's GEMM roofline: the kernel's own start / stop events
     hipExtLaunchKernelGGL(kern, dim3(tm.gx * tm.gy * tm.gs), dim3(x6_threads<BM, BN>()), lds, st, prof.a, prof.b, 0, a, lda, b, ldb, c, ldc, m, n,
                           k, row_scale, bias, k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks, a_idx, a_idx_ld, a_ns,
                           a_zero, a_sums, a_count, a_eps, a_slope, pr, tm);
