@@ -51,6 +51,12 @@ int pcrcg_circle_loss(const float* a, int lda, const float* b, int ldb, const fl
                       void* stream);
 size_t pcrcg_circle_loss_ws_bytes(int n);
 size_t pcrcg_weighted_bce_ws_bytes(void);
+/* The optimiser step of the train loop over FLAT buffers of n floats (parameters, their gradients, the momentum buffer, all
+ * 16-byte aligned): torch.optim.SGD(lr, momentum, weight_decay) with dampening 0 and no Nesterov momentum (ref:main.py:59-66;
+ * a zeroed momentum buffer gives torch's first step), d = g + wd p; m = mu m + d; p -= lr m; zero_grads != 0 also clears
+ * the gradients for the next accumulation.  One launch. */
+int pcrcg_sgd_step(float* params, float* grads, float* momentum_buf, long n, float lr, float momentum, float weight_decay,
+                   int zero_grads, void* stream);
 int pcrcg_weighted_bce(const float* prediction, const float* gt, int n, float* out3, float* grad, void* ws, size_t ws_bytes,
                        void* stream);
 

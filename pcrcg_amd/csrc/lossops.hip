@@ -225,6 +225,34 @@ __global__ void k_bce_final(const double* __restrict__ sums, int n, float* __res
     out[2] = sums[3] > 0 ? (float)(sums[1] / sums[3]) : 0.f;       // recall
 }
 
+// ---- SGD with momentum over flat buffers (torch.optim.SGD, dampening 0, no Nesterov; ref:main.py:59-66) ---------------------
+//   d = g + wd * p;  m = mu * m + d;  p = p - lr * m;  optionally g = 0 (the next step's accumulation starts from zero)
+__global__ void __launch_bounds__(256) k_sgd_step(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, long n,
+                                                   float lr, float mu, float wd, int zero_grad) {
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            const float4 pv = *reinterpret_cast<const float4*>(p + i), gv = *reinterpret_cast<const float4*>(g + i);
+            float4 mv = *reinterpret_cast<const float4*>(m + i);
+            float4 out;
+            mv.x = mu * mv.x + (gv.x + wd * pv.x); out.x = pv.x - lr * mv.x;
+            mv.y = mu * mv.y + (gv.y + wd * pv.y); out.y = pv.y - lr * mv.y;
+            mv.z = mu * mv.z + (gv.z + wd * pv.z); out.z = pv.z - lr * mv.z;
+            mv.w = mu * mv.w + (gv.w + wd * pv.w); out.w = pv.w - lr * mv.w;
+            *reinterpret_cast<float4*>(m + i) = mv;
+            *reinterpret_cast<float4*>(p + i) = out;
+            if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (long j = i; j < n; ++j) {
+                const float mj = mu * m[j] + (g[j] + wd * p[j]);
+                m[j] = mj;
+                p[j] -= lr * mj;
+                if (zero_grad) g[j] = 0.f;
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace pcrcg
 
@@ -247,6 +275,21 @@ int pcrcg_circle_loss(const float* a, int lda, const float* b, int ldb, const fl
     hipLaunchKernelGGL(k_circle_lines, dim3(2 * n), dim3(64), 0, st, a, lda, b, ldb, coords_dist, ldc, n, c, cfg, lines);
     hipLaunchKernelGGL(k_circle_grads, dim3(da ? 2 * n : 1), dim3(256), 0, st, a, lda, b, ldb, coords_dist, ldc, n, c, cfg, lines,
                        out2, da, db);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+int pcrcg_sgd_step(float* params, float* grads, float* momentum_buf, long n, float lr, float momentum, float weight_decay,
+                   int zero_grads, void* stream) {
+    PCRCG_CHECK_ARG(n >= 0 && (n == 0 || (params && grads && momentum_buf)));
+    PCRCG_CHECK_ARG(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) % 16 == 0);
+    if (n > 0) {
+        long blocks = (n / 4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_sgd_step, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), params, grads, momentum_buf, n, lr,
+                           momentum, weight_decay, zero_grads);
+    }
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

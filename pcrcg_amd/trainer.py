@@ -25,15 +25,21 @@ class GradientBucket:
     """One flat fp32 buffer holding every parameter's gradient (p.grad are views into it): the whole
     data-parallel exchange of a step is a single all-reduce, and the NaN/Inf check reads one tensor."""
 
+    ALIGN = 64        # floats: every parameter's slice starts on a 256-byte boundary (the kernels' vector loads want 16)
+
+    @classmethod
+    def padded(cls, n):
+        return (n + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
+
     def __init__(self, params, process_group=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
+        self.sizes = [self.padded(p.numel()) for p in self.params]      # slice lengths in the flat buffer (zero padding)
+        self.flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=self.params[0].device)
         off = 0
-        for p in self.params:
+        for p, n in zip(self.params, self.sizes):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+            off += n
 
         self._chunks = None       # overlap mode: [(start, end, n_params)] slices of the flat buffer
         self._armed = False
@@ -49,7 +55,7 @@ class GradientBucket:
         parameter in it has received its gradient, while backward is still running on the earlier layers.
         xGMI is point-to-point and a ring all-reduce is per-link bound (~1.4 ms for the whole
         bucket), so a few large slices, not many small ones."""
-        sizes = [p.numel() for p in self.params]
+        sizes = self.sizes
         total, target = sum(sizes), sum(sizes) / float(n_chunks)
         self._chunks, self._chunk_of = [], {}
         start = acc = count = 0
@@ -116,6 +122,42 @@ class GradientBucket:
         self.flat.zero_()                        # optimizer.zero_grad() would drop the views
 
 
+class FlatSGD(torch.optim.Optimizer):
+    """torch.optim.SGD(lr, momentum, weight_decay) over a model whose parameters and gradients are views of two flat
+    device buffers: the whole step is ONE launch (pcrcg_sgd_step, csrc/lossops.hip) instead of the multi-tensor kernels
+    of torch.optim over 170 tensors, and it clears the gradient bucket on its way.  An ordinary Optimizer otherwise
+    (param_groups carry lr / momentum / weight_decay, so lr schedulers work on it; state_dict holds the momentum buffer)."""
+
+    def __init__(self, params, flat_param, flat_grad, lr, momentum=0.0, weight_decay=0.0):
+        super().__init__(list(params), dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self.flat_param, self.flat_grad = flat_param, flat_grad
+        self.state["flat"] = {"momentum_buffer": torch.zeros_like(flat_param)}
+
+    @staticmethod
+    def flatten(params, sizes):
+        """Move the parameters into one flat fp32 buffer laid out like the gradient bucket (slice lengths `sizes`, zero
+        padding between them; p.data become views of it) -> the buffer."""
+        params = list(params)
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=params[0].device)
+        off = 0
+        for p, size in zip(params, sizes):
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view_as(p)
+            off += size
+        return flat
+
+    @torch.no_grad()
+    def step(self, closure=None, zero_grad=False):
+        from . import _lib
+        g = self.param_groups[0]
+        _lib.check(_lib.lib().pcrcg_sgd_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
+                                             self.state["flat"]["momentum_buffer"].data_ptr(), self.flat_param.numel(),
+                                             float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), int(bool(zero_grad)),
+                                             torch.cuda.current_stream().cuda_stream), "pcrcg_sgd_step")
+        return None
+
+
 class Trainer:
     def __init__(self, model, desc_loss, lr=0.005, momentum=0.98, weight_decay=1e-6, scheduler_gamma=0.95,
                  iter_size=1, process_group=None, overlap_chunks=4, use_cpp_runner=True):
@@ -127,7 +169,15 @@ class Trainer:
             self.bucket.enable_overlap(overlap_chunks)
         self.params = self.bucket.params
         self.flat_grad = self.bucket.flat
-        self.optimizer = torch.optim.SGD(self.params, lr=lr, momentum=momentum, weight_decay=weight_decay)
+        # one-launch SGD over flat parameter / gradient buffers on the GPU (every requires_grad parameter of the model is in
+        # the bucket); torch.optim.SGD elsewhere (CPU runs of the host logic) and for models with frozen parameters mixed in
+        self.flat_param = None
+        if self.params[0].is_cuda and all(p.dtype == torch.float32 and p.is_cuda for p in self.params):
+            self.flat_param = FlatSGD.flatten(self.params, self.bucket.sizes)
+            self.optimizer = FlatSGD(self.params, self.flat_param, self.flat_grad, lr=lr, momentum=momentum,
+                                     weight_decay=weight_decay)
+        else:
+            self.optimizer = torch.optim.SGD(self.params, lr=lr, momentum=momentum, weight_decay=weight_decay)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=scheduler_gamma)
         self.skipped_steps = 0
         self._iter = 0
@@ -202,12 +252,25 @@ class Trainer:
     def optimizer_step(self):
         self.bucket.all_reduce_mean()
         ok = self.gradient_valid()
+        if ok and self.flat_param is not None:
+            self.optimizer.step(zero_grad=True)          # the launch clears the bucket as well
+            self._bump_versions()
+            return ok
         if ok:
             self.optimizer.step()
         else:
             self.skipped_steps += 1
         self.bucket.zero()
         return ok
+
+    def _bump_versions(self):
+        """The flat step changed every parameter under its view: tell the caches that are keyed by tensor versions (the
+        inference runner's weight signature, KPFCNN's temperature cache)."""
+        r = getattr(self.model, "_runner", None)
+        if r is not None and hasattr(r, "invalidate"):
+            r.invalidate()
+        if hasattr(self.model, "_eps_cache"):
+            self.model._eps_cache = None
 
     def train_step(self, inputs):
         """One iteration of the reference's epoch loop for phase 'train' (ref:lib/trainer.py:340-361)."""

@@ -98,7 +98,9 @@ def test_prepared_loss_equals_the_loss(cuda, golden_dir):
         torch.cuda.current_stream().wait_stream(side)
         ahead = {k: float(v) for k, v in loss(inputs, prepared=prepared).items()}
         assert np.random.rand() == after_plain, case
-        assert ahead == plain, case
+        # (the BCE's sums are accumulated with atomics: the last bits may differ from run to run)
+        for k, v in plain.items():
+            assert abs(ahead[k] - v) <= 1e-6 * max(1.0, abs(v)), (case, k, ahead[k], v)
 
 
 def test_metric_loss_is_differentiable(cuda, golden_dir):

@@ -90,6 +90,37 @@ def test_full_model_gradients_match_oracle_autograd(cuda, golden_dir, path):
     assert np.median(list(worst.values())) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
 
 
+def test_flat_sgd_is_torch_sgd(cuda):
+    """trainer.FlatSGD (one launch over the flat parameter / gradient buffers, pcrcg_sgd_step) against torch.optim.SGD with
+    the train loop's hyper-parameters over four steps; the fused gradient clearing; parameter slices 256-byte aligned."""
+    from pcrcg_amd.trainer import FlatSGD, GradientBucket
+    g = torch.Generator().manual_seed(3)
+    shapes = [(7, 5), (1,), (33,), (64, 3, 2), (130,)]
+    ref = [torch.nn.Parameter(torch.randn(*s, generator=g).to(cuda)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    bucket = GradientBucket(mine)
+    flat = FlatSGD.flatten(mine, bucket.sizes)
+    assert all(p.data_ptr() % 256 == 0 and p.grad.data_ptr() % 256 == 0 for p in mine)
+    opt = FlatSGD(mine, flat, bucket.flat, lr=0.005, momentum=0.98, weight_decay=1e-6)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.95)
+    topt = torch.optim.SGD(ref, lr=0.005, momentum=0.98, weight_decay=1e-6)
+    tsched = torch.optim.lr_scheduler.ExponentialLR(topt, gamma=0.95)
+    for step in range(4):
+        for p, q in zip(ref, mine):
+            gr = torch.randn(p.shape, generator=g).to(cuda)
+            p.grad = gr.clone()
+            q.grad.copy_(gr)
+        topt.step()
+        opt.step(zero_grad=(step % 2 == 0))
+        if step % 2 == 0:
+            assert float(bucket.flat.abs().sum()) == 0.0
+        tsched.step()
+        sched.step()
+        for p, q in zip(ref, mine):
+            assert float((p.data - q.data).abs().max()) <= 1e-6 * float(p.data.abs().max()), step
+    assert "momentum_buffer" in opt.state_dict()["state"]["flat"]
+
+
 def test_weight_gradients_on_the_second_stream_equal_one_stream(cuda, golden_dir):
     """train_side_stream (default on): the backward's weight-gradient products run on a second stream; same gradients as
     with everything on one stream, and complete when backward() returns to the caller's stream."""
