@@ -34,6 +34,51 @@ __global__ void __launch_bounds__(256, 4) k_stream_pairs(const float* __restrict
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = 1.f;
 }
 
+// L2-resident variant: 1024+ workgroups re-read the same 512 rows (3.9 MB at K = 1920: every line is an L2 hit after the
+// first touch): what the L2 -> L1 fill path delivers per CU with D tile-steps of 64 rows x 128 B in flight per workgroup
+template <int D, int WGS_PER_CU>
+__global__ void __launch_bounds__(256, WGS_PER_CU) k_stream_l2(const float* __restrict__ A, int K, float* __restrict__ out) {
+    const int m0 = (blockIdx.x & 7) * 64, tid = threadIdx.x;
+    const int ksteps = K / 32;
+    f4 r[D][2];
+    f4 acc = {0, 0, 0, 0};
+    const float* base = A + (long)(m0 + (tid >> 2)) * K + (tid & 3) * 8;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float* p = base + (long)min(d, ksteps - 1) * 32;
+        r[d][0] = *reinterpret_cast<const f4*>(p);
+        r[d][1] = *reinterpret_cast<const f4*>(p + 4);
+    }
+    for (int rep = 0; rep < 4; ++rep)
+        for (int s = 0; s < ksteps; s += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                acc += r[d][0] + r[d][1];
+                const float* p = base + (long)((s + d + D) % ksteps) * 32;
+                r[d][0] = *reinterpret_cast<const f4*>(p);
+                r[d][1] = *reinterpret_cast<const f4*>(p + 4);
+            }
+        }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = 1.f;
+}
+
+template <int D, int W>
+void run_l2(const float* A, int K, float* out) {
+    const int grid = 256 * W;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) k_stream_l2<D, W><<<grid, 256>>>(A, K, out);
+    hipEventRecord(a);
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) k_stream_l2<D, W><<<grid, 256>>>(A, K, out);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double us = ms * 1e3 / reps, bytes = (double)grid * 4 * K * 64 * 4;
+    printf("L2-resident rows, %d workgroups per CU, depth %d: %7.1f us  %6.2f TB/s of L1 fills = %5.1f bytes per clock and CU (2.4 GHz)\n",
+           W, D, us, bytes / us / 1e6, bytes / us / 1e6 * 1e12 / 256 / 2.4e9);
+}
+
 template <int RB, int D>
 __global__ void __launch_bounds__(256, 4) k_stream(const float* __restrict__ A, int M, int K, float* __restrict__ out) {
     constexpr int F4_PER_ROW = RB / 16;               // float4 per row and step
@@ -105,6 +150,8 @@ int main() {
     hipMalloc(&A, (size_t)60000 * 3840 * 4);
     hipMalloc(&out, 4);
     hipMemset(A, 0, (size_t)60000 * 3840 * 4);
+    run_l2<2, 1>(A, 1920, out); run_l2<2, 2>(A, 1920, out); run_l2<2, 4>(A, 1920, out); run_l2<4, 4>(A, 1920, out);
+    run_l2<2, 8>(A, 1920, out); run_l2<4, 8>(A, 1920, out);
     for (auto& s : shapes) {
         run_pairs<2>(A, s[0], s[1], out);
         run_pairs<3>(A, s[0], s[1], out);
