@@ -21,7 +21,10 @@ worker spent 1.7 ms of interpreter time per pair.
     eng.submit(points, lengths); ...; out = eng.result()      # results come back in submission order
 
 The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): set GPU_MAX_HW_QUEUES=8
-before the first HIP call (bench.py does)."""
+before the first HIP call (bench.py does).  ONE engine per process and device: the GPU schedules four queues at a time,
+which this engine's four streams use up; a second engine -- even the closed, not yet collected one of an earlier
+measurement -- puts more streams on the same queues and both slow down (measured: a fresh engine 453 pairs/s, the third
+one created in the same process 355).  Reuse the engine (set_up_nearest() exists for that reason)."""
 import queue
 import threading
 import time
