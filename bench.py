@@ -6,9 +6,15 @@ resident in HBM -> point pyramid (3 grid subsamplings, 10 radius searches) -> KP
 per-point descriptors / overlap / saliency.  Independent pairs shard across ranks with no data-path
 collective: weak scaling, one pair per rank per step.
 
-  python bench.py --gpus 1 --steps 20 --warmup 3 [--repeats 5]
+  python bench.py --gpus N --steps 20 --warmup 3 [--repeats 5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+
+Without a rank environment `--gpus N` (N > 1) makes this process a parent that never touches the GPU: it starts N
+fresh rank processes (pcrcg_amd/launcher.py: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, one CPU set per rank near its
+GPU), and relays rank 0's line; N above the visible device count exits non-zero.  Under torch.distributed.run the
+script is a rank as before.  `--launcher-dry-run` runs the same N-rank protocol over gloo with a stand-in workload
+on the CPU (tests/test_launcher_cpu.py).
 
 Rank 0 prints ONE JSON line.  The timed region -- exactly --steps steps between two barrier + synchronize fences,
 starting and ending with an empty engine, MAX over ranks -- is run --repeats times back to back; `value` is the MEDIAN
@@ -29,12 +35,35 @@ import time
 # one and serialise (measured: 260 vs 338 pairs/s).  Must be set before the first HIP call.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+
+from pcrcg_amd import launcher  # noqa: E402  (host logic only: no torch, no HIP)
+
+
+def _flag_value(argv, name, default):
+    for i, a in enumerate(argv):
+        if a == name and i + 1 < len(argv):
+            return argv[i + 1]
+        if a.startswith(name + "="):
+            return a.split("=", 1)[1]
+    return default
+
+
+if __name__ == "__main__":
+    # BEFORE anything that could initialise the GPU: the parent of an N-rank run only starts children and relays
+    try:
+        _n = int(_flag_value(sys.argv[1:], "--gpus", "1"))
+    except ValueError:
+        _n = 1
+    if launcher.is_parent(_n):
+        sys.exit(launcher.launch(os.path.abspath(__file__), sys.argv[1:], _n,
+                                 dry_run="--launcher-dry-run" in sys.argv[1:]))
+RANK_CPUS = launcher.apply_rank_affinity()      # a rank started by the launcher: the CPU set planned for its GPU
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from pcrcg_amd import indoor_config, kitti_config, ops, synthetic  # noqa: E402
 from pcrcg_amd.architectures import KPFCNN  # noqa: E402
@@ -193,6 +222,57 @@ def gemm_by_shape(events, forwards):
     return sorted(rows, key=lambda r: -r["us_per_forward"])
 
 
+def dry_run_main(args, rank, world):
+    """--launcher-dry-run: the N-rank protocol of this file -- process group from the launcher's environment, fences,
+    EXACTLY --steps steps per region, MAX over ranks, rank 0's single line with `ranks_seen` and per-rank values --
+    over gloo on the CPU.  The stand-in step is a digest of the rank's own synthetic pair (sharding as in the real
+    run); the line says `dry_run: true` and is not a measurement."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29518")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    seeds = pair_seeds_for_rank(args.warmup + args.steps * max(1, args.repeats), rank, world)
+    cursor, digest = [0], [0.0]
+
+    def step():
+        src, tgt = synthetic.pair("mini", seeds[cursor[0] % len(seeds)])
+        cursor[0] += 1
+        digest[0] += float(src.sum() + tgt.sum())
+
+    for _ in range(args.warmup):
+        step()
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        dist.barrier()
+        own = time.perf_counter() - t0
+        t = torch.tensor([own], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        regions.append((float(t.item()), own))
+    times = sorted(r[0] for r in regions)
+    elapsed = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
+    own = sorted(r[1] for r in regions)[len(regions) // 2]
+    per_rank = launcher.rank_fields(dist, world, rank, round(args.steps / own, 3), RANK_CPUS)
+    seen_seeds = [None] * world
+    dist.all_gather_object(seen_seeds, seeds[:args.steps])
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "fragment-pairs/s KPFCNN+GCN fwd, 30k-pt pairs", "value": round(args.steps * world / elapsed, 3),
+            "unit": "fragment-pairs/s", "n_gpus": world, "ranks_seen": per_rank["ranks_seen"],
+            "per_rank_pairs_per_s": per_rank["per_rank_value"], "per_rank_cpus": per_rank["per_rank_cpus"],
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dry_run": True,
+            "config": {"workload": "launcher dry run: stand-in CPU step (digest of the rank's own `mini` pair) over gloo; "
+                                   "NOT a measurement",
+                       "parallelism": f"pairs sharded over {world} rank(s), no data-path collective",
+                       "pair_seeds_first_region": seen_seeds}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,6 +301,9 @@ def main():
     ap.add_argument("--variant", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: the bf16 feature-storage VARIANT (pcrcg_model.feature_bf16) -- a separate line with its "
                          "measured error against the fp32 path; never the headline")
+    ap.add_argument("--launcher-dry-run", action="store_true",
+                    help="the N-rank protocol (launcher, process group, fences, MAX over ranks, rank 0's line) over gloo "
+                         "on the CPU with a stand-in workload: what tests/test_launcher_cpu.py runs; never a measurement")
     args = ap.parse_args()
     global RECIPE, INPUT_ORDER
     RECIPE = args.workload
@@ -229,6 +312,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; n_gpus reports the ranks that exist" % (args.gpus, world),
+              file=sys.stderr)
+    if args.launcher_dry_run:
+        return dry_run_main(args, rank, world)
+    if local >= torch.cuda.device_count():
+        print("bench.py: rank %d wants device %d, %d visible" % (rank, local, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -350,7 +441,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), submit
+        return float(t.item()), submit, elapsed
 
     # ---- headline: the reference's batch contract inside the engine too (full [N, limit] upsample tables) ----------
     pipe = PairStreams(net, cfg, limits, dev, model_streams=WORKERS, front_threads=FRONTS, up_nearest=False,
@@ -367,6 +458,8 @@ def main():
     regions = [region(pipe) for _ in range(R)]
     events = ops.kpconv_profile_stop()
     stats = pipe.stats_snapshot()
+    own = sorted(r[2] for r in regions)[len(regions) // 2]      # this rank's own clock, median region
+    per_rank = launcher.rank_fields(dist if world > 1 else None, world, rank, round(args.steps / own, 3), RANK_CPUS)
     times = sorted(r[0] for r in regions)
     elapsed = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
     submit = sorted(r[1] for r in regions)[len(regions) // 2]
@@ -376,12 +469,12 @@ def main():
     if not args.no_extras:
         # (a) the GEMM family inside the engine: one more region with start / stop events on every GEMM launch as well
         ops.kpconv_profile_start(gemm=True)
-        t_g, _ = region(pipe)
+        t_g = region(pipe)[0]
         gemm_engine = gemm_roofline(ops.kpconv_profile_stop(), args.steps)
         if gemm_engine:
             gemm_engine["pairs_per_s_of_this_region"] = round(args.steps * world / t_g, 1)
         # (b) inputs in pinned host memory, uploaded inside the clock (SURVEY.md 8d's hand-over; PCIe-inclusive)
-        t_h, _ = region(pipe, from_host=True)
+        t_h = region(pipe, from_host=True)[0]
         extras["pinned_host_inputs"] = {"value": round(args.steps * world / t_h, 3), "unit": "fragment-pairs/s",
                                         "note": "one region; every pair's points + lengths (720 KB) copied from pinned host "
                                                 "memory inside the timed region; reported beside `value`, never as it"}
@@ -453,6 +546,9 @@ def main():
             "value": round(args.steps * world / elapsed, 3),
             "unit": "fragment-pairs/s",
             "n_gpus": world,
+            "ranks_seen": per_rank["ranks_seen"],
+            "per_rank_pairs_per_s": per_rank["per_rank_value"],
+            "per_rank_cpus": per_rank["per_rank_cpus"],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
