@@ -44,7 +44,7 @@ int pcrcg_abi_version(void);
  * read once from the environment variable PCRCG_DEBUG at first use; nothing else in the library reads the environment
  * except PCRCG_GEMM_MODE (pcrcg_gemm_set_mode).  Every switch defaults to the product behaviour:
  *   zero_arena=1 stat_sums=1 stat_sums_rows=2^30 fuse_norm=1 fuse_pack=1 fuse_upsample=1   network runner fusions
- *   radius_blocks=0 radius_eager_redo=0 pyr_wait=1 pyr_trace=0 kd_spin_limit=0            front end
+ *   radius_blocks=0 radius_eager_redo=0 radius_cells=1 radius_prof=0 pyr_wait=1 pyr_trace=0 kd_spin_limit=0   front end
  *   att_tq=16                                                                              attention tile
  *   gemm_log=0 x6_tile=-1 x6_splitk=0 x6_t1=200 x6_t2=1024 x6_order=-1 x6_big=0 gemm_tile=-1 gemm_splitk=0 gemm_split_target=768   GEMM plans
  *   train_side_stream=1                                                                    train-step backward
@@ -115,6 +115,18 @@ int pcrcg_radius_query_ex(const float* q, int nq, const int* qlen, int ns, const
 int pcrcg_radius_query_groups(const float* q, int nq, const int* qlen, int ns, const int* slen, int nb, int group,
                               float radius, const void* grid, int cols, int64_t* out_idx, int* out_count,
                               int* out_max_count, int* status, int* out_tie_rows, int* out_tie_count, void* stream);
+/* The CELL-COOPERATIVE search (round 4; the kernel the pyramid builder uses): the queries are walked cell by cell through
+ * a grid of their own, `qgrid` = pcrcg_cellgrid_build over the QUERY points (any radius: it only sets the size of the
+ * query cells; a level's conv grid serves), nb clouds matching the support grid's.  One workgroup per occupied query cell
+ * resolves the hash probes of the support cells within reach once, stages their candidates and the cell's queries in LDS,
+ * and its wavefronts answer the cell's queries from LDS -- same result set, order, padding, counts, tie rows and group
+ * semantics as pcrcg_radius_query_groups, row for row (replaces the hot loop of
+ * ref:cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:268-301 and :319-325).  Rows of more than 256 hits and cells
+ * whose neighbourhood exceeds the staging capacity are finished by the per-query kernel inside the same call
+ * (status bit 4 is set and cleared on the way; q / qlen / slen are what that pass reads). */
+int pcrcg_radius_query_cells(const void* qgrid, const float* q, int nq, const int* qlen, const void* sgrid, int ns,
+                             const int* slen, int nb, int group, float radius, int cols, int64_t* out_idx, int* out_count,
+                             int* out_max_count, int* status, int* out_tie_rows, int* out_tie_count, void* stream);
 /* Convenience: zero out_max_count/status, build the grid in `ws`, run one query. */
 size_t pcrcg_radius_neighbors_ws_bytes(int ns, int nb);
 int pcrcg_radius_neighbors_batch(const float* q, int nq, const float* sup, int ns, const int* qlen,

@@ -39,6 +39,8 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcrcg_radius_query_groups": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcrcg_radius_query_cells": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_float,
+                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcrcg_kdforest_ws_bytes": (c_size_t, [c_int, c_int]),
     "pcrcg_kdforest_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "pcrcg_radius_reorder": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,

@@ -35,10 +35,14 @@ def batch_query(queries, supports, q_batches, s_batches, *, radius=0.1, tie_orde
     if tie_order not in ("auto", "index"):
         raise ValueError("pcrcg_amd: tie_order must be 'auto' or 'index'")
     want_ties = tie_order == "auto"
-    res = grid.query(q, qb, _FIRST_GUESS_COLS, want_ties=want_ties)
+    # the queries walk a cell grid of their own (the supports' when the call is a self query): the cell-cooperative,
+    # LDS-staged search (csrc/radius.hip: k_radius_cells)
+    same = q.data_ptr() == s.data_ptr() and q.shape == s.shape and torch.equal(qb, sb)
+    qgrid = grid if same else (ops.CellGrid(q, qb, float(radius)) if q.shape[0] > 0 else None)
+    res = grid.query(q, qb, _FIRST_GUESS_COLS, want_ties=want_ties, query_grid=qgrid)
     max_count, status, n_ties = (int(v) for v in res[1].tolist())
     if max_count > _FIRST_GUESS_COLS and status == 0:
-        res = grid.query(q, qb, max_count, want_ties=want_ties)
+        res = grid.query(q, qb, max_count, want_ties=want_ties, query_grid=qgrid)
         max_count, status, n_ties = (int(v) for v in res[1].tolist())
     if status != 0:
         raise RuntimeError("pcrcg_amd: radius search capacity exceeded (status %d)" % status)

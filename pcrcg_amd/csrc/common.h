@@ -52,6 +52,12 @@ int radius_query_pass(const float* q, int nq, const int* qlen, int ns, const int
                       const void* grid, int cols, int64_t* out_idx, int* out_count, int* out_max_count, int* status,
                       int* out_tie_rows, int* out_tie_count, hipStream_t st, int pass);
 
+// radius.hip: the cell-cooperative search over a query grid (pass 0: + the per-query second pass, 1: the cell kernel only)
+int radius_cells_pass(const void* qgrid, const float* q, int nq, const int* qlen, const void* sgrid, int ns, const int* slen,
+                      int nb, int group, float radius, int cols, int64_t* out_idx, int* out_count, int* out_max_count,
+                      int* status, int* out_tie_rows, int* out_tie_count, hipStream_t st, int pass);
+constexpr int kRadiusRedoStatus = 4;   // status bit: rows were handed to the per-query second pass (cleared by that pass)
+
 // gemm_x6.hip: optional extras of a C = A * B^T product (the decoder's fused upsample + concat, runner.hip)
 struct GemmExtra {
     const long long* a_idx = nullptr;   // != NULL: output row r reads A row a_idx[r * a_idx_ld] (first column of a table)
@@ -109,6 +115,8 @@ struct DebugOpts {
     int fuse_upsample = 1;     // runner: nearest_upsample -> cat(skip) -> unary as two products into one output
     int radius_blocks = 0;     // radius search grid (0: 512 workgroups)
     int radius_eager_redo = 0; // pyramid builder: launch the >256-hit redo pass unconditionally
+    int radius_prof = 0;       // cell-cooperative search: per-phase shader-cycle counters, printed at exit (measurement aid)
+    int radius_cells = 1;      // pyramid builder: cell-cooperative LDS-staged search (0: the per-query kernel of rounds 1-3)
     int pyr_wait = 1;          // pyramid builder host round trip: 0 stream sync, 1 event, 2 device-posted flag
     int pyr_trace = 0;         // pyramid builder: host enqueue / wait microseconds at exit
     int att_tq = 16;           // attention kernel: queries per workgroup (8 or 16)

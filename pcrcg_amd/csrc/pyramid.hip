@@ -133,6 +133,7 @@ struct TableRec {
     int nq, limit, sup_level;
     float radius;
     const void* grid;      // cell grid of the supports, their count and cloud lengths (for the redo pass)
+    const void* qgrid;     // a cell grid over the QUERIES (any cell size), or null: the cell-cooperative search walks it
     int ns;
     const int* slen;
 };
@@ -173,8 +174,9 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
         PCRCG_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(feats), 0x3f800000, (size_t)(n0 > 0 ? n0 : 1), st));
     }
 
-    auto add_table = [&](int kind, int level, int q_level, const void* grid, float radius, const float* q, const int* qlen,
-                         int nq, int ns, const int* slen, int limit, int sup_level) -> int {
+    const bool use_cells = debug_opts().radius_cells != 0;
+    auto add_table = [&](int kind, int level, int q_level, const void* grid, const void* qgrid, float radius, const float* q,
+                         const int* qlen, int nq, int ns, const int* slen, int limit, int sup_level) -> int {
         TableRec t;
         t.kind = kind; t.level = level; t.q_level = q_level;
         t.idx = A.take<int64_t>((size_t)nq * limit);
@@ -182,11 +184,15 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
         t.ties = want_ties ? A.take<int>((size_t)nq) : nullptr;
         t.meta = metas + MS * tables.size();
         t.q = q; t.qlen = qlen; t.nq = nq; t.limit = limit; t.sup_level = sup_level; t.radius = radius;
-        t.grid = grid; t.ns = ns; t.slen = slen;
+        t.grid = grid; t.ns = ns; t.slen = slen; t.qgrid = use_cells ? qgrid : nullptr;
         if (!A.ok()) return PCRCG_EWORKSPACE;
-        // first pass only: rows with more than 256 hits are marked and counted; whether any table has one is known
+        // first pass only: rows with more than 256 hits (and, from the cell-cooperative search, rows of a cell whose
+        // neighbourhood does not fit LDS) are marked and announced in the metadata; whether any table has one is known
         // with the metadata round trip below, and only then (normally never) the redo pass runs
-        if (!dry)
+        if (!dry && t.qgrid)
+            PCRCG_PROPAGATE(radius_cells_pass(t.qgrid, q, nq, qlen, grid, ns, slen, nb, group, radius, limit, t.idx, t.counts,
+                                              t.meta, t.meta + P, t.ties, want_ties ? t.meta + P + 1 : nullptr, st, eager ? 0 : 1));
+        else if (!dry)
             PCRCG_PROPAGATE(radius_query_pass(q, nq, qlen, ns, slen, nb, group, radius, grid, limit, t.idx, t.counts, t.meta,
                                               t.meta + P, t.ties, want_ties ? t.meta + P + 1 : nullptr, st, eager ? 0 : 1));
         tables.push_back(t);
@@ -217,7 +223,7 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
         if (cfg->has_conv[l]) {
             if (carried && carried_r == r_conv) { grid = carried; grid_r = carried_r; }
             else { PCRCG_PROPAGATE(build_grid(pts, n, lens, r_conv, &grid)); grid_r = r_conv; }
-            PCRCG_PROPAGATE(add_table(0, l, l, grid, r_conv, pts, lens, n, n, lens, limit, l));
+            PCRCG_PROPAGATE(add_table(0, l, l, grid, grid, r_conv, pts, lens, n, n, lens, limit, l));
         }
         carried = nullptr;
         if (cfg->pooled[l] && l + 1 < L) {
@@ -243,10 +249,12 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
                 PCRCG_PROPAGATE(build_grid(pts, n, lens, r_pool, &grid));
                 grid_r = r_pool;
             }
-            PCRCG_PROPAGATE(add_table(1, l, l + 1, grid, r_pool, sub, sub_len, m, n, lens, limit, l));
+            // the coarse level's grid first: it is the upsample table's support grid, the next level's conv grid AND the
+            // query grid of the pool table (every query set of the pyramid walks a grid of its own, cell by cell)
             void* up_grid = nullptr;
             PCRCG_PROPAGATE(build_grid(sub, m, sub_len, 2 * r_pool, &up_grid));
-            PCRCG_PROPAGATE(add_table(2, l, l, up_grid, 2 * r_pool, pts, lens, n, m, sub_len, cfg->up_nearest ? 1 : limit, l + 1));
+            PCRCG_PROPAGATE(add_table(1, l, l + 1, grid, up_grid, r_pool, sub, sub_len, m, n, lens, limit, l));
+            PCRCG_PROPAGATE(add_table(2, l, l, up_grid, grid, 2 * r_pool, pts, lens, n, m, sub_len, cfg->up_nearest ? 1 : limit, l + 1));
             carried = up_grid;
             carried_r = 2 * r_pool;
             pts = sub;
@@ -269,7 +277,8 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
         for (int i = 0; i < nt; ++i) {
             int widest = 0;
             for (int p = 0; p < P; ++p) widest = hm[MS * i + p] > widest ? hm[MS * i + p] : widest;
-            if (widest <= radius_fast_cap() || eager) continue;
+            const bool handed_over = (hm[MS * i + P] & kRadiusRedoStatus) != 0;     // (the redo pass clears the bit)
+            if ((widest <= radius_fast_cap() && !handed_over) || eager) continue;
             const TableRec& t = tables[i];
             PCRCG_PROPAGATE(radius_query_pass(t.q, t.nq, t.qlen, t.ns, t.slen, nb, group, t.radius, t.grid, t.limit, t.idx,
                                               t.counts, t.meta, t.meta + P, t.ties, want_ties ? t.meta + P + 1 : nullptr, st,

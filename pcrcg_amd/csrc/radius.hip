@@ -10,11 +10,17 @@
 //           (one 64-bit CAS) + in-cell position; per occupied slot a start offset from one global
 //           cursor; scatter supports as float4 (x,y,z,index) so that a cell is one contiguous,
 //           16-byte-aligned run (coalesced reads)
-//   query : lanes 0..26 probe the 27 neighbouring cells; the candidate runs are concatenated with a
-//           wave prefix sum and swept 64 candidates at a time; hits (d2 < r2, the reference's exact
-//           fp32 arithmetic) are compacted into LDS with ballot/popcount; a rank sort over the
-//           (d2, index) keys in LDS writes the row in ascending order, truncated to `cols` and padded
-//           with ns (:319-325).
+//   query : CELL-COOPERATIVE (k_radius_cells, round 4): the queries are taken cell by cell from a grid of their own
+//           (in the pyramid every query set already has one); one workgroup per occupied query cell resolves the
+//           hash probes of the support cells within reach ONCE (27 for a conv / upsample table, 64 for a pool table),
+//           stages their candidate runs and the cell's queries in LDS, and every wavefront then runs queries of the
+//           cell against LDS: hits (d2 < r2, the reference's exact fp32 arithmetic) are compacted with
+//           ballot/popcount, a rank sort over the (d2, index) keys writes the row in ascending order, truncated to
+//           `cols` and padded with ns (:319-325).  ~14 queries share a cell at S30k: the probe -> slot -> run ->
+//           gather chain of dependent global loads is paid once per cell instead of once per query.
+//           PER-QUERY (k_radius_query, rounds 1-3): one wavefront per query probes its own 27 cells and gathers its
+//           candidates from global memory; it serves query sets that have no grid, and as the second pass
+//           (REDO) the rows the cell kernel hands over (more than 256 hits, or a neighbourhood that does not fit LDS).
 //
 // Squared distances follow nanoflann's L2_Simple_Adaptor (zip:cpp_utils/nanoflann/nanoflann.hpp:
 // 432-440): ((0 + dx*dx) + dy*dy) + dz*dz with every product and sum rounded to fp32, strict
@@ -37,28 +43,45 @@ constexpr long long kRedoMark = -2;   // row[0] marker: list did not fit the fir
 constexpr int kQueryWaves = 4;        // waves (= queries in flight) per workgroup
 constexpr int kTieCap = 256;          // tie rows staged per workgroup before they go to the global list
 
+constexpr int kRedoStatus = 4;        // status bit: the cell kernel left rows to the per-query second pass
+constexpr int kCellCand = 1024;       // candidates staged per query cell (16 KiB; a level subsampled at dl = r / 2.5 holds
+                                      // at most 15.6 points per cell: 27 cells 421, the 64 cells of a pool table 1000 in a
+                                      // solid volume, ~225 on scanned surfaces)
+constexpr int kCellListCap = 128;     // hits staged per query by the cell kernel (longer rows: second pass)
+constexpr int kCellTieCap = 128;      // tie rows staged per workgroup of the cell kernel
+constexpr int kCellMaxCells = 256;    // support cells within reach of one query cell
+constexpr int kCellQ = 64;            // queries of a cell staged per batch
+
 struct GridHeader {   // first 256 bytes of the grid workspace
     double inv_cell;  // 1 / (radius * (1 + 1e-5)): cells are a hair wider than the radius
     int ns, nb;
-    int cursor;       // bump allocator for cell runs
+    u64 cursor;       // low word: bump allocator for cell runs; high word: occupied cells listed so far (ONE atomic)
     int overflow;     // coordinate range exceeded
+    int qhead[8], qdone[8];   // k_radius_cells walking THIS grid as its query grid: ticket counters / workgroups that
+                              // have left, one pair per shard (workgroup index mod 8 = its XCD)
+};
+
+struct Slot {         // one 16-byte record per hash slot: a probe is ONE load
+    u64 key;
+    int cnt, start;
 };
 
 struct GridView {
     GridHeader* hdr;
     int* soff;     // [nb+1]
-    u64* tkey;     // [2*ns + 2]
-    int* tcnt;     // [2*ns + 2]
-    int* tstart;   // [2*ns + 2]
+    Slot* tab;     // [2*ns + 2]
     int* slot_of;  // [ns]
     int* pos_in;   // [ns]
-    float4* spts;  // [ns]
+    float4* spts;  // [ns]  supports cell by cell as (x, y, z, index)
+    u64* ckey;     // [ns]  occupied cells, compact (any order): key ...
+    int4* cinfo;   // [ns]  ... and (count, start of the run in spts, cloud, slot)
 };
 
 inline size_t grid_bytes(int ns, int nb) {
     const size_t N = (size_t)(ns > 0 ? ns : 0) + 1;
-    return carve_bytes(1, 256) + carve_bytes((size_t)nb + 1, sizeof(int)) + carve_bytes(2 * N, sizeof(u64)) +
-           2 * carve_bytes(2 * N, sizeof(int)) + 2 * carve_bytes(N, sizeof(int)) + carve_bytes(N, sizeof(float4));
+    return carve_bytes(1, 256) + carve_bytes((size_t)nb + 1, sizeof(int)) + carve_bytes(2 * N, sizeof(Slot)) +
+           2 * carve_bytes(N, sizeof(int)) + carve_bytes(N, sizeof(float4)) + carve_bytes(N, sizeof(u64)) +
+           carve_bytes(N, sizeof(int4));
 }
 
 inline GridView grid_view(void* ws, size_t bytes, int ns, int nb, bool* ok) {
@@ -67,14 +90,23 @@ inline GridView grid_view(void* ws, size_t bytes, int ns, int nb, bool* ok) {
     GridView g;
     g.hdr = reinterpret_cast<GridHeader*>(cv.take<char>(256));
     g.soff = cv.take<int>((size_t)nb + 1);
-    g.tkey = cv.take<u64>(2 * N);
-    g.tcnt = cv.take<int>(2 * N);
-    g.tstart = cv.take<int>(2 * N);
+    g.tab = cv.take<Slot>(2 * N);
     g.slot_of = cv.take<int>(N);
     g.pos_in = cv.take<int>(N);
     g.spts = cv.take<float4>(N);
+    g.ckey = cv.take<u64>(N);
+    g.cinfo = cv.take<int4>(N);
     *ok = cv.ok();
     return g;
+}
+
+__device__ __forceinline__ Slot load_slot(const Slot* p) {     // one global_load_dwordx4
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    Slot s;
+    s.key = (u64)v.x | ((u64)v.y << 32);
+    s.cnt = (int)v.z;
+    s.start = (int)v.w;
+    return s;
 }
 
 __device__ __forceinline__ unsigned mix32(u64 x) {
@@ -114,13 +146,12 @@ __global__ void __launch_bounds__(256) k_grid_init(GridView g, const int* __rest
         g.hdr->inv_cell = inv_cell;
         g.hdr->ns = ns;
         g.hdr->nb = nb;
-        g.hdr->cursor = 0;
+        g.hdr->cursor = 0ull;
         g.hdr->overflow = 0;
+        for (int k = 0; k < 8; ++k) { g.hdr->qhead[k] = 0; g.hdr->qdone[k] = 0; }
     }
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (long)gridDim.x * blockDim.x) {
-        g.tkey[i] = kEmptyKey;
-        g.tcnt[i] = 0;
-    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (long)gridDim.x * blockDim.x)
+        *reinterpret_cast<uint4*>(&g.tab[i]) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
 }
 
 __global__ void __launch_bounds__(256) k_grid_insert(const float* __restrict__ sup, int ns, int nb, GridView g) {
@@ -135,26 +166,34 @@ __global__ void __launch_bounds__(256) k_grid_insert(const float* __restrict__ s
     const long tbase = 2l * g.soff[b];
     unsigned s = __umulhi(mix32(key), tsize);
     for (;;) {
-        u64 prev = atomicCAS(&g.tkey[tbase + s], kEmptyKey, key);
+        u64 prev = atomicCAS(&g.tab[tbase + s].key, kEmptyKey, key);
         if (prev == kEmptyKey || prev == key) break;
         s = s + 1 == tsize ? 0 : s + 1;
     }
     const int slot = (int)(tbase + s);
     g.slot_of[i] = slot;
-    g.pos_in[i] = atomicAdd(&g.tcnt[slot], 1);
+    g.pos_in[i] = atomicAdd(&g.tab[slot].cnt, 1);
 }
 
-__global__ void __launch_bounds__(256) k_grid_starts(int nslots, GridView g) {
+// run start of every occupied slot + the compact list of occupied cells (what the cell-cooperative search walks): one
+// 64-bit atomic hands out both the run's offset (low word) and the cell's list position (high word)
+__global__ void __launch_bounds__(256) k_grid_starts(int nslots, int nb, GridView g) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nslots) return;
-    const int c = g.tcnt[s];
-    if (c > 0) g.tstart[s] = atomicAdd(&g.hdr->cursor, c);
+    const int c = g.tab[s].cnt;
+    if (c > 0) {
+        const u64 got = atomicAdd(&g.hdr->cursor, (1ull << 32) | (u64)(unsigned)c);
+        const int start = (int)(unsigned)got, j = (int)(got >> 32);
+        g.tab[s].start = start;
+        g.ckey[j] = g.tab[s].key;
+        g.cinfo[j] = make_int4(c, start, cloud_of(g.soff, nb, s >> 1), s);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_grid_scatter(const float* __restrict__ sup, int ns, GridView g) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ns) return;
-    const int dst = g.tstart[g.slot_of[i]] + g.pos_in[i];
+    const int dst = g.tab[g.slot_of[i]].start + g.pos_in[i];
     g.spts[dst] = make_float4(sup[3 * (long)i], sup[3 * (long)i + 1], sup[3 * (long)i + 2], __int_as_float(i));
 }
 
@@ -191,7 +230,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
     auto flush_max = [&]() {   // one contended word per group: only the few waves that actually raise the maximum issue an atomic
         if (lane == 0 && wave_max > aload(out_max + wave_grp)) atomicMax(out_max + wave_grp, wave_max);
     };
-    if (REDO && blockIdx.x == 0 && threadIdx.x == 0 && g.hdr->overflow && status) *status = 2;
+    if (REDO && blockIdx.x == 0 && threadIdx.x == 0 && status) {
+        atomicAnd(status, ~kRedoStatus);        // this pass takes every row the cell kernel handed over
+        if (g.hdr->overflow) atomicOr(status, 2);
+    }
     auto one_query = [&](const int qi) {
         // cloud of this query: walk the (few) query lengths
         int b = 0, qacc = 0;
@@ -219,10 +261,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
                 // key, count and start of the slot in ONE round trip (count / start of a foreign or empty slot are
                 // loaded and dropped): the lookup is a chain of dependent global loads, and that latency -- not
                 // bandwidth -- is what a query costs
-                const u64 k = g.tkey[tbase + s];
-                const int kc = g.tcnt[tbase + s], ks = g.tstart[tbase + s];
-                if (k == key) { ccount = kc; cstart = ks; break; }
-                if (k == kEmptyKey) break;
+                const Slot sl = load_slot(&g.tab[tbase + s]);
+                if (sl.key == key) { ccount = sl.cnt; cstart = sl.start; break; }
+                if (sl.key == kEmptyKey) break;
                 s = s + 1 == tsize ? 0 : s + 1;
             }
         }
@@ -341,7 +382,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
         }
         if (lane == 0) {
             if (out_count) out_count[qi] = nhit;
-            if (((fill > CAP) || !inrange) && status) *status = 1;   // (fill > CAP: more columns asked for than the list can select)
+            if (((fill > CAP) || !inrange) && status) atomicOr(status, 1);   // (fill > CAP: more columns asked for than the list can select)
         }
         wave_max = nhit > wave_max ? nhit : wave_max;
         __builtin_amdgcn_wave_barrier();
@@ -368,6 +409,366 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
         if (threadIdx.x == 0 && n > 0) s_tie_base = atomicAdd(tie_count, n);
         __syncthreads();
         for (int j = threadIdx.x; j < n; j += WAVES * 64) tie_rows[s_tie_base + j] = s_tie[j];
+    }
+}
+
+
+// ---- cell-cooperative search --------------------------------------------------------------------------------------
+// One workgroup per occupied cell of the QUERY grid gq (any cell size; in the pyramid the query set's own conv grid).
+// Every support within the radius of a query of that cell lies in the cells of the support grid gs that the query cell,
+// grown by `reach` = radius * (1 + 1e-6), overlaps (fp32 rounding lets d2 < r*r pass for a true distance of at most
+// radius * (1 + 2e-7)): 3x3x3 cells when both grids have the search radius as cell edge (conv), 4x4x4 when the query
+// cells are twice as large (pool), 3x3x3 when they are half as large (upsample).
+//   wave 0      : the cell range, one hash probe per support cell (a lane each), wave prefix sum of the run lengths;
+//                 then the NEXT cell's record and ticket are requested (they arrive during the query phase)
+//   waves 1..   : meanwhile the cell's queries -> LDS
+//   all threads : the candidate runs -> LDS (float4 records; P threads side by side take the P cells, rows of threads walk
+//                 the runs: no search for "which cell does candidate t belong to")
+//   every wave  : queries of the cell one after the other, entirely out of LDS / registers: sweep (64 candidates per
+//                 step, hits compacted with ballot / popcount), rank sort, one coalesced row store
+// The kernel is bound by instruction issue (6 wavefronts per SIMD, ~40 M wavefront instructions for the 60 000-row
+// table in its first form): everything wave-uniform is computed by wave 0 only and handed over through LDS, and the
+// three barriers of a cell wait for LDS only (s_waitcnt lgkmcnt(0) + s_barrier: __syncthreads() also drains every
+// outstanding global load and store, which serialised the prefetch behind the probes).
+// Rank sort: every lane holds one hit (two from 65 hits on) and counts the hits with a smaller d2 while the d2 words
+// are broadcast from LDS, four per ds_read_b128 -- 32-bit compares only; ranks of hits with EXACTLY equal d2 collide,
+// which the scatter itself detects (a lane reads back somebody else's index); only then the (d2, index) order is
+// computed with both words.  (The first version broadcast 64-bit keys through SGPRs, v_readlane + v_cmp_lt_u64 + s_nop
+// per hit: 60 of its 105 us on the 60 000-row table.)
+// Cells are handed out dynamically (cells differ 1..40 queries: a static split leaves the slowest workgroup with twice
+// the mean): a workgroup's first two cells are fixed by its index, further ones come from a ticket counter in the query
+// grid's header -- one counter per shard (workgroup index mod 8 = its XCD; cell c belongs to shard c mod 8), because a
+// single word serves ~88 atomics per microsecond and 1536 workgroups asking at once cost more than the search.  The
+// last workgroup of a shard to leave resets its counters for the next search over this grid.
+// A query cell whose neighbourhood does not fit (more than SC candidates or kCellMaxCells cells) and rows with more
+// than CAP hits are marked for the per-query second pass (k_radius_query<.., REDO = true>) and announced through
+// status bit kRedoStatus (rows of more than CAP hits also through out_max).
+struct CellArgs {
+    GridHeader* qhdr;             // query grid: header (ticket counters), cell runs, compact cell list
+    const float4* qspts;
+    const u64* ckey;
+    const int4* cinfo;
+    const GridHeader* shdr;       // support grid: header, cloud offsets, hash table, cell runs
+    const int* soff;
+    const Slot* tab;
+    const float4* spts;
+    long long* out_idx;
+    int* out_count;
+    int* out_max;
+    int* status;
+    int* tie_rows;
+    int* tie_count;
+    double reach;
+    float r2;
+    int nb, cols, group;
+    long long* prof;              // measurement aid (PROF kernels only)
+};
+
+struct CellState {                // what wave 0 hands to the other waves of the workgroup, per cell
+    int more, nqc, qstart, base, ns_out, grp;
+    int total, log2p, fits;
+};
+
+// workgroup barrier that waits for this wave's LDS operations only (global loads / stores stay in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int SC, int CAP, int WAVES, bool PROF = false>
+__global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
+    __shared__ float4 s_cand[SC];
+    __shared__ float4 s_q[kCellQ];
+    __shared__ unsigned s_key[WAVES][CAP + 8];       // d2 bits of a query's hits ...
+    __shared__ int s_idx[WAVES][CAP];                // ... and their support indices
+    __shared__ int s_excl[kCellMaxCells];
+    __shared__ int s_start[kCellMaxCells];
+    __shared__ int s_cnt[kCellMaxCells];
+    __shared__ int s_tie[kCellTieCap];
+    __shared__ CellState s_state;
+    __shared__ int s_ntie, s_tie_base;
+    // PROF (measurement aid, DebugOpts::radius_prof): shader-clock cycles per phase, summed over wavefronts
+    int pcells = 0, pqueries = 0;
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long pt_last = PROF ? (long long)__builtin_readcyclecounter() : 0;
+    auto stamp = [&](int phase) {
+        if (PROF) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            pt[phase] += now - pt_last;
+            pt_last = now;
+        }
+    };
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int cols = a.cols;
+    const float r2 = a.r2;
+    unsigned* key = s_key[wave];
+    int* idx = s_idx[wave];
+    int wave_max = 0, wave_grp = 0;
+    auto flush_max = [&]() {
+        if (lane == 0 && wave_max > aload(a.out_max + wave_grp)) atomicMax(a.out_max + wave_grp, wave_max);
+    };
+    if (threadIdx.x == 0) s_ntie = 0;
+
+    // ---- wave 0's bookkeeping: c = the cell in hand, c1 = the next one, its record `rec1` (lanes 0..5) on its way ----
+    // Shard k owns the cells c = 8 j + k; its Gk workgroups start with j = w and j = w + Gk, tickets continue from 2 Gk.
+    const int nshard = gridDim.x < 8 ? (int)gridDim.x : 8;
+    const int shard = blockIdx.x % nshard, Gk = ((int)gridDim.x - shard + nshard - 1) / nshard;
+    int ncells_q = 0, ns = 0, c = 0, c1 = 0, ticket = 0;
+    double inv_s = 0.0, cell_q = 0.0;
+    unsigned rec = 0, rec1 = 0;                      // lanes 0,1: the cell's key; lanes 2..5: (count, start, cloud, slot)
+    auto load_rec = [&](int cell) -> unsigned {      // one dword per lane, a VECTOR load: it stays in flight across LDS waits
+        unsigned v = 0;
+        if (cell < ncells_q && lane < 6)
+            v = lane < 2 ? reinterpret_cast<const unsigned*>(a.ckey + cell)[lane]
+                         : reinterpret_cast<const unsigned*>(a.cinfo + cell)[lane - 2];
+        return v;
+    };
+    if (wave == 0) {
+        ncells_q = (int)(a.qhdr->cursor >> 32);
+        ns = a.shdr->ns;
+        inv_s = a.shdr->inv_cell;
+        cell_q = 1.0 / a.qhdr->inv_cell;
+        c = blockIdx.x;
+        c1 = c + Gk * nshard;
+        rec = load_rec(c);
+        if (threadIdx.x == 0 && a.status && (a.qhdr->overflow || a.shdr->overflow)) atomicOr(a.status, 2);
+    }
+
+    for (;;) {
+        int nqc = 0, qstart = 0, b = 0;
+        if (wave == 0) {
+            const bool more = c < ncells_q;
+            nqc = __builtin_amdgcn_readlane((int)rec, 2);
+            qstart = __builtin_amdgcn_readlane((int)rec, 3);
+            b = more ? __builtin_amdgcn_readlane((int)rec, 4) : 0;
+            int base = 0, ns_out = ns, grp = 0;
+            if (a.group > 0 && more) {
+                grp = b / a.group;
+                const int last = min(grp * a.group + a.group, a.nb);
+                base = a.soff[grp * a.group];
+                ns_out = a.soff[last] - base;
+            }
+            if (lane == 0) {
+                s_state.more = more ? 1 : 0;
+                s_state.nqc = nqc; s_state.qstart = qstart; s_state.base = base; s_state.ns_out = ns_out; s_state.grp = grp;
+            }
+        }
+        lds_barrier();                               // A: the cell's state is out; the previous cell's readers are done
+        stamp(0);
+        if (!s_state.more) break;
+        nqc = s_state.nqc;
+        qstart = s_state.qstart;
+        const int base = s_state.base, ns_out = s_state.ns_out;
+        if (s_state.grp != wave_grp) { flush_max(); wave_grp = s_state.grp; wave_max = 0; }
+
+        if (wave == 0) {
+            // support cells the grown query cell overlaps (unbiased cell coordinates; conservative by construction)
+            const u64 qkey = (u64)(unsigned)__builtin_amdgcn_readlane((int)rec, 0) |
+                             ((u64)(unsigned)__builtin_amdgcn_readlane((int)rec, 1) << 32);
+            const int nsb = a.soff[b + 1] - a.soff[b];
+            const int ux = (int)(qkey & 0x1FFFFF) - kCoordBias, uy = (int)((qkey >> 21) & 0x1FFFFF) - kCoordBias,
+                      uz = (int)((qkey >> 42) & 0x1FFFFF) - kCoordBias;
+            const int lox = (int)floor(((double)ux * cell_q - a.reach) * inv_s), hix = (int)floor(((double)(ux + 1) * cell_q + a.reach) * inv_s);
+            const int loy = (int)floor(((double)uy * cell_q - a.reach) * inv_s), hiy = (int)floor(((double)(uy + 1) * cell_q + a.reach) * inv_s);
+            const int loz = (int)floor(((double)uz * cell_q - a.reach) * inv_s), hiz = (int)floor(((double)(uz + 1) * cell_q + a.reach) * inv_s);
+            const int nx = hix - lox + 1, ny = hiy - loy + 1, nz = hiz - loz + 1;
+            const long ncell_l = (long)nx * ny * nz;
+            const bool cells_fit = ncell_l <= kCellMaxCells;
+            const int ncell = cells_fit ? (int)ncell_l : 0;
+            int log2p = 5;                           // the cell table is padded to P = 2^log2p entries
+            while ((1 << log2p) < ncell) ++log2p;
+            const int P = 1 << log2p;
+            int carry = 0;
+            for (int c0 = 0; c0 < P; c0 += 64) {
+                const int t = c0 + lane;
+                int ccount = 0, cstart = 0;
+                if (t < ncell && nsb > 0) {
+                    const int sx = lox + t % nx + kCoordBias, sy = loy + (t / nx) % ny + kCoordBias,
+                              sz = loz + t / (nx * ny) + kCoordBias;
+                    if ((unsigned)sx < (1u << 21) && (unsigned)sy < (1u << 21) && (unsigned)sz < (1u << 21)) {
+                        const u64 ckey = cell_key(sx, sy, sz);
+                        const unsigned tsize = 2u * (unsigned)nsb;
+                        const long tbase = 2l * a.soff[b];
+                        unsigned s = __umulhi(mix32(ckey), tsize);
+                        for (unsigned probe = 0; probe < tsize; ++probe) {
+                            const Slot sl = load_slot(&a.tab[tbase + s]);
+                            if (sl.key == ckey) { ccount = sl.cnt; cstart = sl.start; break; }
+                            if (sl.key == kEmptyKey) break;
+                            s = s + 1 == tsize ? 0 : s + 1;
+                        }
+                    }
+                }
+                const int incl = wave_incl_scan_i32(ccount, lane);
+                if (t < P) { s_excl[t] = carry + incl - ccount; s_start[t] = cstart; s_cnt[t] = ccount; }
+                carry += __shfl(incl, 63, 64);
+            }
+            if (lane == 0) { s_state.total = carry; s_state.log2p = log2p; s_state.fits = cells_fit && carry <= SC ? 1 : 0; }
+            // the probes are in: now ask for the next cell's record and for the ticket after it
+            rec1 = load_rec(c1);
+            ticket = 0x40000000;                     // (no cell behind c1: tickets grow monotonically)
+            if (lane == 0 && c1 < ncells_q) ticket = (2 * Gk + atomicAdd(&a.qhdr->qhead[shard], 1)) * nshard + shard;
+        } else {                                     // the first batch of the cell's queries, beside the probes
+            const int t = (int)threadIdx.x - 64;
+            if (t < kCellQ && t < nqc) s_q[t] = a.qspts[qstart + t];
+        }
+        if (WAVES == 1 && lane < kCellQ && lane < nqc) s_q[lane] = a.qspts[qstart + lane];
+        lds_barrier();                               // B
+        stamp(1);
+        const int total = s_state.total, log2p = s_state.log2p;
+        const bool fits = s_state.fits != 0;
+        if (fits) {
+            const int cell = threadIdx.x & ((1 << log2p) - 1), stride = (WAVES * 64) >> log2p;
+            const int cnt = s_cnt[cell], src = s_start[cell], dst = s_excl[cell];
+            for (int j = threadIdx.x >> log2p; j < cnt; j += stride) s_cand[dst + j] = a.spts[src + j];
+        }
+        stamp(2);
+        for (int q0 = 0; q0 < nqc; q0 += kCellQ) {
+            if (q0 > 0) {
+                lds_barrier();
+                if ((int)threadIdx.x < kCellQ && q0 + (int)threadIdx.x < nqc) s_q[threadIdx.x] = a.qspts[qstart + q0 + threadIdx.x];
+            }
+            lds_barrier();                           // C
+            stamp(3);
+            const int nbatch = min(kCellQ, nqc - q0);
+            for (int k = wave; k < nbatch; k += WAVES) {
+                const float4 qr = s_q[k];
+                const float qx = qr.x, qy = qr.y, qz = qr.z;
+                const int qi = __builtin_amdgcn_readfirstlane(__float_as_int(qr.w));
+                long long* row = a.out_idx + (long)qi * cols;
+                if (!fits) {                         // neighbourhood too large for LDS: the per-query pass takes the row
+                    if (lane == 0) { row[0] = kRedoMark; if (a.status) atomicOr(a.status, kRedoStatus); }
+                    continue;
+                }
+                int nhit = 0;
+#pragma unroll 2
+                for (int t0 = 0; t0 < total; t0 += 64) {
+                    const int t = t0 + lane;
+                    const float4 p = s_cand[t < total ? t : total - 1];
+                    const float d0 = qx - p.x, d1 = qy - p.y, d2c = qz - p.z;
+                    float d2 = 0.0f;
+                    d2 += d0 * d0;
+                    d2 += d1 * d1;
+                    d2 += d2c * d2c;
+                    const bool hit = t < total && d2 < r2;
+                    const u64 mask = __ballot(hit);
+                    const int pos = nhit + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (hit && pos < CAP) { key[pos] = __float_as_uint(d2); idx[pos] = __float_as_int(p.w); }
+                    nhit += __popcll(mask);
+                }
+                stamp(4);
+                if (PROF) ++pqueries;
+                wave_max = nhit > wave_max ? nhit : wave_max;
+                if (nhit > CAP) {                    // leave the row to pass 2
+                    if (lane == 0) { row[0] = kRedoMark; if (a.status) atomicOr(a.status, kRedoStatus); }
+                    continue;
+                }
+                const int nl = nhit;
+                if (lane < 8) key[nl + lane] = 0xFFFFFFFFu;     // the broadcast loop reads eight keys per step
+                __builtin_amdgcn_wave_barrier();
+                // ---- rank sort; the sorted hits go back into the lists in place ----
+                constexpr int R = CAP / 64;                     // hits per lane
+                unsigned mk[R];
+                int mi[R], rank[R];
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    const bool have = lane + 64 * u < nl;
+                    mk[u] = have ? key[lane + 64 * u] : 0xFFFFFFFFu;
+                    mi[u] = have ? idx[lane + 64 * u] : 0x7FFFFFFF;
+                    rank[u] = 0;
+                }
+                if (nl <= 64) {                                 // (nearly always) one hit per lane
+                    int rk = 0;
+                    for (int j = 0; j < nl; j += 8) {
+                        const uint4 k0 = *reinterpret_cast<const uint4*>(&key[j]);
+                        const uint4 k1 = *reinterpret_cast<const uint4*>(&key[j + 4]);
+                        rk += (k0.x < mk[0] ? 1 : 0) + (k0.y < mk[0] ? 1 : 0) + (k0.z < mk[0] ? 1 : 0) + (k0.w < mk[0] ? 1 : 0) +
+                              (k1.x < mk[0] ? 1 : 0) + (k1.y < mk[0] ? 1 : 0) + (k1.z < mk[0] ? 1 : 0) + (k1.w < mk[0] ? 1 : 0);
+                    }
+                    rank[0] = rk;
+                } else {
+                    for (int j = 0; j < nl; j += 4) {
+                        const uint4 k0 = *reinterpret_cast<const uint4*>(&key[j]);
+#pragma unroll
+                        for (int u = 0; u < R; ++u)
+                            rank[u] += (k0.x < mk[u] ? 1 : 0) + (k0.y < mk[u] ? 1 : 0) + (k0.z < mk[u] ? 1 : 0) + (k0.w < mk[u] ? 1 : 0);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < R; ++u)
+                    if (lane + 64 * u < nl) { key[rank[u]] = mk[u]; idx[rank[u]] = mi[u]; }
+                __builtin_amdgcn_wave_barrier();
+                bool collide = false;
+#pragma unroll
+                for (int u = 0; u < R; ++u)
+                    if (lane + 64 * u < nl) collide |= idx[rank[u]] != mi[u];
+                if (__ballot(collide) != 0ull) {
+                    // exactly equal distances in this row: order by (d2, index) with both words
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        if (lane + 64 * u < nl) { key[lane + 64 * u] = mk[u]; idx[lane + 64 * u] = mi[u]; }
+                        rank[u] = 0;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    for (int j = 0; j < nl; ++j) {
+                        const unsigned ok = key[j];
+                        const int oi = idx[j];
+#pragma unroll
+                        for (int u = 0; u < R; ++u) rank[u] += (ok < mk[u] || (ok == mk[u] && oi < mi[u])) ? 1 : 0;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int u = 0; u < R; ++u)
+                        if (lane + 64 * u < nl) { key[rank[u]] = mk[u]; idx[rank[u]] = mi[u]; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                stamp(5);
+                bool tie = false;
+                for (int e = lane; e < cols; e += 64) {
+                    long long vout = (long long)ns_out;
+                    if (e < nl) {
+                        vout = (long long)(idx[e] - base);
+                        tie |= e + 1 < nl && key[e + 1] == key[e];
+                    }
+                    __builtin_nontemporal_store(vout, &row[e]);
+                }
+                if (a.tie_rows && __ballot(tie) != 0ull && lane == 0) {
+                    const int slot = atomicAdd(&s_ntie, 1);
+                    if (slot < kCellTieCap) s_tie[slot] = qi;
+                    else a.tie_rows[atomicAdd(a.tie_count, 1)] = qi;
+                }
+                if (lane == 0 && a.out_count) a.out_count[qi] = nhit;
+                __builtin_amdgcn_wave_barrier();
+                stamp(6);
+            }
+        }
+        if (wave == 0) {                             // next cell: its record and the ticket behind it have arrived meanwhile
+            c = c1;
+            rec = rec1;
+            c1 = __builtin_amdgcn_readfirstlane(ticket);
+        }
+        stamp(7);
+        if (PROF) ++pcells;
+    }
+    if (PROF && lane == 0 && a.prof) {
+        for (int k = 0; k < 8; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(a.prof) + k, (unsigned long long)pt[k]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.prof) + 8, (unsigned long long)pcells);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.prof) + 9, (unsigned long long)pqueries);
+    }
+    flush_max();
+    __syncthreads();
+    if (a.tie_rows) {
+        const int n = s_ntie < kCellTieCap ? s_ntie : kCellTieCap;
+        if (threadIdx.x == 0 && n > 0) s_tie_base = atomicAdd(a.tie_count, n);
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += WAVES * 64) a.tie_rows[s_tie_base + j] = s_tie[j];
+    }
+    // the last workgroup of a shard to leave resets the shard's counters: the next search over this query grid starts
+    // from zero (every workgroup has received its last ticket before it counts itself out)
+    if (threadIdx.x == 0) {
+        const int done = atomicAdd(&a.qhdr->qdone[shard], 1);
+        if (done == Gk - 1) {
+            __hip_atomic_store(&a.qhdr->qhead[shard], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.qhdr->qdone[shard], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -412,10 +813,9 @@ __global__ void __launch_bounds__(256) k_correspond_rows(const float* __restrict
         const unsigned tsize = 2u * (unsigned)ns;
         unsigned s = __umulhi(mix32(key), tsize);
         for (unsigned probe = 0; probe < tsize; ++probe) {
-            const u64 k = g.tkey[s];
-            const int kc = g.tcnt[s], ks = g.tstart[s];
-            if (k == key) { ccount = kc; cstart = ks; break; }
-            if (k == kEmptyKey) break;
+            const Slot sl = load_slot(&g.tab[s]);
+            if (sl.key == key) { ccount = sl.cnt; cstart = sl.start; break; }
+            if (sl.key == kEmptyKey) break;
             s = s + 1 == tsize ? 0 : s + 1;
         }
     }
@@ -502,7 +902,7 @@ int pcrcg_cellgrid_build(const float* sup, int ns, const int* slen, int nb, floa
     if (ns > 0) {
         const int blocks = (ns + 255) / 256;
         hipLaunchKernelGGL(k_grid_insert, dim3(blocks), dim3(256), 0, st, sup, ns, nb, g);
-        hipLaunchKernelGGL(k_grid_starts, dim3((2 * ns + 255) / 256), dim3(256), 0, st, 2 * ns, g);
+        hipLaunchKernelGGL(k_grid_starts, dim3((2 * ns + 255) / 256), dim3(256), 0, st, 2 * ns, nb, g);
         hipLaunchKernelGGL(k_grid_scatter, dim3(blocks), dim3(256), 0, st, sup, ns, g);
     }
     PCRCG_CHECK_LAUNCH();
@@ -601,7 +1001,78 @@ int radius_query_pass(const float* q, int nq, const int* qlen, int ns, const int
 }
 }  // namespace pcrcg
 
+namespace pcrcg {
+// The cell-cooperative search (k_radius_cells) over a query grid; pass 0: followed by the per-query second pass for the
+// rows it hands over (the public entry point), pass 1: the cell kernel only (the pyramid builder reads status / out_max
+// anyway and launches radius_query_pass(.., 2) for the tables that need it: normally none).
+int radius_cells_pass(const void* qgrid, const float* q, int nq, const int* qlen, const void* sgrid, int ns, const int* slen,
+                      int nb, int group, float radius, int cols, int64_t* out_idx, int* out_count, int* out_max_count,
+                      int* status, int* out_tie_rows, int* out_tie_count, hipStream_t st, int pass) {
+    PCRCG_CHECK_ARG(nq >= 0 && ns >= 0 && nb >= 1 && cols >= 1 && group >= 0 && radius > 0.0f);
+    PCRCG_CHECK_ARG((out_tie_rows == nullptr) == (out_tie_count == nullptr));
+    PCRCG_CHECK_ARG(qgrid && sgrid && out_idx && out_max_count);
+    PCRCG_CHECK_ARG(pass == 1 || (q && qlen && slen));
+    if (nq == 0) return PCRCG_OK;
+    bool ok;
+    GridView gq = grid_view(const_cast<void*>(qgrid), grid_bytes(nq, nb), nq, nb, &ok);
+    GridView gs = grid_view(const_cast<void*>(sgrid), grid_bytes(ns, nb), ns, nb, &ok);
+    const float r2 = radius * radius;  // neighbors.cpp:226
+    const double reach = (double)radius * (1.0 + 1e-6);
+    const int max_blocks_env = debug_opts().radius_blocks;
+    // Alone on the GPU the search is fastest with every LDS slot taken (6 workgroups per CU: 1536 -> 93 us for the
+    // 60 000-row table, 1024 -> 99, 512 -> 142).  Inside the pair engine (pass 1: the pyramid builder) the front-end
+    // stream shares the CUs with three model streams and a smaller grid takes less from them: 256 / 512 / 768 / 1024
+    // workgroups -> 455 / 465 / 458 / 447 pairs/s (the per-query kernel on its 512: 460), as in rounds 1-3.
+    const int max_blocks = max_blocks_env > 0 ? max_blocks_env : (pass == 1 ? 512 : 1536);
+    int blocks = (nq + 7) / 8;                     // never more workgroups than there can be cells worth having one
+    if (blocks > max_blocks) blocks = max_blocks;
+    CellArgs ca;
+    ca.qhdr = gq.hdr; ca.qspts = gq.spts; ca.ckey = gq.ckey; ca.cinfo = gq.cinfo;
+    ca.shdr = gs.hdr; ca.soff = gs.soff; ca.tab = gs.tab; ca.spts = gs.spts;
+    ca.out_idx = reinterpret_cast<long long*>(out_idx); ca.out_count = out_count; ca.out_max = out_max_count;
+    ca.status = status; ca.tie_rows = out_tie_rows; ca.tie_count = out_tie_count;
+    ca.reach = reach; ca.r2 = r2; ca.nb = nb; ca.cols = cols; ca.group = group;
+    ca.prof = nullptr;
+    if (debug_opts().radius_prof) {       // measurement aid: per-phase shader cycles, printed when the process exits
+        static long long* prof = nullptr;
+        if (!prof) {
+            (void)hipMalloc(&prof, 16 * sizeof(long long));
+            (void)hipMemset(prof, 0, 16 * sizeof(long long));
+            static struct Dump {
+                ~Dump() {
+                    long long h[16];
+                    if (hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+                    static const char* nm[8] = {"barrier A (state out, previous readers done)", "probes | query staging, barrier B",
+                                                "candidate staging", "barrier C", "sweep", "rank sort", "row store", "hand-over"};
+                    fprintf(stderr, "k_radius_cells: %lld wave-cells, %lld queries\n", h[8], h[9]);
+                    double tot = 0;
+                    for (int k = 0; k < 8; ++k) tot += (double)h[k];
+                    for (int k = 0; k < 8; ++k)
+                        fprintf(stderr, "k_radius_cells phase %d %-46s %6.2f %%  %9.0f cycles per %s\n", k, nm[k], 100.0 * h[k] / (tot > 0 ? tot : 1),
+                                (double)h[k] / (double)((k >= 4 && k <= 6) ? (h[9] ? h[9] : 1) : (h[8] ? h[8] : 1)), (k >= 4 && k <= 6) ? "query" : "wave-cell");
+                }
+            } dump;
+        }
+        ca.prof = prof;
+        hipLaunchKernelGGL((k_radius_cells<kCellCand, kCellListCap, kQueryWaves, true>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, ca);
+    } else {
+        hipLaunchKernelGGL((k_radius_cells<kCellCand, kCellListCap, kQueryWaves>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, ca);
+    }
+    PCRCG_CHECK_LAUNCH();
+    if (pass == 1) return PCRCG_OK;
+    return radius_query_pass(q, nq, qlen, ns, slen, nb, group, radius, sgrid, cols, out_idx, out_count, out_max_count, status,
+                             out_tie_rows, out_tie_count, st, 2);
+}
+}  // namespace pcrcg
+
 extern "C" {
+
+int pcrcg_radius_query_cells(const void* qgrid, const float* q, int nq, const int* qlen, const void* sgrid, int ns,
+                             const int* slen, int nb, int group, float radius, int cols, int64_t* out_idx, int* out_count,
+                             int* out_max_count, int* status, int* out_tie_rows, int* out_tie_count, void* stream) {
+    return pcrcg::radius_cells_pass(qgrid, q, nq, qlen, sgrid, ns, slen, nb, group, radius, cols, out_idx, out_count,
+                                    out_max_count, status, out_tie_rows, out_tie_count, as_stream(stream), 0);
+}
 
 size_t pcrcg_radius_neighbors_ws_bytes(int ns, int nb) { return pcrcg_cellgrid_ws_bytes(ns, nb); }
 

@@ -1,6 +1,9 @@
 // scan.hip -- library plumbing: error string, status check and a device-wide int32 exclusive scan.
 #include <cstring>
 
+#include <atomic>
+#include <mutex>
+
 #include "common.h"
 
 namespace pcrcg {
@@ -209,17 +212,26 @@ const DebugName kDebugNames[] = {
     {"zero_arena", &DebugOpts::zero_arena}, {"stat_sums", &DebugOpts::stat_sums}, {"stat_sums_rows", &DebugOpts::stat_sums_rows},
     {"fuse_norm", &DebugOpts::fuse_norm}, {"fuse_pack", &DebugOpts::fuse_pack}, {"fuse_upsample", &DebugOpts::fuse_upsample},
     {"radius_blocks", &DebugOpts::radius_blocks}, {"radius_eager_redo", &DebugOpts::radius_eager_redo},
+    {"radius_cells", &DebugOpts::radius_cells}, {"radius_prof", &DebugOpts::radius_prof},
     {"pyr_wait", &DebugOpts::pyr_wait}, {"pyr_trace", &DebugOpts::pyr_trace}, {"att_tq", &DebugOpts::att_tq},
     {"kd_spin_limit", &DebugOpts::kd_spin_limit}, {"gemm_log", &DebugOpts::gemm_log}, {"x6_tile", &DebugOpts::x6_tile}, {"x6_order", &DebugOpts::x6_order}, {"x6_big", &DebugOpts::x6_big}, {"train_side_stream", &DebugOpts::train_side_stream},
     {"x6_splitk", &DebugOpts::x6_splitk}, {"x6_t1", &DebugOpts::x6_t1}, {"x6_t2", &DebugOpts::x6_t2},
     {"gemm_tile", &DebugOpts::gemm_tile}, {"gemm_splitk", &DebugOpts::gemm_splitk},
     {"gemm_split_target", &DebugOpts::gemm_split_target}};
-DebugOpts g_debug;
-bool g_debug_init = false;
+// The options are IMMUTABLE snapshots behind one atomic pointer: the engine's front and model threads read them
+// concurrently (their library calls hold no lock), pcrcg_debug_set publishes a new snapshot and never frees an old one
+// (a handful of 100-byte objects per process), so a reader's reference stays valid and no field is ever seen half
+// written.  The environment is read exactly once (std::call_once).  A multi-kernel call (a forward's sizing pass and
+// its live pass) reads the options several times: pcrcg_debug_set must not be called while calls are in flight.
+std::atomic<const DebugOpts*> g_debug{nullptr};
+std::once_flag g_debug_once;
+std::mutex g_debug_set_lock;
+const DebugOpts kDebugDefaults{};
 
-// "name=value,name=value" -> g_debug; false (and the error text) on an unknown name or a malformed item
-bool debug_parse(const char* spec) {
-    DebugOpts d = g_debug;
+// "name=value,name=value" on top of *base -> a new published snapshot; false (and the error text) on an unknown name or a
+// malformed item
+bool debug_parse(const char* spec, const DebugOpts* base) {
+    DebugOpts d = *base;
     const char* p = spec;
     while (p && *p) {
         const char* end = strchr(p, ',');
@@ -239,18 +251,18 @@ bool debug_parse(const char* spec) {
         }
         p = end ? end + 1 : nullptr;
     }
-    g_debug = d;
+    g_debug.store(new DebugOpts(d), std::memory_order_release);
     return true;
 }
 }  // namespace
 
 const DebugOpts& debug_opts() {
-    if (!g_debug_init) {
-        g_debug_init = true;
+    std::call_once(g_debug_once, [] {
+        g_debug.store(&kDebugDefaults, std::memory_order_release);
         if (const char* e = getenv("PCRCG_DEBUG"))
-            if (!debug_parse(e)) fprintf(stderr, "libpcrcg_hip: PCRCG_DEBUG ignored: %s\n", g_err);
-    }
-    return g_debug;
+            if (!debug_parse(e, &kDebugDefaults)) fprintf(stderr, "libpcrcg_hip: PCRCG_DEBUG ignored: %s\n", g_err);
+    });
+    return *g_debug.load(std::memory_order_acquire);
 }
 
 }  // namespace pcrcg
@@ -262,9 +274,11 @@ const char* pcrcg_last_error(void) { return pcrcg::g_err; }
 int pcrcg_abi_version(void) { return 2; }   // 2 (round 3): forward groups, train-step runner, correspondences, debug switches; one-kernel KPConv entries removed
 
 int pcrcg_debug_set(const char* spec) {
-    (void)pcrcg::debug_opts();                       // the environment first, then this call on top of it
-    if (!spec) { pcrcg::g_debug = pcrcg::DebugOpts(); return PCRCG_OK; }
-    return pcrcg::debug_parse(spec) ? PCRCG_OK : PCRCG_EBADARG;
+    const pcrcg::DebugOpts* cur = &pcrcg::debug_opts();   // the environment first, then this call on top of it
+    std::lock_guard<std::mutex> hold(pcrcg::g_debug_set_lock);   // setters serialise; readers never block
+    cur = pcrcg::g_debug.load(std::memory_order_acquire);
+    if (!spec) { pcrcg::g_debug.store(&pcrcg::kDebugDefaults, std::memory_order_release); return PCRCG_OK; }
+    return pcrcg::debug_parse(spec, cur) ? PCRCG_OK : PCRCG_EBADARG;
 }
 
 int pcrcg_check_status(const int* status, void* stream) {

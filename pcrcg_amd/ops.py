@@ -144,10 +144,12 @@ class CellGrid:
                                           self.radius, self.grid.data_ptr(), self.nbytes, _stream()),
                    "pcrcg_cellgrid_build")
 
-    def query(self, queries, q_lengths, cols, want_counts=False, want_ties=False):
+    def query(self, queries, q_lengths, cols, want_counts=False, want_ties=False, query_grid=None):
         """-> (idx [Nq, cols] i64, meta [3] i32 device = (max_count, status, tie_rows)[, counts [Nq] i32]
         [, tie_rows [Nq] i32: the first meta[2] entries are the rows holding a group of exactly equal distances
-        inside the kept columns, whose reference order KdForest.reorder restores])."""
+        inside the kept columns, whose reference order KdForest.reorder restores]).
+        query_grid: a CellGrid over `queries` (any radius; `self` for a self query) -> the cell-cooperative LDS-staged
+        search (pcrcg_radius_query_cells); None -> the per-query kernel."""
         L = _lib.lib()
         queries = _dev(queries, _F32, "queries").contiguous()
         q_lengths = _dev(q_lengths, _I32, "q_batches").contiguous()
@@ -158,6 +160,21 @@ class CellGrid:
         meta = torch.zeros(3, dtype=_I32, device=queries.device)  # [max_count, status, tie_rows]
         counts = torch.empty(nq, dtype=_I32, device=queries.device) if (want_counts or want_ties) else None
         ties = torch.empty(max(nq, 1), dtype=_I32, device=queries.device) if want_ties else None
+        if query_grid is not None:
+            if query_grid.ns != nq or query_grid.nb != self.nb:
+                raise RuntimeError("query_grid was not built over these queries")
+            _lib.check(L.pcrcg_radius_query_cells(query_grid.grid.data_ptr(), queries.data_ptr(), nq, q_lengths.data_ptr(),
+                                                  self.grid.data_ptr(), self.ns, self.lengths.data_ptr(), self.nb, 0,
+                                                  self.radius, int(cols), idx.data_ptr(), _ptr(counts), meta[0:1].data_ptr(),
+                                                  meta[1:2].data_ptr(), _ptr(ties),
+                                                  meta[2:3].data_ptr() if want_ties else None, _stream()),
+                       "pcrcg_radius_query_cells")
+            out = (idx, meta)
+            if want_counts or want_ties:
+                out += (counts,)
+            if want_ties:
+                out += (ties,)
+            return out
         _lib.check(L.pcrcg_radius_query_ex(queries.data_ptr(), nq, q_lengths.data_ptr(), self.ns,
                                            self.lengths.data_ptr(), self.nb, self.radius, self.grid.data_ptr(),
                                            int(cols), idx.data_ptr(), _ptr(counts), meta[0:1].data_ptr(),

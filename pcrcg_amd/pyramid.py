@@ -118,8 +118,8 @@ def pyramid_steps(points, lengths, config, neighborhood_limits, want_counts=Fals
     empty_idx = torch.zeros((0, 1), dtype=torch.int64, device=pts.device)
     carried = None   # grid over the current level's points built for the previous level's upsample search
 
-    def search(grid, key, layer, q_pts, q_lens, sup_level, limit, keep_counts=False):
-        res = grid.query(q_pts, q_lens, limit, want_counts=keep_counts, want_ties=want_ties)
+    def search(grid, key, layer, q_pts, q_lens, sup_level, limit, keep_counts=False, query_grid=None):
+        res = grid.query(q_pts, q_lens, limit, want_counts=keep_counts, want_ties=want_ties, query_grid=query_grid)
         idx, meta = res[0], res[1]
         metas.append(meta)
         tables.append(dict(key=key, layer=layer, q=q_pts, qlen=q_lens, sup_level=sup_level, radius=grid.radius,
@@ -134,7 +134,7 @@ def pyramid_steps(points, lengths, config, neighborhood_limits, want_counts=Fals
         if lv["has_conv"]:
             grid = carried if carried is not None and carried.radius == float(lv["r_conv"]) else \
                 ops.CellGrid(pts, lens, lv["r_conv"])
-            conv_i = search(grid, "neighbors", layer, pts, lens, layer, limit, keep_counts=want_counts)
+            conv_i = search(grid, "neighbors", layer, pts, lens, layer, limit, keep_counts=want_counts, query_grid=grid)
         else:
             conv_i = empty_idx
         if lv["pooled"]:
@@ -145,9 +145,11 @@ def pyramid_steps(points, lengths, config, neighborhood_limits, want_counts=Fals
             if grid is None or grid.radius != float(lv["r_pool"]):
                 grid = carried if carried is not None and carried.radius == float(lv["r_pool"]) else \
                     ops.CellGrid(pts, lens, lv["r_pool"])
-            pool_i = search(grid, "pools", layer, pool_p, pool_b, layer, limit)
+            # the coarse level's grid first: support grid of the upsample search, conv grid of the next level and the
+            # QUERY grid of the pool search (csrc/pyramid.hip does the same: every query set walks a grid of its own)
             up_grid = ops.CellGrid(pool_p, pool_b, 2 * lv["r_pool"])
-            up_i = search(up_grid, "upsamples", layer, pts, lens, layer + 1, limit)
+            pool_i = search(grid, "pools", layer, pool_p, pool_b, layer, limit, query_grid=up_grid)
+            up_i = search(up_grid, "upsamples", layer, pts, lens, layer + 1, limit, query_grid=grid)
             # the next level's conv and pool searches use these supports with this radius: hand it on
             carried = up_grid
         else:
