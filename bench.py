@@ -1,9 +1,9 @@
 """bench.py -- fragment-pairs/s of the PCR-CG hot path on MI355X (BASELINE.json metric).
 
 A step = one pass of the hot path over one synthetic 3DMatch-shaped pair per GPU (configs[1]:
-2 x 30 000 points, indoor hyper-parameters, full-width KPFCNN + GCN, fp32): raw stacked points already
-resident in HBM -> point pyramid (3 grid subsamplings, 10 radius searches) -> KPFCNN+GCN forward ->
-per-point descriptors / overlap / saliency.  Independent pairs shard across ranks with no data-path
+2 x 30 000 points, indoor hyper-parameters, full-width KPFCNN + GCN, fp32): raw stacked points in pinned host
+memory (uploaded inside the timed region; --inputs hbm: already resident) -> point pyramid (3 grid
+subsamplings, 10 radius searches) -> KPFCNN+GCN forward -> per-point descriptors / overlap / saliency.  Independent pairs shard across ranks with no data-path
 collective: weak scaling, one pair per rank per step.
 
   python bench.py --gpus N --steps 20 --warmup 3 [--repeats 5]
@@ -20,8 +20,9 @@ Rank 0 prints ONE JSON line.  The timed region -- exactly --steps steps between 
 starting and ending with an empty engine, MAX over ranks -- is run --repeats times back to back; `value` is the MEDIAN
 region and every region's figure is listed (a 50-step region lasts ~0.1 s: one shot of it has a few percent of noise).
 `roofline` is measured live with HIP start/stop events of every launch of the dominant kernel (the KPConv
-neighbour-gather/aggregate kernel) inside those regions; `roofline.gemm` does the same for the GEMM family in one extra
-region of the same engine; `cpu_baseline` times the CPU oracle (oracle/: C front end + torch-CPU model, a restatement
+neighbour-gather/aggregate kernel) inside those regions; `roofline.gemm` and `roofline.radius` do the same for the GEMM
+family and the radius searches in one extra region of the same engine; `secondary` carries bounded runs of configs[4]
+(K120k engine) and configs[2] (train step); `cpu_baseline` times the CPU oracle (oracle/: C front end + torch-CPU model, a restatement
 pinned against the reference) on a bounded sample on rank 0 at N=1.
 """
 import argparse
@@ -181,7 +182,7 @@ def kpconv_roofline(events, cout_of):
     gather = {"ms": 0.0, "bytes": 0, "n": 0}
     fused = {"ms": 0.0, "bytes": 0, "flops": 0, "n": 0}
     for (ms, nq, h, cin, cout, kind) in events:
-        if kind == 3:
+        if kind >= 3:
             continue
         co = cout if kind == 1 else cout_of[cin]
         d = fused if kind == 1 else gather
@@ -220,6 +221,135 @@ def gemm_by_shape(events, forwards):
              "us_per_forward": round(1e3 * ms / max(forwards, 1), 1), "TFLOPs": round(2.0 * m * n * k * c / (ms * 1e-3) / 1e12, 1)}
             for (m, n, k, pr), (c, ms) in acc.items()]
     return sorted(rows, key=lambda r: -r["us_per_forward"])
+
+
+def radius_roofline(events, pairs):
+    """Radius searches (kind 4 records: queries, columns, supports, kernel flavour) timed by their own start / stop events;
+    algorithmic bytes per SURVEY.md 8d: 12 Nq + 12 Ns + 8 Nq cols per call (every point read once, the int64 table written)."""
+    ev = [e for e in events if e[5] == 4]
+    ms = sum(e[0] for e in ev)
+    if not ev or ms <= 0:
+        return None
+    by = sum(12 * e[1] + 12 * e[3] + 8 * e[1] * e[2] for e in ev)
+    gbs = by / (ms * 1e-3) / 1e9
+    return {"launches_per_pair": round(len(ev) / max(pairs, 1), 1), "kernel_ms_per_pair": round(ms / max(pairs, 1), 3),
+            "algorithmic_MB_per_pair": round(by / max(pairs, 1) / 1e6, 1), "achieved_GBs": round(gbs, 1),
+            "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5), "avg_launch_us": round(1e3 * ms / len(ev), 1),
+            "cell_cooperative_launches": sum(1 for e in ev if e[4] == 1)}
+
+
+def secondary_train_step(dev, steps, warmup=3):
+    """configs[2]: train steps on the 3DLoMatch-shaped S30k pair (full-width model, fp32; pyramid + labels built once):
+    forward with tape -> MetricLoss -> backward -> SGD, ms per step, and the same step phase by phase (each drained before
+    the next is timed).  Mirrors scripts/bench_train.py / scripts/train_phases.py; ref:lib/trainer.py:216-265."""
+    from pcrcg_amd.config import Config
+    from pcrcg_amd.correspondences import get_correspondences
+    from pcrcg_amd.loss import MetricLoss
+    from pcrcg_amd.pyramid import collate_fn_descriptor
+    from pcrcg_amd.trainer import LOSS_KEYS, Trainer
+    cfg = indoor_config()
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = KPFCNN(cfg).to(dev)
+    loss = MetricLoss(Config(pos_margin=0.1, neg_margin=1.4, pos_radius=0.0375, safe_radius=0.1,
+                             matchability_radius=0.05, max_points=256))
+    tr = Trainer(net, loss)
+    src, tgt, rot, trans = synthetic.lomatch_pair("S30k", 0, overlap=0.2)
+    tsfm = np.eye(4)
+    tsfm[:3, :3], tsfm[:3, 3] = rot, trans.flatten()
+    corr = get_correspondences(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), tsfm, 0.0375)
+    item = dict(src_pcd=src, tgt_pcd=tgt, src_feats=np.ones((len(src), 1), np.float32),
+                tgt_feats=np.ones((len(tgt), 1), np.float32), rot=rot, trans=trans, correspondences=corr, sample=0)
+    inputs = collate_fn_descriptor([item], cfg, synthetic.LIMITS["S30k"], device=dev)
+    stats = None
+    for _ in range(warmup):
+        stats = tr.train_step(inputs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stats = tr.train_step(inputs)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    ph = {"forward": 0.0, "loss": 0.0, "backward": 0.0, "sgd": 0.0}
+    n_ph = 4
+    for _ in range(n_ph):
+        net.train(True)
+        t0 = time.perf_counter()
+        out = net.train_runner().forward(inputs)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        len_src = int(inputs["stack_lengths_host"][0][0])
+        f = out["feats_f"]
+        res = loss({"src_feats": f[:len_src], "tgt_feats": f[len_src:], "rot": inputs["rot"], "trans": inputs["trans"],
+                    "scores_overlap": out["scores_overlap"], "scores_saliency": out["scores_saliency"],
+                    "src_pcd_raw": inputs["src_pcd_raw"], "tgt_pcd_raw": inputs["tgt_pcd_raw"],
+                    "correspondences": inputs["correspondences"]})
+        total = sum(res[k] for k in res if k in LOSS_KEYS)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        tr.bucket.arm(True)
+        total.backward()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        tr.optimizer_step()
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        for k, v in zip(ph, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+            ph[k] += 1e3 * v / n_ph
+    return {"workload": "configs[2]: S30k 3DLoMatch-shaped pair (overlap 0.2, %d correspondences), full-width KPFCNN+GCN, fp32; "
+                        "forward with tape + MetricLoss + backward + SGD, pyramid and labels prebuilt" % int(corr.shape[0]),
+            "steps": steps, "ms_per_step": round(ms, 2), "train_pairs_per_s": round(1e3 / ms, 2),
+            "phases_ms_each_drained": {k: round(v, 2) for k, v in ph.items()},
+            "phases_note": "the loss's geometry-only part overlaps the forward inside a real step, so the phases sum to more",
+            "last_stats": {k: round(float(v), 4) for k, v in (stats or {}).items()},
+            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+
+
+def secondary_k120k(dev, steps, warmup, workers, ppf, ppb):
+    """configs[4] on one GPU: the same engine on 2 x 120 000-point KITTI-shaped slabs with the KITTI hyper-parameters
+    (ref:configs/test/kitti.yaml:15-30): pairs/s of one region and the KPConv gather kernels' algorithmic GB/s in it."""
+    cfg = kitti_config()
+    limits = synthetic.LIMITS["K120k"]
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = KPFCNN(cfg).eval().to(dev)
+    cout_of = {blk.KPConv.in_channels: blk.KPConv.out_channels for blk in net.encoder_blocks}
+    pool = []
+    for s_ in range(4):
+        a, b = synthetic.slab_pair(120000, s_)
+        pool.append((torch.from_numpy(np.concatenate([a, b])).pin_memory(), torch.tensor([len(a), len(b)], dtype=torch.int32).pin_memory()))
+    pipe = PairStreams(net, cfg, limits, dev, model_streams=workers, front_threads=1, up_nearest=False,
+                       pairs_per_forward=ppf, pairs_per_build=ppb)
+
+    def run(count):
+        sub = 0
+        for i in range(count):
+            while sub < min(count, i + 8):
+                hp, hl = pool[sub % len(pool)]
+                pipe.submit(hp.to(dev, non_blocking=True), hl.to(dev, non_blocking=True))
+                sub += 1
+            pipe.result(wait=False)
+
+    run(2 * workers * ppf)
+    pipe.drain()
+    run(warmup)
+    pipe.drain()
+    torch.cuda.synchronize()
+    ops.kpconv_profile_start(radius=True)
+    t0 = time.perf_counter()
+    run(steps)
+    pipe.drain()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ev = ops.kpconv_profile_stop()
+    pipe.close()
+    g, _ = kpconv_roofline([e for e in ev if e[5] != 4], cout_of)
+    gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0
+    return {"workload": WORKLOADS["K120k"], "steps": steps, "value": round(steps / dt, 2), "unit": "fragment-pairs/s",
+            "ms_per_step": round(1e3 * dt / steps, 2), "limits": limits,
+            "kpconv_gather_in_engine": {"achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                                        "avg_launch_us": round(1e3 * g["ms"] / max(g["n"], 1), 1)},
+            "radius_search_in_engine": radius_roofline(ev, steps)}
 
 
 def dry_run_main(args, rank, world):
@@ -282,7 +412,11 @@ def main():
                     help="timed regions of --steps steps each, run back to back; `value` is the median region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the secondary regions (GEMM events, one-column upsample tables, pinned-host inputs)")
+                    help="skip the secondary regions (GEMM / radius events, HBM-resident inputs, one-column upsample tables, "
+                         "the configs[2] train step, the configs[4] K120k engine)")
+    ap.add_argument("--inputs", choices=["host", "hbm"], default="host",
+                    help="host (default, SURVEY.md 8d's protocol): every pair is uploaded from pinned host memory inside the "
+                         "timed region; hbm: inputs resident in HBM before the region starts")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="S30k")
     ap.add_argument("--input-order", choices=["generator", "morton"], default="generator",
                     help="experiment: Morton-sort each synthetic cloud (spatially coherent indices); recorded in config")
@@ -429,7 +563,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def region(pipe, from_host=False):
+    HEAD_FROM_HOST = args.inputs == "host"
+
+    def region(pipe, from_host=HEAD_FROM_HOST):
         """EXACTLY --steps steps from an empty engine to an empty engine; -> seconds (MAX over ranks), submit seconds."""
         fence(pipe)
         t0 = time.perf_counter()
@@ -465,19 +601,23 @@ def main():
     submit = sorted(r[1] for r in regions)[len(regions) // 2]
 
     extras = {}
-    gemm_engine = gemm_iso = iso = None
+    gemm_engine = gemm_iso = iso = radius_engine = radius_iso = None
     if not args.no_extras:
-        # (a) the GEMM family inside the engine: one more region with start / stop events on every GEMM launch as well
-        ops.kpconv_profile_start(gemm=True)
+        # (a) the GEMM family and the radius searches inside the engine: one more region with start / stop events on
+        # those launches as well
+        ops.kpconv_profile_start(gemm=True, radius=True)
         t_g = region(pipe)[0]
-        gemm_engine = gemm_roofline(ops.kpconv_profile_stop(), args.steps)
+        ev_g = ops.kpconv_profile_stop()
+        gemm_engine = gemm_roofline(ev_g, args.steps)
+        radius_engine = radius_roofline(ev_g, args.steps)
         if gemm_engine:
             gemm_engine["pairs_per_s_of_this_region"] = round(args.steps * world / t_g, 1)
-        # (b) inputs in pinned host memory, uploaded inside the clock (SURVEY.md 8d's hand-over; PCIe-inclusive)
-        t_h = region(pipe, from_host=True)[0]
-        extras["pinned_host_inputs"] = {"value": round(args.steps * world / t_h, 3), "unit": "fragment-pairs/s",
-                                        "note": "one region; every pair's points + lengths (720 KB) copied from pinned host "
-                                                "memory inside the timed region; reported beside `value`, never as it"}
+        # (b) the other input hand-over: resident in HBM before the region starts (or, with --inputs hbm, pinned host)
+        t_h = region(pipe, from_host=not HEAD_FROM_HOST)[0]
+        extras["hbm_resident_inputs" if HEAD_FROM_HOST else "pinned_host_inputs"] = {
+            "value": round(args.steps * world / t_h, 3), "unit": "fragment-pairs/s",
+            "note": "one region with the OTHER hand-over: " + ("points + lengths already in HBM when the region starts" if HEAD_FROM_HOST
+                    else "every pair's points + lengths (720 KB) copied from pinned host memory inside the region")}
     # the same kernels once more WITHOUT any concurrent stream: the kernels in isolation
     if rank == 0:
         from pcrcg_amd.pyramid import build_pyramid
@@ -490,7 +630,13 @@ def main():
         torch.cuda.synchronize()
         iso = ops.kpconv_profile_stop()
         gemm_iso = gemm_roofline(iso, 3)
-        iso = [e for e in iso if e[5] != 3]
+        iso = [e for e in iso if e[5] < 3]
+        # the front end alone: three pyramid builds on an idle GPU, the radius kernels' own events
+        ops.kpconv_profile_start(radius=True, kpconv=False)
+        for _ in range(3):
+            build_pyramid(*pool[seeds[0] % 16], cfg, limits)
+        torch.cuda.synchronize()
+        radius_iso = radius_roofline(ops.kpconv_profile_stop(), 3)
     if os.environ.get("PCRCG_PIPE_STATS") and rank == 0:       # (verbose host-side engine statistics on stderr)
         n = max(stats["pairs"], 1)
         print("pair engine, host ms per pair: " + ", ".join("%s %.3f" % (k[:-2], 1e3 * v / n) for k, v in stats.items()
@@ -506,6 +652,19 @@ def main():
         extras["one_column_upsample_tables"] = {"value": round(args.steps * world / t_u[len(t_u) // 2], 3),
                                                 "unit": "fragment-pairs/s", "regions": len(t_u)}
     pipe.close()
+    if not args.no_extras and rank == 0 and world == 1 and RECIPE == "S30k" and not BF16:
+        # (d) configs[4] and configs[2] on this GPU, bounded (a dozen steps each): driver-visible numbers for both
+        del pipe
+        torch.cuda.empty_cache()
+        try:
+            extras["K120k"] = secondary_k120k(dev, 12, 3, WORKERS, args.pairs_per_forward, args.pairs_per_build)
+        except Exception as e:       # secondary figures never fail the headline
+            extras["K120k"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            extras["train_step"] = secondary_train_step(dev, 12)
+        except Exception as e:
+            extras["train_step"] = {"error": repr(e)}
 
     if rank == 0:
         gather, fused = kpconv_roofline(events, cout_of)
@@ -514,8 +673,6 @@ def main():
         n_launch = gather["n"] + fused["n"]
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         g_gbs = gather["bytes"] / (gather["ms"] * 1e-3) / 1e9 if gather["ms"] > 0 else 0.0
-        f_gbs = fused["bytes"] / (fused["ms"] * 1e-3) / 1e9 if fused["ms"] > 0 else 0.0
-        f_tf = fused["flops"] / (fused["ms"] * 1e-3) / 1e12 if fused["ms"] > 0 else 0.0
         ig, if_ = kpconv_roofline(iso, cout_of)
         iso_ms, iso_bytes = ig["ms"] + if_["ms"], ig["bytes"] + if_["bytes"]
         iso_gbs = iso_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
@@ -528,7 +685,7 @@ def main():
         # `traffic` (HBM bytes per launch from PMC counters) cannot be collected by this process: rocprofv3 --pmc needs
         # its own passes.  The live line says null; the figure of the committed separate passes is quoted with its source.
         traffic, traffic_offline = None, None
-        for name in ("r03_pmc_kpconv.json", "r02_pmc_kpconv.json"):
+        for name in ("r04_pmc_kpconv.json", "r03_pmc_kpconv.json", "r02_pmc_kpconv.json"):
             pmc_path = os.path.join(REPO, "profiles", name)
             if os.path.exists(pmc_path):
                 traffic_offline = {"hbm_bytes_per_launch": json.load(open(pmc_path)).get("hbm_bytes_per_launch"),
@@ -563,7 +720,8 @@ def main():
                         "min": round(args.steps * world / max(times), 1), "max": round(args.steps * world / min(times), 1)},
             "config": {"workload": WORKLOADS[RECIPE] + ("" if INPUT_ORDER == "generator" else " [clouds Morton-sorted: an "
                                                         "experiment, not the headline workload]") + ", pyramid build + KPFCNN+GCN forward, random-init full-width weights, "
-                                   "1 pair/GPU/step, inputs resident in HBM; pair engine: %d front thread(s) build pyramids "
+                                   "1 pair/GPU/step, " + ("inputs in pinned host memory, uploaded (two async copies, 720 KB) inside the "
+                                   "timed region (SURVEY.md 8d)" if HEAD_FROM_HOST else "inputs resident in HBM") + "; pair engine: %d front thread(s) build pyramids "
                                    "(pcrcg_pyramid_build, %.2f pairs per call on average: two waiting pairs share one kernel "
                                    "chain) on one front-end HIP stream, %d host threads enqueue the forwards "
                                    "(pcrcg_kpfcnn_forward_group: %s) on one model stream each; every table as the batch contract "
@@ -575,13 +733,14 @@ def main():
                                       "up to %d pairs of a build in ONE call, every weight product once for all of them"
                                       % args.pairs_per_forward if args.pairs_per_forward >= 2 else "one call per pair",
                                       tie, _gemm_mode()),
+                       "inputs": "pinned host memory, uploaded inside the timed region" if HEAD_FROM_HOST else "resident in HBM",
                        "tie_order": tie, "up_nearest": 0, "pairs_per_pyramid_build": round(ppb, 2),
                        "pairs_per_forward_call": args.pairs_per_forward,
                        "limits": limits, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
                        "lib_path": os.path.relpath(lib_path, REPO), "lib_sha16": lib_sha},
             "secondary": extras,
-            "roofline": {"bound": "hbm", "kernel": "KPConv neighbour-gather kernels (k_kpconv_mfma / k_kpconv_c1 / "
-                                                     "one-kernel KPConv), %d launches/pair" % per_pair,
+            "roofline": {"bound": "hbm", "kernel": "KPConv neighbour-gather / aggregate kernels (k_kpconv_mfma, k_kpconv_c1), "
+                                                     "%d launches/pair" % per_pair,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_offline": traffic_offline,
                          "avg_launch_us": round(k_ms * 1e3 / max(n_launch, 1), 2),
@@ -595,15 +754,20 @@ def main():
                          "gather_only_kernels": {"launches_per_pair": gather["n"] // max(args.steps * R, 1),
                                                  "achieved_GBs": round(g_gbs, 1),
                                                  "frac": round(g_gbs / HBM_PEAK_GBS, 4)},
-                         "fused_kernels": {"launches_per_pair": fused["n"] // max(args.steps * R, 1),
-                                           "achieved_GBs": round(f_gbs, 1), "frac_hbm": round(f_gbs / HBM_PEAK_GBS, 4),
-                                           "achieved_TFLOPs_f32_mfma": round(f_tf, 1),
-                                           "frac_mfma_f32_157TF": round(f_tf / MFMA_F32_TF, 4)},
+                         "radius": {"bound": "hbm", "kernel": "k_radius_cells (cell-cooperative, LDS-staged; the pyramid's ten "
+                                              "searches per pair), algorithmic bytes 12 Nq + 12 Ns + 8 Nq cols per call",
+                                    "in_engine": radius_engine, "isolated": radius_iso,
+                                    "note": "integer / latency work: the algorithmic bytes are tiny against what the kernel "
+                                            "does per query (27-64 hash probes per CELL, ~130 candidates swept and ~36 hits "
+                                            "rank-sorted per query), so the fraction is small by construction; durations are "
+                                            "the kernels' own events (in_engine: beside three model streams)"},
                          "gemm": {"bound": "mfma", "kernel": "k_gemm_x6 family (every C = A * B^T product of the forward)",
                                   "unit": "TFLOP/s (fp32-equivalent: 2*M*N*K per launch)",
                                   "in_engine": gemm_engine, "isolated": gemm_iso,
                                   "note": "in_engine: one extra region of the same engine with start/stop events on every "
-                                          "GEMM launch as well; isolated: three forwards alone on one stream"}},
+                                          "GEMM launch as well -- GEMMs of three model streams overlap there (kernel_ms_per_pair "
+                                          "can exceed ms_per_step), so in-engine durations are stretched by the concurrent "
+                                          "streams and are NOT roofline evidence; isolated: three forwards alone on one stream"}},
         }
         n = max(stats["pairs"], 1)
         line["host"] = {"note": "host_submit_ms_per_step is the main thread's time until the last pair is accepted; it blocks on "

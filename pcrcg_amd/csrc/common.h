@@ -132,7 +132,9 @@ const DebugOpts& debug_opts();
 // include/pcrcg.h.  The events are handed to hipExtLaunchKernelGGL, so they stamp the kernel's own begin and
 // end (what rocprofv3 reports), not the time its dispatch waited behind other streams.  a/b are NULL when
 // profiling is off (a plain launch).  kind 0 = gather/aggregate kernel, 1 = fused kernel, 2 = bf16-storage gather kernel,
-// 3 = a GEMM of the k_gemm_x6 family (nq = M, h = N, cin = K, cout = bf16 products per element: 6, or 3 with a bf16 A).
+// 3 = a GEMM of the k_gemm_x6 family (nq = M, h = N, cin = K, cout = bf16 products per element: 6, or 3 with a bf16 A),
+// 4 = a radius search (nq = queries, h = columns, cin = supports, cout = 1 cell-cooperative kernel / 0 per-query kernel);
+// pcrcg_profile_kpconv(flags): 1 = KPConv kernels, 2 = GEMMs, 4 = radius searches.
 struct KpProfScope {
     hipStream_t st;
     hipEvent_t a, b;

@@ -39,7 +39,7 @@ static std::mutex g_prof_mu;   // forwards may be enqueued from several host thr
 
 KpProfScope::KpProfScope(hipStream_t s, int nq_, int h_, int cin_, int cout_, int kind_)
     : st(s), a(nullptr), b(nullptr), nq(nq_), h(h_), cin(cin_), cout(cout_), kind(kind_),
-      on((g_prof_on & (kind_ == 3 ? 2 : 1)) != 0) {
+      on((g_prof_on & (kind_ == 3 ? 2 : kind_ == 4 ? 4 : 1)) != 0) {
     if (!on) return;
     (void)hipEventCreate(&a);
     (void)hipEventCreate(&b);

@@ -25,6 +25,8 @@
 // Squared distances follow nanoflann's L2_Simple_Adaptor (zip:cpp_utils/nanoflann/nanoflann.hpp:
 // 432-440): ((0 + dx*dx) + dy*dy) + dz*dz with every product and sum rounded to fp32, strict
 // d2 < r*r (:249-253, neighbors.cpp:226).  Compiled with -ffp-contract=off.
+#include <hip/hip_ext.h>
+
 #include "block_scan.h"
 #include <cstdlib>
 
@@ -985,10 +987,12 @@ int radius_query_pass(const float* q, int nq, const int* qlen, int ns, const int
     // workgroup appends its tie rows with one atomic on one word (4096 workgroups: 264 us per 60k-row table)
     const int max_blocks = max_blocks_env > 0 ? max_blocks_env : 256 * 2;
     if (blocks > max_blocks) blocks = max_blocks;
-    if (pass != 2)
-        hipLaunchKernelGGL((k_radius_query<kListCapFast, false, kQueryWaves>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, q, nq,
-                           qlen, nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count, out_max_count, status,
-                           out_tie_rows, out_tie_count, group);
+    if (pass != 2) {
+        KpProfScope ev(st, nq, cols, ns, 0, 4);
+        hipExtLaunchKernelGGL((k_radius_query<kListCapFast, false, kQueryWaves>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, ev.a,
+                              ev.b, 0, q, nq, qlen, nb, r2, g, cols, reinterpret_cast<long long*>(out_idx), out_count,
+                              out_max_count, status, out_tie_rows, out_tie_count, group);
+    }
     // second pass: one wavefront per workgroup, 16 KB of LDS -- it finds a free slot at once on a busy GPU and
     // normally has nothing to do
     const int redo_blocks = blocks < 64 ? blocks : 64;
@@ -1056,7 +1060,9 @@ int radius_cells_pass(const void* qgrid, const float* q, int nq, const int* qlen
         ca.prof = prof;
         hipLaunchKernelGGL((k_radius_cells<kCellCand, kCellListCap, kQueryWaves, true>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, ca);
     } else {
-        hipLaunchKernelGGL((k_radius_cells<kCellCand, kCellListCap, kQueryWaves>), dim3(blocks), dim3(kQueryWaves * 64), 0, st, ca);
+        KpProfScope ev(st, nq, cols, ns, 1, 4);        // bench.py's radius roofline: the kernel's own start / stop events
+        hipExtLaunchKernelGGL((k_radius_cells<kCellCand, kCellListCap, kQueryWaves>), dim3(blocks), dim3(kQueryWaves * 64), 0, st,
+                              ev.a, ev.b, 0, ca);
     }
     PCRCG_CHECK_LAUNCH();
     if (pass == 1) return PCRCG_OK;

@@ -57,16 +57,17 @@ class _Workspaces:
 
 _ws = _Workspaces()
 
-def kpconv_profile_start(gemm=False):
-    """Bracket every KPConv gather/aggregate launch -- with gemm=True also every GEMM of the split-bf16 family -- with
-    HIP start / stop events (on the launching stream)."""
-    _lib.lib().pcrcg_profile_kpconv(3 if gemm else 1)
+def kpconv_profile_start(gemm=False, radius=False, kpconv=True):
+    """Bracket every KPConv gather/aggregate launch -- with gemm=True also every GEMM of the split-bf16 family, with
+    radius=True every radius search of the front end -- with HIP start / stop events (on the launching stream)."""
+    _lib.lib().pcrcg_profile_kpconv((1 if kpconv else 0) | (2 if gemm else 0) | (4 if radius else 0))
 
 
 def kpconv_profile_stop(cap=1 << 16):
     """-> list of (milliseconds, nq, h, cin, cout, kind) per KPConv kernel launch since
     kpconv_profile_start(); kind 0 = gather/aggregate kernel (cout unknown: 0), 1 = fused kernel, 2 = bf16-storage
-    gather kernel, 3 = GEMM (then the fields are M, N, K, bf16 products per element)."""
+    gather kernel, 3 = GEMM (then the fields are M, N, K, bf16 products per element), 4 = radius search (queries, columns,
+    supports, 1 = cell-cooperative kernel)."""
     import ctypes
     L = _lib.lib()
     ms = (ctypes.c_float * cap)()
