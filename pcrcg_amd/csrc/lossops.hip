@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(64) k_circle_lines(const float* __restrict__ a
     for (int o = lane; o < n; o += 64) {
         const float* other = is_row ? b + (long)o * ldb : a + (long)o * lda;
         const float d = is_row ? cd[(long)me * ldc + o] : cd[(long)o * ldc + me];
-        const float fd = sqrtf(fmaxf(-2.0f * dotc(mine, other, c) + 2.0f, 1e-12f));
+        const float q = -2.0f * dotc(mine, other, c) + 2.0f;
+        const float fd = sqrtf(q != q ? q : fmaxf(q, 1e-12f));   // torch.clamp propagates NaN (fmaxf would return 1e-12)
         const bool pos = d < cfg.pos_radius, neg = d > cfg.safe_radius;
         npos += pos;
         nneg += neg;
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(256) k_circle_grads(const float* __restrict__ 
         const float d = is_row ? cd[(long)me * ldc + o] : cd[(long)o * ldc + me];
         const float q = -2.0f * dotc(mine, other, c) + 2.0f;
         float g = 0.f;
-        if (q > 1e-12f) {                                      // clamped entries pass no gradient
+        if (q > 1e-12f || q != q) {                            // clamped entries pass no gradient; NaN flows on (as in torch)
             const float fd = sqrtf(q);
             const bool pos = d < cfg.pos_radius, neg = d > cfg.safe_radius;
             const float pw = fmaxf(0.f, fd - (pos ? 0.f : 1e5f) - cfg.pos_optimal);

@@ -49,8 +49,9 @@ class _CircleLoss(torch.autograd.Function):
                                                 da.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel() * 4,
                                                 torch.cuda.current_stream().cuda_stream), "pcrcg_circle_loss")
         ctx.save_for_backward(da, db)
-        ctx.mark_non_differentiable(out[1])
-        return out[0], out[1]
+        loss, recall = out[0], out[1]              # bind the views ONCE: the marking applies to the object that is returned
+        ctx.mark_non_differentiable(recall)
+        return loss, recall
 
     @staticmethod
     def backward(ctx, g_loss, g_recall):
@@ -73,8 +74,9 @@ class _WeightedBCE(torch.autograd.Function):
         _lib.check(L.pcrcg_weighted_bce(p.data_ptr(), g.data_ptr(), n, out.data_ptr(), grad.data_ptr(), ws.data_ptr(), ws.numel(),
                                         torch.cuda.current_stream().cuda_stream), "pcrcg_weighted_bce")
         ctx.save_for_backward(grad)
-        ctx.mark_non_differentiable(out[1], out[2])
-        return out[0], out[1], out[2]
+        loss, precision, recall = out[0], out[1], out[2]     # (bound once: see _CircleLoss)
+        ctx.mark_non_differentiable(precision, recall)
+        return loss, precision, recall
 
     @staticmethod
     def backward(ctx, g_loss, g_p, g_r):

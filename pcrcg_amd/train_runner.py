@@ -88,20 +88,26 @@ class TrainRunner:
         def direct(dst_v, dst_g, name, param, view=None):
             """A parameter used as stored (optionally through a reshaping VIEW of it and of its gradient)."""
             val = param.data if view is None else view(param.data)
-            grd = _grad(param) if view is None else view(_grad(param))
+            if param.requires_grad:
+                grd = _grad(param) if view is None else view(_grad(param))
+            else:
+                grd = None                          # frozen: a NULL gradient pointer, the backward skips its dW product
             pv, pg = self._pair(keep, val, grd)
             setattr(dst_v, name, pv)
             setattr(dst_g, name, pg)
 
-        def derived(dst_v, dst_g, name, value, fold_back):
-            """A re-packed copy of a parameter: its gradient lands in a zeroed buffer of the same shape and
-            fold_back(buffer) adds it to the parameter's gradient after the backward."""
+        def derived(dst_v, dst_g, name, value, fold_back, *sources):
+            """A re-packed copy of one or more parameters (`sources`): its gradient lands in a zeroed buffer of the same
+            shape and fold_back(buffer) adds it to the parameters' gradients after the backward.  All sources frozen:
+            no buffer, a NULL gradient pointer."""
             value = value.contiguous()
-            buf = torch.zeros_like(value)
+            trainable = any(p.requires_grad for p in sources) if sources else True
+            buf = torch.zeros_like(value) if trainable else None
             pv, pg = self._pair(keep, value, buf)
             setattr(dst_v, name, pv)
             setattr(dst_g, name, pg)
-            fold.append(lambda: fold_back(buf))
+            if trainable:
+                fold.append(lambda: fold_back(buf))
 
         def kp_block(bv, bg, kp):
             if kp.in_channels != 1 and kp.in_channels % 4 != 0:
@@ -150,7 +156,7 @@ class TrainRunner:
                     kp4 = (k + 3) // 4 * 4
                     padded = torch.zeros((w.shape[0], kp4), dtype=w.dtype, device=w.device)
                     padded[:, :k].copy_(w.data)
-                    derived(bv, bg, "mlp", padded, lambda buf, w=w, k=k: _grad(w).add_(buf[:, :k]))
+                    derived(bv, bg, "mlp", padded, lambda buf, w=w, k=k: _grad(w).add_(buf[:, :k]), w)
                     bv.mlp_ld = kp4
             elif isinstance(mod, NearestUpsampleBlock):
                 bv.type, bv.layer = BLK_UPSAMPLE, mod.layer_ind
@@ -174,7 +180,7 @@ class TrainRunner:
                         cout = gw.shape[0]
                         gw[:, :cin].add_(buf[:cout])                       # d(Wa - Wb) -> Wa
                         gw[:, cin:].add_(buf[cout:] - buf[:cout])          # Wb sits in both terms
-                    derived(lv, lg, name, torch.cat([wa - wb, wb], 0), back)
+                    derived(lv, lg, name, torch.cat([wa - wb, wb], 0), back, w)
                 packed("edge1", layer.conv1)
                 packed("edge2", layer.conv2)
                 direct(lv, lg, "conv3", layer.conv3.weight, lambda t: t.flatten(1))
@@ -187,11 +193,11 @@ class TrainRunner:
                 perm = (torch.arange(h, device=dev)[:, None] + h * torch.arange(d, device=dev)[None, :]).reshape(-1)
                 for name, proj in zip("qkv", att.proj):
                     derived(lv, lg, "w" + name, proj.weight.data.squeeze(-1)[perm],
-                            lambda buf, p=proj.weight: _grad(p).squeeze(-1).index_add_(0, perm, buf))
+                            lambda buf, p=proj.weight: _grad(p).squeeze(-1).index_add_(0, perm, buf), proj.weight)
                     derived(lv, lg, "b" + name, proj.bias.data[perm],
-                            lambda buf, p=proj.bias: _grad(p).index_add_(0, perm, buf))
+                            lambda buf, p=proj.bias: _grad(p).index_add_(0, perm, buf), proj.bias)
                 derived(lv, lg, "wm", att.merge.weight.data.squeeze(-1)[:, perm],
-                        lambda buf, p=att.merge.weight: _grad(p).squeeze(-1).index_add_(1, perm, buf))
+                        lambda buf, p=att.merge.weight: _grad(p).squeeze(-1).index_add_(1, perm, buf), att.merge.weight)
                 direct(lv, lg, "bm", att.merge.bias)
                 direct(lv, lg, "w0", layer.mlp[0].weight, lambda t: t.squeeze(-1))
                 direct(lv, lg, "b0", layer.mlp[0].bias)
@@ -216,7 +222,16 @@ class TrainRunner:
         The three tensors are views into the step's workspace, which the NEXT training forward reuses once this one's
         backward has run: clone what must outlive the step.  (A forward issued while an earlier one still awaits its
         backward gets a workspace of its own.)"""
-        outs = _TrainNet.apply(self.model.epsilon, self, batch)
+        # the node's differentiable input: epsilon when it trains; otherwise a dummy that only anchors the node in the
+        # graph (with epsilon frozen and no anchor the outputs would carry no grad_fn and NO parameter would get a gradient)
+        eps = self.model.epsilon
+        if eps.requires_grad:
+            anchor = eps
+        else:
+            if getattr(self, "_anchor", None) is None or self._anchor.device != eps.device:
+                self._anchor = torch.zeros((), dtype=torch.float32, device=eps.device, requires_grad=True)
+            anchor = self._anchor
+        outs = _TrainNet.apply(anchor, self, batch)
         return {"feats_f": outs[0], "scores_overlap": outs[1], "scores_saliency": outs[2]}
 
     def _forward(self, batch):
@@ -291,4 +306,7 @@ class _TrainNet(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_f, d_so, d_ss):
         d_eps = ctx.runner._backward(ctx.state, d_f, d_so, d_ss)
-        return d_eps.reshape(ctx.runner.model.epsilon.shape), None, None
+        eps = ctx.runner.model.epsilon
+        if not eps.requires_grad:                  # the input was the anchor: its "gradient" is discarded
+            return torch.zeros((), dtype=torch.float32, device=eps.device), None, None
+        return d_eps.reshape(eps.shape), None, None

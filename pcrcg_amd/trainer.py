@@ -126,12 +126,76 @@ class FlatSGD(torch.optim.Optimizer):
     """torch.optim.SGD(lr, momentum, weight_decay) over a model whose parameters and gradients are views of two flat
     device buffers: the whole step is ONE launch (pcrcg_sgd_step, csrc/lossops.hip) instead of the multi-tensor kernels
     of torch.optim over 170 tensors, and it clears the gradient bucket on its way.  An ordinary Optimizer otherwise
-    (param_groups carry lr / momentum / weight_decay, so lr schedulers work on it; state_dict holds the momentum buffer)."""
+    (param_groups carry lr / momentum / weight_decay, so lr schedulers work on it; state_dict / load_state_dict speak
+    torch.optim.SGD's per-parameter format)."""
 
-    def __init__(self, params, flat_param, flat_grad, lr, momentum=0.0, weight_decay=0.0):
-        super().__init__(list(params), dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+    def __init__(self, params, flat_param, flat_grad, lr, momentum=0.0, weight_decay=0.0, sizes=None):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.flat_param, self.flat_grad = flat_param, flat_grad
-        self.state["flat"] = {"momentum_buffer": torch.zeros_like(flat_param)}
+        self._flat_params = params
+        self._sizes = list(sizes) if sizes is not None else [GradientBucket.padded(p.numel()) for p in params]
+        if sum(self._sizes) != flat_param.numel():
+            raise ValueError("FlatSGD: slice sizes do not add up to the flat parameter buffer")
+        self.momentum_flat = torch.zeros_like(flat_param)      # the only state: one flat momentum buffer (device)
+
+    # ---- checkpoints: torch.optim.SGD's format, so that they are interchangeable with the reference's
+    # (ref:lib/trainer.py:133,174 saves / loads optimizer.state_dict()) ---------------------------------------------
+    def _slices(self):
+        off = 0
+        for p, size in zip(self._flat_params, self._sizes):
+            yield p, off, p.numel()
+            off += size
+
+    def state_dict(self):
+        """Per-parameter momentum_buffer slices (clones, shaped like the parameters) under integer parameter ids and one
+        param_group with torch.optim.SGD's keys: torch.optim.SGD(model.parameters(), ...).load_state_dict() accepts it."""
+        g = self.param_groups[0]
+        state = {i: {"momentum_buffer": self.momentum_flat[off:off + n].view_as(p).clone()}
+                 for i, (p, off, n) in enumerate(self._slices())}
+        group = {"lr": g["lr"], "momentum": g["momentum"], "dampening": 0, "weight_decay": g["weight_decay"],
+                 "nesterov": False, "maximize": False, "foreach": None, "differentiable": False, "fused": None,
+                 "params": list(range(len(self._flat_params)))}
+        for k, v in g.items():                                  # (scheduler bookkeeping such as initial_lr)
+            if k not in group and k != "params":
+                group[k] = v
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, state_dict):
+        """Accepts torch.optim.SGD's / this class's state_dict (per-parameter momentum buffers, any device; missing or
+        None = zero, as before SGD's first step) and the round-3 form (one 'flat' buffer).  Values are COPIED into the
+        existing device buffer: nothing loaded from a checkpoint is ever handed to the kernel directly."""
+        groups = state_dict["param_groups"]
+        if len(groups) != 1:
+            raise ValueError("FlatSGD.load_state_dict: exactly one param_group expected")
+        st = state_dict.get("state", {})
+        if "flat" in st:                                        # round-3 checkpoints of this class
+            buf = st["flat"]["momentum_buffer"]
+            if buf.numel() != self.momentum_flat.numel():
+                raise ValueError("FlatSGD.load_state_dict: flat momentum buffer of %d elements, %d expected"
+                                 % (buf.numel(), self.momentum_flat.numel()))
+            self.momentum_flat.copy_(buf.to(self.momentum_flat.device, torch.float32).reshape(-1))
+        else:
+            ids = groups[0]["params"]
+            if len(ids) != len(self._flat_params):
+                raise ValueError("FlatSGD.load_state_dict: %d parameters in the checkpoint, %d in the model"
+                                 % (len(ids), len(self._flat_params)))
+            self.momentum_flat.zero_()
+            for pid, (p, off, n) in zip(ids, self._slices()):
+                entry = st.get(pid, st.get(str(pid)))
+                buf = None if entry is None else entry.get("momentum_buffer")
+                if buf is None:
+                    continue
+                if buf.numel() != n:
+                    raise ValueError("FlatSGD.load_state_dict: momentum buffer of parameter %s has %d elements, %d expected"
+                                     % (pid, buf.numel(), n))
+                self.momentum_flat[off:off + n].copy_(buf.to(self.momentum_flat.device, torch.float32).reshape(-1))
+        g = self.param_groups[0]
+        if groups[0].get("nesterov") or groups[0].get("dampening", 0) not in (0, 0.0) or groups[0].get("maximize"):
+            raise ValueError("FlatSGD.load_state_dict: nesterov / dampening / maximize are not implemented by pcrcg_sgd_step")
+        for k, v in groups[0].items():
+            if k != "params" and k not in ("dampening", "nesterov", "maximize", "foreach", "differentiable", "fused"):
+                g[k] = v
 
     @staticmethod
     def flatten(params, sizes):
@@ -152,7 +216,7 @@ class FlatSGD(torch.optim.Optimizer):
         from . import _lib
         g = self.param_groups[0]
         _lib.check(_lib.lib().pcrcg_sgd_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
-                                             self.state["flat"]["momentum_buffer"].data_ptr(), self.flat_param.numel(),
+                                             self.momentum_flat.data_ptr(), self.flat_param.numel(),
                                              float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), int(bool(zero_grad)),
                                              torch.cuda.current_stream().cuda_stream), "pcrcg_sgd_step")
         return None
@@ -175,7 +239,7 @@ class Trainer:
         if self.params[0].is_cuda and all(p.dtype == torch.float32 and p.is_cuda for p in self.params):
             self.flat_param = FlatSGD.flatten(self.params, self.bucket.sizes)
             self.optimizer = FlatSGD(self.params, self.flat_param, self.flat_grad, lr=lr, momentum=momentum,
-                                     weight_decay=weight_decay)
+                                     weight_decay=weight_decay, sizes=self.bucket.sizes)
         else:
             self.optimizer = torch.optim.SGD(self.params, lr=lr, momentum=momentum, weight_decay=weight_decay)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=scheduler_gamma)

@@ -3,7 +3,7 @@ gain when a family of launches simply does not happen?  Results are wrong, timin
 fusion is worth building before it is built (round 2: the row-positive pass +4 %, the normalisation passes +11 %, the
 finishing launches of tall statistics +5.6 % that no rewrite could realise, the concat copies +0.3 %).
 
-    python scripts/knockout.py build      (build container or GPU box: writes pcrcg_amd/libpcrcg_hip_knock.so)
+    python scripts/knockout.py build      (build container or GPU box: writes scripts/micro/libpcrcg_hip_knock.so)
     python scripts/knockout.py run        (GPU box: bench.py once per family with PCRCG_KNOCK=<family>)
 
 The knock-out library is the normal library with runner.hip patched so that the wrapped calls return PCRCG_OK without
@@ -17,7 +17,7 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "pcrcg_amd", "csrc")
-LIB = os.path.join(REPO, "pcrcg_amd", "libpcrcg_hip_knock.so")
+LIB = os.path.join(REPO, "scripts", "micro", "libpcrcg_hip_knock.so")   # a wrong-results measurement build: never next to the product library
 FAMILIES = [("pcrcg_copy2d(", "K_COPY"), ("pcrcg_gather_max(", "K_GMAX"), ("pcrcg_instnorm_colsums(", "K_CSUM"),
             ("pcrcg_instnorm_stats_from_partials(", "K_CFIN"), ("pcrcg_instnorm_apply_sums(", "K_APPLY"),
             ("pcrcg_instnorm_apply(", "K_APPLY"), ("instnorm_apply_pack(t.p[g]", "K_PACK"), ("pcrcg_attention(q.p[g]", "K_ATT"),

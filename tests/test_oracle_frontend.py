@@ -182,3 +182,18 @@ def test_reference_tie_order_against_reference_library():
     s = (rng.integers(0, 6, (20000, 3)) / 8).astype(np.float32)
     assert (OF.oracle_batch_query(s[:100], s, [100], [20000], 0.4, tie_order="reference")
             == OF.ref_batch_query(s[:100], s, [100], [20000], 0.4)).all()
+
+
+def test_sanitizer_job_of_the_cpu_checkers():
+    """`make -C oracle asan`: oracle/front_end.c (+ oracle/ref_shim.cpp over the unmodified reference C++ when
+    /root/reference is present) under -fsanitize=address,undefined, driven by oracle/asan_driver.c over ragged, EMPTY,
+    duplicate-ridden and dense clouds; with the reference linked the driver also checks restatement == reference entry for
+    entry.  A sanitizer report or a mismatch fails the target.  (SURVEY.md section 5: the reference has no sanitizer job;
+    GPU AddressSanitizer is not available on the pool, so the CPU build is what can be instrumented.)"""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-s", "-C", os.path.join(here, "oracle"), "asan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "asan_driver ok" in r.stdout
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr

@@ -81,6 +81,33 @@ def test_fused_loss_kernels_equal_the_torch_mirror(cuda, golden_dir, case):
         assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-9, k
 
 
+def test_fused_loss_propagates_nan_and_marks_statistics_non_differentiable(cuda, golden_dir):
+    """A NaN descriptor makes the reference's circle loss NaN (torch.clamp propagates NaN, ref:lib/loss.py:20-34 via
+    square_distance): the fused kernel must report NaN too, not the clamp's lower bound; and the statistics that come out
+    of the fused autograd functions (recall, precision) carry no grad_fn."""
+    from pcrcg_amd.loss import _CircleLoss, _WeightedBCE
+    gold = torch.load(os.path.join(golden_dir, "loss_mini.pt"), weights_only=False)
+    cs = next(iter(gold["cases"].values()))
+    out = {}
+    for fused in (True, False):
+        loss = MetricLoss(Config(gold["config"]), fused=fused)
+        inputs = {k: v.to(cuda) for k, v in cs["inputs"].items()}
+        inputs["src_feats"] = inputs["src_feats"].clone()
+        inputs["src_feats"][:] = float("nan")                      # every source descriptor: whatever the max_points draw keeps
+        np.random.seed(cs["numpy_seed"])
+        out[fused] = {k: float(v) for k, v in loss(inputs).items()}
+    assert np.isnan(out[False]["circle_loss"]) and np.isnan(out[True]["circle_loss"]), out
+    g = torch.Generator().manual_seed(0)
+    a = torch.nn.functional.normalize(torch.randn(40, 32, generator=g), dim=1).to(cuda).requires_grad_(True)
+    b = torch.nn.functional.normalize(torch.randn(40, 32, generator=g), dim=1).to(cuda).requires_grad_(True)
+    cd = torch.rand(40, 40, generator=g).to(cuda) * 0.2
+    lv, rec = _CircleLoss.apply(a, b, cd, (0.0375, 0.1, 0.1, 1.4, 0.1, 1.4, 16.0))
+    assert lv.requires_grad and not rec.requires_grad and rec.grad_fn is None
+    p = torch.rand(100, generator=g).to(cuda).requires_grad_(True)
+    lv, prec, rec = _WeightedBCE.apply(p, (torch.rand(100, generator=g) > 0.5).float().to(cuda))
+    assert lv.requires_grad and not prec.requires_grad and not rec.requires_grad
+
+
 def test_prepared_loss_equals_the_loss(cuda, golden_dir):
     """MetricLoss.prepare() (the geometry-only part, which a trainer runs beside the network's forward) handed to forward()
     gives the same statistics as forward() alone, and consumes the host generator identically."""

@@ -118,7 +118,70 @@ def test_flat_sgd_is_torch_sgd(cuda):
         sched.step()
         for p, q in zip(ref, mine):
             assert float((p.data - q.data).abs().max()) <= 1e-6 * float(p.data.abs().max()), step
-    assert "momentum_buffer" in opt.state_dict()["state"]["flat"]
+    # ---- checkpoints are interchangeable with torch.optim.SGD's (ref:lib/trainer.py:133,174 saves / loads the optimizer's
+    # state_dict): FlatSGD -> torch, torch (mapped to the CPU, as a checkpoint is) -> FlatSGD, then both step on identically
+    sd = opt.state_dict()
+    assert set(sd["state"]) == set(range(len(mine))) and all(sd["state"][i]["momentum_buffer"].shape == mine[i].shape for i in sd["state"])
+    topt2 = torch.optim.SGD([torch.nn.Parameter(q.detach().clone()) for q in mine], lr=1.0)
+    topt2.load_state_dict(sd)                                  # torch accepts the format, hyper-parameters included
+    assert topt2.param_groups[0]["momentum"] == 0.98 and abs(topt2.param_groups[0]["lr"] - opt.param_groups[0]["lr"]) < 1e-12
+    tsd = {"state": {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in topt.state_dict()["state"].items()},
+           "param_groups": topt.state_dict()["param_groups"]}
+    mine2 = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    bucket2 = GradientBucket(mine2)
+    opt2 = FlatSGD(mine2, FlatSGD.flatten(mine2, bucket2.sizes), bucket2.flat, lr=1.0, momentum=0.0, sizes=bucket2.sizes)
+    opt2.load_state_dict(tsd)
+    assert opt2.momentum_flat.is_cuda and opt2.param_groups[0]["momentum"] == 0.98          # copied INTO the device buffer
+    for p, q in zip(ref, mine2):
+        gr = torch.randn(p.shape, generator=g).to(cuda)
+        p.grad = gr.clone()
+        q.grad.copy_(gr)
+    topt.step()
+    opt2.step()
+    for p, q in zip(ref, mine2):
+        assert float((p.data - q.data).abs().max()) <= 1e-6 * float(p.data.abs().max())     # momentum was NOT reset
+    # round-3 checkpoints (one flat buffer) still load; wrong sizes are refused
+    opt2.load_state_dict({"state": {"flat": {"momentum_buffer": opt.momentum_flat.cpu()}}, "param_groups": sd["param_groups"]})
+    assert torch.equal(opt2.momentum_flat, opt.momentum_flat)
+    with pytest.raises(ValueError):
+        opt2.load_state_dict({"state": {"flat": {"momentum_buffer": torch.zeros(3)}}, "param_groups": sd["param_groups"]})
+
+
+def test_partly_frozen_model_trains_the_rest(cuda, golden_dir):
+    """Frozen parameters (requires_grad = False) -- `epsilon`, the node's former only differentiable input, among them --
+    get NO gradient tensor and no dW product (NULL gradient pointer in the C ABI), and every other parameter gets exactly
+    the gradient it gets in the unfrozen model."""
+    gold = torch.load(os.path.join(golden_dir, "model_mini.pt"))
+    col = torch.load(os.path.join(golden_dir, "collate_mini.pt"))
+    cfg = indoor_config(**{k: v for k, v in gold["config"].items() if k in ("first_feats_dim", "gnn_feats_dim")})
+    batch = _to(col["batch"], cuda)
+    grads = {}
+    frozen = ("epsilon", "encoder_blocks.1.KPConv.weights", "decoder_blocks.1.mlp.weight", "gnn.layers.0.conv1.weight",
+              "gnn.layers.1.attn.proj.0.weight", "bottle.bias")
+    for freeze in (False, True):
+        net = KPFCNN(cfg)
+        net.load_state_dict(gold["state_dict"])
+        net = net.to(cuda).train()
+        params = dict(net.named_parameters())
+        if freeze:
+            for name in frozen:
+                params[name].requires_grad_(False)
+        out = net.train_runner().forward(batch)
+        assert out["feats_f"].grad_fn is not None                  # (epsilon frozen: the node is still in the graph)
+        (out["feats_f"].square().sum() + out["scores_overlap"].sum() + 2.0 * out["scores_saliency"].sum()).backward()
+        grads[freeze] = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in params.items()}
+    # (biases in front of an InstanceNorm have an exactly zero gradient: both runs return rounding noise there, and the
+    # atomically accumulated products differ in their last bits from run to run -- errors are measured against a floor)
+    floor = 1e-4 * max(float(v.abs().max()) for v in grads[False].values() if v is not None)
+    for name, want in grads[False].items():
+        got = grads[True][name]
+        if name in frozen:
+            assert got is None, name                               # no .grad allocated, nothing accumulated
+        elif want is None:                                         # (kernel_points: never trainable)
+            assert got is None, name
+        else:
+            assert got is not None, name
+            assert float((got - want).abs().max()) <= 1e-5 * max(float(want.abs().max()), floor), name
 
 
 def test_weight_gradients_on_the_second_stream_equal_one_stream(cuda, golden_dir):
