@@ -208,32 +208,48 @@ def test_s30k_lomatch_forward_and_train_step(cuda, golden_dir, monkeypatch):
     grads = {n: p.grad.detach().clone().cpu() for n, p in model.named_parameters() if p.requires_grad}
     cpu_inputs = {k: ([t.cpu() if isinstance(t, torch.Tensor) else t for t in v] if isinstance(v, list)
                       else (v.cpu() if isinstance(v, torch.Tensor) else v)) for k, v in inputs.items()}
-    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
-    o = MR.kpfcnn_forward_with_grad(sd, dict(cfg), cpu_inputs)
     n_src = len(src)
-    np.random.seed(5)
     # the loss on the CPU: the saliency labels' nearest-descriptor search as the reference writes it, a dense
     # matmul + arg-max (ref:lib/loss.py:207-219), in place of the fused HIP kernel
     from pcrcg_amd import loss as loss_mod
     monkeypatch.setattr(loss_mod.ops, "feature_argmax", lambda a, b, want_best=False: (a @ b.t()).argmax(1))
-    res = MetricLoss(LOSS_CFG)({"src_feats": o["feats_f"][:n_src], "tgt_feats": o["feats_f"][n_src:],
-                                "rot": cpu_inputs["rot"], "trans": cpu_inputs["trans"],
-                                "scores_overlap": o["scores_overlap"], "scores_saliency": o["scores_saliency"],
-                                "src_pcd_raw": cpu_inputs["src_pcd_raw"], "tgt_pcd_raw": cpu_inputs["tgt_pcd_raw"],
-                                "correspondences": cpu_inputs["correspondences"]})
-    total = sum(res[k] for k in res if k in ("circle_loss", "overlap_loss", "saliency_loss"))
+
+    def oracle(dt):
+        """Network in `dt` on the CPU (torch autograd over oracle/model_ref.py), MetricLoss's torch formulation on its
+        outputs (in fp32, as the reference computes it: its BCE takes float labels), gradients wrt every parameter."""
+        sd = {k: (v.clone().to(dt).requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        b = {k: ([t.to(dt) if isinstance(t, torch.Tensor) and t.is_floating_point() else t for t in v] if isinstance(v, list)
+                 else (v.to(dt) if isinstance(v, torch.Tensor) and v.is_floating_point() else v)) for k, v in cpu_inputs.items()}
+        o = MR.kpfcnn_forward_with_grad(sd, dict(cfg), b)
+        np.random.seed(5)
+        res = MetricLoss(LOSS_CFG)({"src_feats": o["feats_f"][:n_src].float(), "tgt_feats": o["feats_f"][n_src:].float(),
+                                    "rot": cpu_inputs["rot"], "trans": cpu_inputs["trans"],
+                                    "scores_overlap": o["scores_overlap"].float(), "scores_saliency": o["scores_saliency"].float(),
+                                    "src_pcd_raw": cpu_inputs["src_pcd_raw"], "tgt_pcd_raw": cpu_inputs["tgt_pcd_raw"],
+                                    "correspondences": cpu_inputs["correspondences"]})
+        sum(res[k] for k in res if k in ("circle_loss", "overlap_loss", "saliency_loss")).backward()
+        return res, sd
+
+    res, s32 = oracle(torch.float32)
     for k in ("circle_loss", "overlap_loss", "saliency_loss"):
         assert abs(stats[k] - float(res[k].detach())) < 2e-3 * max(abs(float(res[k].detach())), 1e-3), (k, stats[k], float(res[k].detach()))
-    total.backward()
+    # Gradients: MEASURED against float64 at this size (round 3 asserted the band from the C1 measurement).  fp32 through
+    # ~60 layers with data-dependent LeakyReLU / max-pool / neighbour-count decisions sits a few 1e-3 from float64 per
+    # parameter tensor whoever computes it; the HIP path must be no further from the float64 oracle than 3x what the fp32
+    # CPU oracle is, percentile by percentile (the form of tests/test_train_step_gpu.py::test_full_width_gradients_c1_vs_oracle)
+    _, s64 = oracle(torch.float64)
     names = list(grads)
-    floor = 1e-4 * max(float(sd[n].grad.abs().max()) for n in names)
-    errs = np.array([float((grads[n].double() - sd[n].grad.double()).abs().max()
-                           / max(float(sd[n].grad.abs().max()), floor)) for n in names])
-    # fp32 against fp32 through ~60 layers with data-dependent LeakyReLU / max-pool / neighbour-count decisions: the
-    # C1 full-width test (tests/test_train_step_gpu.py) measures the fp32 oracle itself a median 3e-3 away from the
-    # float64 one; the same band is required here
-    print("S30k-lomatch gradient errors: median %.2e p90 %.2e max %.2e" % (np.median(errs), np.percentile(errs, 90), errs.max()))
-    assert np.median(errs) < 2e-2 and np.percentile(errs, 90) < 1e-1, (np.median(errs), np.percentile(errs, 90), errs.max())
+    floor = 1e-4 * max(float(s64[n].grad.abs().max()) for n in names)
+
+    def errs(get):
+        return np.array([float((get(n).double() - s64[n].grad).abs().max() / max(float(s64[n].grad.abs().max()), floor))
+                         for n in names])
+    e_hip, e_ref = errs(lambda n: grads[n]), errs(lambda n: s32[n].grad)
+    print("S30k-lomatch gradient errors vs float64: HIP median %.2e p90 %.2e max %.2e | fp32 CPU oracle median %.2e p90 %.2e max %.2e"
+          % (np.median(e_hip), np.percentile(e_hip, 90), e_hip.max(), np.median(e_ref), np.percentile(e_ref, 90), e_ref.max()))
+    assert np.median(e_hip) <= 3 * np.median(e_ref), (np.median(e_hip), np.median(e_ref))
+    assert np.percentile(e_hip, 90) <= 3 * np.percentile(e_ref, 90), (np.percentile(e_hip, 90), np.percentile(e_ref, 90))
+    assert e_hip.max() <= 3 * e_ref.max() + 1e-2, (e_hip.max(), e_ref.max())
     assert trainer.optimizer_step() is True
 
 
