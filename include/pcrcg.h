@@ -549,6 +549,14 @@ size_t pcrcg_pyramid_ws_bytes(int n0, int nb, const pcrcg_pyramid_cfg* cfg, doub
 int pcrcg_pyramid_build(const float* pts, int n0, const int* len, int nb, const pcrcg_pyramid_cfg* cfg, void* ws,
                         size_t ws_bytes, int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status,
                         pcrcg_pyramid_restore* deferred, void* stream);
+/* The same build with the input clouds given in `parts` pieces (e.g. the two pairs of a cfg.group = 2 build, each where
+ * its producer left it): part i has n_parts[i] rows at pts_parts[i] and nb_parts[i] cloud lengths at len_parts[i] (device);
+ * the builder copies them behind each other into its arena -- it copies its input anyway -- so the caller runs no
+ * concatenation kernel.  Row for row the result of pcrcg_pyramid_build on the concatenated input. */
+int pcrcg_pyramid_build_parts(const float* const* pts_parts, const int* n_parts, const int* const* len_parts,
+                              const int* nb_parts, int parts, const pcrcg_pyramid_cfg* cfg, void* ws, size_t ws_bytes,
+                              int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status,
+                              pcrcg_pyramid_restore* deferred, void* stream);
 int pcrcg_pyramid_restore_run(const pcrcg_pyramid_restore* r, int* h_status, void* stream);
 
 /* A non-blocking HIP stream created by the library (hipStreamCreateWithPriority(hipStreamNonBlocking); priority 0 =

@@ -106,6 +106,8 @@ SIGNATURES = {
     "pcrcg_pyramid_ws_bytes": (c_size_t, [c_int, c_int, c_void_p, ctypes.c_double]),
     "pcrcg_pyramid_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcrcg_pyramid_build_parts": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcrcg_pyramid_restore_run": (c_int, [c_void_p, c_void_p, c_void_p]),
     "pcrcg_stream_create": (c_int, [c_void_p, c_int]),
     "pcrcg_stream_destroy": (c_int, [c_void_p]),

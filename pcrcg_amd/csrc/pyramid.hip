@@ -143,7 +143,18 @@ struct TableRec {
 
 using namespace pcrcg;
 
-static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const pcrcg_pyramid_cfg* cfg, Arena& A,
+// The input clouds may come in several PARTS (the pairs of a grouped build, each where its caller left it): part i holds
+// n_parts[i] rows and nb_parts[i] cloud lengths; they are copied behind each other into the arena (the builder copies its
+// input anyway), so stacking pairs costs no concatenation kernel on the caller's side.
+struct Parts {
+    const float* const* pts;
+    const int* n;
+    const int* const* len;
+    const int* nb;
+    int count;
+};
+
+static int pyramid_run(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg* cfg, Arena& A,
                        int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status, pcrcg_pyramid_restore* deferred,
                        double shrink, hipStream_t st) {
     const int L = cfg->n_levels;
@@ -169,8 +180,14 @@ static int pyramid_run(const float* pts0, int n0, const int* len0, int nb, const
     if (!dry) {
         PCRCG_CHECK_HIP(hipMemsetAsync(metas, 0, sizeof(int) * ((size_t)MS * max_tables + L), st));
         PCRCG_CHECK_HIP(hipMemsetAsync(tie_status, 0, sizeof(int), st));
-        PCRCG_CHECK_HIP(hipMemcpyAsync(pts_all, pts0, sizeof(float) * 3 * (size_t)n0, hipMemcpyDeviceToDevice, st));
-        PCRCG_CHECK_HIP(hipMemcpyAsync(lens_all, len0, sizeof(int) * nb, hipMemcpyDeviceToDevice, st));
+        size_t row = 0, cloud = 0;
+        for (int i = 0; i < in.count; ++i) {
+            if (in.n[i] > 0)
+                PCRCG_CHECK_HIP(hipMemcpyAsync(pts_all + 3 * row, in.pts[i], sizeof(float) * 3 * (size_t)in.n[i], hipMemcpyDeviceToDevice, st));
+            PCRCG_CHECK_HIP(hipMemcpyAsync(lens_all + cloud, in.len[i], sizeof(int) * in.nb[i], hipMemcpyDeviceToDevice, st));
+            row += (size_t)in.n[i];
+            cloud += (size_t)in.nb[i];
+        }
         PCRCG_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(feats), 0x3f800000, (size_t)(n0 > 0 ? n0 : 1), st));
     }
 
@@ -362,7 +379,8 @@ size_t pcrcg_pyramid_ws_bytes(int n0, int nb, const pcrcg_pyramid_cfg* cfg, doub
     if (!cfg || n0 < 0 || nb < 1 || cfg->n_levels < 1 || cfg->n_levels > PCRCG_MAX_LEVELS) return 0;
     if (!(shrink > 0.0) || shrink > 1.0) shrink = 1.0;
     Arena A(nullptr, 0, true);
-    if (pyramid_run(nullptr, n0, nullptr, nb, cfg, A, nullptr, nullptr, nullptr, nullptr, nullptr, shrink, nullptr) != PCRCG_OK) return 0;
+    const Parts none{nullptr, nullptr, nullptr, nullptr, 0};
+    if (pyramid_run(none, n0, nb, cfg, A, nullptr, nullptr, nullptr, nullptr, nullptr, shrink, nullptr) != PCRCG_OK) return 0;
     // the KD-forest of the restore step over all levels' rows
     size_t rows = 0;
     double r = n0;
@@ -398,10 +416,10 @@ int pcrcg_pyramid_restore_run(const pcrcg_pyramid_restore* r, int* h_status, voi
     return PCRCG_OK;
 }
 
-int pcrcg_pyramid_build(const float* pts, int n0, const int* len, int nb, const pcrcg_pyramid_cfg* cfg, void* ws,
-                        size_t ws_bytes, int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status,
-                        pcrcg_pyramid_restore* deferred, void* stream) {
-    PCRCG_CHECK_ARG(cfg && pts && len && ws && h_scratch && out && h_lengths);
+static int pyramid_build_checked(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg* cfg, void* ws, size_t ws_bytes,
+                                 int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status,
+                                 pcrcg_pyramid_restore* deferred, void* stream) {
+    PCRCG_CHECK_ARG(cfg && ws && h_scratch && out && h_lengths);
     PCRCG_CHECK_ARG(n0 >= 1 && nb >= 1 && nb <= 16);
     PCRCG_CHECK_ARG(cfg->group >= 0 && (cfg->group == 0 || nb % cfg->group == 0));
     PCRCG_CHECK_ARG((cfg->group > 0 ? nb / cfg->group : 1) + 2 <= 16 && cfg->n_levels * nb <= 64);
@@ -411,10 +429,34 @@ int pcrcg_pyramid_build(const float* pts, int n0, const int* len, int nb, const 
     Arena A(ws, ws_bytes, false);
     hipStream_t st = as_stream(stream);
     const double t0 = g_trace.on ? now_us() : 0.0, w0 = g_trace.wait;
-    const int rc = pyramid_run(pts, n0, len, nb, cfg, A, h_scratch, out, h_lengths, h_status, deferred, 1.0, st);
+    const int rc = pyramid_run(in, n0, nb, cfg, A, h_scratch, out, h_lengths, h_status, deferred, 1.0, st);
     if (g_trace.on) { g_trace.enq += now_us() - t0 - (g_trace.wait - w0); g_trace.calls += 1; }
     if (rc == PCRCG_EWORKSPACE)
         set_error("pcrcg_pyramid_build: arena too small (%zu needed so far, %zu given): size it with a larger `shrink`", A.off, ws_bytes);
     return rc;
+}
+
+int pcrcg_pyramid_build(const float* pts, int n0, const int* len, int nb, const pcrcg_pyramid_cfg* cfg, void* ws,
+                        size_t ws_bytes, int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status,
+                        pcrcg_pyramid_restore* deferred, void* stream) {
+    PCRCG_CHECK_ARG(pts && len);
+    const Parts in{&pts, &n0, &len, &nb, 1};
+    return pyramid_build_checked(in, n0, nb, cfg, ws, ws_bytes, h_scratch, out, h_lengths, h_status, deferred, stream);
+}
+
+int pcrcg_pyramid_build_parts(const float* const* pts_parts, const int* n_parts, const int* const* len_parts,
+                              const int* nb_parts, int parts, const pcrcg_pyramid_cfg* cfg, void* ws, size_t ws_bytes,
+                              int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status,
+                              pcrcg_pyramid_restore* deferred, void* stream) {
+    PCRCG_CHECK_ARG(pts_parts && n_parts && len_parts && nb_parts && parts >= 1 && parts <= 8);
+    long n0 = 0, nb = 0;
+    for (int i = 0; i < parts; ++i) {
+        PCRCG_CHECK_ARG(n_parts[i] >= 0 && nb_parts[i] >= 1 && len_parts[i] && (n_parts[i] == 0 || pts_parts[i]));
+        n0 += n_parts[i];
+        nb += nb_parts[i];
+    }
+    PCRCG_CHECK_ARG(n0 <= 0x7fffffffL);
+    const Parts in{pts_parts, n_parts, len_parts, nb_parts, parts};
+    return pyramid_build_checked(in, (int)n0, (int)nb, cfg, ws, ws_bytes, h_scratch, out, h_lengths, h_status, deferred, stream);
 }
 }

@@ -196,8 +196,8 @@ class PairStreams:
                     else:
                         # several pairs stacked into ONE kernel chain (the chain is latency-bound: k pairs cost little
                         # more than one); the restore step covers all of them and runs here
-                        batches, arena, lens_h, slot = pyr.build(torch.cat([it[1] for it in items]),
-                                                                 torch.cat([it[2] for it in items]), group=2)
+                        # (the pairs are handed over as PARTS: the builder copies them into its arena itself, no torch.cat)
+                        batches, arena, lens_h, slot = pyr.build([it[1] for it in items], [it[2] for it in items], group=2)
                         deferred = None
                     self._stat(arena_wait_s=t1 - t0, build_s=time.perf_counter() - t1, pairs=k, builds=1)
                     built = torch.cuda.Event()

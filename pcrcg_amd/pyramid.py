@@ -264,7 +264,9 @@ class NativePyramid:
                         "pcrcg_pyramid_restore_run")
 
     def build(self, points, lengths, fresh_arena=False, defer_restore=False, group=0):
-        """points [N0,3] f32, lengths [B] i32 on the device; enqueues on the CURRENT stream.
+        """points [N0,3] f32, lengths [B] i32 on the device -- or LISTS of such tensors, one entry per part (the pairs of a
+        grouped build): the builder copies the parts behind each other into its arena (pcrcg_pyramid_build_parts), no
+        torch.cat kernel runs; enqueues on the CURRENT stream.
         -> (pcrcg_batch mirror, arena tensor it points into, per-level cloud lengths (python lists),
             slot of this call's status word in self.status -- valid once the stream has drained).
         defer_restore: the tie-order restore step is not enqueued; a fifth value, its descriptor, is returned for
@@ -273,11 +275,13 @@ class NativePyramid:
         call (the front end's kernel chain is latency-bound: two pairs cost little more than one); the first value then
         is a ctypes array of that many pcrcg_batch mirrors, each with its own tables."""
         ct, L = self._ct, self._lib.lib()
-        if not points.is_cuda:
+        parts = isinstance(points, (list, tuple))
+        pts_l = [p.to(torch.float32).contiguous() for p in (points if parts else [points])]
+        lens_l = [l.to(_I32).contiguous() for l in (lengths if parts else [lengths])]
+        if not all(p.is_cuda for p in pts_l):
             raise RuntimeError("pcrcg_amd.build_pyramid: points must be on a HIP device (no CPU path)")
-        pts = points.to(torch.float32).contiguous()
-        lens = lengths.to(_I32).contiguous()
-        n0, nb = int(pts.shape[0]), int(lens.shape[0])
+        pts, lens = pts_l[0], lens_l[0]
+        n0, nb = sum(int(p.shape[0]) for p in pts_l), sum(int(l.shape[0]) for l in lens_l)
         stream = torch.cuda.current_stream().cuda_stream
         if group and nb % group:
             raise RuntimeError("pcrcg_amd.NativePyramid: the number of clouds is not a multiple of `group`")
@@ -298,10 +302,21 @@ class NativePyramid:
                 if not fresh_arena:
                     self.arena = arena
             b = (self._Batch * nbatch)() if group else self._Batch()
-            rc = L.pcrcg_pyramid_build(pts.data_ptr(), n0, lens.data_ptr(), nb, ct.byref(self.cfg), arena.data_ptr(),
-                                       arena.numel(), self.scratch.data_ptr(), ct.byref(b), h_len,
-                                       self.status.data_ptr() + 4 * slot,
-                                       ct.byref(deferred) if defer_restore else None, stream)
+            if parts:
+                k = len(pts_l)
+                pp = (ct.c_void_p * k)(*[p.data_ptr() for p in pts_l])
+                lp = (ct.c_void_p * k)(*[l.data_ptr() for l in lens_l])
+                pn = (ct.c_int * k)(*[int(p.shape[0]) for p in pts_l])
+                ln = (ct.c_int * k)(*[int(l.shape[0]) for l in lens_l])
+                rc = L.pcrcg_pyramid_build_parts(pp, pn, lp, ln, k, ct.byref(self.cfg), arena.data_ptr(), arena.numel(),
+                                                 self.scratch.data_ptr(), ct.byref(b), h_len,
+                                                 self.status.data_ptr() + 4 * slot,
+                                                 ct.byref(deferred) if defer_restore else None, stream)
+            else:
+                rc = L.pcrcg_pyramid_build(pts.data_ptr(), n0, lens.data_ptr(), nb, ct.byref(self.cfg), arena.data_ptr(),
+                                           arena.numel(), self.scratch.data_ptr(), ct.byref(b), h_len,
+                                           self.status.data_ptr() + 4 * slot,
+                                           ct.byref(deferred) if defer_restore else None, stream)
             if rc == -2 and self.shrink < 1.0:      # PCRCG_EWORKSPACE: this cloud keeps more rows per level than assumed
                 self.shrink = 1.0
                 continue
