@@ -50,7 +50,8 @@ constexpr int kCellCand = 1024;       // candidates staged per query cell (16 Ki
                                       // at most 15.6 points per cell: 27 cells 421, the 64 cells of a pool table 1000 in a
                                       // solid volume, ~225 on scanned surfaces)
 constexpr int kCellListCap = 128;     // hits staged per query by the cell kernel (longer rows: second pass)
-constexpr int kCellTieCap = 128;      // tie rows staged per workgroup of the cell kernel
+constexpr int kCellTieCap = 512;      // tie rows staged per workgroup of the cell kernel (beyond: one global atomic per row -- 1 ms per
+                                      // 60k-row table on voxelised data; two stacked T30k pairs on 512 workgroups give ~235 per workgroup)
 constexpr int kCellMaxCells = 256;    // support cells within reach of one query cell
 constexpr int kCellQ = 64;            // queries of a cell staged per batch
 
@@ -479,7 +480,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
     __shared__ float4 s_cand[SC];
     __shared__ float4 s_q[kCellQ];
     __shared__ unsigned s_key[WAVES][CAP + 8];       // d2 bits of a query's hits ...
-    __shared__ int s_idx[WAVES][CAP];                // ... and their support indices
+    __shared__ int s_idx[WAVES][CAP + 8];            // ... and their support indices
     __shared__ int s_excl[kCellMaxCells];
     __shared__ int s_start[kCellMaxCells];
     __shared__ int s_cnt[kCellMaxCells];
@@ -710,11 +711,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
                         rank[u] = 0;
                     }
                     __builtin_amdgcn_wave_barrier();
-                    for (int j = 0; j < nl; ++j) {
-                        const unsigned ok = key[j];
-                        const int oi = idx[j];
+                    for (int j = 0; j < nl; j += 4) {            // four hits per step (voxelised scans: most rows come here)
+                        const uint4 k0 = *reinterpret_cast<const uint4*>(&key[j]);
+                        const int4 i0 = *reinterpret_cast<const int4*>(&idx[j]);
 #pragma unroll
-                        for (int u = 0; u < R; ++u) rank[u] += (ok < mk[u] || (ok == mk[u] && oi < mi[u])) ? 1 : 0;
+                        for (int u = 0; u < R; ++u)
+                            rank[u] += ((k0.x < mk[u] || (k0.x == mk[u] && i0.x < mi[u])) ? 1 : 0) +
+                                       ((k0.y < mk[u] || (k0.y == mk[u] && i0.y < mi[u])) ? 1 : 0) +
+                                       ((k0.z < mk[u] || (k0.z == mk[u] && i0.z < mi[u])) ? 1 : 0) +
+                                       ((k0.w < mk[u] || (k0.w == mk[u] && i0.w < mi[u])) ? 1 : 0);
                     }
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll

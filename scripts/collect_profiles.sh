@@ -9,7 +9,7 @@ python3 $R/bench.py --steps 50 --warmup 5 2> $O/${TAG}_bench.err | tail -1 > $O/
 db() { find "$1" -name "*results.db" | head -1; }
 # 1. the timed bench under the kernel tracer
 rm -rf /tmp/p1; rocprofv3 --kernel-trace --stats -d /tmp/p1 -o p -- python3 $R/bench.py --steps 50 --warmup 5 --repeats 1 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprof.json
-# pairs under the tracer: 24 priming (4 x model streams x pairs per forward) + 5 warm-up + 50 timed + 3 isolated forwards
+# pairs under the tracer: 24 priming (4 x model streams x pairs per forward) + 5 warm-up + 50 timed + 3 isolated forwards (+ 3 isolated pyramid builds)
 python3 $R/scripts/prof_summary.py $(db /tmp/p1) $O/${TAG}_kernel_stats.csv 82
 python3 $R/scripts/front_chain.py $(db /tmp/p1) > $O/${TAG}_front_chain.txt 2>&1
 python3 $R/scripts/concurrency.py $(db /tmp/p1) > $O/${TAG}_concurrency.txt 2>&1

@@ -29,7 +29,7 @@ for g in big[-3:]:
         streams.setdefault(s, []).append((n, a, b))
     for s, ks in sorted(streams.items(), key=lambda kv: kv[1][0][1]):
         busy = sum(b - a for _, a, b in ks) / 1e6
-        rq = sum(1 for k in ks if "k_radius_query" in k[0])
+        rq = sum(1 for k in ks if "k_radius_query" in k[0] or "k_radius_cells" in k[0])
         print(f"  stream {s}: {len(ks):5d} kernels, first at {(ks[0][1] - t0) / 1e6:6.2f} ms, last ends {(ks[-1][2] - t0) / 1e6:6.2f} ms, "
               f"busy {busy:6.2f} ms{'  (front end)' if rq else ''}")
     nb = int((t1 - t0) / 0.5e6) + 1

@@ -30,7 +30,7 @@ for sid, ks in sorted(streams.items(), key=lambda kv: -len(kv[1])):
     print(f"stream {sid}: {len(ks):6d} kernels, busy {busy:8.2f} ms ({100 * busy / wall:5.1f}% of window)  top: " +
           ", ".join(f"{n} {t / 1e6:.1f}ms" for n, t in top))
 # front-end chains: from k_init/k_minmax of level 0 ... use k_grid_init occurrences with the largest grid as pair starts
-front = max(streams.items(), key=lambda kv: sum(1 for k in kv[1] if "k_radius_query" in k[0]))[1]
+front = max(streams.items(), key=lambda kv: sum(1 for k in kv[1] if ("k_radius_query" in k[0] or "k_radius_cells" in k[0])))[1]
 starts = [s for n, s, e in front if "k_kd_init" in n]
 if starts:
     print(f"tie phases in window: {len(starts)}; mean period {(starts[-1] - starts[0]) / max(len(starts) - 1, 1) / 1e6:.3f} ms")
