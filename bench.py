@@ -595,7 +595,7 @@ def main():
     events = ops.kpconv_profile_stop()
     stats = pipe.stats_snapshot()
     own = sorted(r[2] for r in regions)[len(regions) // 2]      # this rank's own clock, median region
-    per_rank = launcher.rank_fields(dist if world > 1 else None, world, rank, round(args.steps / own, 3), RANK_CPUS)
+    per_rank = launcher.rank_fields(dist, world, rank, round(args.steps / own, 3), RANK_CPUS, device=dev)
     times = sorted(r[0] for r in regions)
     elapsed = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
     submit = sorted(r[1] for r in regions)[len(regions) // 2]

@@ -640,7 +640,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
                     continue;
                 }
                 int nhit = 0;
-#pragma unroll 2
                 for (int t0 = 0; t0 < total; t0 += 64) {
                     const int t = t0 + lane;
                     const float4 p = s_cand[t < total ? t : total - 1];
@@ -650,10 +649,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
                     d2 += d1 * d1;
                     d2 += d2c * d2c;
                     const bool hit = t < total && d2 < r2;
-                    const u64 mask = __ballot(hit);
-                    const int pos = nhit + __popcll(mask & ((1ull << lane) - 1ull));
+                    const u64 mask = __builtin_amdgcn_ballot_w64(hit);
+                    const int pos = nhit + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                     if (hit && pos < CAP) { key[pos] = __float_as_uint(d2); idx[pos] = __float_as_int(p.w); }
-                    nhit += __popcll(mask);
+                    nhit += __builtin_popcountll(mask);
                 }
                 stamp(4);
                 if (PROF) ++pqueries;

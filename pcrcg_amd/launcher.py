@@ -248,17 +248,27 @@ def launch(script, argv, gpus, dry_run=False, env_extra=None, timeout=None):
     return rc
 
 
-def rank_fields(dist, world, rank, local_value, cpus):
+def rank_fields(dist, world, rank, local_value, cpus, device=None):
     """What every rank contributes to rank 0's line: -> dict with ranks_seen (from the process group), per-rank values
-    and CPU sets.  `dist` is torch.distributed (initialised) or None for a single process."""
-    mine = {"rank": rank, "value": local_value, "cpus": format_cpulist(cpus) if cpus else None,
-            "host": socket.gethostname(), "pid": os.getpid()}
+    and CPU sets.  `dist` is torch.distributed (initialised) or None for a single process.  Plain tensor collectives
+    only (one all_gather of a fixed-size record on `device`, the process group's device): no pickled objects through
+    RCCL."""
+    text = format_cpulist(cpus) if cpus else ""
     if dist is None:
-        got = [mine]
-    else:
-        got = [None] * world
-        dist.all_gather_object(got, mine)
-    got = sorted(got, key=lambda d: d["rank"])
-    return {"ranks_seen": len({d["rank"] for d in got}),
-            "per_rank_value": [d["value"] for d in got],
-            "per_rank_cpus": [d["cpus"] for d in got]}
+        return {"ranks_seen": 1, "per_rank_value": [local_value], "per_rank_cpus": [text or None]}
+    import torch
+    rec = torch.zeros(2 + 240, dtype=torch.float64)
+    rec[0], rec[1] = float(rank), float(local_value)
+    raw = text.encode()[:240]
+    rec[2:2 + len(raw)] = torch.tensor(list(raw), dtype=torch.float64)
+    rec = rec.to(device) if device is not None else rec
+    got = [torch.zeros_like(rec) for _ in range(world)]
+    dist.all_gather(got, rec)
+    rows = sorted((t.cpu() for t in got), key=lambda t: int(t[0]))
+    cpus_out = []
+    for t in rows:
+        b = bytes(int(v) for v in t[2:].tolist() if int(v) != 0)
+        cpus_out.append(b.decode() or None)
+    return {"ranks_seen": len({int(t[0]) for t in rows}),
+            "per_rank_value": [round(float(t[1]), 3) for t in rows],
+            "per_rank_cpus": cpus_out}

@@ -195,7 +195,7 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         identical = float(lo) == float(hi)
         assert identical, "replicas diverged"
-    fields = launcher.rank_fields(dist if world > 1 else None, world, rank, round(1.0 / own, 3), RANK_CPUS)
+    fields = launcher.rank_fields(dist, world, rank, round(1.0 / own, 3), RANK_CPUS, device=dev)
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
