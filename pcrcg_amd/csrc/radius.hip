@@ -50,6 +50,7 @@ constexpr int kCellCand = 1024;       // candidates staged per query cell (16 Ki
                                       // at most 15.6 points per cell: 27 cells 421, the 64 cells of a pool table 1000 in a
                                       // solid volume, ~225 on scanned surfaces)
 constexpr int kCellListCap = 128;     // hits staged per query by the cell kernel (longer rows: second pass)
+constexpr unsigned kPadKey = 0x7FFFFFFFu;   // padding "d2" of the cell kernel's hit lists: above every real d2 word, INT_MAX as an int
 constexpr int kCellTieCap = 512;      // tie rows staged per workgroup of the cell kernel (beyond: one global atomic per row -- 1 ms per
                                       // 60k-row table on voxelised data; two stacked T30k pairs on 512 workgroups give ~235 per workgroup)
 constexpr int kCellMaxCells = 256;    // support cells within reach of one query cell
@@ -477,7 +478,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 template <int SC, int CAP, int WAVES, bool PROF = false>
 __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
-    __shared__ float4 s_cand[SC];
+    __shared__ float4 s_cand[SC];                    // (SC is a multiple of 64: the padded tail of the last step fits)
     __shared__ float4 s_q[kCellQ];
     __shared__ unsigned s_key[WAVES][CAP + 8];       // d2 bits of a query's hits ...
     __shared__ int s_idx[WAVES][CAP + 8];            // ... and their support indices
@@ -503,6 +504,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
     const float r2 = a.r2;
     unsigned* key = s_key[wave];
     int* idx = s_idx[wave];
+    constexpr int kTrash = CAP + 7;                  // last slot of both lists: where lanes without a hit write
     int wave_max = 0, wave_grp = 0;
     auto flush_max = [&]() {
         if (lane == 0 && wave_max > aload(a.out_max + wave_grp)) atomicMax(a.out_max + wave_grp, wave_max);
@@ -620,6 +622,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
             const int cell = threadIdx.x & ((1 << log2p) - 1), stride = (WAVES * 64) >> log2p;
             const int cnt = s_cnt[cell], src = s_start[cell], dst = s_excl[cell];
             for (int j = threadIdx.x >> log2p; j < cnt; j += stride) s_cand[dst + j] = a.spts[src + j];
+            if ((int)threadIdx.x < 64 && total + (int)threadIdx.x < ((total + 63) & ~63))      // far-away tail: never a hit
+                s_cand[total + threadIdx.x] = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.0f);
         }
         stamp(2);
         for (int q0 = 0; q0 < nqc; q0 += kCellQ) {
@@ -639,20 +643,25 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
                     if (lane == 0) { row[0] = kRedoMark; if (a.status) atomicOr(a.status, kRedoStatus); }
                     continue;
                 }
+                // sweep: 64 staged candidates per step (the tail of the last step is padded with far-away points: no bounds
+                // test); hits are compacted with ballot / mbcnt.  The kernel is bound by its SCALAR instructions (round 4:
+                // SQ_ACTIVE_INST_SCA + _MISC = 85 % of the CU cycles), so per-lane conditions are VALU selects with
+                // unconditional LDS accesses -- a non-hit writes into a trash slot -- instead of exec-mask branches.
                 int nhit = 0;
                 for (int t0 = 0; t0 < total; t0 += 64) {
-                    const int t = t0 + lane;
-                    const float4 p = s_cand[t < total ? t : total - 1];
+                    const float4 p = s_cand[t0 + lane];
                     const float d0 = qx - p.x, d1 = qy - p.y, d2c = qz - p.z;
                     float d2 = 0.0f;
                     d2 += d0 * d0;
                     d2 += d1 * d1;
                     d2 += d2c * d2c;
-                    const bool hit = t < total && d2 < r2;
+                    const bool hit = d2 < r2;
                     const u64 mask = __builtin_amdgcn_ballot_w64(hit);
-                    const int pos = nhit + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (hit && pos < CAP) { key[pos] = __float_as_uint(d2); idx[pos] = __float_as_int(p.w); }
+                    int pos = nhit + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    pos = hit ? pos : kTrash;
+                    pos = pos < kTrash ? pos : kTrash;           // (more than CAP hits: the row goes to pass 2 anyway)
+                    key[pos] = __float_as_uint(d2);
+                    idx[pos] = __float_as_int(p.w);
                     nhit += __builtin_popcountll(mask);
                 }
                 stamp(4);
@@ -663,16 +672,82 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
                     continue;
                 }
                 const int nl = nhit;
-                if (lane < 8) key[nl + lane] = 0xFFFFFFFFu;     // the broadcast loop reads eight keys per step
-                __builtin_amdgcn_wave_barrier();
-                // ---- rank sort; the sorted hits go back into the lists in place ----
+                key[nl + (lane & 7)] = kPadKey;                 // the broadcast loop reads eight keys per step (all lanes
+                __builtin_amdgcn_wave_barrier();                // write: eight addresses, one value -- no exec mask)
+                if (nl <= 64 && cols <= 64) {
+                    // ---- the common row, scalar-lean: one hit per lane, rank = number of hits with a smaller d2 ----
+                    // (d2 words are positive floats, i.e. below 2^31, and the padding is INT_MAX: "k < mine" is the sign
+                    // of the signed difference -- pure VGPR arithmetic, no v_cmp -> VCC -> v_addc chain and its wait states)
+                    const bool have = lane < nl;
+                    const int mkey = have ? (int)key[lane] : (int)kPadKey;
+                    const int midx = idx[lane];
+                    int acc = 0;
+#pragma unroll
+                    for (int j = 0; j < 64; j += 8) {
+                        if (j >= nl) break;                     // wave-uniform
+                        const int4 k0 = *reinterpret_cast<const int4*>(&key[j]);
+                        const int4 k1 = *reinterpret_cast<const int4*>(&key[j + 4]);
+                        acc += ((k0.x - mkey) >> 31) + ((k0.y - mkey) >> 31);
+                        acc += ((k0.z - mkey) >> 31) + ((k0.w - mkey) >> 31);
+                        acc += ((k1.x - mkey) >> 31) + ((k1.y - mkey) >> 31);
+                        acc += ((k1.z - mkey) >> 31) + ((k1.w - mkey) >> 31);
+                    }
+                    int dst = have ? -acc : kTrash;
+                    __builtin_amdgcn_wave_barrier();
+                    key[dst] = (unsigned)mkey;
+                    idx[dst] = midx;
+                    __builtin_amdgcn_wave_barrier();
+                    const bool collide = have && idx[dst] != midx;
+                    if (__builtin_amdgcn_ballot_w64(collide) != 0ull) {
+                        // exactly equal distances in this row: order by (d2, index) with both words
+                        __builtin_amdgcn_wave_barrier();
+                        const int home = have ? lane : kTrash;
+                        key[home] = (unsigned)mkey;
+                        idx[home] = midx;
+                        key[nl + (lane & 7)] = kPadKey;
+                        __builtin_amdgcn_wave_barrier();
+                        int rk = 0;
+                        for (int j = 0; j < nl; j += 4) {
+                            const int4 k0 = *reinterpret_cast<const int4*>(&key[j]);
+                            const int4 i0 = *reinterpret_cast<const int4*>(&idx[j]);
+                            rk += ((k0.x < mkey || (k0.x == mkey && i0.x < midx)) ? 1 : 0) + ((k0.y < mkey || (k0.y == mkey && i0.y < midx)) ? 1 : 0) +
+                                  ((k0.z < mkey || (k0.z == mkey && i0.z < midx)) ? 1 : 0) + ((k0.w < mkey || (k0.w == mkey && i0.w < midx)) ? 1 : 0);
+                        }
+                        dst = have ? rk : kTrash;
+                        __builtin_amdgcn_wave_barrier();
+                        key[dst] = (unsigned)mkey;
+                        idx[dst] = midx;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    stamp(5);
+                    // the row: lane e writes column e
+                    const int e = lane < CAP ? lane : 0;
+                    const unsigned ke = key[e], kn = key[e + 1];
+                    const int ie = idx[e];
+                    const bool valid = lane < nl;
+                    const long long vout = valid ? (long long)(ie - base) : (long long)ns_out;
+                    const bool tie = valid && lane < cols && lane + 1 < nl && kn == ke;
+                    if (lane < cols) __builtin_nontemporal_store(vout, &row[lane]);
+                    if (__builtin_amdgcn_ballot_w64(tie) != 0ull && a.tie_rows) {
+                        if (lane == 0) {
+                            const int slot = atomicAdd(&s_ntie, 1);
+                            if (slot < kCellTieCap) s_tie[slot] = qi;
+                            else a.tie_rows[atomicAdd(a.tie_count, 1)] = qi;
+                        }
+                    }
+                    if (a.out_count) a.out_count[qi] = nhit;    // (every lane, one address, one value)
+                    __builtin_amdgcn_wave_barrier();
+                    stamp(6);
+                    continue;
+                }
+                // ---- rank sort (rows of 65..CAP hits, tables of more than 64 columns); the sorted hits go back in place ----
                 constexpr int R = CAP / 64;                     // hits per lane
                 unsigned mk[R];
                 int mi[R], rank[R];
 #pragma unroll
                 for (int u = 0; u < R; ++u) {
                     const bool have = lane + 64 * u < nl;
-                    mk[u] = have ? key[lane + 64 * u] : 0xFFFFFFFFu;
+                    mk[u] = have ? key[lane + 64 * u] : kPadKey;
                     mi[u] = have ? idx[lane + 64 * u] : 0x7FFFFFFF;
                     rank[u] = 0;
                 }
