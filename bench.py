@@ -66,6 +66,9 @@ RANK_CPUS = launcher.apply_rank_affinity()      # a rank started by the launcher
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+if RANK_CPUS:                              # pinned to a CPU set: torch's host thread pool must not exceed it
+    torch.set_num_threads(max(1, len(RANK_CPUS)))
+
 from pcrcg_amd import indoor_config, kitti_config, ops, synthetic  # noqa: E402
 from pcrcg_amd.architectures import KPFCNN  # noqa: E402
 from pcrcg_amd.pairstream import PairStreams  # noqa: E402

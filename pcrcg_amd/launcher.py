@@ -144,14 +144,27 @@ def plan_affinity(n, available, gpu_numa=None, node_cpus=None):
 
 
 def apply_rank_affinity():
-    """In a rank: pin the process (and the threads it will start) to the CPU set the parent planned.  -> the set."""
-    txt = os.environ.get(CPUS_ENV)
-    if not txt:
+    """In a rank: pin the process (and the threads it will start) to a CPU set near its GPU.  Started by launch(): the
+    set the parent planned (PCRCG_RANK_CPUS).  Started by torch.distributed.run (LOCAL_RANK / LOCAL_WORLD_SIZE set, more
+    than one rank on the node): every rank computes the same plan from sysfs and takes its own entry -- the driver's
+    launch gets the NUMA-near placement too.  PCRCG_NO_AFFINITY=1 switches it off.  -> the set, or None."""
+    if os.environ.get("PCRCG_NO_AFFINITY") == "1":
         return None
-    cpus = parse_cpulist(txt)
+    txt = os.environ.get(CPUS_ENV)
     try:
+        if txt:
+            cpus = parse_cpulist(txt)
+        else:
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+            local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+            if local_world <= 1 or not (0 <= local_rank < local_world):
+                return None
+            available = sorted(os.sched_getaffinity(0))
+            cpus = plan_affinity(local_world, available, gpu_numa_nodes(visible=_visible_indices()), numa_cpus())[local_rank]
+        if not cpus:
+            return None
         os.sched_setaffinity(0, cpus)
-    except OSError:
+    except (OSError, ValueError, AttributeError):
         return None
     return cpus
 

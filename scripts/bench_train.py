@@ -38,6 +38,9 @@ RANK_CPUS = launcher.apply_rank_affinity()
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+if RANK_CPUS:                              # pinned to a CPU set: torch's host thread pool must not exceed it
+    torch.set_num_threads(max(1, len(RANK_CPUS)))
+
 
 def time_allreduce(dist, flat, reps, sync):
     """The step's one collective alone: all-reduce(sum) of the flat gradient bucket, `reps` times back to back between

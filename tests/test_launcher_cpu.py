@@ -77,6 +77,30 @@ def test_numa_near_plan_from_sysfs(tmp_path):
     assert sorted(c for p in plan3 for c in p) == list(range(8))
 
 
+def test_ranks_under_torchrun_plan_their_own_cpu_set(monkeypatch):
+    """torch.distributed.run sets LOCAL_RANK / LOCAL_WORLD_SIZE and no PCRCG_RANK_CPUS: every rank derives the same plan and
+    takes its own entry (child processes: the affinity of the test process itself is left alone)."""
+    code = ("import os, sys; sys.path.insert(0, %r); from pcrcg_amd import launcher; "
+            "c = launcher.apply_rank_affinity(); print(launcher.format_cpulist(c) if c else '-', len(os.sched_getaffinity(0)))" % REPO)
+    allowed = sorted(os.sched_getaffinity(0))
+    outs = []
+    for r in range(2):
+        env = _env()
+        env.update({"LOCAL_RANK": str(r), "LOCAL_WORLD_SIZE": "2"})
+        env.pop(launcher.CPUS_ENV, None)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        outs.append(out.stdout.split())
+    if len(allowed) >= 2:
+        a, b = (set(launcher.parse_cpulist(o[0])) for o in outs)
+        assert a and b and not (a & b) and (a | b) <= set(allowed)
+        assert int(outs[0][1]) == len(a)                                # the set was applied to the process
+    env = _env()
+    env.update({"LOCAL_RANK": "0", "LOCAL_WORLD_SIZE": "2", "PCRCG_NO_AFFINITY": "1"})
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.stdout.split()[0] == "-"
+
+
 def test_parent_detection(monkeypatch):
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.delenv("RANK", raising=False)
