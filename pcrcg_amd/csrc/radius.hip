@@ -61,9 +61,10 @@ struct GridHeader {   // first 256 bytes of the grid workspace
     int ns, nb;
     u64 cursor;       // low word: bump allocator for cell runs; high word: occupied cells listed so far (ONE atomic)
     int overflow;     // coordinate range exceeded
-    int qhead[8], qdone[8];   // k_radius_cells walking THIS grid as its query grid: ticket counters / workgroups that
-                              // have left, one pair per shard (workgroup index mod 8 = its XCD)
 };
+constexpr int kTickStride = 64;       // ints between two ticket words: every counter in a 256-byte block of its own (eight
+                                      // counters in ONE cache line were served one after the other, ~50 atomics per microsecond
+                                      // for the whole chip: 84 of the 94 us of the 60 000-row search)
 
 struct Slot {         // one 16-byte record per hash slot: a probe is ONE load
     u64 key;
@@ -79,13 +80,15 @@ struct GridView {
     float4* spts;  // [ns]  supports cell by cell as (x, y, z, index)
     u64* ckey;     // [ns]  occupied cells, compact (any order): key ...
     int4* cinfo;   // [ns]  ... and (count, start of the run in spts, cloud, slot)
+    int* qtick;    // [16 * kTickStride]  k_radius_cells walking THIS grid as its query grid: ticket counter of shard k at
+                   // [k * kTickStride], workgroups of shard k that have left at [(8 + k) * kTickStride]
 };
 
 inline size_t grid_bytes(int ns, int nb) {
     const size_t N = (size_t)(ns > 0 ? ns : 0) + 1;
     return carve_bytes(1, 256) + carve_bytes((size_t)nb + 1, sizeof(int)) + carve_bytes(2 * N, sizeof(Slot)) +
            2 * carve_bytes(N, sizeof(int)) + carve_bytes(N, sizeof(float4)) + carve_bytes(N, sizeof(u64)) +
-           carve_bytes(N, sizeof(int4));
+           carve_bytes(N, sizeof(int4)) + carve_bytes(16 * kTickStride, sizeof(int));
 }
 
 inline GridView grid_view(void* ws, size_t bytes, int ns, int nb, bool* ok) {
@@ -100,6 +103,7 @@ inline GridView grid_view(void* ws, size_t bytes, int ns, int nb, bool* ok) {
     g.spts = cv.take<float4>(N);
     g.ckey = cv.take<u64>(N);
     g.cinfo = cv.take<int4>(N);
+    g.qtick = cv.take<int>(16 * kTickStride);
     *ok = cv.ok();
     return g;
 }
@@ -152,7 +156,7 @@ __global__ void __launch_bounds__(256) k_grid_init(GridView g, const int* __rest
         g.hdr->nb = nb;
         g.hdr->cursor = 0ull;
         g.hdr->overflow = 0;
-        for (int k = 0; k < 8; ++k) { g.hdr->qhead[k] = 0; g.hdr->qdone[k] = 0; }
+        for (int k = 0; k < 16; ++k) g.qtick[k * kTickStride] = 0;
     }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (long)gridDim.x * blockDim.x)
         *reinterpret_cast<uint4*>(&g.tab[i]) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
@@ -448,7 +452,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
 // than CAP hits are marked for the per-query second pass (k_radius_query<.., REDO = true>) and announced through
 // status bit kRedoStatus (rows of more than CAP hits also through out_max).
 struct CellArgs {
-    GridHeader* qhdr;             // query grid: header (ticket counters), cell runs, compact cell list
+    const GridHeader* qhdr;       // query grid: header, ticket counters, cell runs, compact cell list
+    int* qtick;
     const float4* qspts;
     const u64* ckey;
     const int4* cinfo;
@@ -608,7 +613,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
             // the probes are in: now ask for the next cell's record and for the ticket after it
             rec1 = load_rec(c1);
             ticket = 0x40000000;                     // (no cell behind c1: tickets grow monotonically)
-            if (lane == 0 && c1 < ncells_q) ticket = (2 * Gk + atomicAdd(&a.qhdr->qhead[shard], 1)) * nshard + shard;
+            if (lane == 0 && c1 < ncells_q) ticket = (2 * Gk + atomicAdd(&a.qtick[shard * kTickStride], 1)) * nshard + shard;
         } else {                                     // the first batch of the cell's queries, beside the probes
             const int t = (int)threadIdx.x - 64;
             if (t < kCellQ && t < nqc) s_q[t] = a.qspts[qstart + t];
@@ -846,10 +851,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
     // the last workgroup of a shard to leave resets the shard's counters: the next search over this query grid starts
     // from zero (every workgroup has received its last ticket before it counts itself out)
     if (threadIdx.x == 0) {
-        const int done = atomicAdd(&a.qhdr->qdone[shard], 1);
+        const int done = atomicAdd(&a.qtick[(8 + shard) * kTickStride], 1);
         if (done == Gk - 1) {
-            __hip_atomic_store(&a.qhdr->qhead[shard], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.qhdr->qdone[shard], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.qtick[shard * kTickStride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.qtick[(8 + shard) * kTickStride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -1111,7 +1116,7 @@ int radius_cells_pass(const void* qgrid, const float* q, int nq, const int* qlen
     int blocks = (nq + 7) / 8;                     // never more workgroups than there can be cells worth having one
     if (blocks > max_blocks) blocks = max_blocks;
     CellArgs ca;
-    ca.qhdr = gq.hdr; ca.qspts = gq.spts; ca.ckey = gq.ckey; ca.cinfo = gq.cinfo;
+    ca.qhdr = gq.hdr; ca.qtick = gq.qtick; ca.qspts = gq.spts; ca.ckey = gq.ckey; ca.cinfo = gq.cinfo;
     ca.shdr = gs.hdr; ca.soff = gs.soff; ca.tab = gs.tab; ca.spts = gs.spts;
     ca.out_idx = reinterpret_cast<long long*>(out_idx); ca.out_count = out_count; ca.out_max = out_max_count;
     ca.status = status; ca.tie_rows = out_tie_rows; ca.tie_count = out_tie_count;
