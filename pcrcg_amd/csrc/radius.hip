@@ -523,6 +523,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
     int ncells_q = 0, ns = 0, c = 0, c1 = 0, ticket = 0;
     double inv_s = 0.0, cell_q = 0.0;
     unsigned rec = 0, rec1 = 0;                      // lanes 0,1: the cell's key; lanes 2..5: (count, start, cloud, slot)
+    int soff_reg = 0;                                // wave 0, lane i: soff[i] -- the clouds of a launch are few: no load (and
+                                                     // no dependent round trip in front of the probes) per cell
+    auto soff_at = [&](int i) -> int { return a.nb < 63 ? __builtin_amdgcn_readlane(soff_reg, i) : a.soff[i]; };
     auto load_rec = [&](int cell) -> unsigned {      // one dword per lane, a VECTOR load: it stays in flight across LDS waits
         unsigned v = 0;
         if (cell < ncells_q && lane < 6)
@@ -535,6 +538,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
         ns = a.shdr->ns;
         inv_s = a.shdr->inv_cell;
         cell_q = 1.0 / a.qhdr->inv_cell;
+        if (a.nb < 63) soff_reg = lane <= a.nb ? a.soff[lane] : 0;
         c = blockIdx.x;
         c1 = c + Gk * nshard;
         rec = load_rec(c);
@@ -552,8 +556,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
             if (a.group > 0 && more) {
                 grp = b / a.group;
                 const int last = min(grp * a.group + a.group, a.nb);
-                base = a.soff[grp * a.group];
-                ns_out = a.soff[last] - base;
+                base = soff_at(grp * a.group);
+                ns_out = soff_at(last) - base;
             }
             if (lane == 0) {
                 s_state.more = more ? 1 : 0;
@@ -572,7 +576,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
             // support cells the grown query cell overlaps (unbiased cell coordinates; conservative by construction)
             const u64 qkey = (u64)(unsigned)__builtin_amdgcn_readlane((int)rec, 0) |
                              ((u64)(unsigned)__builtin_amdgcn_readlane((int)rec, 1) << 32);
-            const int nsb = a.soff[b + 1] - a.soff[b];
+            const int nsb = soff_at(b + 1) - soff_at(b);
+            const long tbase = 2l * soff_at(b);
             const int ux = (int)(qkey & 0x1FFFFF) - kCoordBias, uy = (int)((qkey >> 21) & 0x1FFFFF) - kCoordBias,
                       uz = (int)((qkey >> 42) & 0x1FFFFF) - kCoordBias;
             const int lox = (int)floor(((double)ux * cell_q - a.reach) * inv_s), hix = (int)floor(((double)(ux + 1) * cell_q + a.reach) * inv_s);
@@ -595,7 +600,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_cells(const CellArgs a) {
                     if ((unsigned)sx < (1u << 21) && (unsigned)sy < (1u << 21) && (unsigned)sz < (1u << 21)) {
                         const u64 ckey = cell_key(sx, sy, sz);
                         const unsigned tsize = 2u * (unsigned)nsb;
-                        const long tbase = 2l * a.soff[b];
                         unsigned s = __umulhi(mix32(ckey), tsize);
                         for (unsigned probe = 0; probe < tsize; ++probe) {
                             const Slot sl = load_slot(&a.tab[tbase + s]);
