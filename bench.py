@@ -406,6 +406,58 @@ def dry_run_main(args, rank, world):
                        "pair_seeds_first_region": seen_seeds}}), flush=True)
 
 
+def live_pmc_traffic(timeout_s=240):
+    """HBM bytes per KPConv gather launch from the PMC counters, collected NOW: two child runs of this script (`--isolated-only`,
+    three forwards of one prepared pair, nothing else on the GPU) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and
+    `... --pmc WRITE_SIZE` -- separate passes with the kernel trace only, as MI355X_MICROARCH.md prescribes (the two
+    counters do not fit one pass), read with its gfx950 correction: fetch bytes = 2 x FETCH_SIZE[KiB] x 1024 (FETCH_SIZE
+    tallies 128-byte requests at 64 bytes), write bytes = WRITE_SIZE[KiB] x 1024.  The children are started as ordinary
+    child processes (this process keeps its GPU context and waits).  -> (bytes per launch or None, detail dict)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("PCRCG_BENCH_CHILD") or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return None, {"skipped": "already running under a profiler"}
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, {"skipped": "rocprofv3 not found"}
+    tot = {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]}
+    t0 = time.perf_counter()
+    for counter in tot:
+        tmp = tempfile.mkdtemp(prefix="pcrcg_pmc_", dir="/tmp")
+        env = dict(os.environ, PCRCG_BENCH_CHILD="1", TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--isolated-only", "--steps", "3", "--warmup", "1", "--workload", RECIPE]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, {"failed": f"{counter} pass: rc {r.returncode}, {len(files)} counter file(s)",
+                              "stderr_tail": r.stderr.decode(errors="replace")[-300:]}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter and "k_kpconv" in row["Kernel_Name"]:
+                    tot[counter][0] += 1
+                    tot[counter][1] += float(row["Counter_Value"])
+        except subprocess.TimeoutExpired:
+            return None, {"failed": f"{counter} pass: no result within {timeout_s} s"}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    nf, nw = tot["FETCH_SIZE"][0], tot["WRITE_SIZE"][0]
+    if not nf or not nw:
+        return None, {"failed": "no KPConv gather launch in the counter files"}
+    fetch = 2.0 * tot["FETCH_SIZE"][1] / nf * 1024.0
+    write = tot["WRITE_SIZE"][1] / nw * 1024.0
+    return int(fetch + write), {"fetch_bytes_per_launch": int(fetch), "write_bytes_per_launch": int(write), "launches_counted": nf,
+                                "passes": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE, one child run each of "
+                                          "`bench.py --isolated-only --steps 3 --warmup 1` (the launches alone on the GPU)",
+                                "correction": "fetch = 2 x FETCH_SIZE[KiB] x 1024 (gfx950), write = WRITE_SIZE[KiB] x 1024",
+                                "seconds": round(time.perf_counter() - t0, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -430,6 +482,8 @@ def main():
                     help="pairs built together that share one pcrcg_kpfcnn_forward_group call (weight products once for all)")
     ap.add_argument("--pairs-per-build", type=int, default=2, choices=[1, 2, 3, 4],
                     help="pairs one front-end kernel chain (pcrcg_pyramid_build call) carries")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs behind roofline.traffic (traffic: null, ~30 s less)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="A/B aid: no start/stop events on the KPConv launches of the timed regions (roofline comes out empty)")
     ap.add_argument("--isolated-only", action="store_true",
@@ -685,9 +739,12 @@ def main():
             b = kpconv_algorithmic_bytes(nq, h, cin, co, 2 if kind == 2 else 4)
             iso_rows.append({"nq": nq, "h": h, "cin": cin, "cout": co, "kind": kind, "us": round(ms * 1e3, 1),
                              "GBs": round(b / (ms * 1e-3) / 1e9, 0) if ms > 0 else None})
-        # `traffic` (HBM bytes per launch from PMC counters) cannot be collected by this process: rocprofv3 --pmc needs
-        # its own passes.  The live line says null; the figure of the committed separate passes is quoted with its source.
-        traffic, traffic_offline = None, None
+        # `traffic` (HBM bytes per launch from PMC counters): rocprofv3 --pmc needs its own passes, so this process runs them
+        # as two child runs once its own measurements are over (live_pmc_traffic).  The committed separate passes of the
+        # round are quoted next to it with their source.
+        traffic, traffic_detail, traffic_offline = None, {"skipped": "--no-pmc / --no-extras / N > 1 / not the S30k fp32 line"}, None
+        if not args.no_pmc and not args.no_extras and world == 1 and RECIPE == "S30k" and not BF16:
+            traffic, traffic_detail = live_pmc_traffic()
         for name in ("r04_pmc_kpconv.json", "r03_pmc_kpconv.json", "r02_pmc_kpconv.json"):
             pmc_path = os.path.join(REPO, "profiles", name)
             if os.path.exists(pmc_path):
@@ -745,7 +802,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "KPConv neighbour-gather / aggregate kernels (k_kpconv_mfma, k_kpconv_c1), "
                                                      "%d launches/pair" % per_pair,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_offline": traffic_offline,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_live": traffic_detail, "traffic_offline": traffic_offline,
                          "avg_launch_us": round(k_ms * 1e3 / max(n_launch, 1), 2),
                          "algorithmic_bytes_per_pair": int(k_bytes / max(args.steps * R, 1)),
                          "note": "durations are the kernels' own start/stop events (hipExtLaunchKernel); achieved/frac "
