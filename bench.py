@@ -482,6 +482,9 @@ def main():
                     help="pairs built together that share one pcrcg_kpfcnn_forward_group call (weight products once for all)")
     ap.add_argument("--pairs-per-build", type=int, default=2, choices=[1, 2, 3, 4],
                     help="pairs one front-end kernel chain (pcrcg_pyramid_build call) carries")
+    ap.add_argument("--fixed-jobs", action="store_true",
+                    help="A/B aid: forward jobs always carry --pairs-per-forward pairs (default: one pair each while model "
+                         "streams stand idle or nothing else is queued -- an engine filling up or running empty)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs behind roofline.traffic (traffic: null, ~30 s less)")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -638,7 +641,8 @@ def main():
 
     # ---- headline: the reference's batch contract inside the engine too (full [N, limit] upsample tables) ----------
     pipe = PairStreams(net, cfg, limits, dev, model_streams=WORKERS, front_threads=FRONTS, up_nearest=False,
-                       pairs_per_forward=args.pairs_per_forward, pairs_per_build=args.pairs_per_build)
+                       pairs_per_forward=args.pairs_per_forward, pairs_per_build=args.pairs_per_build,
+                       adaptive_jobs=not args.fixed_jobs)
     # engine priming (untimed, before the W warm-up steps): every model stream's first call allocates its workspace
     # and every front-end arena its tables; a handful of pairs per stream gets that out of the way
     run_pairs(pipe, 4 * WORKERS * args.pairs_per_forward)

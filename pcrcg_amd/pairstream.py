@@ -56,7 +56,8 @@ class PairStreams:
     ARENAS = 4        # per front thread: pairs whose tables may be alive at once (built, forward not yet passed)
 
     def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=1, tie_order=None,
-                 pairs_per_build=2, up_nearest=False, front_streams=1, front_priority=0, pairs_per_forward=2):
+                 pairs_per_build=2, up_nearest=False, front_streams=1, front_priority=0, pairs_per_forward=2,
+                 adaptive_jobs=True):
         """pairs_per_forward = 2 .. 4: pairs that were built together also go through the network together, up to that
         many per pcrcg_kpfcnn_forward_group call on one model stream, in which every product with a weight matrix runs
         once for all of them (the pairs never mix; outputs equal separate forwards up to summation order).  1: one call
@@ -95,8 +96,12 @@ class PairStreams:
         self._per_build = min(4, max(1, int(pairs_per_build)))
         self._users = [[1] * self.ARENAS for _ in range(nf)]   # forwards that read the arena's current contents
         self._per_forward = min(4, max(1, int(pairs_per_forward)))
+        self._adaptive = bool(adaptive_jobs)
+        self._last_done = [None] * len(self.models)       # per model stream: the event behind its newest forward
         self._mid = [_Mailbox() for _ in self.models]     # jobs (one or two pairs) by job index: thread m serves m, m + M, ...
         self._jobs = 0                                     # job indices are handed out under self._take, with the pairs
+        self._queued = [0] * len(self.models)              # jobs handed out to a model thread whose forward is not enqueued yet
+        self._qlock = threading.Lock()                     # (its own lock: a front thread WAITS for input holding self._take)
         self._results = _Mailbox()                         # (outputs, done event) or an exception, by submission index
         self._submitted = self._returned = 0
         self._pending = []                     # (status tensor, slot, event) of pairs whose tie status is unread
@@ -124,6 +129,23 @@ class PairStreams:
         for ring in self._pyr:
             for pyr in ring:
                 pyr.cfg.up_nearest = int(self.up_nearest)
+
+    @staticmethod
+    def job_sizes(n_pairs, per_forward, one_each):
+        """Pairs per forward job for a build of `n_pairs` consecutive pairs: up to `per_forward` each, or one each."""
+        per = 1 if one_each else max(1, per_forward)
+        return [min(per, n_pairs - i) for i in range(0, n_pairs, per)]
+
+    def _idle_models(self):
+        """Model streams with nothing queued or running: no job waiting in the stream's mailbox and its newest forward passed."""
+        with self._qlock:
+            waiting = list(self._queued)
+        n = 0
+        for m in range(len(self.models)):
+            ev = self._last_done[m]
+            if waiting[m] == 0 and (ev is None or ev.query()):
+                n += 1
+        return n
 
     def _stat(self, **add):
         with self._stats_lock:
@@ -156,14 +178,16 @@ class PairStreams:
                 if items[-1] is None:
                     self._in.put(None)         # pass the shutdown token on to the other front threads
                     items.pop()
-                # the pairs' forward jobs, in submission order: consecutive pairs of this build, up to per_forward each
-                sizes = []
-                left = len(items)
-                while left > 0:
-                    sizes.append(min(self._per_forward, left))
-                    left -= sizes[-1]
+                # the pairs' forward jobs, in submission order: consecutive pairs of this build, up to per_forward each --
+                # one pair each while model streams stand idle (an engine filling up) or when nothing else is queued (an
+                # engine running empty): two streams then start / finish a pair each instead of one carrying both
+                sizes = self.job_sizes(len(items), self._per_forward, self._adaptive and len(items) > 1 and
+                                       (self._in.empty() or self._idle_models() >= 2))
                 job0 = self._jobs
                 self._jobs += len(sizes)
+                with self._qlock:
+                    for j in range(len(sizes)):
+                        self._queued[(job0 + j) % len(self.models)] += 1
             if not items:
                 return
             self._stat(front_idle_s=time.perf_counter() - t0)
@@ -238,6 +262,8 @@ class PairStreams:
             self._stat(model_idle_s=time.perf_counter() - t0)
             seqs = item[0]
             if isinstance(item[1], BaseException):
+                with self._qlock:
+                    self._queued[m] -= 1
                 for q in seqs:
                     self._results.put(q, item[1])
                 continue
@@ -258,6 +284,7 @@ class PairStreams:
                     self._stat(launch_s=time.perf_counter() - t0)
                     done = torch.cuda.Event()
                     done.record(stream)
+                self._last_done[m] = done
                 for q, out in zip(seqs, outs):
                     self._free[f][a].put(done)                 # one token per pair that read the arena
                     out["_tie_status"] = (pyr.status, slot)
@@ -269,6 +296,9 @@ class PairStreams:
                 for q in seqs:
                     self._free[f][a].put(None)
                     self._results.put(q, e)
+            finally:
+                with self._qlock:
+                    self._queued[m] -= 1
 
     # ---- caller --------------------------------------------------------------------------------
     def submit(self, points, lengths):

@@ -135,3 +135,19 @@ def test_probabilistic_sample_draws_like_the_reference():
     assert torch.equal(p2, pcd[want]) and torch.equal(f2, feats[want])
     p3, f3, none = probabilistic_sample(pcd, feats, scores, 700)
     assert none is None and p3 is pcd and f3 is feats
+
+
+def test_engine_job_sizes():
+    """pairstream.PairStreams.job_sizes: the pairs of one front-end build go to the model streams in jobs of up to
+    `pairs_per_forward`, or one pair per job while the engine fills up / runs empty (every pair exactly once, in order)."""
+    from pcrcg_amd.pairstream import PairStreams
+    assert PairStreams.job_sizes(2, 2, False) == [2]
+    assert PairStreams.job_sizes(2, 2, True) == [1, 1]
+    assert PairStreams.job_sizes(4, 3, False) == [3, 1]
+    assert PairStreams.job_sizes(3, 2, False) == [2, 1]
+    assert PairStreams.job_sizes(1, 4, True) == [1]
+    assert PairStreams.job_sizes(4, 1, False) == [1, 1, 1, 1]
+    for n in range(1, 5):
+        for per in range(1, 5):
+            for one in (False, True):
+                assert sum(PairStreams.job_sizes(n, per, one)) == n
