@@ -72,7 +72,9 @@ __global__ void __launch_bounds__(64) k_circle_lines(const float* __restrict__ a
         const float nw = fmaxf(0.f, cfg.neg_optimal - (fd + (neg ? 0.f : 1e5f)));
         lse_push(ls * (fd - cfg.pos_margin) * pw, mp, sp);
         lse_push(ls * (cfg.neg_margin - fd) * nw, mn, sn);
-        if (fd < best) { best = fd; arg = o; }                 // torch.min: the first index attaining the minimum
+        // torch.min: the first index attaining the minimum, and NaN counts as the minimum (the first NaN of a row wins).
+        // The first entry a lane sees is always taken, so `arg` is a valid column whenever the lane saw one.
+        if (arg == 0x7fffffff || fd < best || (fd != fd && best == best)) { best = fd; arg = o; }
     }
     for (int off = 32; off >= 1; off >>= 1) {
         lse_merge(mp, sp, __shfl_xor(mp, off), __shfl_xor(sp, off));
@@ -81,7 +83,10 @@ __global__ void __launch_bounds__(64) k_circle_lines(const float* __restrict__ a
         nneg += __shfl_xor(nneg, off);
         const float b2 = __shfl_xor(best, off);
         const int a2 = __shfl_xor(arg, off);
-        if (b2 < best || (b2 == best && a2 < arg)) { best = b2; arg = a2; }
+        const bool nan1 = best != best, nan2 = b2 != b2;
+        const bool take = a2 != 0x7fffffff &&
+                          (arg == 0x7fffffff || (nan2 && (!nan1 || a2 < arg)) || (!nan1 && !nan2 && (b2 < best || (b2 == best && a2 < arg))));
+        if (take) { best = b2; arg = a2; }
     }
     if (lane == 0) {
         const float lp = mp + logf(sp), ln = mn + logf(sn), z = lp + ln;
@@ -93,7 +98,7 @@ __global__ void __launch_bounds__(64) k_circle_lines(const float* __restrict__ a
         r[3] = sel ? (z > 20.f ? z : log1pf(expf(z))) / ls : 0.f;                // F.softplus (threshold 20)
         r[4] = sel ? 1.f : 0.f;
         r[5] = is_row && npos > 0 ? 1.f : 0.f;
-        r[6] = is_row && npos > 0 && cd[(long)me * ldc + arg] < cfg.pos_radius ? 1.f : 0.f;      // recall (:106-116)
+        r[6] = is_row && npos > 0 && cd[(long)me * ldc + min(arg, n - 1)] < cfg.pos_radius ? 1.f : 0.f;      // recall (:106-116)
         r[7] = 0.f;
     }
 }

@@ -97,6 +97,10 @@ def test_fused_loss_propagates_nan_and_marks_statistics_non_differentiable(cuda,
         np.random.seed(cs["numpy_seed"])
         out[fused] = {k: float(v) for k, v in loss(inputs).items()}
     assert np.isnan(out[False]["circle_loss"]) and np.isnan(out[True]["circle_loss"]), out
+    # torch.min treats NaN as the minimum (first NaN of the row): the recall statistic reads the same column in both forms --
+    # and the kernel's arg-min is a valid column even when no comparison ever succeeds (it once stayed at INT_MAX: a read
+    # 8 GB past the matrix, an intermittent memory fault)
+    assert abs(out[True]["recall"] - out[False]["recall"]) <= 1e-6, out
     g = torch.Generator().manual_seed(0)
     a = torch.nn.functional.normalize(torch.randn(40, 32, generator=g), dim=1).to(cuda).requires_grad_(True)
     b = torch.nn.functional.normalize(torch.randn(40, 32, generator=g), dim=1).to(cuda).requires_grad_(True)
