@@ -406,7 +406,7 @@ def dry_run_main(args, rank, world):
                        "pair_seeds_first_region": seen_seeds}}), flush=True)
 
 
-def live_pmc_traffic(timeout_s=240):
+def live_pmc_traffic(timeout_s=90):
     """HBM bytes per KPConv gather launch from the PMC counters, collected NOW: two child runs of this script (`--isolated-only`,
     three forwards of one prepared pair, nothing else on the GPU) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and
     `... --pmc WRITE_SIZE` -- separate passes with the kernel trace only, as MI355X_MICROARCH.md prescribes (the two
