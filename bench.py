@@ -718,7 +718,7 @@ def main():
         del pipe
         torch.cuda.empty_cache()
         try:
-            extras["K120k"] = secondary_k120k(dev, 12, 3, WORKERS, args.pairs_per_forward, args.pairs_per_build)
+            extras["K120k"] = secondary_k120k(dev, 24, 4, WORKERS, args.pairs_per_forward, args.pairs_per_build)
         except Exception as e:       # secondary figures never fail the headline
             extras["K120k"] = {"error": repr(e)}
         torch.cuda.empty_cache()

@@ -1112,10 +1112,10 @@ int radius_cells_pass(const void* qgrid, const float* q, int nq, const int* qlen
     const float r2 = radius * radius;  // neighbors.cpp:226
     const double reach = (double)radius * (1.0 + 1e-6);
     const int max_blocks_env = debug_opts().radius_blocks;
-    // Alone on the GPU the search is fastest with every LDS slot taken (6 workgroups per CU: 1536 -> 93 us for the
-    // 60 000-row table, 1024 -> 99, 512 -> 142).  Inside the pair engine (pass 1: the pyramid builder) the front-end
-    // stream shares the CUs with three model streams and a smaller grid takes less from them: 256 / 512 / 768 / 1024
-    // workgroups -> 455 / 465 / 458 / 447 pairs/s (the per-query kernel on its 512: 460), as in rounds 1-3.
+    // Alone on the GPU the search is fastest with the CUs full (86 VGPRs: five workgroups per CU; 1536 workgroups -> 56 us
+    // for the 60 000-row table, 1280 -> 59).  Inside the pair engine (pass 1: the pyramid builder) the front-end stream
+    // shares the CUs with three model streams and the grid size hardly matters: 256 / 512 / 768 / 1024 / 1536 workgroups
+    // -> 457 / 463 / 461 / 460 / 463 pairs/s (same box); 512 as in rounds 1-3.
     const int max_blocks = max_blocks_env > 0 ? max_blocks_env : (pass == 1 ? 512 : 1536);
     int blocks = (nq + 7) / 8;                     // never more workgroups than there can be cells worth having one
     if (blocks > max_blocks) blocks = max_blocks;
