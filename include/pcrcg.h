@@ -123,7 +123,10 @@ int pcrcg_radius_query_groups(const float* q, int nq, const int* qlen, int ns, c
  * semantics as pcrcg_radius_query_groups, row for row (replaces the hot loop of
  * ref:cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:268-301 and :319-325).  Rows of more than 256 hits and cells
  * whose neighbourhood exceeds the staging capacity are finished by the per-query kernel inside the same call
- * (status bit 4 is set and cleared on the way; q / qlen / slen are what that pass reads). */
+ * (status bit 4 is set and cleared on the way; q / qlen / slen are what that pass reads).
+ * The kernel's work counters live in `qgrid` (it leaves them zeroed): searches that walk the SAME query grid must be
+ * ordered on one stream (or by events) -- two of them running at once would share the counters.  Searches over
+ * different query grids, and any number of searches reading the same SUPPORT grid, may overlap freely. */
 int pcrcg_radius_query_cells(const void* qgrid, const float* q, int nq, const int* qlen, const void* sgrid, int ns,
                              const int* slen, int nb, int group, float radius, int cols, int64_t* out_idx, int* out_count,
                              int* out_max_count, int* status, int* out_tie_rows, int* out_tie_count, void* stream);
