@@ -121,7 +121,7 @@ int pcrcg_radius_query_groups(const float* q, int nq, const int* qlen, int ns, c
  * resolves the hash probes of the support cells within reach once, stages their candidates and the cell's queries in LDS,
  * and its wavefronts answer the cell's queries from LDS -- same result set, order, padding, counts, tie rows and group
  * semantics as pcrcg_radius_query_groups, row for row (replaces the hot loop of
- * ref:cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:268-301 and :319-325).  Rows of more than 256 hits and cells
+ * ref:cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:268-301 and :319-325).  Rows of more than 128 hits and cells
  * whose neighbourhood exceeds the staging capacity are finished by the per-query kernel inside the same call
  * (status bit 4 is set and cleared on the way; q / qlen / slen are what that pass reads).
  * The kernel's work counters live in `qgrid` (it leaves them zeroed): searches that walk the SAME query grid must be
