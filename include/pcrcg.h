@@ -46,7 +46,7 @@ int pcrcg_abi_version(void);
  *   zero_arena=1 stat_sums=1 stat_sums_rows=2^30 fuse_norm=1 fuse_pack=1 fuse_upsample=1   network runner fusions
  *   radius_blocks=0 radius_eager_redo=0 radius_cells=1 radius_prof=0 pyr_wait=1 pyr_trace=0 kd_spin_limit=0   front end
  *   att_tq=16                                                                              attention tile
- *   gemm_log=0 x6_tile=-1 x6_splitk=0 x6_t1=200 x6_t2=1024 x6_order=-1 x6_big=0 gemm_tile=-1 gemm_splitk=0 gemm_split_target=768   GEMM plans
+ *   gemm_log=0 x6_tile=-1 x6_splitk=0 x6_t1=200 x6_t2=1024 x6_order=-1 x6_big=0 x6_h2=1 gemm_tile=-1 gemm_splitk=0 gemm_split_target=768   GEMM plans
  *   train_side_stream=1                                                                    train-step backward
  * Returns PCRCG_EBADARG (and changes nothing) on an unknown name. */
 int pcrcg_debug_set(const char* spec);
@@ -262,10 +262,16 @@ int pcrcg_gemm_f32_fused(const float* a, int lda, const int64_t* idx, int ld_idx
 
 /* Arithmetic of the C = A @ B^T products (trans_b = 1) behind pcrcg_gemm_f32 / _colstats / _ex:
  *   0: v_mfma_f32_32x32x2_f32 on the fp32 operands (the fp32 matrix rate, 157 TF on MI355X);
- *   1: (default) every fp32 operand value is split EXACTLY into three bf16 terms and the six leading
- *      cross products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: the dropped terms are
- *      below 2^-23 relative per product, i.e. fp32-class accuracy (measured against float64 it is no
- *      worse than mode 0), at 16/6 of the fp32 matrix rate.
+ *   1: (default) the fp32 operands are split into 16-bit terms and the products run on the 16-bit matrix cores with
+ *      fp32 accumulation.  The forward products (k-contiguous fp32 operands) use the TWO-term fp16 form
+ *      x = h + 2^-11 l, three v_mfma_f32_32x32x16_f16 per 16-deep chunk (representation and dropped term: 2^-22
+ *      relative per product; measured against float64 no worse than the bf16 form or mode 0).  fp16 ends at 65504: a
+ *      workgroup whose operands reach beyond finds a non-finite partial sum after its loop and redoes its tile in the
+ *      bf16 form below, so the RESULT has fp32's range -- only operands that are ALL below 2^-14 in magnitude lose
+ *      relative precision (absolute error floor 2^-36 per operand value).  The other products (the training rows'
+ *      k-major forms, bf16-stored operands) and PCRCG_DEBUG=x6_h2=0 use the EXACT three-term bf16 form: three bf16
+ *      terms per value, the six leading cross products on v_mfma_f32_32x32x16_bf16, dropped terms below 2^-23
+ *      relative per product, at 16/6 of the fp32 matrix rate (the fp16 form: 16/3).
  * Process-wide; also read once from the environment variable PCRCG_GEMM_MODE.  Interface: fp32 in,
  * fp32 out in both modes.
  * Non-finite operands: mode 1 turns an operand value of +-inf into NaN in every output it touches (the split's residual

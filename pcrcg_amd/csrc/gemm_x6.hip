@@ -38,6 +38,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK = 32;
 
@@ -152,6 +155,29 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigne
     p3 = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
 }
 
+// The fp16 TWO-term form (H2 kernels): x = h + 2^-11 l with h = fp16_rn(x), l = fp16_rn((x - h) * 2^11) -- x - h is exact
+// and at most half an ulp of h, so the scaled remainder is no larger than x and l loses nothing to the fp16 subnormal
+// range that h did not.  |x - h - 2^-11 l| <= 2^-22 |x| (2^-36 absolute below 2^-14), and
+//     a b = ha hb + 2^-11 (ha lb + la hb) + [2^-22 la lb]
+// with the bracket and the representation error both at 2^-22 |ab|: three v_mfma_f32_32x32x16_f16 per 16-deep k-chunk
+// (fp16 x fp16 products are exact in the matrix core's fp32 accumulation, fp16 subnormals are kept: scripts/micro/
+// mfma_f16_denormal.hip) instead of six bf16 ones, two LDS planes instead of three, 8 instead of 11 VALU operations per
+// operand pair.  Measured on the path's shapes: 4.5-5.8e-7 of a float64 product, a plain fp32 GEMM's error (the
+// three-term bf16 form: 2.4e-7).  The ONE thing the form cannot do is hold |x| >= 65520: such an operand leaves a
+// non-finite partial sum behind (see the check after the loop), and a workgroup that finds one throws its sums away and
+// runs its tile again with the three-term bf16 loop, which has fp32's range -- no flag for the host, no different
+// result contract.
+constexpr float kH2Scale = 2048.0f;          // 2^11
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned& p1, unsigned& p2) {
+    const f32x2 x = {x0, x1};
+    const f16x2 h = __builtin_convertvector(x, f16x2);                        // v_cvt_pk_f16_f32, round to nearest even
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const f32x2 r = {(x0 - hf[0]) * kH2Scale, (x1 - hf[1]) * kH2Scale};     // exact difference, exact scaling
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    p1 = __builtin_bit_cast(unsigned, h);
+    p2 = __builtin_bit_cast(unsigned, l);
+}
+
 template <int BM, int BN>
 constexpr int lds_bytes() { return 3 * (BM + BN) * ROWB; }
 template <int BM, int BN>
@@ -192,7 +218,7 @@ static int x6_tile_order(int gx, int gy, int gs, int bm, int bn, int k_per_split
 // KNOCK (always 0 in the library; scripts/micro/x6_knock.hip instantiates other values to time the kernel with one of
 // its parts removed -- results wrong, timing meaningful): 1 no global loads inside the k-loop, 2 no split arithmetic,
 // 4 no LDS stores, 8 no MFMA, 16 no LDS operand reads, 32 no barriers.
-template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY, int ANORM = 0, int KNOCK = 0>
+template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY, int ANORM = 0, int KNOCK = 0, int H2 = 0>
 __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                         int ldb, float* __restrict__ C, int ldc, int M, int N, int Kdim,
                                                         const float* __restrict__ row_scale,
@@ -266,12 +292,16 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
     const int k_end = min(Kdim, k_begin + k_per_split);
 
     f32x16 acc[TM][TN];
+    f32x16 acc_lo[H2 ? TM : 1][H2 ? TN : 1];       // H2: the cross terms ha lb + la hb (worth 2^-11 of acc's units)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.0f;
+                if constexpr (H2) acc_lo[i][j][r] = 0.0f;
+            }
 
     // k-contiguous fp32 A: the row of every A item of this thread is the same in all k-steps, so its address is formed
     // once -- and may come through a gather: a_idx != NULL reads row a_idx[r * a_idx_ld] of A for output row r, a zero
@@ -302,6 +332,11 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
     // behind the operand planes.  A gathered shadow row stays zero (closest_pool pads AFTER the normalisation).
     float* const s_mean = reinterpret_cast<float*>(smem + 3 * (A_PLANE + B_PLANE));
     float* const s_rstd = s_mean + (ANORM ? ((k_per_split + BK - 1) / BK) * BK : 0);
+    int* const s_ovf = reinterpret_cast<int*>(s_rstd + (ANORM ? ((k_per_split + BK - 1) / BK) * BK : 0));   // H2: see below
+    if constexpr (H2) {
+        if (tid == 0) *s_ovf = 0;
+        if constexpr (!ANORM) __syncthreads();
+    }
     if constexpr (ANORM) {
         for (int kk = tid; kk < k_end - k_begin; kk += NT) {
             const double mu = a_sums[k_begin + kk] / a_count;
@@ -510,7 +545,117 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
             }
         }
     };
-    if (nfast > 0) {
+    bool run_x6 = true;
+    if constexpr (H2) {
+        // ---- the fp16 two-term loop (see split2h): the structure of the loop below with two planes, three products and the
+        // range check; a workgroup that meets a value fp16 cannot hold leaves it and starts over with the bf16 loop
+        static_assert(ATERMS == 3 && ALAY == 0 && BLAY == 0, "the fp16 form is built for k-contiguous fp32 operands");
+        auto store_one_h = [&](unsigned char* base, int plane_bytes, int row, int kg, auto& src) {
+            unsigned q1[4], q2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split2h(src.get(2 * j), src.get(2 * j + 1), q1[j], q2[j]);
+            const u32x4 p1 = {q1[0], q1[1], q1[2], q1[3]}, p2 = {q2[0], q2[1], q2[2], q2[3]};
+            unsigned char* d = base + row * ROWB + kg * 16;
+            *reinterpret_cast<u32x4*>(d) = p1;
+            *reinterpret_cast<u32x4*>(d + plane_bytes) = p2;
+        };
+        auto multiply_h = [&]() {
+#pragma unroll
+            for (int c = 0; c < BK / 16; ++c) {
+                f16x8 a[TM][2], b[TN][2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        a[i][p] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(
+                            As + p * A_PLANE + (wm * WM + i * 32 + l31) * ROWB + (c * 2 + half) * 16));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        b[j][p] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(
+                            Bs + p * B_PLANE + (wn * WN + j * 32 + l31) * ROWB + (c * 2 + half) * 16));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc_lo[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc_lo[i][j], 0, 0, 0);
+                    }
+            }
+        };
+        auto consume_h = [&](Item<ALAY>* qa, Item<BLAY>* qb, bool live, int k0) {
+            vm_wait<TILE_LOADS>();
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) qa[it].hold();
+#pragma unroll
+            for (int it = 0; it < B_ITERS; ++it) qb[it].hold();
+            if (!live) {
+#pragma unroll
+                for (int it = 0; it < A_ITERS; ++it)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) qa[it].set(j, 0.f);
+            } else {
+                normalise(qa, k0, false);
+            }
+            __syncthreads();                                              // previous tile fully read
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) {
+                int row, kg;
+                item_pos<ALAY, BM>(tid + it * NT, row, kg);
+                store_one_h(As, A_PLANE, row, kg, qa[it]);
+            }
+#pragma unroll
+            for (int it = 0; it < B_ITERS; ++it) {
+                int row, kg;
+                item_pos<BLAY, BN>(tid + it * NT, row, kg);
+                store_one_h(Bs, B_PLANE, row, kg, qb[it]);
+            }
+        };
+        if (nfast > 0) {
+            std::true_type fast;
+            const int k_last = k_begin + (nfast - 1) * BK;
+            load_tiles(fast, k_begin, ra[0], rb[0]);
+            load_tiles(fast, min(k_begin + BK, k_last), ra[1], rb[1]);
+            for (int s = 0; s < nfast; s += 2) {
+                consume_h(ra[0], rb[0], true, k_begin + s * BK);
+                load_tiles(fast, min(k_begin + (s + 2) * BK, k_last), ra[0], rb[0]);
+                __syncthreads();
+                multiply_h();
+                consume_h(ra[1], rb[1], s + 1 < nfast, k_begin + (s + 1) * BK);
+                load_tiles(fast, min(k_begin + (s + 3) * BK, k_last), ra[1], rb[1]);
+                __syncthreads();
+                multiply_h();
+            }
+            vm_wait<0>();
+        }
+        // The range check costs the loop nothing: an operand at or beyond fp16's range became +-inf in BOTH of its terms
+        // (h = inf, l = (x - inf) * 2^11 = -inf), and inf times anything -- zero included -- leaves inf or NaN in every
+        // sum of its row (A) or column (B) of the tile, which nothing can cancel.  So: any non-finite partial sum anywhere
+        // in the workgroup -> the whole tile again with the loop below (which also gives inf / NaN INPUTS the result it
+        // always gave them).
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bad = bad || !(fabsf(acc[i][j][r]) <= 3.0e38f) || !(fabsf(acc_lo[i][j][r]) <= 3.0e38f);
+        if (bad) *s_ovf = 1;
+        __syncthreads();
+        run_x6 = *s_ovf != 0;
+        if (run_x6) {                   // out of fp16's range: everything again, with the loop that has fp32's
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; acc_lo[i][j][r] = 0.0f; }
+            __syncthreads();            // nobody still reads the fp16 planes
+        }
+    }
+    if (run_x6 && nfast > 0) {
         // ONE region without control-flow joins between a load and its wait: every join makes hipcc copy the
         // (still in flight) destination registers of the asm loads, which is exactly the garbage the guide warns of
         // (seen in the ISA of an earlier version with peeled tail steps: v_mov of a set before its s_waitcnt).
@@ -542,6 +687,14 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
         multiply();
     }
 
+    if constexpr (H2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += acc_lo[i][j][r] * (1.0f / kH2Scale);
+    }
     // epilogue (as k_gemm_f32): C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool first_split = split == 0;
     float rs[TM][16], bv[TN];
@@ -617,7 +770,7 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
     }
 }
 
-template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY, int ANORM = 0, int KNOCK = 0>
+template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY, int ANORM = 0, int KNOCK = 0, int H2 = 0>
 int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n,
               int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b, int atomic_out,
               double* colp, int colp_chunks, const long long* a_idx = nullptr, int a_idx_ld = 0, int a_ns = 0,
@@ -629,8 +782,8 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
     tm.gy = (int)grid.y;
     tm.gs = (int)grid.z;
     tm.order = x6_tile_order(tm.gx, tm.gy, tm.gs, BM, BN, k_per_split);
-    const size_t lds = lds_bytes<BM, BN>() + (ANORM ? 2 * sizeof(float) * (size_t)(((k_per_split + BK - 1) / BK) * BK) : 0);
-    auto kern = k_gemm_x6<BM, BN, MINB, ATERMS, ALAY, BLAY, ANORM, KNOCK>;
+    const size_t lds = lds_bytes<BM, BN>() + (ANORM ? 2 * sizeof(float) * (size_t)(((k_per_split + BK - 1) / BK) * BK) : 0) + (H2 ? 16 : 0);
+    auto kern = k_gemm_x6<BM, BN, MINB, ATERMS, ALAY, BLAY, ANORM, KNOCK, H2>;
     static size_t configured = 0;
     if (lds > configured) {
         PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -639,7 +792,7 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
     }
     int m_all = m;                                             // a grouped launch's products all count
     for (int e = 0; e < pr.extra; ++e) m_all += pr.m[e];
-    KpProfScope prof(st, m_all, n, k, ATERMS == 1 ? 3 : 6, 3);  // bench.py's GEMM roofline: the kernel's own start / stop events
+    KpProfScope prof(st, m_all, n, k, (ATERMS == 1 || H2) ? 3 : 6, 3);  // bench.py's GEMM roofline: the kernel's own start / stop events
     hipExtLaunchKernelGGL(kern, dim3(tm.gx * tm.gy * tm.gs), dim3(x6_threads<BM, BN>()), lds, st, prof.a, prof.b, 0, a, lda, b, ldb, c, ldc, m, n,
                           k, row_scale, bias, k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks, a_idx, a_idx_ld, a_ns,
                           a_zero, a_sums, a_count, a_eps, a_slope, pr, tm);
@@ -805,8 +958,15 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
     if (b_kmajor)   // dX = dY * W
         return launch_x6<64, 64, 4, 3, 0, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
                                              vec_b, atomic_out, colp, colp_chunks);
+    const bool h2 = debug_opts().x6_h2 != 0 && !a_bf16;
 #define GO(BMV, BNV, MINB)                                                                                              \
     do {                                                                                                                \
+        if (h2)                                                                                                         \
+            return launch_x6<BMV, BNV, MINB, 3, 0, 0, 0, 0, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,  \
+                                                      k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks,             \
+                                                      gather ? ex->a_idx : nullptr, gather ? ex->a_idx_ld : 0,              \
+                                                      gather ? ex->a_ns : 0, gather ? ex->a_zero : nullptr, nullptr, 0.0,   \
+                                                      0.f, 1.f, pa);                                                        \
         if (a_bf16)                                                                                                     \
             return launch_x6<BMV, BNV, MINB, 1, 0, 0>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,           \
                                                       k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks, nullptr, 0, \
@@ -816,6 +976,12 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
                                                   gather ? ex->a_idx_ld : 0, gather ? ex->a_ns : 0,                         \
                                                   gather ? ex->a_zero : nullptr, nullptr, 0.0, 0.f, 1.f, pa);               \
     } while (0)
+    if (anorm && h2)
+        return launch_x6<64, 64, 4, 3, 0, 0, 1, 0, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
+                                                      vec_b, atomic_out, colp, colp_chunks, gather ? ex->a_idx : nullptr,
+                                                      gather ? ex->a_idx_ld : 0, gather ? ex->a_ns : 0,
+                                                      gather ? ex->a_zero : nullptr, ex->a_sums, ex->a_count, ex->a_eps, ex->a_slope,
+                                                      pa);
     if (anorm)
         return launch_x6<64, 64, 4, 3, 0, 0, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
                                                 vec_b, atomic_out, colp, colp_chunks, gather ? ex->a_idx : nullptr,

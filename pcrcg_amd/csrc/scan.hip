@@ -214,7 +214,7 @@ const DebugName kDebugNames[] = {
     {"radius_blocks", &DebugOpts::radius_blocks}, {"radius_eager_redo", &DebugOpts::radius_eager_redo},
     {"radius_cells", &DebugOpts::radius_cells}, {"radius_prof", &DebugOpts::radius_prof},
     {"pyr_wait", &DebugOpts::pyr_wait}, {"pyr_trace", &DebugOpts::pyr_trace}, {"att_tq", &DebugOpts::att_tq},
-    {"kd_spin_limit", &DebugOpts::kd_spin_limit}, {"gemm_log", &DebugOpts::gemm_log}, {"x6_tile", &DebugOpts::x6_tile}, {"x6_order", &DebugOpts::x6_order}, {"x6_big", &DebugOpts::x6_big}, {"train_side_stream", &DebugOpts::train_side_stream},
+    {"kd_spin_limit", &DebugOpts::kd_spin_limit}, {"gemm_log", &DebugOpts::gemm_log}, {"x6_tile", &DebugOpts::x6_tile}, {"x6_order", &DebugOpts::x6_order}, {"x6_big", &DebugOpts::x6_big}, {"x6_h2", &DebugOpts::x6_h2}, {"train_side_stream", &DebugOpts::train_side_stream},
     {"x6_splitk", &DebugOpts::x6_splitk}, {"x6_t1", &DebugOpts::x6_t1}, {"x6_t2", &DebugOpts::x6_t2},
     {"gemm_tile", &DebugOpts::gemm_tile}, {"gemm_splitk", &DebugOpts::gemm_splitk},
     {"gemm_split_target", &DebugOpts::gemm_split_target}};

@@ -82,6 +82,54 @@ def test_gemm_tile_maps_and_big_tile_agree(cuda, m, n, k):
         assert rel(out, outs["x6_order=0"]) < 2e-6, spec
 
 
+@pytest.mark.parametrize("m,n,k", [(15456, 128, 1920), (763, 512, 7680), (3000, 34, 384), (2000, 257, 1538), (60000, 64, 128)])
+def test_gemm_fp16_two_term_form_and_its_range_fallback(cuda, m, n, k):
+    """The default arithmetic of the forward products (csrc/gemm_x6.hip, H2): x = h + 2^-11 l in fp16, three products --
+    (1) as close to float64 as the exact three-term bf16 form (x6_h2=0), (2) any operand value fp16 cannot hold (|x| >=
+    65520, in A or in B) makes the workgroups that meet it redo their tiles with the bf16 form: same result as x6_h2=0 within
+    summation order, finite where fp32 is finite, (3) inf / NaN operands poison exactly the outputs they poison in the bf16
+    form, (4) tiny values (1e-30) change nothing."""
+    g = torch.Generator().manual_seed(m + 3 * n + k)
+    a = torch.randn(m, k, generator=g)
+    b = (torch.randn(k, n, generator=g) / k ** 0.5)
+    ref = a.double() @ b.double()
+
+    def run(spec, aa, bb):
+        _debug(spec)
+        return ops.gemm(aa.to(cuda), bb.to(cuda)).cpu()
+
+    try:
+        h2, x6 = run("x6_h2=1", a, b), run("x6_h2=0", a, b)
+        e_h2, e_x6 = rel(h2, ref.float()), rel(x6, ref.float())
+        assert e_h2 < 1.5e-6 and e_x6 < 1.5e-6, (e_h2, e_x6)
+        assert e_h2 < 2.0 * e_x6 + 2e-7, (e_h2, e_x6)
+        # out of fp16's range, in A and in B, beside tiny values
+        a2, b2 = a.clone(), b.clone()
+        a2[5, 7] = 3.0e7
+        a2[m // 2, k - 1] = -1.0e30
+        a2[m - 1, 0] = 1.0e-30
+        b2[3, n - 1] = 7.0e4
+        b2[k - 1, 0] = 1.0e-30
+        ref2 = a2.double() @ b2.double()
+        h2, x6 = run("x6_h2=1", a2, b2), run("x6_h2=0", a2, b2)
+        assert torch.isfinite(h2).all() and torch.isfinite(x6).all()
+        # rows / columns the huge values touch: scale by the row's own magnitude (the huge term dominates it)
+        for rows in ([5, m // 2], slice(None)):
+            r2, hh, xx = ref2[rows], h2[rows].double(), x6[rows].double()
+            scale = r2.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+            assert float(((hh - r2).abs() / scale).max()) < 3e-6
+            assert float(((hh - xx).abs() / scale).max()) < 3e-6
+        # non-finite operands: the same outputs are NaN / inf in both forms
+        a3 = a.clone()
+        a3[3, 3] = float("inf")
+        a3[9, 1] = float("nan")
+        h2, x6 = run("x6_h2=1", a3, b), run("x6_h2=0", a3, b)
+        assert torch.equal(torch.isnan(h2), torch.isnan(x6)) and torch.equal(torch.isinf(h2), torch.isinf(x6))
+        assert not torch.isfinite(h2[3]).any() and not torch.isfinite(h2[9]).any() and torch.isfinite(h2[4]).all()
+    finally:
+        _debug("x6_h2=1")
+
+
 @pytest.mark.parametrize("m,ns,n,k1,k2", [(3934, 763, 257, 514, 1024), (60000, 15456, 34, 128, 256), (100, 7, 5, 6, 12),
                                          (15456, 3934, 128, 257, 512)])
 def test_gemm_gather_and_accumulate(cuda, m, ns, n, k1, k2):
