@@ -53,6 +53,16 @@ int radius_query_pass(const float* q, int nq, const int* qlen, int ns, const int
                       int* out_tie_rows, int* out_tie_count, hipStream_t st, int pass);
 
 // radius.hip: the cell-cooperative search over a query grid (pass 0: + the per-query second pass, 1: the cell kernel only)
+// gemm_x6.hip: split-K targets of a caller that runs (nearly) alone on the GPU, for the calling thread (see x6_plan_for)
+bool gemm_x6_alone();
+void gemm_x6_alone_enter();
+void gemm_x6_alone_leave();
+struct GemmAloneScope {
+    GemmAloneScope() { gemm_x6_alone_enter(); }
+    ~GemmAloneScope() { gemm_x6_alone_leave(); }
+    GemmAloneScope(const GemmAloneScope&) = delete;
+    GemmAloneScope& operator=(const GemmAloneScope&) = delete;
+};
 int radius_cells_pass(const void* qgrid, const float* q, int nq, const int* qlen, const void* sgrid, int ns, const int* slen,
                       int nb, int group, float radius, int cols, int64_t* out_idx, int* out_count, int* out_max_count,
                       int* status, int* out_tie_rows, int* out_tie_count, hipStream_t st, int pass);
@@ -122,7 +132,7 @@ struct DebugOpts {
     int att_tq = 16;           // attention kernel: queries per workgroup (8 or 16)
     int kd_spin_limit = 0;     // KD-forest task queue: spin bound (0: default)
     int gemm_log = 0;          // print every GEMM's shape and grid
-    int x6_tile = -1, x6_splitk = 0, x6_t1 = 200, x6_t2 = 1024, x6_order = -1, x6_big = 0, x6_h2 = 1;   // split-bf16 GEMM plan overrides
+    int x6_tile = -1, x6_splitk = 0, x6_t1 = 32, x6_t2 = 128, x6_order = -1, x6_big = 0, x6_h2 = 1;   // split-bf16 GEMM plan overrides
     int train_side_stream = 1; // train-step backward: weight-gradient products on a second stream
     int gemm_tile = -1, gemm_splitk = 0, gemm_split_target = 768;        // fp32-MFMA GEMM plan overrides
 };

