@@ -281,6 +281,13 @@ int pcrcg_gemm_f32_fused(const float* a, int lda, const int64_t* idx, int ld_idx
  * validate_gradient) treats inf and NaN alike, so the skip decision does not depend on the mode. */
 void pcrcg_gemm_set_mode(int mode);
 int pcrcg_gemm_get_mode(void);
+/* Declares that the CALLING HOST THREAD enqueues its network calls beside other streams that keep the GPU busy (on = 1;
+ * 0 takes it back; per thread, default off).  The products of such a thread are planned with far fewer split-K slices:
+ * alone on the GPU a small product is split until ~200 workgroups exist, which fills the chip; beside other streams
+ * their kernels fill the idle CUs anyway and every slice only costs fp32 atomics and a zeroed output (+4.5 % pairs/s in
+ * the four-stream pair engine, whose model threads make this call; -1.9 % for a forward that does run alone).  Results
+ * differ by summation order only.  No reference counterpart (ref:main.py:15 one process, one stream). */
+void pcrcg_thread_shares_gpu(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Point-wise blocks

@@ -53,16 +53,9 @@ int radius_query_pass(const float* q, int nq, const int* qlen, int ns, const int
                       int* out_tie_rows, int* out_tie_count, hipStream_t st, int pass);
 
 // radius.hip: the cell-cooperative search over a query grid (pass 0: + the per-query second pass, 1: the cell kernel only)
-// gemm_x6.hip: split-K targets of a caller that runs (nearly) alone on the GPU, for the calling thread (see x6_plan_for)
-bool gemm_x6_alone();
-void gemm_x6_alone_enter();
-void gemm_x6_alone_leave();
-struct GemmAloneScope {
-    GemmAloneScope() { gemm_x6_alone_enter(); }
-    ~GemmAloneScope() { gemm_x6_alone_leave(); }
-    GemmAloneScope(const GemmAloneScope&) = delete;
-    GemmAloneScope& operator=(const GemmAloneScope&) = delete;
-};
+// gemm_x6.hip: the calling host thread enqueues beside other streams (see x6_plan_for; C ABI: pcrcg_thread_shares_gpu)
+bool gemm_x6_shared();
+void gemm_x6_set_shared(int on);
 int radius_cells_pass(const void* qgrid, const float* q, int nq, const int* qlen, const void* sgrid, int ns, const int* slen,
                       int nb, int group, float radius, int cols, int64_t* out_idx, int* out_count, int* out_max_count,
                       int* status, int* out_tie_rows, int* out_tie_count, hipStream_t st, int pass);

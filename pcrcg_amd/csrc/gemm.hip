@@ -355,6 +355,7 @@ static int gemm_mode() {
     return g_gemm_mode;
 }
 extern "C" void pcrcg_gemm_set_mode(int mode) { g_gemm_mode = mode != 0; }
+extern "C" void pcrcg_thread_shares_gpu(int on) { gemm_x6_set_shared(on); }
 extern "C" int pcrcg_gemm_get_mode(void) { return gemm_mode(); }
 
 static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc,

@@ -808,11 +808,11 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
 // zeroed C) only when the tiles alone leave most CUs idle, or when K is so long that one block's k-loop
 // dominates; each split costs atomic traffic (and a memset unless the caller hands over a zeroed C), so never
 // below 256 k per split.
-// set by a caller whose launches have the GPU (nearly) to themselves -- the train-step runner; read by the plan below
-static thread_local int g_x6_alone = 0;
-bool gemm_x6_alone() { return g_x6_alone > 0; }
-void gemm_x6_alone_enter() { ++g_x6_alone; }
-void gemm_x6_alone_leave() { --g_x6_alone; }
+// set (per host thread) by a caller that enqueues its forwards beside other streams' -- the pair engine's model threads
+// (pcrcg_thread_shares_gpu, include/pcrcg.h); read by the plan below
+static thread_local int g_x6_shared = 0;
+bool gemm_x6_shared() { return g_x6_shared > 0; }
+void gemm_x6_set_shared(int on) { g_x6_shared = on ? 1 : 0; }
 
 struct X6Plan { int pick, bm, bn, gx, gy, splits, k_per_split; };
 static X6Plan x6_plan_for(int pick, int m, int n, int k, bool reduce_rows) {
@@ -827,13 +827,13 @@ static X6Plan x6_plan_for(int pick, int m, int n, int k, bool reduce_rows) {
     const int ktiles = (k + BK - 1) / BK;
     const int max_splits = reduce_rows ? 128 : 32;            // dW = X^T dY reduces over the points: few tiles, very long K
     // Split targets.  Alone on the GPU a product wants ~200 workgroups before it stops splitting (and 1024 while K is very
-    // long); inside the pair engine the other streams' kernels fill the CUs a small product leaves idle, and every split
-    // costs fp32 atomics and a zeroed output: targets 200 / 1024 -> 32 / 128 is +4.5 % there (483 -> 505 pairs/s; no
-    // splitting at all: 506) for +1.9 % on a forward running alone (3.24 -> 3.30 ms).  dW = X^T dY (reduce_rows: a handful
-    // of tiles, K = all points) and the train-step runner (one stream and its side stream: 15.4 vs 16.1 ms per step) keep
-    // the old targets (gemm_x6_alone_scope).
-    int t1 = debug_opts().x6_t1, t2 = debug_opts().x6_t2;                   // tuning aids (defaults 32 / 128)
-    if (reduce_rows || gemm_x6_alone()) { t1 = t1 < 200 ? 200 : t1; t2 = t2 < 1024 ? 1024 : t2; }
+    // long).  Beside the pair engine's other streams the idle CUs of a small product are filled by their kernels anyway,
+    // while every split costs fp32 atomics and a zeroed output: a host thread that has declared the GPU shared
+    // (pcrcg_thread_shares_gpu) gets the targets 32 / 128 -- +4.5 % in the engine (483 -> 505 pairs/s; no splitting at all:
+    // 506), where the same targets cost a forward running alone 1.9 % (3.24 -> 3.30 ms) and the train step 4 % (15.4 ->
+    // 16.1 ms).  dW = X^T dY (reduce_rows: a handful of tiles, K = all points) always keeps the lone-stream targets.
+    int t1 = 200, t2 = 1024;
+    if (gemm_x6_shared() && !reduce_rows) { t1 = debug_opts().x6_t1; t2 = debug_opts().x6_t2; }   // tuning aids (defaults 32 / 128)
     while ((long)p.gx * p.gy * splits < t1 && k / (2 * splits) >= 256 && splits < max_splits) splits *= 2;
     while ((long)p.gx * p.gy * splits < t2 && k / splits > 1024 && splits < max_splits) splits *= 2;
     if (debug_opts().x6_splitk > 0) splits = debug_opts().x6_splitk;        // tuning aid

@@ -517,7 +517,6 @@ int pcrcg_kpfcnn_train_ws_bytes(const pcrcg_model* model, const pcrcg_model* gra
                                 size_t* value_bytes, size_t* grad_bytes, size_t* scratch_bytes) {
     PCRCG_PROPAGATE(validate(model, grads, batch));
     PCRCG_CHECK_ARG(value_bytes && grad_bytes && scratch_bytes);
-    GemmAloneScope alone;               // the same product plans as the live passes (split-K outputs size the arenas)
     Tape t;
     forward(t, *model, *grads, *batch);
     const int n0 = batch->n_points[0];
@@ -532,7 +531,6 @@ int pcrcg_kpfcnn_train_forward(const pcrcg_model* model, const pcrcg_model* grad
                                void** tape, void* stream) {
     PCRCG_PROPAGATE(validate(model, grads, batch));
     PCRCG_CHECK_ARG(ws && tape && out);
-    GemmAloneScope alone;               // a train step has the GPU to itself: its products split as a lone stream's should
     *tape = nullptr;
     Tape* t = new Tape();
     t->dry = false;
@@ -577,7 +575,6 @@ int pcrcg_kpfcnn_train_forward(const pcrcg_model* model, const pcrcg_model* grad
 int pcrcg_kpfcnn_train_backward(void* tape, const float* d_feats_f, const float* d_scores_overlap,
                                 const float* d_scores_saliency, void* stream) {
     PCRCG_CHECK_ARG(tape);
-    GemmAloneScope alone;
     Tape& t = *static_cast<Tape*>(tape);
     t.st = as_stream(stream);
     t.rc = PCRCG_OK;

@@ -252,6 +252,8 @@ class PairStreams:
 
     def _serve_model(self, m):
         torch.cuda.set_device(self.device)
+        from . import _lib
+        _lib.lib().pcrcg_thread_shares_gpu(1)      # this thread's forwards run beside the other streams': fewer split-K slices
         stream, job = self.models[m], m
         while True:
             t0 = time.perf_counter()
