@@ -118,6 +118,7 @@ struct DebugOpts {
     int fuse_upsample = 1;     // runner: nearest_upsample -> cat(skip) -> unary as two products into one output
     int radius_blocks = 0;     // radius search grid (0: 512 workgroups)
     int radius_eager_redo = 0; // pyramid builder: launch the >256-hit redo pass unconditionally
+    int kd_blocks = 0;
     int radius_prof = 0;       // cell-cooperative search: per-phase shader-cycle counters, printed at exit (measurement aid)
     int radius_cells = 1;      // pyramid builder: cell-cooperative LDS-staged search (0: the per-query kernel of rounds 1-3)
     int pyr_wait = 1;          // pyramid builder host round trip: 0 stream sync, 1 event, 2 device-posted flag

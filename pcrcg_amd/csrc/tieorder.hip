@@ -56,7 +56,12 @@ constexpr int kSubThreads = 512;       // = kBigThreads: big nodes and LDS subtr
 constexpr int kBigThreads = 512;      // each scan step of a big node covers kBigThreads * kBigVec positions
 constexpr int kBigVec = 4;
 constexpr int kOwnMax = 4096;          // a workgroup that splits a node up to this size also splits its big descendants itself
-constexpr int kForestBlocks = 160;    // workgroups of the forest kernel (they pull tasks from a device-side queue)
+constexpr int kForestBlocks = 48;     // workgroups of the forest kernel (they pull tasks from a device-side queue).  Each is 512
+                                      // threads that mostly WAIT for tasks while the top of every tree is split by one workgroup:
+                                      // beside the engine's other streams more of them only take wavefront slots and LDS from
+                                      // kernels that have work (S30k two-pair builds asked for 94: 502 pairs/s, 48: 520, 32: 520,
+                                      // 24: 510, 160: 457; K120k 160: 119.5, 48: 133.1, 16: 131.7), and alone the build is as fast
+                                      // (S30k 2.00 vs 1.94 ms per two-pair pyramid) or faster (K120k 5.41 vs 6.16 ms)
 constexpr int kSpinLimitDefault = 1 << 18;   // polls of an empty queue before a workgroup gives up (status 1)
 constexpr int kTravStack = 128;       // pending far children per query (<= tree depth)
 constexpr int kReorderWaves = 4;      // rows per workgroup of the reorder kernel
@@ -893,6 +898,7 @@ int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, void
         // one workgroup per ~1024 points can be busy at the deepest level of big nodes / the LDS subtrees
         int blocks = ns / (2 * kSubMax) + nb;
         if (blocks > kForestBlocks) blocks = kForestBlocks;
+        if (debug_opts().kd_blocks > 0) blocks = debug_opts().kd_blocks;      // tuning aid
         const int spin = debug_opts().kd_spin_limit;          // debugging aid
         hipLaunchKernelGGL(k_kd_forest, dim3(blocks), dim3(kBigThreads), 0, st, sup, v, spin > 0 ? spin : kSpinLimitDefault);
     }
