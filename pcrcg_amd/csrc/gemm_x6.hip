@@ -15,6 +15,11 @@
 // The three-term split is the point: the two-term variant (3 MFMAs) leaves 2^-16 per product and moved
 // intermediate activations by 1.7e-4 in the same experiment -- outside this path's 1e-4 bar.
 //
+// Since round 4 the forward products (k-contiguous fp32 operands) run the fp16 TWO-term form instead -- three matrix
+// instructions per chunk, two LDS planes, the same loop structure; see split2h and the H2 kernels below -- and fall back to
+// the three-term form above, inside the kernel, for any tile whose operands leave fp16's range.  The training rows'
+// k-major products and bf16-stored operands use the three-term form directly.
+//
 // Structure: 256 threads = 4 wavefronts (2 x 2), block tile BM x BN x 32.  Operand tiles are loaded as
 // float4 pairs (8 consecutive k of one row per thread and pass), split on the VALU and written to LDS as
 // three bf16 planes with 80-byte rows (64 B of data + 16 B pad: the ds_read_b128 of 8 consecutive k for the
