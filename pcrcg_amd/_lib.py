@@ -115,6 +115,8 @@ SIGNATURES = {
     # include/pcrcg_train.h -- the "next" rows
     "pcrcg_gemm_f32_ex": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p]),
+    "pcrcg_gemm_f32_grad": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_void_p, c_void_p, c_int, c_void_p]),
     "pcrcg_kpconv_backward_dx": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                          c_void_p, c_float, c_void_p, c_void_p]),
     "pcrcg_kpconv_forward_ws_bytes": (c_size_t, [c_int, c_int, c_int]),

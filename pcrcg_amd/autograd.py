@@ -35,13 +35,13 @@ class _Matmul(torch.autograd.Function):
         dy = _c(dy)
         da = db = dbias = None
         if ctx.needs_input_grad[0]:
-            da = ops.gemm(dy, b.t(), row_scale=rs)
+            da = ops.gemm(dy, b.t(), row_scale=rs, grad_operand=1)
         if ctx.needs_input_grad[1]:
             dys = dy if rs is None else dy * rs[:, None]
-            db = ops.gemm(a.t(), dys)
+            db = ops.gemm(a.t(), dys, grad_operand=2)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             ones = torch.ones((1, dy.shape[0]), dtype=_F32, device=dy.device)
-            dbias = ops.gemm(ones, dy).reshape(-1)
+            dbias = ops.gemm(ones, dy, grad_operand=2).reshape(-1)
         return da, db, None, dbias
 
 
@@ -86,9 +86,9 @@ class _KPConv(torch.autograd.Function):
         dy = _c(dy)
         dx = dw = None
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm(wf.t(), dy * inv_n[:, None]).reshape(wshape)
+            dw = ops.gemm(wf.t(), dy * inv_n[:, None], grad_operand=2).reshape(wshape)
         if ctx.needs_input_grad[0]:
-            d_wf = ops.gemm(dy, w2.t(), row_scale=inv_n)               # [nq, 15*cin]
+            d_wf = ops.gemm(dy, w2.t(), row_scale=inv_n, grad_operand=1)               # [nq, 15*cin]
             dx = torch.zeros((ns, cin), dtype=_F32, device=dy.device)
             nq, h = idx2.shape
             _lib.check(L.pcrcg_kpconv_backward_dx(q_pts.data_ptr(), nq, s_pts.data_ptr(), ns, idx2.data_ptr(), h, ld_idx,

@@ -70,6 +70,7 @@ struct GemmExtra {
     const double* a_sums = nullptr;     // != NULL: A is normalised on load, a' = lrelu((a - mean_k) * rstd_k, a_slope), with
     double a_count = 0.0;               // the statistics of its columns given as fp64 sums [2][k] over a_count rows
     float a_eps = 1e-5f, a_slope = 1.0f;
+    int grad_operand = 0;               // train step: 1 = A holds gradients, 2 = B does (the fp16 form scales that operand by 2^16)
 };
 
 // gemm_x6.hip: a SECOND product C1 = f(A1) * B^T that shares B (and the bias, the leading dimensions, n, k and every

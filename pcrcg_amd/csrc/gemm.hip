@@ -412,7 +412,7 @@ int gemm_bt_extra_pair(const float* a, int lda, const float* b, int ldb, float* 
 // as in pcrcg_gemm_f32_ex; accumulate adds the product onto C with fp32 atomics (gradients of tensors with several
 // consumers, parameter gradients of shared weights).  Split-bf16 arithmetic only.
 int gemm_general(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc, int m, int n,
-                 int k, const float* row_scale, const float* bias, bool accumulate, hipStream_t st) {
+                 int k, const float* row_scale, const float* bias, bool accumulate, hipStream_t st, int grad_operand) {
     PCRCG_CHECK_ARG(m >= 0 && n >= 0 && k >= 0);
     if (m == 0 || n == 0 || k == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(a && b && c && !(trans_a && trans_b));
@@ -423,8 +423,9 @@ int gemm_general(const float* a, int lda, int trans_a, const float* b, int ldb, 
     }
     GemmExtra ex;
     ex.accumulate = accumulate;
+    ex.grad_operand = grad_operand;
     return gemm_x6_dispatch(a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, nullptr, 0, nullptr, st, false, false,
-                            trans_a ? 1 : 0, trans_b ? 0 : 1, false, accumulate ? &ex : nullptr);
+                            trans_a ? 1 : 0, trans_b ? 0 : 1, false, (accumulate || grad_operand) ? &ex : nullptr);
 }
 int gemm_bt_colstats(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
                      const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
@@ -507,6 +508,16 @@ extern "C" int pcrcg_gemm_f32_fused(const float* a, int lda, const int64_t* idx,
 extern "C" int pcrcg_gemm_f32_ex(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c,
                                  int ldc, int m, int n, int k, const float* row_scale, const float* bias, void* stream) {
     return gemm_dispatch(a, lda, trans_a, b, ldb, trans_b, c, ldc, m, n, k, row_scale, bias, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int pcrcg_gemm_f32_grad(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c,
+                                   int ldc, int m, int n, int k, const float* row_scale, const float* bias, int grad_operand,
+                                   void* stream) {
+    PCRCG_CHECK_ARG(grad_operand >= 0 && grad_operand <= 2);
+    if (grad_operand == 0 || pcrcg_gemm_get_mode() != 1 || (trans_a && trans_b))
+        return gemm_dispatch(a, lda, trans_a, b, ldb, trans_b, c, ldc, m, n, k, row_scale, bias, nullptr, 0, nullptr, stream);
+    return pcrcg::gemm_general(a, lda, trans_a, b, ldb, trans_b, c, ldc, m, n, k, row_scale, bias, false, as_stream(stream),
+                               grad_operand);
 }
 
 static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc,

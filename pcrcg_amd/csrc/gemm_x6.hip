@@ -232,7 +232,7 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
                                                         int colp_chunks, const long long* __restrict__ a_idx,
                                                         int a_idx_ld, int a_ns, const float* __restrict__ a_zero,
                                                         const double* __restrict__ a_sums, double a_count, float a_eps,
-                                                        float a_slope, GemmPairArgs pr, TileMap tm) {
+                                                        float a_slope, GemmPairArgs pr, TileMap tm, float h2_sa, float h2_sb) {
     // 256 threads = 2 x 2 wavefronts; the 128 x 128 tile runs 512 threads = 2 x 4 wavefronts (64 x 32 each): the same
     // registers per thread and wavefronts per CU as the 64 x 64 tile at half its L1 fills per flop
     constexpr int NT = x6_threads<BM, BN>();
@@ -554,7 +554,10 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
     if constexpr (H2) {
         // ---- the fp16 two-term loop (see split2h): the structure of the loop below with two planes, three products and the
         // range check; a workgroup that meets a value fp16 cannot hold leaves it and starts over with the bf16 loop
-        static_assert(ATERMS == 3 && ALAY == 0 && BLAY == 0, "the fp16 form is built for k-contiguous fp32 operands");
+        static_assert(ATERMS == 3, "the fp16 form is built for fp32 operands");
+        // h2_sa / h2_sb: exact power-of-two factors applied to A / B before the split (1 for activations and weights; the
+        // train step's GRADIENT operands, whose values live far below fp16's normal range, are lifted by 2^16) and taken
+        // out of the sums again right after the loop
         auto store_one_h = [&](unsigned char* base, int plane_bytes, int row, int kg, auto& src) {
             unsigned q1[4], q2[4];
 #pragma unroll
@@ -603,6 +606,18 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
                     for (int j = 0; j < 8; ++j) qa[it].set(j, 0.f);
             } else {
                 normalise(qa, k0, false);
+            }
+            if (h2_sa != 1.0f) {
+#pragma unroll
+                for (int it = 0; it < A_ITERS; ++it)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) qa[it].set(j, qa[it].get(j) * h2_sa);
+            }
+            if (h2_sb != 1.0f) {
+#pragma unroll
+                for (int it = 0; it < B_ITERS; ++it)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) qb[it].set(j, qb[it].get(j) * h2_sb);
             }
             __syncthreads();                                              // previous tile fully read
 #pragma unroll
@@ -658,6 +673,14 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; acc_lo[i][j][r] = 0.0f; }
             __syncthreads();            // nobody still reads the fp16 planes
+        } else {                        // the fp16 sums stand: cross terms in, operand scales out (the k tail below adds plain sums)
+            const float unscale = 1.0f / (h2_sa * h2_sb);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] + acc_lo[i][j][r] * (1.0f / kH2Scale)) * unscale;
         }
     }
     if (run_x6 && nfast > 0) {
@@ -692,14 +715,6 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
         multiply();
     }
 
-    if constexpr (H2) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += acc_lo[i][j][r] * (1.0f / kH2Scale);
-    }
     // epilogue (as k_gemm_f32): C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool first_split = split == 0;
     float rs[TM][16], bv[TN];
@@ -780,7 +795,7 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
               int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b, int atomic_out,
               double* colp, int colp_chunks, const long long* a_idx = nullptr, int a_idx_ld = 0, int a_ns = 0,
               const float* a_zero = nullptr, const double* a_sums = nullptr, double a_count = 0.0, float a_eps = 0.f,
-              float a_slope = 1.f, GemmPairArgs pr = GemmPairArgs()) {
+              float a_slope = 1.f, GemmPairArgs pr = GemmPairArgs(), float h2_sa = 1.f, float h2_sb = 1.f) {
     // grid = (column tiles, row tiles, splits) as the caller counts them; launched 1-D (see the kernel's tile order)
     TileMap tm;
     tm.gx = (int)grid.x;
@@ -800,7 +815,7 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
     KpProfScope prof(st, m_all, n, k, (ATERMS == 1 || H2) ? 3 : 6, 3);  // bench.py's GEMM roofline: the kernel's own start / stop events
     hipExtLaunchKernelGGL(kern, dim3(tm.gx * tm.gy * tm.gs), dim3(x6_threads<BM, BN>()), lds, st, prof.a, prof.b, 0, a, lda, b, ldb, c, ldc, m, n,
                           k, row_scale, bias, k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks, a_idx, a_idx_ld, a_ns,
-                          a_zero, a_sums, a_count, a_eps, a_slope, pr, tm);
+                          a_zero, a_sums, a_count, a_eps, a_slope, pr, tm, h2_sa, h2_sb);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -970,13 +985,29 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
             }
         }
     }
-    if (a_kmajor)   // dW = X^T * dY
+    // The train step tells which operand holds GRADIENTS (GemmExtra::grad_operand): the fp16 form lifts it by 2^16 (exactly;
+    // values down to ~1e-11 keep fp32-class relative precision, values beyond 1 send the tile to the bf16 redo).  A k-major
+    // product whose caller says nothing keeps the bf16 form.
+    const int grad_op = ex ? ex->grad_operand : 0;
+    const float h2_sa = grad_op == 1 ? 65536.0f : 1.0f, h2_sb = grad_op == 2 ? 65536.0f : 1.0f;
+    const bool h2_on = debug_opts().x6_h2 != 0 && !a_bf16;
+    if (a_kmajor) {  // dW = X^T * dY
+        if (h2_on && grad_op)
+            return launch_x6<64, 64, 3, 3, 1, 1, 0, 0, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
+                                                          vec_b, atomic_out, colp, colp_chunks, nullptr, 0, 0, nullptr, nullptr, 0.0, 0.f,
+                                                          1.f, GemmPairArgs(), h2_sa, h2_sb);
         return launch_x6<64, 64, 3, 3, 1, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
                                              vec_b, atomic_out, colp, colp_chunks);
-    if (b_kmajor)   // dX = dY * W
+    }
+    if (b_kmajor) {  // dX = dY * W
+        if (h2_on && grad_op)
+            return launch_x6<64, 64, 4, 3, 0, 1, 0, 0, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
+                                                          vec_b, atomic_out, colp, colp_chunks, nullptr, 0, 0, nullptr, nullptr, 0.0, 0.f,
+                                                          1.f, GemmPairArgs(), h2_sa, h2_sb);
         return launch_x6<64, 64, 4, 3, 0, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
                                              vec_b, atomic_out, colp, colp_chunks);
-    const bool h2 = debug_opts().x6_h2 != 0 && !a_bf16;
+    }
+    const bool h2 = h2_on;
 #define GO(BMV, BNV, MINB)                                                                                              \
     do {                                                                                                                \
         if (h2)                                                                                                         \
@@ -984,7 +1015,7 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
                                                       k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks,             \
                                                       gather ? ex->a_idx : nullptr, gather ? ex->a_idx_ld : 0,              \
                                                       gather ? ex->a_ns : 0, gather ? ex->a_zero : nullptr, nullptr, 0.0,   \
-                                                      0.f, 1.f, pa);                                                        \
+                                                      0.f, 1.f, pa, h2_sa, h2_sb);                                          \
         if (a_bf16)                                                                                                     \
             return launch_x6<BMV, BNV, MINB, 1, 0, 0>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias,           \
                                                       k_per_split, vec_a, vec_b, atomic_out, colp, colp_chunks, nullptr, 0, \

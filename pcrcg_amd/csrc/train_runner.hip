@@ -29,8 +29,9 @@
 
 namespace pcrcg {
 // gemm.hip / trainops.hip
+// grad_operand: 1 = A holds gradients, 2 = B does, 0 = neither (see GemmExtra::grad_operand, common.h)
 int gemm_general(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc, int m, int n,
-                 int k, const float* row_scale, const float* bias, bool accumulate, hipStream_t st);
+                 int k, const float* row_scale, const float* bias, bool accumulate, hipStream_t st, int grad_operand = 0);
 int tr_scale_rows(const float* src, int ld_src, const float* s, float* dst, int rows, int cols, hipStream_t st);
 int tr_add_lrelu(const float* a, int lda, const float* b, int ldb, float slope, float* y, int ldy, int rows, int cols,
                  hipStream_t st);
@@ -183,11 +184,11 @@ TT linear(Tape& t, const TT& x, Wt w, int ldw, Wt bias, int out, TT* into = null
         t.check(gemm_general(x.p, x.ld, 0, w.p, ldw, 1, y.p, y.ld, x.rows, out, x.cols, nullptr, bias.p, false, t.st));
     t.record([x, y, w, ldw, bias, out](Tape& b) {
         if (x.g)     // dx += dy @ W
-            b.check(gemm_general(y.g, y.ld, 0, w.p, ldw, 0, x.g, x.ld, x.rows, x.cols, out, nullptr, nullptr, true, b.st));
+            b.check(gemm_general(y.g, y.ld, 0, w.p, ldw, 0, x.g, x.ld, x.rows, x.cols, out, nullptr, nullptr, true, b.st, 1));
         if (w.g || bias.g) {
             hipStream_t side = b.off_path();
             if (w.g)     // dW += dy^T @ x
-                b.check(gemm_general(y.g, y.ld, 1, x.p, x.ld, 0, w.g, ldw, out, x.cols, x.rows, nullptr, nullptr, true, side));
+                b.check(gemm_general(y.g, y.ld, 1, x.p, x.ld, 0, w.g, ldw, out, x.cols, x.rows, nullptr, nullptr, true, side, 1));
             if (bias.g) b.check(tr_bias_grad(y.g, y.ld, y.rows, out, bias.g, side));
         }
     });
@@ -200,8 +201,8 @@ TT matmul_bt(Tape& t, const TT& a, const TT& bm) {
     if (t.live())
         t.check(gemm_general(a.p, a.ld, 0, bm.p, bm.ld, 1, y.p, y.ld, a.rows, bm.rows, a.cols, nullptr, nullptr, false, t.st));
     t.record([a, bm, y](Tape& b) {
-        if (a.g) b.check(gemm_general(y.g, y.ld, 0, bm.p, bm.ld, 0, a.g, a.ld, a.rows, a.cols, bm.rows, nullptr, nullptr, true, b.st));
-        if (bm.g) b.check(gemm_general(y.g, y.ld, 1, a.p, a.ld, 0, bm.g, bm.ld, bm.rows, a.cols, a.rows, nullptr, nullptr, true, b.st));
+        if (a.g) b.check(gemm_general(y.g, y.ld, 0, bm.p, bm.ld, 0, a.g, a.ld, a.rows, a.cols, bm.rows, nullptr, nullptr, true, b.st, 1));
+        if (bm.g) b.check(gemm_general(y.g, y.ld, 1, a.p, a.ld, 0, bm.g, bm.ld, bm.rows, a.cols, a.rows, nullptr, nullptr, true, b.st, 1));
     });
     return y;
 }
@@ -212,8 +213,8 @@ TT matmul_nn(Tape& t, const TT& p, const TT& v, TT* into = nullptr) {
     if (t.live())
         t.check(gemm_general(p.p, p.ld, 0, v.p, v.ld, 0, y.p, y.ld, p.rows, v.cols, p.cols, nullptr, nullptr, false, t.st));
     t.record([p, v, y](Tape& b) {
-        if (p.g) b.check(gemm_general(y.g, y.ld, 0, v.p, v.ld, 1, p.g, p.ld, p.rows, p.cols, v.cols, nullptr, nullptr, true, b.st));
-        if (v.g) b.check(gemm_general(p.p, p.ld, 1, y.g, y.ld, 0, v.g, v.ld, p.cols, v.cols, p.rows, nullptr, nullptr, true, b.st));
+        if (p.g) b.check(gemm_general(y.g, y.ld, 0, v.p, v.ld, 1, p.g, p.ld, p.rows, p.cols, v.cols, nullptr, nullptr, true, b.st, 1));
+        if (v.g) b.check(gemm_general(p.p, p.ld, 1, y.g, y.ld, 0, v.g, v.ld, p.cols, v.cols, p.rows, nullptr, nullptr, true, b.st, 2));
     });
     return y;
 }
@@ -280,10 +281,10 @@ TT kpconv(Tape& t, const pcrcg_batch& b, const pcrcg_block& blk, Wt w, const TT&
     t.record([=](Tape& bk) {
         bk.check(tr_scale_rows(y.g, y.ld, inv_n, dys, nq, cout, bk.st));          // dy / n
         if (w.g)                                                                  // dW += wf^T @ (dy / n)
-            bk.check(gemm_general(wf, kc, 1, dys, cout, 0, w.g, cout, kc, cout, nq, nullptr, nullptr, true, bk.off_path()));
+            bk.check(gemm_general(wf, kc, 1, dys, cout, 0, w.g, cout, kc, cout, nq, nullptr, nullptr, true, bk.off_path(), 2));
         if (x.g) {                                                                // d wf = (dy / n) @ W^T, scattered through w
             float* d_wf = bk.tmp((size_t)(nq > 0 ? nq : 1) * kc + 64);
-            bk.check(gemm_general(dys, cout, 0, w.p, cout, 1, d_wf, kc, nq, kc, cout, nullptr, nullptr, false, bk.st));
+            bk.check(gemm_general(dys, cout, 0, w.p, cout, 1, d_wf, kc, nq, kc, cout, nullptr, nullptr, false, bk.st, 1));
             bk.check(pcrcg_kpconv_backward_dx(q, nq, s_pts, ns, tab.idx, tab.cols, tab.ld, d_wf, cin, kp, extent, x.g, bk.st));
         }
     });

@@ -285,9 +285,10 @@ def _operand_a(a):
     return a.contiguous(), k, 0
 
 
-def gemm(a, b, row_scale=None, bias=None, out=None):
+def gemm(a, b, row_scale=None, bias=None, out=None, grad_operand=0):
     """out[m,n] = (a[m,k] @ b[k,n]) * row_scale[m] + bias[n] on the fp32 matrix cores.  Transposed views
-    of row-major matrices are consumed in place (no copies) for either operand."""
+    of row-major matrices are consumed in place (no copies) for either operand.  grad_operand (backward products):
+    1 = `a` holds gradients, 2 = `b` does -- include/pcrcg_train.h pcrcg_gemm_f32_grad."""
     L = _lib.lib()
     a, lda, trans_a = _operand_a(a)
     b, ldb, trans_b = _operand_b(b)
@@ -304,6 +305,10 @@ def gemm(a, b, row_scale=None, bias=None, out=None):
         row_scale = _dev(row_scale, _F32, "row_scale").contiguous()
     if bias is not None:
         bias = _dev(bias, _F32, "bias").contiguous()
+    if grad_operand:
+        _lib.check(L.pcrcg_gemm_f32_grad(a.data_ptr(), lda, int(trans_a), b.data_ptr(), ldb, trans_b, out.data_ptr(), ldc, m, n, k,
+                                         _ptr(row_scale), _ptr(bias), int(grad_operand), _stream()), "pcrcg_gemm_f32_grad")
+        return out
     if trans_a:
         _lib.check(L.pcrcg_gemm_f32_ex(a.data_ptr(), lda, 1, b.data_ptr(), ldb, trans_b, out.data_ptr(), ldc, m, n, k,
                                        _ptr(row_scale), _ptr(bias), _stream()), "pcrcg_gemm_f32_ex")

@@ -259,3 +259,30 @@ def test_gemm_transposed_a(cuda, m, n, k, tb):
     # a column slice of a wider matrix as A^T (lda > m, unaligned start)
     wide = torch.randn(k, m + 5, generator=g).to(cuda)
     assert rel(ops.gemm(wide[:, 1:m + 1].t(), b), wide[:, 1:m + 1].double().t() @ b.double()) < 2e-5
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-4, 1e-8])
+def test_backward_products_keep_precision_for_tiny_gradients(cuda, scale):
+    """include/pcrcg_train.h pcrcg_gemm_f32_grad (ops.gemm(..., grad_operand=)): the three backward forms dX = dY W,
+    dW = X^T dY and the k-contiguous dX = dY W^T with gradient values around `scale` -- far below fp16's normal range at
+    1e-8 -- stay within fp32-class distance of a float64 product (the gradient operand is lifted by 2^16 before the fp16
+    split, csrc/gemm_x6.hip); a gradient beyond 1 (here 300) takes the bf16 redo and is exact as well."""
+    g = torch.Generator().manual_seed(11)
+    m, n, k = 3000, 128, 256
+    dy = (torch.randn(m, n, generator=g) * scale).to(cuda)
+    w = (torch.randn(n, k, generator=g) / n ** 0.5).to(cuda)         # [Cout, Cin]: dX = dY @ W
+    x = torch.randn(m, k, generator=g).to(cuda)
+
+    def rel64(got, ref):
+        return float((got.double() - ref).abs().max() / ref.abs().max())
+
+    dx = ops.gemm(dy, w, grad_operand=1)                              # A = gradient, B k-major
+    assert rel64(dx, dy.double() @ w.double()) < 2e-6
+    dx2 = ops.gemm(dy, w.t().contiguous().t(), grad_operand=1)        # the k-contiguous form (B^T stored)
+    assert rel64(dx2, dy.double() @ w.double()) < 2e-6
+    dw = ops.gemm(x.t(), dy, grad_operand=2)                          # A^T activations, B = gradient
+    assert rel64(dw, x.double().t() @ dy.double()) < 2e-6
+    big = dy.clone()
+    big[7, 3] = 300.0
+    dxb = ops.gemm(big, w.t().contiguous().t(), grad_operand=1)
+    assert torch.isfinite(dxb).all() and rel64(dxb, big.double() @ w.double()) < 2e-6
