@@ -37,17 +37,30 @@ extern "C" {
 #define PCRCG_KPOINTS 15 /* kernel points per KPConv (ref:configs/test/indoor.yaml num_kernel_points) */
 
 const char* pcrcg_last_error(void);
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header: bumped on any signature change, on any change of a caller-held workspace's layout or size,
+ * and on any change of the default arithmetic.  A binding compares pcrcg_abi_version() (what the loaded library was built
+ * from) with the PCRCG_ABI_VERSION it was written against (pcrcg_amd/_lib.py does, at load time).
+ *   2 (round 3)  forward groups, train-step runner, correspondences, debug switches; one-kernel KPConv entries removed
+ *   3 (round 4/5) cell-grid workspace: 64-bit run cursor, 16-byte slots, compact cell list and ticket block (a grid built
+ *                by a version-2 library cannot be walked); new entries pcrcg_radius_query_cells,
+ *                pcrcg_pyramid_build_parts, pcrcg_gemm_f32_grad, pcrcg_thread_shares_gpu; pcrcg_profile_kpconv flag bits;
+ *                forward products in the fp16 two-term form with both range ends handled in the kernel (see
+ *                pcrcg_gemm_set_mode); deterministic=1 debug switch */
+#define PCRCG_ABI_VERSION 3
 int pcrcg_abi_version(void);
 
 /* Tuning / A-B switches, for measurements only: "name=value,name=value" (NULL resets everything).  The same string is
  * read once from the environment variable PCRCG_DEBUG at first use; nothing else in the library reads the environment
  * except PCRCG_GEMM_MODE (pcrcg_gemm_set_mode).  Every switch defaults to the product behaviour:
- *   zero_arena=1 stat_sums=1 stat_sums_rows=2^30 fuse_norm=1 fuse_pack=1 fuse_upsample=1   network runner fusions
+ *   zero_arena=1 stat_sums=1 stat_sums_rows=2^30 fuse_norm=1 fuse_pack=1 fuse_upsample=1 gnn_merge=1 edge_rows=1   network runner fusions
  *   radius_blocks=0 radius_eager_redo=0 radius_cells=1 radius_prof=0 pyr_wait=1 pyr_trace=0 kd_spin_limit=0 kd_blocks=0   front end
  *   att_tq=16                                                                              attention tile
  *   gemm_log=0 x6_tile=-1 x6_splitk=0 x6_t1=32 x6_t2=128 x6_order=-1 x6_big=0 x6_h2=1 gemm_tile=-1 gemm_splitk=0 gemm_split_target=768   GEMM plans
  *   train_side_stream=1                                                                    train-step backward
+ *   deterministic=0    1: bit-reproducible results -- no floating-point atomics (no split-K, InstanceNorm statistics from
+ *                      stored partials, fixed-point scatter sums in the train step); implies stat_sums=0 x6_splitk=1
+ *                      gemm_splitk=1.  Together with a fixed pairing of the pair engine (PairStreams(adaptive_jobs=False))
+ *                      outputs are a function of the inputs alone.
  * Returns PCRCG_EBADARG (and changes nothing) on an unknown name. */
 int pcrcg_debug_set(const char* spec);
 
@@ -265,19 +278,29 @@ int pcrcg_gemm_f32_fused(const float* a, int lda, const int64_t* idx, int ld_idx
  *   1: (default) the fp32 operands are split into 16-bit terms and the products run on the 16-bit matrix cores with
  *      fp32 accumulation.  The forward products (k-contiguous fp32 operands) use the TWO-term fp16 form
  *      x = h + 2^-11 l, three v_mfma_f32_32x32x16_f16 per 16-deep chunk (representation and dropped term: 2^-22
- *      relative per product; measured against float64 no worse than the bf16 form or mode 0).  fp16 ends at 65504: a
- *      workgroup whose operands reach beyond finds a non-finite partial sum after its loop and redoes its tile in the
- *      bf16 form below, so the RESULT has fp32's range -- only operands that are ALL below 2^-14 in magnitude lose
- *      relative precision (absolute error floor 2^-36 per operand value).  The other products (the training rows'
- *      k-major forms, bf16-stored operands) and PCRCG_DEBUG=x6_h2=0 use the EXACT three-term bf16 form: three bf16
- *      terms per value, the six leading cross products on v_mfma_f32_32x32x16_bf16, dropped terms below 2^-23
- *      relative per product, at 16/6 of the fp32 matrix rate (the fp16 form: 16/3).
- * Process-wide; also read once from the environment variable PCRCG_GEMM_MODE.  Interface: fp32 in,
+ *      relative per product; measured against float64 no worse than the bf16 form or mode 0).  fp16's normal range is
+ *      2^-14 .. 65504, and BOTH ends are handled inside the kernel, per tile, with no flag for the host and no different
+ *      result contract (round 5):
+ *        above   an operand value beyond 65504 leaves a non-finite partial sum behind;
+ *        below   every thread keeps the largest |x| of the values it splits, per tile row of A and of B (an output row /
+ *                an output column); a row that is not all zeros and holds no value of at least 2^-14 is one whose h terms
+ *                are all fp16 subnormals (absolute floor 2^-36 per value instead of 2^-22 relative);
+ *      a workgroup that finds either after its loop throws its sums away and redoes its tile in the exact bf16 form
+ *      below.  What the fp16 form keeps is therefore, for every finite fp32 operand: each element's representation error
+ *      is at most 2^-22 of the LARGEST value of its row (not of the element itself: a 1e-9 entry beside O(1) entries of
+ *      the same row is carried with an absolute error of 2^-36) -- a normwise-per-row fp32-class bound, measured
+ *      <= 5e-7 of a float64 product at every whole-operand scale from 1 to 1e-12 (tests/test_gemm_range_gpu.py).
+ *      The other products (the training rows' k-major forms without a named gradient operand, bf16-stored operands) and
+ *      PCRCG_DEBUG=x6_h2=0 use the EXACT three-term bf16 form: three bf16 terms per value, the six leading cross products
+ *      on v_mfma_f32_32x32x16_bf16, dropped terms below 2^-23 relative per product, at 16/6 of the fp32 matrix rate (the
+ *      fp16 form: 16/3).
+ * Process-wide (one atomic word); also read once from the environment variable PCRCG_GEMM_MODE.  Interface: fp32 in,
  * fp32 out in both modes.
  * Non-finite operands: mode 1 turns an operand value of +-inf into NaN in every output it touches (the split's residual
  * is inf - inf), where mode 0 / an fp32 GEMM would produce +-inf or, against a zero, NaN as well; NaN operands give NaN in
- * both modes.  Finite operands are unaffected, however large (the three terms are exact for every finite fp32 value,
- * subnormal terms included).  The train step's non-finite check (pcrcg_amd/trainer.py: the reference's
+ * both modes.  Finite operands keep fp32's range in both forms: the bf16 form's three terms are exact for every finite
+ * fp32 value whose magnitude is at least 2^-110 (below that the third term leaves fp32's own subnormal range), and the fp16
+ * form hands every tile it cannot hold to it.  The train step's non-finite check (pcrcg_amd/trainer.py: the reference's
  * validate_gradient) treats inf and NaN alike, so the skip decision does not depend on the mode. */
 void pcrcg_gemm_set_mode(int mode);
 int pcrcg_gemm_get_mode(void);

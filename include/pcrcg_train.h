@@ -70,8 +70,10 @@ int pcrcg_gemm_f32_ex(const float* a, int lda, int trans_a, const float* b, int 
 /* The same product with the caller saying which operand holds GRADIENTS (grad_operand: 1 = A, 2 = B, 0 = neither = 
  * pcrcg_gemm_f32_ex).  Gradients of this network live far below fp16's normal range (1e-4 ... 1e-9): in the default
  * arithmetic (pcrcg_gemm_set_mode 1, include/pcrcg.h) that operand is multiplied by 2^16 -- exactly -- before the two-term
- * fp16 split and the factor is taken out of the sums again, so values down to ~1e-11 keep fp32-class relative precision;
- * values beyond 1 send their tile to the exact bf16 form.  The train-step runner does this for every backward product;
+ * fp16 split and the factor is taken out of the sums again: rows whose gradients reach 2^-30 (9.3e-10) split as normal
+ * fp16 values; rows entirely below that, and values beyond 1, send their tile to the exact bf16 form (the kernel's two range
+ * checks, include/pcrcg.h) -- the result is fp32-class at every gradient scale (tests/test_gemm_range_gpu.py: 1e-6 ... 1e-20),
+ * naming the operand only decides how often the cheaper loop suffices.  The train-step runner does this for every backward product;
  * the op-by-op autograd mirror (pcrcg_amd/autograd.py) calls this entry point. */
 int pcrcg_gemm_f32_grad(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc,
                         int m, int n, int k, const float* row_scale, const float* bias, int grad_operand, void* stream);

@@ -18,6 +18,8 @@ def lib_identity():
     with open(LIB_PATH, "rb") as f:
         return LIB_PATH, hashlib.sha256(f.read()).hexdigest()[:16]
 
+ABI_VERSION = 3      # PCRCG_ABI_VERSION of the include/pcrcg.h these signatures were written against
+
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
 # name -> (restype, argtypes); mirrors include/pcrcg.h and include/pcrcg_train.h one to one
@@ -173,6 +175,10 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the library does not export it
             fn.restype = res
             fn.argtypes = args
+        got = handle.pcrcg_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} speaks ABI version {got}, this binding was written against {ABI_VERSION}: "
+                               "rebuild it with `make -C pcrcg_amd/csrc`")
         _lib = handle
     return _lib
 

@@ -106,6 +106,14 @@ int kpconv_aggregate_bf16(const float* q_pts, int nq, const float* s_pts, int ns
                           const float* x, unsigned short* x_bf16, int cin, const float* kp, float extent,
                           unsigned short* wf_bf16, float* inv_n, void* ws, size_t ws_bytes, hipStream_t st);
 
+// DGCNN edge convolution (gnn.hip): emax + InstanceNorm2d statistics of up to four clouds in one launch (k_edgeconv_rows)
+struct EdgeCloud {
+    const float* ctr; const float* nbr; const int* idx; float* emax; double* sums; int n, k;
+};
+bool edgeconv_rows_ok(const EdgeCloud* cl, int count, int ld_ctr, int ld_nbr, int ld_emax, int c);
+int edgeconv_rows_multi(const EdgeCloud* cl, int count, int ld_ctr, int ld_nbr, int ld_emax, int c, bool atomic, int* nchunks_out,
+                        hipStream_t st);
+
 // Tuning / A-B switches of the library, in ONE place.  Every field defaults to the product behaviour; they are set by
 // pcrcg_debug_set("name=value,name=value") or, once at first use, from the environment variable PCRCG_DEBUG (same
 // syntax) -- include/pcrcg.h lists the names.  Nothing else in csrc/ reads the environment, except PCRCG_GEMM_MODE
@@ -117,6 +125,8 @@ struct DebugOpts {
     int fuse_norm = 1;         // runner: normalise-on-load inside the consuming product
     int fuse_pack = 1;         // runner: the normalisation that feeds a KPConv also packs its support records
     int fuse_upsample = 1;     // runner: nearest_upsample -> cat(skip) -> unary as two products into one output
+    int gnn_merge = 1;         // runner: source and target clouds of a self-attention layer through ONE pass (round 5)
+    int edge_rows = 1;         // edge convolution: the row-parallel multi-cloud kernel (0: the per-cloud chunked kernel)
     int radius_blocks = 0;     // radius search grid (0: 512 workgroups)
     int radius_eager_redo = 0; // pyramid builder: launch the >256-hit redo pass unconditionally
     int kd_blocks = 0;
@@ -130,6 +140,12 @@ struct DebugOpts {
     int x6_tile = -1, x6_splitk = 0, x6_t1 = 32, x6_t2 = 128, x6_order = -1, x6_big = 0, x6_h2 = 1;   // split-bf16 GEMM plan overrides
     int train_side_stream = 1; // train-step backward: weight-gradient products on a second stream
     int gemm_tile = -1, gemm_splitk = 0, gemm_split_target = 768;        // fp32-MFMA GEMM plan overrides
+    // deterministic=1: results that are a function of the inputs alone, bit for bit, run after run -- no floating-point
+    // atomics anywhere on the path: the products never split K over workgroups (x6_splitk = gemm_splitk = 1), InstanceNorm
+    // statistics come from stored partials and a fixed-order finishing pass (stat_sums = 0), and the train step's scatter
+    // kernels accumulate in 64-bit fixed point (integer addition is associative; trainops.hip).  Slower (DESIGN.md has the
+    // price); the default keeps the atomics.  Setting it overrides the three switches it implies.
+    int deterministic = 0;
 };
 const DebugOpts& debug_opts();
 

@@ -24,6 +24,8 @@
 //   * split-K (grid.z) with fp32 atomics only when even the smallest tile leaves the chip idle.
 #include <cstdlib>
 
+#include <atomic>
+
 #include "common.h"
 #include "pcrcg_train.h"
 
@@ -346,15 +348,19 @@ using namespace pcrcg;
 // Arithmetic of the C = A * B^T products: 0 = v_mfma_f32_32x32x2_f32 (fp32 operands), 1 = six
 // v_mfma_f32_32x32x16_bf16 on the exact three-term bf16 split of the fp32 operands (gemm_x6.hip; fp32-class
 // accuracy at 2.7x the matrix rate).  Default 1; PCRCG_GEMM_MODE / pcrcg_gemm_set_mode override.
-static int g_gemm_mode = -1;
+// (One process-wide atomic word: read by every host thread that enqueues products, written by pcrcg_gemm_set_mode.)
+static std::atomic<int> g_gemm_mode{-1};
 static int gemm_mode() {
-    if (g_gemm_mode < 0) {
+    int mode = g_gemm_mode.load(std::memory_order_relaxed);
+    if (mode < 0) {
         const char* e = getenv("PCRCG_GEMM_MODE");
-        g_gemm_mode = e ? (atoi(e) != 0) : 1;
+        int want = e ? (atoi(e) != 0) : 1, expect = -1;
+        g_gemm_mode.compare_exchange_strong(expect, want, std::memory_order_relaxed);   // an explicit set_mode wins the race
+        mode = g_gemm_mode.load(std::memory_order_relaxed);
     }
-    return g_gemm_mode;
+    return mode;
 }
-extern "C" void pcrcg_gemm_set_mode(int mode) { g_gemm_mode = mode != 0; }
+extern "C" void pcrcg_gemm_set_mode(int mode) { g_gemm_mode.store(mode != 0, std::memory_order_relaxed); }
 extern "C" void pcrcg_thread_shares_gpu(int on) { gemm_x6_set_shared(on); }
 extern "C" int pcrcg_gemm_get_mode(void) { return gemm_mode(); }
 

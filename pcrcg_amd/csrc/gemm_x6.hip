@@ -173,14 +173,21 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigne
 // runs its tile again with the three-term bf16 loop, which has fp32's range -- no flag for the host, no different
 // result contract.
 constexpr float kH2Scale = 2048.0f;          // 2^11
+// Four VALU instructions per operand pair (round 5; the compiler's own code for the same arithmetic takes six): h by
+// v_cvt_pk_f16_f32, y = 2^11 x by one packed multiply, and l = fp16_rn(y - 2^11 h) by the mixed-precision FMAs, which read
+// h's halves as fp16 operands and round their (exact) fp32 result straight into the two halves of l.
+// scripts/micro/split_mix.hip checks the pair bit for bit against the plain C++ form over random, subnormal and special values.
 __device__ __forceinline__ void split2h(float x0, float x1, unsigned& p1, unsigned& p2) {
     const f32x2 x = {x0, x1};
     const f16x2 h = __builtin_convertvector(x, f16x2);                        // v_cvt_pk_f16_f32, round to nearest even
-    const f32x2 hf = __builtin_convertvector(h, f32x2);
-    const f32x2 r = {(x0 - hf[0]) * kH2Scale, (x1 - hf[1]) * kH2Scale};     // exact difference, exact scaling
-    const f16x2 l = __builtin_convertvector(r, f16x2);
-    p1 = __builtin_bit_cast(unsigned, h);
-    p2 = __builtin_bit_cast(unsigned, l);
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    const f32x2 y = x * kH2Scale;                                             // exact
+    const float m = -kH2Scale;
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hb), "s"(m), "v"(y[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hb), "s"(m), "v"(y[1]));
+    p1 = hb;
+    p2 = l;
 }
 
 template <int BM, int BN>
@@ -338,8 +345,13 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
     float* const s_mean = reinterpret_cast<float*>(smem + 3 * (A_PLANE + B_PLANE));
     float* const s_rstd = s_mean + (ANORM ? ((k_per_split + BK - 1) / BK) * BK : 0);
     int* const s_ovf = reinterpret_cast<int*>(s_rstd + (ANORM ? ((k_per_split + BK - 1) / BK) * BK : 0));   // H2: see below
+    // H2: one word per tile row of A and of B collecting the row's largest |x| (the underflow check after the fp16 loop); it
+    // lives in A's third plane, which the fp16 loop never touches
+    unsigned* const s_seen = reinterpret_cast<unsigned*>(As + 2 * A_PLANE);
+    static_assert(!H2 || (BM + BN) * 4 <= A_PLANE, "row words must fit the unused plane");
     if constexpr (H2) {
         if (tid == 0) *s_ovf = 0;
+        for (int i = tid; i < BM + BN; i += NT) s_seen[i] = 0u;
         if constexpr (!ANORM) __syncthreads();
     }
     if constexpr (ANORM) {
@@ -555,9 +567,14 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
         // ---- the fp16 two-term loop (see split2h): the structure of the loop below with two planes, three products and the
         // range check; a workgroup that meets a value fp16 cannot hold leaves it and starts over with the bf16 loop
         static_assert(ATERMS == 3, "the fp16 form is built for fp32 operands");
-        // h2_sa / h2_sb: exact power-of-two factors applied to A / B before the split (1 for activations and weights; the
-        // train step's GRADIENT operands, whose values live far below fp16's normal range, are lifted by 2^16) and taken
-        // out of the sums again right after the loop
+        // H2 == 2 (the train step's products): h2_sa / h2_sb are exact power-of-two factors applied to A / B before the split
+        // (the GRADIENT operand, whose values live far below fp16's normal range, is lifted by 2^16) and taken out of the
+        // sums again right after the loop.  H2 == 1 (every forward product): no lift, no code for it.
+        float seen_a[A_ITERS], seen_b[B_ITERS];
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) seen_a[it] = 0.f;
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it) seen_b[it] = 0.f;
         auto store_one_h = [&](unsigned char* base, int plane_bytes, int row, int kg, auto& src) {
             unsigned q1[4], q2[4];
 #pragma unroll
@@ -566,6 +583,14 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
             unsigned char* d = base + row * ROWB + kg * 16;
             *reinterpret_cast<u32x4*>(d) = p1;
             *reinterpret_cast<u32x4*>(d + plane_bytes) = p2;
+        };
+        // the row's largest |x| so far: four v_max3_f32 per item.  Taken BEFORE the split, while the loaded registers are
+        // still what the split reads: a later use of them lengthens their live range, the allocator then moves the
+        // asm-loaded values to other registers, and it places those copies before the s_waitcnt that completes the loads
+        // (seen in the ISA of the first form of this check; tests/test_isa_hazards.py scans every build for it).
+        auto track = [&](auto& src, float& seen) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) seen = fmaxf(fmaxf(fabsf(src.get(2 * j)), fabsf(src.get(2 * j + 1))), seen);
         };
         auto multiply_h = [&]() {
 #pragma unroll
@@ -597,8 +622,10 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
             vm_wait<TILE_LOADS>();
 #pragma unroll
             for (int it = 0; it < A_ITERS; ++it) qa[it].hold();
+            if constexpr (!ANORM) {
 #pragma unroll
-            for (int it = 0; it < B_ITERS; ++it) qb[it].hold();
+                for (int it = 0; it < B_ITERS; ++it) qb[it].hold();
+            }
             if (!live) {
 #pragma unroll
                 for (int it = 0; it < A_ITERS; ++it)
@@ -607,18 +634,26 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
             } else {
                 normalise(qa, k0, false);
             }
-            if (h2_sa != 1.0f) {
+            if constexpr (ANORM) {        // B is taken up only now: its registers stay where the loads put them while A is normalised
+#pragma unroll
+                for (int it = 0; it < B_ITERS; ++it) qb[it].hold();
+            }
+            if constexpr (H2 == 2) {      // the lifted form only (as a run-time test hipcc turns this into a multiply AND a
+                                          // select per element -- 12 of the 36 VALU instructions per item, in every product)
 #pragma unroll
                 for (int it = 0; it < A_ITERS; ++it)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) qa[it].set(j, qa[it].get(j) * h2_sa);
-            }
-            if (h2_sb != 1.0f) {
 #pragma unroll
                 for (int it = 0; it < B_ITERS; ++it)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) qb[it].set(j, qb[it].get(j) * h2_sb);
             }
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) track(qa[it], seen_a[it]);
+#pragma unroll
+            for (int it = 0; it < B_ITERS; ++it) track(qb[it], seen_b[it]);
+            __builtin_amdgcn_sched_barrier(0);                            // (keeps the maxima HERE: see track)
             __syncthreads();                                              // previous tile fully read
 #pragma unroll
             for (int it = 0; it < A_ITERS; ++it) {
@@ -663,6 +698,34 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) bad = bad || !(fabsf(acc[i][j][r]) <= 3.0e38f) || !(fabsf(acc_lo[i][j][r]) <= 3.0e38f);
         if (bad) *s_ovf = 1;
+        // ... and the other end of fp16's range.  Below 2^-14 h is an fp16 SUBNORMAL (below 2^-25 it is zero): the split then
+        // has an absolute floor of 2^-36 per value instead of 2^-22 relative.  That is harmless for small values BESIDE larger
+        // ones of the same row (the floor stays below 2^-22 of the row's largest value as long as that one is a normal fp16),
+        // and it is a loss of fp32's contract for a row -- of A or of B, i.e. an output row or column -- whose values are ALL
+        // that small (measured 1e-6 relative at |x| ~ 1e-5, 1e-3 at 1e-8, everything at 1e-11).  So every thread keeps the
+        // largest |x| of what it splits (four v_max3_f32 per item, the only cost inside the loop; after the lift, if any),
+        // the row's maxima meet in LDS here (as integers: non-negative floats order like their bit patterns), and a row that
+        // is not all zeros but has no value of at least 2^-14 sends the tile to the three-term bf16 loop, whose terms are
+        // exact for every finite fp32 value down to 2^-110.
+        if (nfast > 0) {
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) {
+                int row, kg;
+                item_pos<ALAY, BM>(tid + it * NT, row, kg);
+                if (seen_a[it] > 0.f) atomicMax(&s_seen[row], __float_as_uint(seen_a[it]));
+            }
+#pragma unroll
+            for (int it = 0; it < B_ITERS; ++it) {
+                int row, kg;
+                item_pos<BLAY, BN>(tid + it * NT, row, kg);
+                if (seen_b[it] > 0.f) atomicMax(&s_seen[BM + row], __float_as_uint(seen_b[it]));
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < BM + BN; i += NT) {
+            const unsigned v = s_seen[i];
+            if (v != 0u && v < 0x38800000u) *s_ovf = 1;          // 0x38800000 = 2^-14, the smallest normal fp16
+        }
         __syncthreads();
         run_x6 = *s_ovf != 0;
         if (run_x6) {                   // out of fp16's range: everything again, with the loop that has fp32's
@@ -674,7 +737,7 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
                     for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; acc_lo[i][j][r] = 0.0f; }
             __syncthreads();            // nobody still reads the fp16 planes
         } else {                        // the fp16 sums stand: cross terms in, operand scales out (the k tail below adds plain sums)
-            const float unscale = 1.0f / (h2_sa * h2_sb);
+            const float unscale = H2 == 2 ? 1.0f / (h2_sa * h2_sb) : 1.0f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -904,7 +967,9 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
     }
     long m_total = m;
     for (int e = 0; e < n_extra; ++e) m_total += grp->p[e].m;
-    const X6Plan plan = x6_plan(m_plan, n, k, a_kmajor || b_kmajor || (ex && ex->a_sums), a_kmajor != 0, m_total);
+    // (the lifted fp16 form of the train step's products is built for the 64 x 64 tile only, like the k-major forms)
+    const bool lifted = ex && ex->grad_operand && debug_opts().x6_h2 != 0 && !a_bf16;
+    const X6Plan plan = x6_plan(m_plan, n, k, a_kmajor || b_kmajor || (ex && ex->a_sums) || lifted, a_kmajor != 0, m_total);
     const int pick = plan.pick, BM = plan.bm, BN = plan.bn, gx = plan.gx, splits = plan.splits;
     const int gy0 = (m + BM - 1) / BM;
     int gy = gy0, gye[kGroupExtra] = {0, 0, 0};
@@ -985,15 +1050,16 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
             }
         }
     }
-    // The train step tells which operand holds GRADIENTS (GemmExtra::grad_operand): the fp16 form lifts it by 2^16 (exactly;
-    // values down to ~1e-11 keep fp32-class relative precision, values beyond 1 send the tile to the bf16 redo).  A k-major
-    // product whose caller says nothing keeps the bf16 form.
+    // The train step tells which operand holds GRADIENTS (GemmExtra::grad_operand): the fp16 form lifts it by 2^16 (exactly):
+    // rows whose gradients reach 2^-30 = 9.3e-10 then split as normal fp16 values; rows entirely below that, and values
+    // beyond 1, send their tile to the bf16 redo (the kernel's two range checks) -- fp32-class at every scale, the lift only
+    // decides how often the cheap loop suffices.  A k-major product whose caller says nothing keeps the bf16 form.
     const int grad_op = ex ? ex->grad_operand : 0;
     const float h2_sa = grad_op == 1 ? 65536.0f : 1.0f, h2_sb = grad_op == 2 ? 65536.0f : 1.0f;
     const bool h2_on = debug_opts().x6_h2 != 0 && !a_bf16;
     if (a_kmajor) {  // dW = X^T * dY
         if (h2_on && grad_op)
-            return launch_x6<64, 64, 3, 3, 1, 1, 0, 0, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
+            return launch_x6<64, 64, 3, 3, 1, 1, 0, 0, 2>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
                                                           vec_b, atomic_out, colp, colp_chunks, nullptr, 0, 0, nullptr, nullptr, 0.0, 0.f,
                                                           1.f, GemmPairArgs(), h2_sa, h2_sb);
         return launch_x6<64, 64, 3, 3, 1, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
@@ -1001,13 +1067,18 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
     }
     if (b_kmajor) {  // dX = dY * W
         if (h2_on && grad_op)
-            return launch_x6<64, 64, 4, 3, 0, 1, 0, 0, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
+            return launch_x6<64, 64, 4, 3, 0, 1, 0, 0, 2>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
                                                           vec_b, atomic_out, colp, colp_chunks, nullptr, 0, 0, nullptr, nullptr, 0.0, 0.f,
                                                           1.f, GemmPairArgs(), h2_sa, h2_sb);
         return launch_x6<64, 64, 4, 3, 0, 1>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
                                              vec_b, atomic_out, colp, colp_chunks);
     }
     const bool h2 = h2_on;
+    if (h2 && grad_op && !anorm)      // the k-contiguous dX = dY W^T of the autograd mirror (pcrcg_gemm_f32_grad): the lifted 64 x 64 form
+        return launch_x6<64, 64, 4, 3, 0, 0, 0, 0, 2>(grid, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split, vec_a,
+                                                      vec_b, atomic_out, colp, colp_chunks, gather ? ex->a_idx : nullptr,
+                                                      gather ? ex->a_idx_ld : 0, gather ? ex->a_ns : 0,
+                                                      gather ? ex->a_zero : nullptr, nullptr, 0.0, 0.f, 1.f, pa, h2_sa, h2_sb);
 #define GO(BMV, BNV, MINB)                                                                                              \
     do {                                                                                                                \
         if (h2)                                                                                                         \

@@ -266,6 +266,69 @@ __global__ void __launch_bounds__(256) k_knn_reg(const float* __restrict__ coord
     if (tie && n > k && k <= KNN_K_MAX) knn_replay_row(coords, n, i, k, s_q[threadIdx.x >> 6], idx + (long)i * k);
 }
 
+// Round 5: the same reduction with the ROWS in parallel.  k_edgeconv_reduce below walks its rows with one 4-byte load per
+// lane and neighbour (a dependent chain of rows_per_chunk / 4 x (index -> k loads): 20 us for 381 x 10 x 512 values that
+// fit L2 ten times over).  Here a wavefront takes one row at a time: lanes 0 .. k-1 load the row's neighbour indices, which
+// are then wave-uniform scalars, and every lane carries FOUR channels, so a neighbour row is one 16-byte load per lane
+// with all k of them in flight; 64 lanes x 4 = a 256-channel block (blockIdx.y), 4 wavefronts x RPW rows per workgroup
+// (blockIdx.x), up to four clouds per launch (blockIdx.z: the source and target clouds of the pairs of one forward call
+// share the layer).  Column sums: fp64 per lane, the four wavefronts meet in LDS, then one fp64 atomic per channel and
+// workgroup (ATOMIC) or a stored partial (the deterministic form: [2][c][nchunks], finished by k_colstats_final).
+struct EdgeMulti { EdgeCloud cl[4]; int ld_ctr, ld_nbr, ld_emax, c, rows_per_block, nchunks; };
+
+template <bool ATOMIC>
+__global__ void __launch_bounds__(256) k_edgeconv_rows(EdgeMulti a) {
+    __shared__ double s_sum[4][256], s_sq[4][256];
+    const EdgeCloud cl = a.cl[blockIdx.z];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c0 = blockIdx.y * 256 + lane * 4;
+    const bool cok = c0 < a.c;
+    const int r0 = blockIdx.x * a.rows_per_block, r1 = min(cl.n, r0 + a.rows_per_block);
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const int mine = lane < cl.k ? cl.idx[(long)r * cl.k + lane] : 0;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f), m = q;
+        if (cok) q = *reinterpret_cast<const float4*>(cl.ctr + (long)r * a.ld_ctr + c0);
+        for (int j0 = 0; j0 < cl.k; j0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                      // all eight rows in flight (indices past k re-read a valid row)
+                const int nb = __builtin_amdgcn_readlane(mine, min(j0 + u, cl.k - 1));
+                v[u] = cok ? *reinterpret_cast<const float4*>(cl.nbr + (long)nb * a.ld_nbr + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j0 + u >= cl.k) continue;
+                const float e[4] = {q.x + v[u].x, q.y + v[u].y, q.z + v[u].z, q.w + v[u].w};
+                if (j0 + u == 0) m = make_float4(e[0], e[1], e[2], e[3]);
+                else { m.x = fmaxf(m.x, e[0]); m.y = fmaxf(m.y, e[1]); m.z = fmaxf(m.z, e[2]); m.w = fmaxf(m.w, e[3]); }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { s[t] += (double)e[t]; sq[t] += (double)e[t] * (double)e[t]; }
+            }
+        }
+        if (cok) *reinterpret_cast<float4*>(cl.emax + (long)r * a.ld_emax + c0) = m;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { s_sum[wave][lane * 4 + t] = s[t]; s_sq[wave][lane * 4 + t] = sq[t]; }
+    __syncthreads();
+    const int ch = blockIdx.y * 256 + threadIdx.x;
+    if (ch < a.c && r0 < r1) {
+        const int t = threadIdx.x;
+        const double ss = (s_sum[0][t] + s_sum[1][t]) + (s_sum[2][t] + s_sum[3][t]);
+        const double qq = (s_sq[0][t] + s_sq[1][t]) + (s_sq[2][t] + s_sq[3][t]);
+        if (ATOMIC) {
+            unsafeAtomicAdd(&cl.sums[ch], ss);
+            unsafeAtomicAdd(&cl.sums[(long)a.c + ch], qq);
+        } else {
+            cl.sums[(long)ch * a.nchunks + blockIdx.x] = ss;                     // layout [2][c][nchunks]
+            cl.sums[((long)a.c + ch) * a.nchunks + blockIdx.x] = qq;
+        }
+    } else if (!ATOMIC && ch < a.c) {
+        cl.sums[(long)ch * a.nchunks + blockIdx.x] = 0.0;
+        cl.sums[((long)a.c + ch) * a.nchunks + blockIdx.x] = 0.0;
+    }
+}
+
 template <bool ATOMIC>      // ATOMIC: the chunk's sums are added into zeroed [2][c] accumulators instead of stored as partials
 __global__ void __launch_bounds__(256) k_edgeconv_reduce(const float* __restrict__ ctr, int ld_ctr,
                                                           const float* __restrict__ nbr, int ld_nbr,
@@ -454,6 +517,37 @@ __global__ void __launch_bounds__(256) k_softmax_matvec(const float* __restrict_
 }
 
 }  // namespace
+
+// the layout rules of k_edgeconv_rows: four channels per lane as one 16-byte access, the row's indices on one wavefront
+bool edgeconv_rows_ok(const EdgeCloud* cl, int count, int ld_ctr, int ld_nbr, int ld_emax, int c) {
+    if (!debug_opts().edge_rows || count < 1 || count > 4 || c % 4 != 0 || ld_ctr % 4 != 0 || ld_nbr % 4 != 0 || ld_emax % 4 != 0) return false;
+    for (int i = 0; i < count; ++i) {
+        if (cl[i].k < 1 || cl[i].k > 64 || cl[i].n < 1) return false;
+        if ((reinterpret_cast<uintptr_t>(cl[i].ctr) | reinterpret_cast<uintptr_t>(cl[i].nbr) | reinterpret_cast<uintptr_t>(cl[i].emax)) & 15)
+            return false;
+    }
+    return true;
+}
+// emax + InstanceNorm2d statistics of up to four clouds in ONE launch.  atomic: cl[i].sums = zeroed [2][c] fp64 accumulators;
+// else cl[i].sums = a partial buffer of colstats_ws_bytes(c) each, *nchunks_out = the chunk count colstats_finalize takes.
+int edgeconv_rows_multi(const EdgeCloud* cl, int count, int ld_ctr, int ld_nbr, int ld_emax, int c, bool atomic, int* nchunks_out,
+                        hipStream_t st) {
+    EdgeMulti a;
+    int nmax = 0;
+    for (int i = 0; i < count; ++i) { a.cl[i] = cl[i]; nmax = cl[i].n > nmax ? cl[i].n : nmax; }
+    for (int i = count; i < 4; ++i) a.cl[i] = cl[0];
+    a.ld_ctr = ld_ctr; a.ld_nbr = ld_nbr; a.ld_emax = ld_emax; a.c = c;
+    int rpb = 8;                                             // two rows per wavefront: ~48 row blocks for a 381-point cloud
+    while ((nmax + rpb - 1) / rpb > colstats_chunks()) rpb += 4;
+    a.rows_per_block = rpb;
+    a.nchunks = (nmax + rpb - 1) / rpb;
+    if (nchunks_out) *nchunks_out = a.nchunks;
+    const dim3 grid(a.nchunks, (c + 255) / 256, count);
+    if (atomic) hipLaunchKernelGGL(k_edgeconv_rows<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_edgeconv_rows<false>, grid, dim3(256), 0, st, a);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
 }  // namespace pcrcg
 
 using namespace pcrcg;
@@ -486,6 +580,14 @@ int pcrcg_edgeconv_reduce(const float* ctr, int ld_ctr, const float* nbr, int ld
     double* partial = cv.take<double>((size_t)chunks * 2 * c);
     PCRCG_CHECK_WS(cv);
     hipStream_t st = as_stream(stream);
+    {
+        const EdgeCloud one = {ctr, nbr, idx, emax, partial, n, k};
+        if (edgeconv_rows_ok(&one, 1, ld_ctr, ld_nbr, ld_emax, c)) {
+            int nchunks = 0;
+            PCRCG_PROPAGATE(edgeconv_rows_multi(&one, 1, ld_ctr, ld_nbr, ld_emax, c, false, &nchunks, st));
+            return colstats_finalize(partial, nchunks, c, (double)n * (double)k, eps, stats, st);
+        }
+    }
     hipLaunchKernelGGL(k_edgeconv_reduce<false>, dim3(chunks, (c + 63) / 64), dim3(256), 0, st, ctr, ld_ctr, nbr, ld_nbr,
                        idx, n, k, c, emax, ld_emax, partial);
     return colstats_finalize(partial, chunks, c, (double)n * (double)k, eps, stats, st);
@@ -495,6 +597,11 @@ int pcrcg_edgeconv_reduce_sums(const float* ctr, int ld_ctr, const float* nbr, i
                                int c, float* emax, int ld_emax, void* sums, void* stream) {
     PCRCG_CHECK_ARG(n >= 1 && k >= 1 && c >= 1 && ld_ctr >= c && ld_nbr >= c && ld_emax >= c);
     PCRCG_CHECK_ARG(ctr && nbr && idx && emax && sums);
+    {
+        const EdgeCloud one = {ctr, nbr, idx, emax, static_cast<double*>(sums), n, k};
+        if (edgeconv_rows_ok(&one, 1, ld_ctr, ld_nbr, ld_emax, c))
+            return edgeconv_rows_multi(&one, 1, ld_ctr, ld_nbr, ld_emax, c, true, nullptr, as_stream(stream));
+    }
     int chunks = (n + 15) / 16;                      // ~16 rows per workgroup row slice
     if (chunks > colstats_chunks()) chunks = colstats_chunks();
     hipLaunchKernelGGL(k_edgeconv_reduce<true>, dim3(chunks, (c + 63) / 64), dim3(256), 0, as_stream(stream), ctr, ld_ctr,

@@ -203,7 +203,7 @@ static int pyramid_run(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg*
         t.q = q; t.qlen = qlen; t.nq = nq; t.limit = limit; t.sup_level = sup_level; t.radius = radius;
         t.grid = grid; t.ns = ns; t.slen = slen; t.qgrid = use_cells ? qgrid : nullptr;
         if (!A.ok()) return PCRCG_EWORKSPACE;
-        // first pass only: rows with more than 256 hits (and, from the cell-cooperative search, rows of a cell whose
+        // first pass only: rows with more than 128 hits (kCellListCap; 256 = kListCapFast for the per-query kernel) (and, from the cell-cooperative search, rows of a cell whose
         // neighbourhood does not fit LDS) are marked and announced in the metadata; whether any table has one is known
         // with the metadata round trip below, and only then (normally never) the redo pass runs
         if (!dry && t.qgrid)
@@ -289,7 +289,7 @@ static int pyramid_run(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg*
     const int nt = (int)tables.size();
     PCRCG_PROPAGATE(fetch(h_scratch, metas, MS * nt, lens_all, L * nb, st));
     const int* hm = h_scratch + 1;
-    {   // tables with a row of more than 256 hits: redo pass now, then the metadata once more (it appends tie rows)
+    {   // tables with a row of more hits than the first pass stages (128 in the cell search, 256 in the per-query kernel): redo pass now, then the metadata once more (it appends tie rows)
         int redone = 0;
         for (int i = 0; i < nt; ++i) {
             int widest = 0;

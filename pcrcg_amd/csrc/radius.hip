@@ -20,7 +20,7 @@
 //           gather chain of dependent global loads is paid once per cell instead of once per query.
 //           PER-QUERY (k_radius_query, rounds 1-3): one wavefront per query probes its own 27 cells and gathers its
 //           candidates from global memory; it serves query sets that have no grid, and as the second pass
-//           (REDO) the rows the cell kernel hands over (more than 256 hits, or a neighbourhood that does not fit LDS).
+//           (REDO) the rows the cell kernel hands over (more than kCellListCap = 128 hits, or a neighbourhood that does not fit LDS).
 //
 // Squared distances follow nanoflann's L2_Simple_Adaptor (zip:cpp_utils/nanoflann/nanoflann.hpp:
 // 432-440): ((0 + dx*dx) + dy*dy) + dz*dz with every product and sum rounded to fp32, strict
@@ -1126,6 +1126,12 @@ int radius_cells_pass(const void* qgrid, const float* q, int nq, const int* qlen
     ca.status = status; ca.tie_rows = out_tie_rows; ca.tie_count = out_tie_count;
     ca.reach = reach; ca.r2 = r2; ca.nb = nb; ca.cols = cols; ca.group = group;
     ca.prof = nullptr;
+    // The ticket block lives in the QUERY grid and cleans itself (the last workgroup of a shard to leave zeroes it), which
+    // is enough for the pyramid builder: it owns its grids, rebuilds them per call and walks them on one stream.  A caller
+    // of the public entry point may have aborted an earlier walk or may hand over a grid some other walk left mid-way, so
+    // here the block is reset on the launch stream first (4 KB; walks of ONE query grid must still not overlap in time:
+    // include/pcrcg.h, and pcrcg_amd/ops.py orders them by event).
+    if (pass != 1) PCRCG_CHECK_HIP(hipMemsetAsync(gq.qtick, 0, 16 * kTickStride * sizeof(int), st));
     if (debug_opts().radius_prof) {       // measurement aid: per-phase shader cycles, printed when the process exits
         static long long* prof = nullptr;
         if (!prof) {

@@ -117,6 +117,7 @@ struct Ctx {
     void check(int r) { if (r != PCRCG_OK && rc == PCRCG_OK) rc = r; }
     // several pairs in one launch: only with the split-bf16 arithmetic (PCRCG_GEMM_MODE=0 runs the products pair by pair)
     bool paired() const { return G >= 2 && gemm_pair_ok(); }
+    bool paired_ok() const { return gemm_pair_ok(); }
 };
 
 inline int pad4(int v) { return (v + 3) & ~3; }
@@ -538,6 +539,26 @@ void edge_norm(Ctx& c, const float* cn, int ld_cn, int cw, const int* idx, int n
     c.check(pcrcg_instnorm_apply(emax, n, cw, ld_emax, stats, nullptr, 0, nullptr, 0.2f, out, ld_out, c.st));
 }
 
+// edge_norm for every cloud of the call: the reductions of all of them in ONE launch where the row-parallel kernel applies
+void edge_norm_all(Ctx& c, const Mat& cn, int cw, int* const* idx, const int* n, const int* k, const Mat& e, const Mat& out,
+                   void* const* sums, bool sums_ok, float* stats, void* ws, size_t wsb) {
+    bool multi = sums_ok;
+    EdgeCloud cl[GMAX];
+    for (int g = 0; g < c.G; ++g) {
+        multi = multi && sums[g] != nullptr;
+        cl[g] = EdgeCloud{cn.p[g], cn.p[g] + cw, idx[g], e.p[g], static_cast<double*>(sums[g]), n[g], k[g]};
+    }
+    if (multi && edgeconv_rows_ok(cl, c.G, cn.ld, cn.ld, e.ld, cw)) {
+        c.check(edgeconv_rows_multi(cl, c.G, cn.ld, cn.ld, e.ld, cw, true, nullptr, c.st));
+        for (int g = 0; g < c.G; ++g)
+            c.check(pcrcg_instnorm_apply_sums(e.p[g], n[g], cw, e.ld, sums[g], (double)n[g] * (double)k[g], 1e-5f, nullptr, 0, nullptr,
+                                              0.2f, out.p[g], out.ld, c.st));
+        return;
+    }
+    for (int g = 0; g < c.G; ++g)
+        edge_norm(c, cn.p[g], cn.ld, cw, idx[g], n[g], k[g], e.p[g], e.ld, out.p[g], out.ld, sums[g], sums_ok, stats, ws, wsb);
+}
+
 // SelfAttention.forward (ref:models/gcn.py:110-134) on row-major [n, ch]: one cloud of every pair
 Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, const float* const* coords, const Mat& f) {
     const int ch = f.cols;
@@ -572,13 +593,10 @@ Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, co
         }
         // x1 = max_k lrelu(IN2d(conv1(cat(f_i, f_j - f_i))))  (:121-125)
         linear(c, f, gl.edge1, ch, nullptr, cn1);
-        for (int g = 0; g < c.G; ++g)
-            edge_norm(c, cn1.p[g], cn1.ld, ch, idx[g], f.rows[g], kq[g], e1.p[g], e1.ld, cat1.p[g], cat.ld, sums1[g], ok1, stats, ws, wsb);
+        edge_norm_all(c, cn1, ch, idx, f.rows, kq, e1, cat1, sums1, ok1, stats, ws, wsb);
         // x2 from x1 with conv2 (:127-129)
         linear(c, cat1, gl.edge2, ch, nullptr, cn2);
-        for (int g = 0; g < c.G; ++g)
-            edge_norm(c, cn2.p[g], cn2.ld, 2 * ch, idx[g], f.rows[g], kq[g], e2.p[g], e2.ld, cat2.p[g], cat.ld, sums2[g], ok2, stats, ws,
-                      wsb);
+        edge_norm_all(c, cn2, 2 * ch, idx, f.rows, kq, e2, cat2, sums2, ok2, stats, ws, wsb);
         // x3 = lrelu(IN(conv3(cat(x0,x1,x2))))  (:131-132)
         linear(c, cat, gl.conv3, 4 * ch, nullptr, x3, &x3s);
     }
@@ -672,6 +690,27 @@ void forward(Ctx& c, const pcrcg_model& mdl, const Batches& B, const pcrcg_outpu
         if (gl.cross) {
             d0 = cross_attention(c, mdl, gl, d0, d1);
             d1 = cross_attention(c, mdl, gl, d1, d0);   // sees the updated d0 (:214)
+        } else if (2 * c.G <= GMAX && c.paired_ok() && debug_opts().gnn_merge) {
+            // The layer is applied to the source cloud and to the target cloud of every pair with the SAME weights and no
+            // exchange between them (ref:models/gcn.py:207-211): 2 G independent clouds through ONE pass -- every weight
+            // product of the layer once for all of them (round 5: three launches per layer instead of six; the
+            // per-cloud kernels are unchanged)
+            const int G0 = c.G;
+            Mat f2;
+            const float* cc[GMAX];
+            f2.cols = d0.cols; f2.ld = d0.ld;
+            for (int g = 0; g < G0; ++g) {
+                f2.p[g] = d0.p[g]; f2.rows[g] = d0.rows[g]; cc[g] = c0[g];
+                f2.p[G0 + g] = d1.p[g]; f2.rows[G0 + g] = d1.rows[g]; cc[G0 + g] = c1[g];
+            }
+            c.G = 2 * G0;
+            const Mat y2 = self_attention(c, mdl, gl, cc, f2);
+            c.G = G0;
+            d0 = y2; d1 = y2;
+            for (int g = 0; g < GMAX; ++g) {
+                d0.p[g] = g < G0 ? y2.p[g] : nullptr; d0.rows[g] = g < G0 ? y2.rows[g] : 0;
+                d1.p[g] = g < G0 ? y2.p[G0 + g] : nullptr; d1.rows[g] = g < G0 ? y2.rows[G0 + g] : 0;
+            }
         } else {
             d0 = self_attention(c, mdl, gl, c0, d0);
             d1 = self_attention(c, mdl, gl, c1, d1);

@@ -210,14 +210,14 @@ namespace {
 struct DebugName { const char* name; int DebugOpts::*field; };
 const DebugName kDebugNames[] = {
     {"zero_arena", &DebugOpts::zero_arena}, {"stat_sums", &DebugOpts::stat_sums}, {"stat_sums_rows", &DebugOpts::stat_sums_rows},
-    {"fuse_norm", &DebugOpts::fuse_norm}, {"fuse_pack", &DebugOpts::fuse_pack}, {"fuse_upsample", &DebugOpts::fuse_upsample},
+    {"fuse_norm", &DebugOpts::fuse_norm}, {"fuse_pack", &DebugOpts::fuse_pack}, {"fuse_upsample", &DebugOpts::fuse_upsample}, {"gnn_merge", &DebugOpts::gnn_merge}, {"edge_rows", &DebugOpts::edge_rows},
     {"radius_blocks", &DebugOpts::radius_blocks}, {"radius_eager_redo", &DebugOpts::radius_eager_redo},
     {"radius_cells", &DebugOpts::radius_cells}, {"kd_blocks", &DebugOpts::kd_blocks}, {"radius_prof", &DebugOpts::radius_prof},
     {"pyr_wait", &DebugOpts::pyr_wait}, {"pyr_trace", &DebugOpts::pyr_trace}, {"att_tq", &DebugOpts::att_tq},
     {"kd_spin_limit", &DebugOpts::kd_spin_limit}, {"gemm_log", &DebugOpts::gemm_log}, {"x6_tile", &DebugOpts::x6_tile}, {"x6_order", &DebugOpts::x6_order}, {"x6_big", &DebugOpts::x6_big}, {"x6_h2", &DebugOpts::x6_h2}, {"train_side_stream", &DebugOpts::train_side_stream},
     {"x6_splitk", &DebugOpts::x6_splitk}, {"x6_t1", &DebugOpts::x6_t1}, {"x6_t2", &DebugOpts::x6_t2},
     {"gemm_tile", &DebugOpts::gemm_tile}, {"gemm_splitk", &DebugOpts::gemm_splitk},
-    {"gemm_split_target", &DebugOpts::gemm_split_target}};
+    {"gemm_split_target", &DebugOpts::gemm_split_target}, {"deterministic", &DebugOpts::deterministic}};
 // The options are IMMUTABLE snapshots behind one atomic pointer: the engine's front and model threads read them
 // concurrently (their library calls hold no lock), pcrcg_debug_set publishes a new snapshot and never frees an old one
 // (a handful of 100-byte objects per process), so a reader's reference stays valid and no field is ever seen half
@@ -251,6 +251,11 @@ bool debug_parse(const char* spec, const DebugOpts* base) {
         }
         p = end ? end + 1 : nullptr;
     }
+    if (d.deterministic) {           // what the switch implies (common.h)
+        d.stat_sums = 0;
+        d.x6_splitk = 1;
+        d.gemm_splitk = 1;
+    }
     g_debug.store(new DebugOpts(d), std::memory_order_release);
     return true;
 }
@@ -271,7 +276,7 @@ extern "C" {
 
 const char* pcrcg_last_error(void) { return pcrcg::g_err; }
 
-int pcrcg_abi_version(void) { return 2; }   // 2 (round 3): forward groups, train-step runner, correspondences, debug switches; one-kernel KPConv entries removed
+int pcrcg_abi_version(void) { return PCRCG_ABI_VERSION; }   // include/pcrcg.h lists what each version changed
 
 int pcrcg_debug_set(const char* spec) {
     const pcrcg::DebugOpts* cur = &pcrcg::debug_opts();   // the environment first, then this call on top of it

@@ -19,6 +19,23 @@ import sys
 import threading
 
 CPUS_ENV = "PCRCG_RANK_CPUS"          # "0-15,64-79": the CPU set the parent planned for this rank
+# PCRCG_SYSFS_ROOT (tests only): a stand-in /sys tree.  The topology is then read from it, the "available" CPUs are the
+# union of its NUMA nodes' lists, and ranks REPORT the set planned for them without applying it (the stand-in machine's
+# CPUs do not exist here) -- how tests/test_launcher_cpu.py plans an 8-GPU two-socket node inside an 8-CPU container.
+SYSFS_ENV = "PCRCG_SYSFS_ROOT"
+
+
+def _sysfs():
+    return os.environ.get(SYSFS_ENV) or "/sys"
+
+
+def _available_cpus():
+    if os.environ.get(SYSFS_ENV):
+        return sorted({c for cpus in numa_cpus().values() for c in cpus})
+    try:
+        return sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return list(range(os.cpu_count() or 1))
 
 
 def is_parent(gpus):
@@ -64,11 +81,12 @@ def _read(path):
         return None
 
 
-def gpu_numa_nodes(sysfs="/sys", visible=None):
+def gpu_numa_nodes(sysfs=None, visible=None):
     """NUMA node of every GPU in HIP device order, from sysfs only (no HIP call in the parent): KFD topology nodes
     with simd_count > 0 are the GPUs, in the order the runtime enumerates them; `domain` + `location_id`
     (bus << 8 | devfn) name the PCI function whose `numa_node` is read.  -> list (None where unknown).  `visible`:
     the index list of HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES, applied afterwards."""
+    sysfs = sysfs or _sysfs()
     nodes = []
     for d in sorted(glob.glob(os.path.join(sysfs, "class/kfd/kfd/topology/nodes/*")),
                     key=lambda p: int(os.path.basename(p)) if os.path.basename(p).isdigit() else 1 << 30):
@@ -92,7 +110,8 @@ def gpu_numa_nodes(sysfs="/sys", visible=None):
     return nodes
 
 
-def numa_cpus(sysfs="/sys"):
+def numa_cpus(sysfs=None):
+    sysfs = sysfs or _sysfs()
     out = {}
     for d in glob.glob(os.path.join(sysfs, "devices/system/node/node*")):
         name = os.path.basename(d)[4:]
@@ -159,36 +178,53 @@ def apply_rank_affinity():
             local_rank = int(os.environ.get("LOCAL_RANK", "0"))
             if local_world <= 1 or not (0 <= local_rank < local_world):
                 return None
-            available = sorted(os.sched_getaffinity(0))
-            cpus = plan_affinity(local_world, available, gpu_numa_nodes(visible=_visible_indices()), numa_cpus())[local_rank]
+            cpus = plan_affinity(local_world, _available_cpus(), gpu_numa_nodes(visible=_visible_indices()), numa_cpus())[local_rank]
         if not cpus:
             return None
-        os.sched_setaffinity(0, cpus)
+        if not os.environ.get(SYSFS_ENV):
+            os.sched_setaffinity(0, cpus)
     except (OSError, ValueError, AttributeError):
         return None
     return cpus
 
 
-def visible_gpu_count():
-    """Devices the children will see.  torch.cuda.device_count() does not initialise the GPU on this image."""
+def visible_gpu_count(sysfs=None):
+    """Devices the children will see, WITHOUT loading the HIP runtime in the parent: the KFD topology's GPU nodes (the
+    enumeration gpu_numa_nodes() walks), cut down by HIP_/ROCR_/CUDA_VISIBLE_DEVICES.  Only where sysfs shows no KFD
+    topology at all (a container without it) does the parent ask torch.cuda.device_count(), which on this image counts
+    through amdsmi/sysfs too but may initialise HIP elsewhere."""
+    sysfs = sysfs or _sysfs()
+    n = len(gpu_numa_nodes(sysfs, visible=_visible_indices()))
+    if n > 0 or os.path.isdir(os.path.join(sysfs, "class/kfd/kfd/topology/nodes")):
+        if sysfs == "/sys" and _visible_indices() is None:
+            # a container may be handed fewer GPUs than the host's sysfs lists: it then holds only their render nodes
+            render = [p for p in glob.glob("/dev/dri/renderD*") if os.access(p, os.R_OK | os.W_OK)]
+            if render:
+                n = min(n, len(render))
+        return n
     import torch
     return int(torch.cuda.device_count())
 
 
-def launch(script, argv, gpus, dry_run=False, env_extra=None, timeout=None):
+DEFAULT_TIMEOUT_S = 3600.0      # a rank wedged in a collective must not block the parent forever
+
+
+def launch(script, argv, gpus, dry_run=False, env_extra=None, timeout=DEFAULT_TIMEOUT_S):
     """Start `gpus` ranks of `script argv...`, relay rank 0's LAST JSON line on stdout (everything else any rank
     prints goes to stderr, prefixed with its rank) and return the exit code: 0 only if every rank exited 0 and rank 0
-    printed a line.  dry_run: no device check (the ranks run their CPU / gloo stand-in)."""
+    printed a line.  dry_run: no device check (the ranks run their CPU / gloo stand-in).  timeout (seconds, None: wait
+    forever; PCRCG_LAUNCH_TIMEOUT overrides): when it expires the remaining ranks are killed and 124 is returned."""
+    if os.environ.get("PCRCG_LAUNCH_TIMEOUT"):
+        try:
+            timeout = float(os.environ["PCRCG_LAUNCH_TIMEOUT"]) or None
+        except ValueError:
+            pass
     if not dry_run:
         have = visible_gpu_count()
         if gpus > have:
             print("launcher: --gpus %d but only %d device(s) are visible" % (gpus, have), file=sys.stderr)
             return 2
-    try:
-        available = sorted(os.sched_getaffinity(0))
-    except AttributeError:
-        available = list(range(os.cpu_count() or 1))
-    plan = plan_affinity(gpus, available, gpu_numa_nodes(visible=_visible_indices()), numa_cpus())
+    plan = plan_affinity(gpus, _available_cpus(), gpu_numa_nodes(visible=_visible_indices()), numa_cpus())
     port = free_port()
     procs, pumps, last_json = [], [], [None]
 
@@ -240,6 +276,7 @@ def launch(script, argv, gpus, dry_run=False, env_extra=None, timeout=None):
                         procs[q].terminate()          # our own children, by PID
             if pending:
                 if t_end is not None and time.monotonic() > t_end:
+                    print("launcher: timeout after %.0f s; killing rank(s) %s" % (timeout, sorted(pending)), file=sys.stderr)
                     rc = rc or 124
                     for q in pending:
                         procs[q].kill()

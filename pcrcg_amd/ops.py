@@ -164,12 +164,21 @@ class CellGrid:
         if query_grid is not None:
             if query_grid.ns != nq or query_grid.nb != self.nb:
                 raise RuntimeError("query_grid was not built over these queries")
+            # the cell search keeps its work-distribution tickets inside the query grid: two walks of one grid must not
+            # overlap in time.  Same stream: ordered anyway; another stream: it waits for the previous walk's event.
+            cur = torch.cuda.current_stream(queries.device)
+            last = getattr(query_grid, "_walk", None)
+            if last is not None and last[0] != cur.cuda_stream:
+                cur.wait_event(last[1])
             _lib.check(L.pcrcg_radius_query_cells(query_grid.grid.data_ptr(), queries.data_ptr(), nq, q_lengths.data_ptr(),
                                                   self.grid.data_ptr(), self.ns, self.lengths.data_ptr(), self.nb, 0,
                                                   self.radius, int(cols), idx.data_ptr(), _ptr(counts), meta[0:1].data_ptr(),
                                                   meta[1:2].data_ptr(), _ptr(ties),
                                                   meta[2:3].data_ptr() if want_ties else None, _stream()),
                        "pcrcg_radius_query_cells")
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            query_grid._walk = (cur.cuda_stream, ev)
             out = (idx, meta)
             if want_counts or want_ties:
                 out += (counts,)

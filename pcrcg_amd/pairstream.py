@@ -65,7 +65,14 @@ class PairStreams:
         up_nearest: the engine's internal pyramids carry ONE-column upsample tables (the nearest coarse point: the only
         column KPFCNN.forward reads, ref:models/blocks.py:77-87) instead of the batch contract's [N, limit] tables:
         ~1 % less front-end work, same outputs.  Off by default: the tables are then exactly what build_pyramid()
-        hands to any other consumer."""
+        hands to any other consumer.
+        adaptive_jobs (default on): whether two pairs of one build share a forward call is decided from the state of the
+        queues and of the model streams at that moment, i.e. from host and GPU TIMING.  Grouping changes the summation
+        order of the weight products (split-K plans, row tiles), so with it on the low-order bits of a pair's outputs
+        can differ from run to run (never beyond the 1e-5 the grouped and the single forward differ by).  Parity and
+        regression tests, and anyone who needs run-to-run identical bits, construct the engine with
+        adaptive_jobs=False (bench.py --fixed-jobs) -- together with PCRCG_DEBUG=deterministic=1 (atomics-free sums)
+        the outputs are then a function of the inputs alone."""
         self.net, self.config, self.limits = net, config, neighborhood_limits
         self.device = torch.device(device if device is not None else "cuda")
         if not getattr(net, "use_runner", False):
@@ -197,6 +204,7 @@ class PairStreams:
             # hand-back accounting of the arena: `owed` tokens (one per forward that reads its current contents) are
             # in its queue or still to come; `taken` of them have been consumed by this build so far
             owed, taken, claimed = self._users[f][a], 0, False
+            posted = 0                                            # jobs of this build already handed to a model thread
             try:
                 with torch.cuda.stream(front), torch.no_grad():
                     for _, points, lengths, ready in items:
@@ -232,6 +240,7 @@ class PairStreams:
                     self._mid[(job0 + j) % len(self.models)].put(job0 + j, (seqs, (batches, start, n), arena, built, pyr, slot,
                                                                              deferred, f, a))
                     start += n
+                    posted = j + 1
             except BaseException as e:                            # surfaced by result()
                 if claimed:
                     # the arena was taken over for k forwards that will not happen: one token for each of them
@@ -247,7 +256,8 @@ class PairStreams:
                     self._users[f][a] = left
                 start = 0
                 for j, n in enumerate(sizes):
-                    self._mid[(job0 + j) % len(self.models)].put(job0 + j, ([it[0] for it in items[start:start + n]], e))
+                    if j >= posted:                               # (a job index is posted exactly once)
+                        self._mid[(job0 + j) % len(self.models)].put(job0 + j, ([it[0] for it in items[start:start + n]], e))
                     start += n
 
     def _serve_model(self, m):

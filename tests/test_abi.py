@@ -25,7 +25,7 @@ def test_library_exports_whole_header():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "pcrcg_amd/_lib.py must bind exactly the declared ABI"
-    assert lib.pcrcg_abi_version() == 2
+    assert lib.pcrcg_abi_version() == 3
 
 
 def test_workspace_queries():

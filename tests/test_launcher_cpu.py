@@ -145,3 +145,33 @@ def test_more_ranks_than_devices_exits_nonzero():
     assert r.returncode != 0
     assert "visible" in r.stderr
     assert not r.stdout.strip()
+
+
+def test_eight_rank_dry_run_on_a_two_socket_node(tmp_path):
+    """`--gpus 8` kept boring: eight dry-run ranks (gloo) planned on a stand-in two-socket machine -- four GPUs per NUMA
+    node, 2 x 64 cores with SMT siblings -- must report eight ranks, eight disjoint CPU sets of at least four CPUs, every
+    rank on its GPU's socket, and every pair seed exactly once.  (No 8-GPU hardware was available to this build: this
+    covers the protocol, not a scaling number.)"""
+    gpus = [(2 + i, 0, 0x05 + 0x10 * i, 0 if i < 4 else 1) for i in range(8)]
+    nodes = {0: "0-63,128-191", 1: "64-127,192-255"}
+    _fake_sysfs(tmp_path, gpus, nodes)
+    env = _env()
+    env[launcher.SYSFS_ENV] = str(tmp_path)
+    env["OMP_NUM_THREADS"] = "1"
+    assert launcher.visible_gpu_count(str(tmp_path)) == 8
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--launcher-dry-run", "--steps", "2",
+                        "--warmup", "1", "--repeats", "1"], env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["scaling"] == "weak"
+    sets = [set(launcher.parse_cpulist(c)) for c in line["per_rank_cpus"]]
+    assert len(sets) == 8 and all(len(s) >= 4 for s in sets)
+    assert sum(len(s) for s in sets) == len(set().union(*sets))            # disjoint
+    socket_cpus = {k: set(launcher.parse_cpulist(v)) for k, v in nodes.items()}
+    for rank, s in enumerate(sets):
+        assert s <= socket_cpus[0 if rank < 4 else 1]
+    seeds = line["config"]["pair_seeds_first_region"]
+    assert sorted(x for per_rank in seeds for x in per_rank) == list(range(2 * 8))
+    assert len(line["per_rank_pairs_per_s"]) == 8

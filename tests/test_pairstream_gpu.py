@@ -162,7 +162,8 @@ def test_pair_engine_matches_sequential(cuda):
     # per call, and builds / calls of up to four pairs
     for workers, fronts, per_build, per_fwd in ((1, 1, 2, 1), (3, 2, 2, 2), (2, 1, 4, 4), (2, 1, 3, 2)):
         eng = PairStreams(net, cfg, limits, cuda, model_streams=workers, front_threads=fronts, up_nearest=(workers == 3),
-                          pairs_per_build=per_build, pairs_per_forward=per_fwd)
+                          pairs_per_build=per_build, pairs_per_forward=per_fwd,
+                          adaptive_jobs=(workers == 3))      # the timing-dependent grouping in ONE configuration only
         outs, submitted, total = [], 0, 3 * len(pairs)
         for i in range(total):
             while submitted < min(total, i + 5):
