@@ -114,6 +114,12 @@ bool edgeconv_rows_ok(const EdgeCloud* cl, int count, int ld_ctr, int ld_nbr, in
 int edgeconv_rows_multi(const EdgeCloud* cl, int count, int ld_ctr, int ld_nbr, int ld_emax, int c, bool atomic, int* nchunks_out,
                         hipStream_t st);
 
+// multi-head attention on the fp32 matrix cores (gnn.hip): up to four clouds in one launch (k_attention_mfma)
+struct AttnCloud { const float* q; const float* k; const float* v; float* out; int n, ms; };
+bool attention_mfma_ok(const AttnCloud* cl, int count, int ldq, int ldk, int ldv, int d);
+int attention_mfma_multi(const AttnCloud* cl, int count, int ldq, int ldk, int ldv, int ldo, int heads, int d, float scale,
+                         hipStream_t st);
+
 // Tuning / A-B switches of the library, in ONE place.  Every field defaults to the product behaviour; they are set by
 // pcrcg_debug_set("name=value,name=value") or, once at first use, from the environment variable PCRCG_DEBUG (same
 // syntax) -- include/pcrcg.h lists the names.  Nothing else in csrc/ reads the environment, except PCRCG_GEMM_MODE
@@ -127,6 +133,7 @@ struct DebugOpts {
     int fuse_upsample = 1;     // runner: nearest_upsample -> cat(skip) -> unary as two products into one output
     int gnn_merge = 1;         // runner: source and target clouds of a self-attention layer through ONE pass (round 5)
     int edge_rows = 1;         // edge convolution: the row-parallel multi-cloud kernel (0: the per-cloud chunked kernel)
+    int att_mfma = 1;          // attention: the fp32-MFMA kernel, all clouds of a call in one launch (0: the VALU kernel per cloud)
     int radius_blocks = 0;     // radius search grid (0: 512 workgroups)
     int radius_eager_redo = 0; // pyramid builder: launch the >256-hit redo pass unconditionally
     int kd_blocks = 0;

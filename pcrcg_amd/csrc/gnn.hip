@@ -266,6 +266,141 @@ __global__ void __launch_bounds__(256) k_knn_reg(const float* __restrict__ coord
     if (tie && n > k && k <= KNN_K_MAX) knn_replay_row(coords, n, i, k, s_q[threadIdx.x >> 6], idx + (long)i * k);
 }
 
+// Round 5: multi-head attention on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: fp32 operands, fp32 accumulation -- the
+// reference's arithmetic, no split).  k_attention below is a VALU kernel of 16 lanes per query that walks the keys in
+// chunks of 64 behind three barriers each: 63 us for 381 x 382 x 2 heads of 128, the largest single launch of the coarse
+// level.  Here one workgroup of four wavefronts takes 32 queries of one head of one cloud (blockIdx = (query tile, head,
+// cloud); up to four clouds per launch):
+//   1 scores   S = scale * Q K^T as 32 x 32 tiles, a key block per wavefront and turn.  The sum over the head dimension may
+//              run in any order as long as both operands agree, so lane (l31, half) takes the CONTIGUOUS half
+//              [half * D/2, half * D/2 + D/2) of its query row (kept in registers for the whole kernel) and of its key row
+//              (D/8 16-byte loads per block, all in flight) and step kk multiplies element kk of the two halves;
+//              S goes to LDS ([32][ms] with an odd row stride);
+//   2 softmax  a wavefront per 8 rows: row maximum, exp, row sum (wave reductions), P = exp(S - max) back in place;
+//   3 P V      the keys split over the wavefronts; per step one key per half, V rows read 128 bytes per half-wave (coalesced),
+//              D/32 output tiles; the four wavefronts' partial tiles meet in LDS and leave as one store, scaled by 1 / sum.
+// Needs D % 32 == 0 and the scores of a 32-query tile in LDS: ms <= 1024 (the larger clouds take the per-head GEMM path).
+struct AttCloud { const float* q; const float* k; const float* v; float* out; int n, ms; };
+struct AttMulti { AttCloud cl[4]; int ldq, ldk, ldv, ldo; float scale; int ms_max; };
+
+typedef float attf16 __attribute__((ext_vector_type(16)));
+
+template <int D>
+__global__ void __launch_bounds__(256) k_attention_mfma(AttMulti a) {
+    constexpr int DH = D / 2, NT = D / 32;
+    extern __shared__ __attribute__((aligned(16))) float att2_lds[];
+    const AttCloud cl = a.cl[blockIdx.z];
+    const int n = cl.n, ms = cl.ms;
+    const int q0 = blockIdx.x * 32;
+    if (q0 >= n) return;
+    const int head = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l31 = lane & 31, half = lane >> 5;
+    const int sld = ((a.ms_max + 31) / 32) * 32 + 1;          // odd row stride: a column of S walks all banks
+    float* const S = att2_lds;                                 // [32][sld]
+    float* const rinv = S + 32 * sld;                          // [32] 1 / row sum
+    float* const red = rinv + 32;                              // [3][32][D] partial output tiles of wavefronts 1..3
+    const int nkb = (ms + 31) / 32;
+    // ---- 1: scores
+    float qr[DH];
+    {
+        const float* qrow = cl.q + (long)min(q0 + l31, n - 1) * a.ldq + head * D + half * DH;
+#pragma unroll
+        for (int c = 0; c < DH / 4; ++c) {
+            const float4 t = *reinterpret_cast<const float4*>(qrow + 4 * c);
+            qr[4 * c] = t.x; qr[4 * c + 1] = t.y; qr[4 * c + 2] = t.z; qr[4 * c + 3] = t.w;
+        }
+    }
+    for (int kb = wave; kb < nkb; kb += 4) {
+        const int key = kb * 32 + l31;
+        const float* krow = cl.k + (long)min(key, ms - 1) * a.ldk + head * D + half * DH;
+        float kr[DH];
+#pragma unroll
+        for (int c = 0; c < DH / 4; ++c) {
+            const float4 t = *reinterpret_cast<const float4*>(krow + 4 * c);
+            kr[4 * c] = t.x; kr[4 * c + 1] = t.y; kr[4 * c + 2] = t.z; kr[4 * c + 3] = t.w;
+        }
+        attf16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < DH; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[kk], kr[kk], acc, 0, 0, 0);
+        // C/D layout: column = l31 (the key), rows (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            S[row * sld + kb * 32 + l31] = key < ms ? acc[r] * a.scale : -INFINITY;
+        }
+    }
+    __syncthreads();
+    // ---- 2: softmax, rows 8 wave .. 8 wave + 7
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr;
+        float* const srow = S + row * sld;
+        float mx = -INFINITY;
+        for (int j = lane; j < nkb * 32; j += 64) mx = fmaxf(mx, srow[j]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+        for (int j = lane; j < nkb * 32; j += 64) {
+            const float e = expf(srow[j] - mx);                 // exp(-inf) = 0 for the padded keys
+            srow[j] = e;
+            sum += e;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0) rinv[row] = 1.0f / sum;
+    }
+    __syncthreads();
+    // ---- 3: P V, wavefront w takes the key blocks [w * per, (w + 1) * per)
+    attf16 o[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    {
+        const int per = (nkb + 3) / 4;
+        const int kb0 = min(wave * per, nkb), kb1 = min(kb0 + per, nkb);
+        // within a block of 32 keys, half 0 takes keys 0..15 and half 1 keys 16..31: step j multiplies key (16 half + j)
+        for (int kb = kb0; kb < kb1; ++kb) {
+            float pv[16], vv[NT][16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int key = kb * 32 + 16 * half + j;
+                pv[j] = S[l31 * sld + key];                      // A[row = l31][k]: P of this lane's query row
+                const float* vrow = cl.v + (long)min(key, ms - 1) * a.ldv + head * D;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) vv[t][j] = key < ms ? vrow[t * 32 + l31] : 0.f;     // B[k][col = l31]
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[j], vv[t][j], o[t], 0, 0, 0);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                red[((wave - 1) * 32 + row) * D + t * 32 + l31] = o[t][r];
+            }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int at = row * D + t * 32 + l31;
+                const float v = ((o[t][r] + red[at]) + (red[32 * D + at] + red[64 * D + at])) * rinv[row];
+                if (q0 + row < n) cl.out[(long)(q0 + row) * a.ldo + head * D + t * 32 + l31] = v;
+            }
+    }
+}
+
 // Round 5: the same reduction with the ROWS in parallel.  k_edgeconv_reduce below walks its rows with one 4-byte load per
 // lane and neighbour (a dependent chain of rows_per_chunk / 4 x (index -> k loads): 20 us for 381 x 10 x 512 values that
 // fit L2 ten times over).  Here a wavefront takes one row at a time: lanes 0 .. k-1 load the row's neighbour indices, which
@@ -548,6 +683,48 @@ int edgeconv_rows_multi(const EdgeCloud* cl, int count, int ld_ctr, int ld_nbr, 
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
+bool attention_mfma_ok(const AttnCloud* cl, int count, int ldq, int ldk, int ldv, int d) {
+    if (!debug_opts().att_mfma || count < 1 || count > 4 || (d != 32 && d != 64 && d != 128)) return false;
+    if (ldq % 4 != 0 || ldk % 4 != 0 || ldv % 4 != 0) return false;
+    for (int i = 0; i < count; ++i) {
+        // the scores of a 32-query tile + the partial output tiles must fit the CU's 160 KB of LDS
+        const size_t sld = (size_t)((cl[i].ms + 31) / 32) * 32 + 1;
+        if (cl[i].n < 1 || cl[i].ms < 1 || sizeof(float) * (32 * sld + 32 + (size_t)96 * d) > 160 * 1024) return false;
+        if ((reinterpret_cast<uintptr_t>(cl[i].q) | reinterpret_cast<uintptr_t>(cl[i].k)) & 15) return false;
+    }
+    return true;
+}
+// out[:, h d:(h + 1) d] = softmax(scale q_h k_h^T) v_h for every head of up to four clouds in ONE launch (k_attention_mfma)
+int attention_mfma_multi(const AttnCloud* cl, int count, int ldq, int ldk, int ldv, int ldo, int heads, int d, float scale,
+                         hipStream_t st) {
+    AttMulti a;
+    int nmax = 0, msmax = 0;
+    for (int i = 0; i < 4; ++i) {
+        const AttnCloud& c = cl[i < count ? i : 0];
+        a.cl[i] = AttCloud{c.q, c.k, c.v, c.out, c.n, c.ms};
+        if (i < count) { nmax = c.n > nmax ? c.n : nmax; msmax = c.ms > msmax ? c.ms : msmax; }
+    }
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale; a.ms_max = msmax;
+    const int sld = ((msmax + 31) / 32) * 32 + 1;
+    const size_t lds = sizeof(float) * ((size_t)32 * sld + 32 + (size_t)3 * 32 * d);
+    const dim3 grid((nmax + 31) / 32, heads, count);
+#define ATT2(DD)                                                                                                          \
+    do {                                                                                                                  \
+        static size_t configured = 0;                                                                                     \
+        if (lds > configured) {                                                                                           \
+            PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_mfma<DD>),                      \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+            configured = lds;                                                                                             \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((k_attention_mfma<DD>), grid, dim3(256), lds, st, a);                                          \
+    } while (0)
+    if (d == 128) ATT2(128);
+    else if (d == 64) ATT2(64);
+    else ATT2(32);
+#undef ATT2
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
 }  // namespace pcrcg
 
 using namespace pcrcg;
@@ -621,6 +798,10 @@ int pcrcg_attention(const float* q, int ldq, const float* k, int ldk, const floa
     PCRCG_CHECK_ARG(q && k && v && out);
     PCRCG_CHECK_ARG(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
     hipStream_t st = as_stream(stream);
+    {
+        const AttnCloud one = {q, k, v, out, n, ms};
+        if (attention_mfma_ok(&one, 1, ldq, ldk, ldv, d)) return attention_mfma_multi(&one, 1, ldq, ldk, ldv, ldo, heads, d, scale, st);
+    }
 #define ATT(DD, TQ)                                                                                                  \
     do {                                                                                                             \
         constexpr size_t lds = sizeof(float) * (64 * (DD + 4) + 64 * DD + TQ * 64);                                  \

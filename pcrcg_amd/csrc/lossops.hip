@@ -126,11 +126,15 @@ __global__ void __launch_bounds__(256) k_circle_grads(const float* __restrict__ 
             v[4] += r[5];
             v[5] += r[6];
         }
+        // the four wavefronts' sums meet in a FIXED order (an LDS atomic here made the loss value depend on which wavefront
+        // arrived first: run-to-run differences in its last bits)
         for (int q = 0; q < 6; ++q) {
             float x = v[q];
             for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
-            if ((t & 63) == 0) atomicAdd(&red[q], x);
+            if ((t & 63) == 0) part[(t >> 6) * 6 + q] = x;
         }
+        __syncthreads();
+        if (t < 6) red[t] = (part[t] + part[6 + t]) + (part[12 + t] + part[18 + t]);
     }
     __syncthreads();
     const float nrow = red[0], ncol = red[1];
@@ -310,8 +314,9 @@ int pcrcg_weighted_bce(const float* prediction, const float* gt, int n, float* o
     PCRCG_CHECK_HIP(hipMemsetAsync(sums, 0, 64, st));
     int blocks = (n + 255) / 256;
     if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(k_bce_sums, dim3(blocks), dim3(256), 0, st, prediction, gt, n, sums);
-    hipLaunchKernelGGL(k_bce_loss, dim3(blocks), dim3(256), 0, st, prediction, gt, n, sums, grad);
+    hipLaunchKernelGGL(k_bce_sums, dim3(blocks), dim3(256), 0, st, prediction, gt, n, sums);      // (counts: exact in any order)
+    // the loss sum meets in one fp64 atomic per workgroup: deterministic=1 runs ONE workgroup (grid-stride loop, n is a cloud)
+    hipLaunchKernelGGL(k_bce_loss, dim3(debug_opts().deterministic ? 1 : blocks), dim3(256), 0, st, prediction, gt, n, sums, grad);
     hipLaunchKernelGGL(k_bce_final, dim3(1), dim3(1), 0, st, sums, n, out3);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;

@@ -606,11 +606,25 @@ Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, co
 }
 
 // x + AttentionalPropagation(x, src)  (ref:models/gcn.py:151-185, 213-214)
-Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, const Mat& x, const Mat& src) {
+// q_given: the query projection of x, computed by the caller (both directions of a layer in one launch), or NULL
+Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, const Mat& x, const Mat& src, const Mat* q_given = nullptr) {
     const int ch = x.cols, h = mdl.heads, d = ch / h;
     Mat y = c.mat(x.rows, ch);
     const size_t m = c.mark();
-    Mat q = c.gemm_out(x.rows, ch, ch), kk = c.gemm_out(src.rows, ch, ch), v = c.gemm_out(src.rows, ch, ch), msg = c.mat(x.rows, ch);
+    // the key and value projections read the same rows: ONE product of width 2 ch when the caller packed the two weight
+    // matrices (and biases) behind each other (pcrcg_amd/runner.py does), k and v are then column blocks of its output
+    const bool kv_fused = gl.wv == gl.wk + (size_t)ch * ch && gl.bv == gl.bk + ch && debug_opts().gnn_merge;
+    Mat q = q_given ? *q_given : c.gemm_out(x.rows, ch, ch), kk, v, msg = c.mat(x.rows, ch);
+    if (kv_fused) {
+        Mat kv = c.gemm_out(src.rows, 2 * ch, ch);
+        linear(c, src, gl.wk, ch, gl.bk, kv);
+        kk = cols(kv, 0, ch);
+        v = cols(kv, ch, ch);
+        kk.zeroed = v.zeroed = false;
+    } else {
+        kk = c.gemm_out(src.rows, ch, ch);
+        v = c.gemm_out(src.rows, ch, ch);
+    }
     int sc_rows[GMAX] = {};
     for (int g = 0; g < c.G; ++g) sc_rows[g] = x.rows[g];
     int ms_max = 0;
@@ -619,13 +633,25 @@ Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, c
     int r2[GMAX];
     for (int g = 0; g < GMAX; ++g) r2[g] = x.rows[g];
     Mat cat = c.mat(r2, 2 * ch), h0 = c.gemm_out(r2, 2 * ch, 2 * ch), h1 = c.mat(r2, 2 * ch), delta = c.gemm_out(r2, ch, 2 * ch);
-    linear(c, x, gl.wq, ch, gl.bq, q);
-    linear(c, src, gl.wk, ch, gl.bk, kk);
-    linear(c, src, gl.wv, ch, gl.bv, v);
+    if (!q_given) linear(c, x, gl.wq, ch, gl.bq, q);
+    if (!kv_fused) {
+        linear(c, src, gl.wk, ch, gl.bk, kk);
+        linear(c, src, gl.wv, ch, gl.bv, v);
+    }
+    bool att_done = false;
+    if (c.live()) {       // every pair's attention in ONE launch where the matrix-core kernel applies (round 5)
+        AttnCloud cl[GMAX];
+        for (int g = 0; g < c.G; ++g) cl[g] = AttnCloud{q.p[g], kk.p[g], v.p[g], msg.p[g], x.rows[g], src.rows[g]};
+        if (attention_mfma_ok(cl, c.G, q.ld, kk.ld, v.ld, d)) {
+            c.check(attention_mfma_multi(cl, c.G, q.ld, kk.ld, v.ld, msg.ld, h, d, 1.0f / sqrtf((float)d), c.st));
+            att_done = true;
+        }
+    }
     if (c.live())
         for (int g = 0; g < c.G; ++g) {
             const int n = x.rows[g], ms = src.rows[g];
-            if (pcrcg_attention_supported(d) && (long)n * ms <= 1000000) {
+            if (att_done) {
+            } else if (pcrcg_attention_supported(d) && (long)n * ms <= 1000000) {
                 // all heads in one launch (heads are contiguous column blocks after the weight permutation); a latency win on
                 // the few hundred coarse points of an indoor pair (49 vs 138 us of kernels + 11 launches less per call,
                 // scripts/attention_bench.py) -- beyond ~1000 x 1000 the GEMM path below is faster (1900 x 1900: 228 vs 640 us)
@@ -687,7 +713,27 @@ void forward(Ctx& c, const pcrcg_model& mdl, const Batches& B, const pcrcg_outpu
     Mat d0 = rows(fc, zero, ns), d1 = rows(fc, ns, nt);
     for (int i = 0; i < mdl.n_gnn; ++i) {
         const pcrcg_gnn_layer& gl = mdl.gnn[i];
-        if (gl.cross) {
+        if (gl.cross && 2 * c.G <= GMAX && c.paired_ok() && debug_opts().gnn_merge) {
+            // the second direction's queries come from d1, which the first direction does not change: both query
+            // projections in one launch (2 G products sharing wq)
+            const int G0 = c.G, ch = d0.cols;
+            const size_t mk = c.mark();
+            Mat x2 = d0;
+            for (int g = 0; g < G0; ++g) { x2.p[G0 + g] = d1.p[g]; x2.rows[G0 + g] = d1.rows[g]; }
+            c.G = 2 * G0;
+            Mat q2 = c.gemm_out(x2.rows, ch, ch);
+            linear(c, x2, gl.wq, ch, gl.bq, q2);
+            c.G = G0;
+            Mat q0 = q2, q1 = q2;
+            for (int g = 0; g < GMAX; ++g) {
+                q0.p[g] = g < G0 ? q2.p[g] : nullptr; q0.rows[g] = g < G0 ? q2.rows[g] : 0;
+                q1.p[g] = g < G0 ? q2.p[G0 + g] : nullptr; q1.rows[g] = g < G0 ? q2.rows[G0 + g] : 0;
+            }
+            // (the results are allocated above the projections: the arena is a stack, so they stay until the forward ends)
+            d0 = cross_attention(c, mdl, gl, d0, d1, &q0);
+            d1 = cross_attention(c, mdl, gl, d1, d0, &q1);   // sees the updated d0 (:214)
+            (void)mk;
+        } else if (gl.cross) {
             d0 = cross_attention(c, mdl, gl, d0, d1);
             d1 = cross_attention(c, mdl, gl, d1, d0);   // sees the updated d0 (:214)
         } else if (2 * c.G <= GMAX && c.paired_ok() && debug_opts().gnn_merge) {

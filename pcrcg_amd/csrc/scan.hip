@@ -210,7 +210,7 @@ namespace {
 struct DebugName { const char* name; int DebugOpts::*field; };
 const DebugName kDebugNames[] = {
     {"zero_arena", &DebugOpts::zero_arena}, {"stat_sums", &DebugOpts::stat_sums}, {"stat_sums_rows", &DebugOpts::stat_sums_rows},
-    {"fuse_norm", &DebugOpts::fuse_norm}, {"fuse_pack", &DebugOpts::fuse_pack}, {"fuse_upsample", &DebugOpts::fuse_upsample}, {"gnn_merge", &DebugOpts::gnn_merge}, {"edge_rows", &DebugOpts::edge_rows},
+    {"fuse_norm", &DebugOpts::fuse_norm}, {"fuse_pack", &DebugOpts::fuse_pack}, {"fuse_upsample", &DebugOpts::fuse_upsample}, {"gnn_merge", &DebugOpts::gnn_merge}, {"edge_rows", &DebugOpts::edge_rows}, {"att_mfma", &DebugOpts::att_mfma},
     {"radius_blocks", &DebugOpts::radius_blocks}, {"radius_eager_redo", &DebugOpts::radius_eager_redo},
     {"radius_cells", &DebugOpts::radius_cells}, {"kd_blocks", &DebugOpts::kd_blocks}, {"radius_prof", &DebugOpts::radius_prof},
     {"pyr_wait", &DebugOpts::pyr_wait}, {"pyr_trace", &DebugOpts::pyr_trace}, {"att_tq", &DebugOpts::att_tq},

@@ -1,5 +1,8 @@
 // trainops.hip -- kernels of the training-side rows: loss labels and backward passes.
 // ABI: include/pcrcg_train.h.
+#include <map>
+#include <mutex>
+
 #include "common.h"
 #include "pcrcg_train.h"
 
@@ -82,6 +85,50 @@ __global__ void __launch_bounds__(256) k_feature_argmax_unpack(const unsigned lo
     }
 }
 
+// ---- deterministic accumulation (PCRCG_DEBUG=deterministic=1, include/pcrcg.h) ----------------------------------------
+// The scatter kernels below add into a support row from many queries at once; with fp32 atomics the order of those adds --
+// and so the last bits of the result -- changes from run to run.  Integer addition is associative: under the switch every
+// contribution is rounded ONCE to 64-bit fixed point (scale 2^S, S chosen on the device from the largest magnitude of the
+// source gradient so that 2^22 contributions cannot overflow: resolution 2^-39 of that magnitude, finer than fp32) and added
+// with a 64-bit integer atomic into a zeroed scratch buffer of the destination's shape; k_fix_flush then adds the exact
+// integer sums to the destination (one fp32 rounding per element) and leaves the scratch zeroed for the next use.  The
+// scratch is the library's own (one buffer per stream, grown on demand): a debugging mode pays for its memory itself.
+struct FixAcc {
+    long long* acc;            // NULL: plain fp32 atomics (the default)
+    const unsigned* maxbits;   // bit pattern of the largest |source gradient| (k_absmax_bits)
+    int fan_log2;              // log2 of (contributions per element x the largest factor a contribution carries)
+};
+__device__ __forceinline__ float fix_scale(const FixAcc& f) {
+    const int e = (int)((*f.maxbits >> 23) & 0xff) - 127;          // largest magnitude < 2^(e + 1)
+    return ldexpf(1.0f, 62 - f.fan_log2 - (e + 1));
+}
+template <bool DET>
+__device__ __forceinline__ void scatter_add(float* dst, long off, float v, const FixAcc& f, float scale) {
+    if constexpr (DET) atomicAdd(reinterpret_cast<unsigned long long*>(f.acc) + off, (unsigned long long)__float2ll_rn(v * scale));
+    else atomicAdd(dst + off, v);
+}
+__global__ void __launch_bounds__(256) k_absmax_bits(const float* __restrict__ x, long rows, int cols, long ld, unsigned* __restrict__ out) {
+    unsigned m = 0u;
+    const long total = rows * cols;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long r = t / cols;
+        const unsigned b = __float_as_uint(x[r * ld + (t - r * cols)]) & 0x7fffffffu;
+        m = b > m && b < 0x7f800000u ? b : m;                      // (non-finite gradients poison the step anyway)
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+__global__ void __launch_bounds__(256) k_fix_flush(long long* __restrict__ acc, float* __restrict__ dst, long n, FixAcc f) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const long long v = acc[t];
+    if (v != 0) {
+        dst[t] += (float)((double)v / (double)fix_scale(f));
+        acc[t] = 0;
+    }
+}
+
 // ---- KPConv backward w.r.t. the input features ---------------------------------------------------
 //   dx[idx[q,h], c] += sum_k w[q,h,k] * d_wf[q,k,c],   w as in kpconv.hip (rigid kernel, linear influence)
 // One wavefront per (query, 64-channel chunk): lanes = channels hold the 15 rows d_wf[q,k,c0+lane] in
@@ -91,14 +138,16 @@ __global__ void __launch_bounds__(256) k_feature_argmax_unpack(const unsigned lo
 // neighbour of ~H queries, so its row receives ~H contributions in arbitrary order.
 constexpr int K = PCRCG_KPOINTS;
 
+template <bool DET>
 __global__ void __launch_bounds__(256) k_kpconv_bwd_dx(const float* __restrict__ q_pts, int nq,
                                                         const float* __restrict__ s_pts, int ns,
                                                         const long long* __restrict__ idx, int H, int ld_idx,
                                                         const float* __restrict__ d_wf, int cin,
                                                         const float* __restrict__ kp, float extent,
-                                                        float* __restrict__ dx, int nchunk) {
+                                                        float* __restrict__ dx, int nchunk, FixAcc fx) {
     const int lane = threadIdx.x & 63;
     const int hsub = lane >> 4, j = lane & 15;
+    const float fscale = DET ? fix_scale(fx) : 1.0f;
     const long item = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (item >= (long)nq * nchunk) return;
     const int q = (int)(item / nchunk), chunk = (int)(item - (long)q * nchunk);
@@ -136,7 +185,7 @@ __global__ void __launch_bounds__(256) k_kpconv_bwd_dx(const float* __restrict__
 #pragma unroll
                 for (int k = 0; k < K; ++k)
                     acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(wi, s * 16 + k)), g[k], acc);
-                if (cok) atomicAdd(dx + (long)is * cin + cc, acc);
+                if (cok) scatter_add<DET>(dx, (long)is * cin + cc, acc, fx, fscale);
             }
         }
     }
@@ -145,16 +194,18 @@ __global__ void __launch_bounds__(256) k_kpconv_bwd_dx(const float* __restrict__
 // ---- pooling backward ---------------------------------------------------------------------------
 // max_pool: the gradient of y[q,c] = max_h x[idx[q,h],c] goes to the FIRST neighbour attaining the maximum
 // (shadow neighbours contribute the value 0 and swallow the gradient when they win, ref:models/blocks.py:95).
+template <bool DET>
 __global__ void __launch_bounds__(256) k_gather_max_bwd(const float* __restrict__ x, int ns, int c,
                                                          const long long* __restrict__ idx, int nq, int h, int ld_idx,
                                                          const float* __restrict__ y, const float* __restrict__ dy,
-                                                         float* __restrict__ dx, int nchunk) {
+                                                         float* __restrict__ dx, int nchunk, FixAcc fx) {
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (item >= (long)nq * nchunk) return;
     const int q = (int)(item / nchunk), chunk = (int)(item - (long)q * nchunk);
     const int cc = chunk * 64 + lane;
     if (cc >= c) return;
+    const float fscale = DET ? fix_scale(fx) : 1.0f;
     const float m = y[(long)q * c + cc], gq = dy[(long)q * c + cc];
     const long long* row = idx + (long)q * ld_idx;
     for (int jn = 0; jn < h; ++jn) {
@@ -162,22 +213,24 @@ __global__ void __launch_bounds__(256) k_gather_max_bwd(const float* __restrict_
         const bool real = i >= 0 && i < ns;
         const float v = real ? x[i * c + cc] : 0.f;
         if (v == m) {
-            if (real) atomicAdd(dx + i * c + cc, gq);
+            if (real) scatter_add<DET>(dx, i * c + cc, gq, fx, fscale);
             break;
         }
     }
 }
 
 // closest_pool: dx[idx[q,0], :] += dy[q, :]
+template <bool DET>
 __global__ void __launch_bounds__(256) k_gather_first_bwd(const float* __restrict__ dy, int ld_dy, int c,
                                                            const long long* __restrict__ idx, int nq, int ld_idx, int ns,
-                                                           float* __restrict__ dx) {
+                                                           float* __restrict__ dx, FixAcc fx) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (q >= nq) return;
     const long long i = idx[(long)q * ld_idx];
     if (i < 0 || i >= ns) return;
-    for (int cc = lane; cc < c; cc += 64) atomicAdd(dx + i * c + cc, dy[(long)q * ld_dy + cc]);
+    const float fscale = DET ? fix_scale(fx) : 1.0f;
+    for (int cc = lane; cc < c; cc += 64) scatter_add<DET>(dx, i * c + cc, dy[(long)q * ld_dy + cc], fx, fscale);
 }
 
 // ---- InstanceNorm (+ LeakyReLU) backward ----------------------------------------------------------
@@ -334,11 +387,12 @@ __global__ void __launch_bounds__(256) k_edge_bwd_sums(const float* __restrict__
     atomicAdd(&sums[c + ch], b);
 }
 
+template <bool DET>
 __global__ void __launch_bounds__(256) k_edge_bwd_apply(const float* __restrict__ ctr, const float* __restrict__ nbr,
                                                          const int* __restrict__ idx, int n, int k, int c,
                                                          const float* __restrict__ stats, const float* __restrict__ dy,
                                                          float slope, const double* __restrict__ sums,
-                                                         float* __restrict__ dctr, float* __restrict__ dnbr) {
+                                                         float* __restrict__ dctr, float* __restrict__ dnbr, FixAcc fx) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int ch = blockIdx.y * 64 + lane;
@@ -355,13 +409,14 @@ __global__ void __launch_bounds__(256) k_edge_bwd_apply(const float* __restrict_
     }
     const float nm = (m - mean) * rstd;
     const float dn = dy[(long)r * c + ch] * (nm > 0.f ? 1.0f : slope);
+    const float fscale = DET ? fix_scale(fx) : 1.0f;
     float acc = 0.f;
     for (int j = 0; j < k; ++j) {
         const int s = idx[(long)r * k + j];
         const float nv = (q + nbr[(long)s * c + ch] - mean) * rstd;
         const float de = rstd * ((j == jstar ? dn : 0.f) - s1 - nv * s2);
         acc += de;
-        atomicAdd(dnbr + (long)s * c + ch, de);
+        scatter_add<DET>(dnbr, (long)s * c + ch, de, fx, fscale);
     }
     dctr[(long)r * c + ch] = acc;
 }
@@ -370,6 +425,48 @@ __global__ void __launch_bounds__(256) k_edge_bwd_apply(const float* __restrict_
 }  // namespace pcrcg
 
 using namespace pcrcg;
+
+// ---- the deterministic mode's scratch (see FixAcc): one zeroed 64-bit buffer + one word per stream, grown on demand ----
+namespace {
+struct DetScratch { long long* acc = nullptr; size_t elems = 0; unsigned* word = nullptr; };
+std::mutex g_det_lock;
+std::map<hipStream_t, DetScratch> g_det;
+// -> a FixAcc over a zeroed buffer of at least `elems` elements whose scale follows the largest |src| value; NULL acc on failure
+int det_begin(hipStream_t st, size_t elems, const float* src, long rows, int cols, long ld, int fan_log2, FixAcc* out) {
+    DetScratch d;
+    {
+        std::lock_guard<std::mutex> g(g_det_lock);
+        DetScratch& slot = g_det[st];
+        if (slot.elems < elems) {
+            // (a debugging mode: synchronous allocation; the old buffer is idle once the stream has drained)
+            PCRCG_CHECK_HIP(hipStreamSynchronize(st));
+            if (slot.acc) (void)hipFree(slot.acc);
+            const size_t want = elems + elems / 4;
+            PCRCG_CHECK_HIP(hipMalloc(&slot.acc, want * sizeof(long long)));
+            PCRCG_CHECK_HIP(hipMemset(slot.acc, 0, want * sizeof(long long)));
+            slot.elems = want;
+        }
+        if (!slot.word) PCRCG_CHECK_HIP(hipMalloc(&slot.word, 256));
+        d = slot;
+    }
+    PCRCG_CHECK_HIP(hipMemsetAsync(d.word, 0, sizeof(unsigned), st));
+    const long total = rows * cols;
+    long blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (total > 0) hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)blocks), dim3(256), 0, st, src, rows, cols, ld, d.word);
+    PCRCG_CHECK_LAUNCH();
+    out->acc = d.acc;
+    out->maxbits = d.word;
+    out->fan_log2 = fan_log2;
+    return PCRCG_OK;
+}
+int det_end(hipStream_t st, const FixAcc& fx, float* dst, size_t elems) {
+    hipLaunchKernelGGL(k_fix_flush, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, fx.acc, dst, (long)elems, fx);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+const FixAcc kNoFix{nullptr, nullptr, 0};
+}  // namespace
 
 extern "C" size_t pcrcg_feature_argmax_ws_bytes(int n) { return carve_bytes((size_t)(n > 0 ? n : 1), 8); }
 
@@ -407,8 +504,16 @@ extern "C" int pcrcg_kpconv_backward_dx(const float* q_pts, int nq, const float*
     PCRCG_CHECK_ARG(q_pts && s_pts && idx && d_wf && kp && dx);
     const int nchunk = (cin + 63) / 64;
     const long items = (long)nq * nchunk;
-    hipLaunchKernelGGL(k_kpconv_bwd_dx, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), q_pts, nq,
-                       s_pts, ns, reinterpret_cast<const long long*>(idx), h, ld_idx, d_wf, cin, kp, extent, dx, nchunk);
+    if (debug_opts().deterministic) {       // |contribution| <= 15 max|d_wf| (influence weights <= 1), at most nq of them per element
+        FixAcc fx;
+        PCRCG_PROPAGATE(det_begin(as_stream(stream), (size_t)ns * cin, d_wf, nq, PCRCG_KPOINTS * cin, (long)PCRCG_KPOINTS * cin, 22, &fx));
+        hipLaunchKernelGGL(k_kpconv_bwd_dx<true>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), q_pts, nq,
+                           s_pts, ns, reinterpret_cast<const long long*>(idx), h, ld_idx, d_wf, cin, kp, extent, dx, nchunk, fx);
+        PCRCG_CHECK_LAUNCH();
+        return det_end(as_stream(stream), fx, dx, (size_t)ns * cin);
+    }
+    hipLaunchKernelGGL(k_kpconv_bwd_dx<false>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), q_pts, nq,
+                       s_pts, ns, reinterpret_cast<const long long*>(idx), h, ld_idx, d_wf, cin, kp, extent, dx, nchunk, kNoFix);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -420,8 +525,16 @@ extern "C" int pcrcg_gather_max_backward(const float* x, int ns, int c, const in
     PCRCG_CHECK_ARG(x && idx && y && dy && dx);
     const int nchunk = (c + 63) / 64;
     const long items = (long)nq * nchunk;
-    hipLaunchKernelGGL(k_gather_max_bwd, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), x, ns, c,
-                       reinterpret_cast<const long long*>(idx), nq, h, ld_idx, y, dy, dx, nchunk);
+    if (debug_opts().deterministic) {
+        FixAcc fx;
+        PCRCG_PROPAGATE(det_begin(as_stream(stream), (size_t)ns * c, dy, nq, c, c, 20, &fx));
+        hipLaunchKernelGGL(k_gather_max_bwd<true>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), x, ns, c,
+                           reinterpret_cast<const long long*>(idx), nq, h, ld_idx, y, dy, dx, nchunk, fx);
+        PCRCG_CHECK_LAUNCH();
+        return det_end(as_stream(stream), fx, dx, (size_t)ns * c);
+    }
+    hipLaunchKernelGGL(k_gather_max_bwd<false>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), x, ns, c,
+                       reinterpret_cast<const long long*>(idx), nq, h, ld_idx, y, dy, dx, nchunk, kNoFix);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -431,8 +544,16 @@ extern "C" int pcrcg_gather_first_backward(const float* dy, int ld_dy, int c, co
     PCRCG_CHECK_ARG(c >= 1 && nq >= 0 && ld_idx >= 1 && ld_dy >= c && ns >= 0);
     if (nq == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(dy && idx && dx);
-    hipLaunchKernelGGL(k_gather_first_bwd, dim3((nq + 3) / 4), dim3(256), 0, as_stream(stream), dy, ld_dy, c,
-                       reinterpret_cast<const long long*>(idx), nq, ld_idx, ns, dx);
+    if (debug_opts().deterministic) {
+        FixAcc fx;
+        PCRCG_PROPAGATE(det_begin(as_stream(stream), (size_t)ns * c, dy, nq, c, ld_dy, 20, &fx));
+        hipLaunchKernelGGL(k_gather_first_bwd<true>, dim3((nq + 3) / 4), dim3(256), 0, as_stream(stream), dy, ld_dy, c,
+                           reinterpret_cast<const long long*>(idx), nq, ld_idx, ns, dx, fx);
+        PCRCG_CHECK_LAUNCH();
+        return det_end(as_stream(stream), fx, dx, (size_t)ns * c);
+    }
+    hipLaunchKernelGGL(k_gather_first_bwd<false>, dim3((nq + 3) / 4), dim3(256), 0, as_stream(stream), dy, ld_dy, c,
+                       reinterpret_cast<const long long*>(idx), nq, ld_idx, ns, dx, kNoFix);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -496,12 +617,24 @@ extern "C" int pcrcg_edgeconv_backward(const float* ctr, const float* nbr, const
     PCRCG_CHECK_WS(cv);
     hipStream_t st = as_stream(stream);
     PCRCG_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)c * sizeof(double), st));
+    const bool det = debug_opts().deterministic != 0;
     int gx = (n + 3) / 4;
     if (gx > 64) gx = 64;
+    if (det) gx = 1;      // one workgroup per channel block: every sum receives exactly one add
     hipLaunchKernelGGL(k_edge_bwd_sums, dim3(gx, (c + 63) / 64), dim3(256), 0, st, ctr, nbr, idx, n, k, c, stats, dy, slope,
                        sums);
-    hipLaunchKernelGGL(k_edge_bwd_apply, dim3((n + 3) / 4, (c + 63) / 64), dim3(256), 0, st, ctr, nbr, idx, n, k, c, stats,
-                       dy, slope, sums, dctr, dnbr);
+    if (det) {
+        // |de| <= rstd (|dn| + |S1/E| + |n| |S2/E|) <= 2^9 max|dy| (2 + 2^11) (rstd <= eps^-1/2, |n| <= sqrt(E), mean|n| <= 1),
+        // at most n k <= 2^15 edges per neighbour row
+        FixAcc fx;
+        PCRCG_PROPAGATE(det_begin(st, (size_t)n * c, dy, n, c, c, 36, &fx));
+        hipLaunchKernelGGL(k_edge_bwd_apply<true>, dim3((n + 3) / 4, (c + 63) / 64), dim3(256), 0, st, ctr, nbr, idx, n, k, c, stats,
+                           dy, slope, sums, dctr, dnbr, fx);
+        PCRCG_CHECK_LAUNCH();
+        return det_end(st, fx, dnbr, (size_t)n * c);
+    }
+    hipLaunchKernelGGL(k_edge_bwd_apply<false>, dim3((n + 3) / 4, (c + 63) / 64), dim3(256), 0, st, ctr, nbr, idx, n, k, c, stats,
+                       dy, slope, sums, dctr, dnbr, kNoFix);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -715,6 +848,7 @@ int tr_bias_grad(const float* dy, int ld, int rows, int cols, float* db, hipStre
     if (rows > 0 && cols > 0) {
         int gy = (rows + 255) / 256;
         if (gy > 64) gy = 64;
+        if (debug_opts().deterministic) gy = 1;      // one add per column: no order to depend on
         hipLaunchKernelGGL(k_bias_grad, dim3((cols + 63) / 64, gy), dim3(256), 0, st, dy, ld, rows, cols, db);
     }
     PCRCG_CHECK_LAUNCH();
@@ -734,6 +868,7 @@ int tr_dot_acc(const float* a, const float* b, long n, float scale, float* out, 
     if (n > 0) {
         long blocks = (n + 255) / 256;
         if (blocks > 256) blocks = 256;
+        if (debug_opts().deterministic) blocks = 1;
         hipLaunchKernelGGL(k_dot_acc, dim3((unsigned)blocks), dim3(256), 0, st, a, b, n, scale, out);
     }
     PCRCG_CHECK_LAUNCH();

@@ -214,9 +214,15 @@ class Runner:
             h, d = att.num_heads, att.dim
             dev = att.merge.weight.device
             perm = (torch.arange(h, device=dev)[:, None] + h * torch.arange(d, device=dev)[None, :]).reshape(-1)
-            for name, proj in zip("qkv", att.proj):
-                setattr(g, "w" + name, self._w(proj.weight.data.squeeze(-1)[perm]))
-                setattr(g, "b" + name, self._w(proj.bias.data[perm]))
+            g.wq = self._w(att.proj[0].weight.data.squeeze(-1)[perm])
+            g.bq = self._w(att.proj[0].bias.data[perm])
+            # key and value projections behind each other ([2 ch, ch] and [2 ch]): csrc/runner.hip then runs them as ONE
+            # product of width 2 ch over the rows they share (wv = wk + ch * ch, bv = bk + ch is what it looks for)
+            wkv = torch.cat([att.proj[1].weight.data.squeeze(-1)[perm], att.proj[2].weight.data.squeeze(-1)[perm]], 0).contiguous()
+            bkv = torch.cat([att.proj[1].bias.data[perm], att.proj[2].bias.data[perm]], 0).contiguous()
+            ch = wkv.shape[1]
+            g.wk, g.bk = self._w(wkv), self._w(bkv)
+            g.wv, g.bv = g.wk + 4 * ch * ch, g.bk + 4 * ch
             g.wm = self._w(att.merge.weight.data.squeeze(-1)[:, perm])
             g.bm = self._w(att.merge.bias.data)
             g.w0, g.b0 = self._w(layer.mlp[0].weight.data.squeeze(-1)), self._w(layer.mlp[0].bias.data)

@@ -56,3 +56,59 @@ def test_two_s30k_forwards_are_bit_identical(cuda):
         assert d < 1e-5, (k, d)
         d = float((groups[0][0][k].double() - runs[0][k].double()).abs().max() / runs[0][k].double().abs().max())
         assert d < 1e-5, (k, d)
+
+
+def _c1_train_inputs(cfg, dev):
+    from pcrcg_amd.correspondences import get_correspondences
+    from pcrcg_amd.pyramid import collate_fn_descriptor
+    src, tgt, rot, trans = synthetic.lomatch_pair("C1", 2, overlap=0.3)
+    tsfm = np.eye(4)
+    tsfm[:3, :3], tsfm[:3, 3] = rot, trans.flatten()
+    corr = get_correspondences(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), tsfm, 0.0375)
+    item = dict(src_pcd=src, tgt_pcd=tgt, src_feats=np.ones((len(src), 1), np.float32),
+                tgt_feats=np.ones((len(tgt), 1), np.float32), rot=rot, trans=trans, correspondences=corr.cpu(), sample=0)
+    return collate_fn_descriptor([item], cfg, synthetic.LIMITS["C1"], device=dev)
+
+
+def test_two_c1_train_steps_are_bit_identical(cuda):
+    """Forward with tape + MetricLoss + backward + SGD on the C1 pair, full-width model, twice from the same start: under
+    deterministic=1 every loss value, every parameter gradient of the first step and every parameter after two steps agree
+    bit for bit (split-K-free products, stored-partial statistics, fixed-point scatter sums, ordered loss reductions), and
+    the gradients stay within the usual distance of the default path's."""
+    from pcrcg_amd.config import Config
+    from pcrcg_amd.loss import MetricLoss
+    from pcrcg_amd.trainer import Trainer
+    loss_cfg = Config(pos_margin=0.1, neg_margin=1.4, pos_radius=0.0375, safe_radius=0.1, matchability_radius=0.05, max_points=256)
+    cfg = indoor_config()
+
+    def run(spec):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        net = KPFCNN(cfg).to(cuda)
+        trainer = Trainer(net, MetricLoss(loss_cfg), lr=0.005, momentum=0.98)
+        inputs = _c1_train_inputs(cfg, cuda)
+        try:
+            _debug(spec)
+            np.random.seed(3)
+            stats = trainer.inference_one_batch(inputs, "train")          # forward + loss + backward, gradients kept
+            grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+            trainer.optimizer_step()
+            np.random.seed(3)
+            stats2 = trainer.train_step(inputs)
+            torch.cuda.synchronize()
+        finally:
+            _debug(None)
+        return stats, stats2, grads, {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+    a, b, ref = run("deterministic=1"), run("deterministic=1"), run(None)
+    for k in ("circle_loss", "overlap_loss", "saliency_loss", "total_loss"):
+        assert a[0][k] == b[0][k] and a[1][k] == b[1][k], k
+    assert a[2].keys() == b[2].keys() and len(a[2]) > 100
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+    # the same gradients as the default arithmetic up to summation order
+    worst = max(float((a[2][k].double() - ref[2][k].double()).abs().max() / ref[2][k].double().abs().max().clamp(min=1e-30))
+                for k in a[2])
+    assert worst < 2e-3, worst

@@ -334,7 +334,8 @@ def test_softmax_rows(cuda):
 
 
 @pytest.mark.parametrize("n,ms,heads,d", [(381, 382, 4, 128), (381, 382, 4, 64), (1, 1, 1, 16), (17, 65, 2, 32), (100, 64, 3, 48), (763, 700, 4, 64),
-                                          (33, 1500, 4, 16)])
+                                          (33, 1500, 4, 16), (382, 381, 2, 128), (50, 860, 2, 128), (1, 1, 1, 32), (40, 1050, 3, 64),
+                                          (31, 33, 1, 64)])
 def test_attention_one_launch(cuda, n, ms, heads, d):
     """pcrcg_attention against the reference formulation (ref:models/gcn.py:151-155) in float64, and against the
     per-head GEMM / softmax / GEMM path it replaces in the runner."""
@@ -348,6 +349,13 @@ def test_attention_one_launch(cuda, n, ms, heads, d):
         prob = torch.softmax(q[:, sl].double() @ k[:, sl].double().t() / d ** 0.5, 1)
         want[:, sl] = prob @ v[:, sl].double()
     assert rel(got, want) < 5e-6
+    # the matrix-core kernel (round 5: d in {32, 64, 128}, scores of a 32-query tile in LDS) and the VALU kernel it replaces
+    try:
+        _debug("att_mfma=0")
+        old = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), heads)
+    finally:
+        _debug("att_mfma=1")
+    assert rel(old, want) < 5e-6 and rel(got, old) < 5e-6
     # strided operands (column slices of wider matrices, as the runner's workspace has them)
     wide = torch.randn(max(n, ms), 3 * ch + 8, generator=g).to(cuda)
     qs, ks, vs = wide[:n, 4:4 + ch], wide[:ms, 4 + ch:4 + 2 * ch], wide[:ms, 4 + 2 * ch:4 + 3 * ch]
