@@ -304,6 +304,10 @@ int pcrcg_gemm_f32_fused(const float* a, int lda, const int64_t* idx, int ld_idx
  * validate_gradient) treats inf and NaN alike, so the skip decision does not depend on the mode. */
 void pcrcg_gemm_set_mode(int mode);
 int pcrcg_gemm_get_mode(void);
+/* Diagnostics of the fp16 form's range checks (synchronous; not for the hot path): out2[0] = tiles redone in the bf16 form
+ * since the last reset because an operand value lay beyond fp16's range, out2[1] = because a row lay below it.  reset != 0
+ * clears the counters afterwards.  out2 may be NULL (reset only). */
+int pcrcg_gemm_redo_counts(unsigned long long* out2, int reset);
 /* Declares that the CALLING HOST THREAD enqueues its network calls beside other streams that keep the GPU busy (on = 1;
  * 0 takes it back; per thread, default off).  The products of such a thread are planned with far fewer split-K slices:
  * alone on the GPU a small product is split until ~200 workgroups exist, which fills the chip; beside other streams

@@ -71,6 +71,7 @@ SIGNATURES = {
                                      c_float, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "pcrcg_gemm_set_mode": (None, [c_int]),
     "pcrcg_gemm_get_mode": (c_int, []),
+    "pcrcg_gemm_redo_counts": (c_int, [c_void_p, c_int]),
     "pcrcg_instnorm_stats_from_partials": (c_int, [c_void_p, c_int, c_int, ctypes.c_double, c_float, c_void_p,
                                                    c_void_p]),
     "pcrcg_gather_max": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -362,6 +362,8 @@ static int gemm_mode() {
 }
 extern "C" void pcrcg_gemm_set_mode(int mode) { g_gemm_mode.store(mode != 0, std::memory_order_relaxed); }
 extern "C" void pcrcg_thread_shares_gpu(int on) { gemm_x6_set_shared(on); }
+namespace pcrcg { int gemm_x6_redo_counts(unsigned long long* out, int reset); }
+extern "C" int pcrcg_gemm_redo_counts(unsigned long long* out2, int reset) { return gemm_x6_redo_counts(out2, reset); }
 extern "C" int pcrcg_gemm_get_mode(void) { return gemm_mode(); }
 
 static int gemm_dispatch(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc,

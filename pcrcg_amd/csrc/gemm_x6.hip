@@ -49,6 +49,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK = 32;
 
+// Diagnostics of the fp16 form's two range checks: tiles that took the bf16 redo because of a value beyond fp16's range [0]
+// or because of a row below it [1] (one atomic per such tile; read and reset through pcrcg_gemm_redo_counts)
+__device__ unsigned long long g_x6_redo[2];
+
 // kernel-side form of GemmGroup (common.h): the operands of up to 3 further products; extra = 0: a single product.
 // Product e's row tiles start at row off[e] of the launch's tile space.
 constexpr int kGroupExtra = 3;
@@ -698,6 +702,8 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) bad = bad || !(fabsf(acc[i][j][r]) <= 3.0e38f) || !(fabsf(acc_lo[i][j][r]) <= 3.0e38f);
         if (bad) *s_ovf = 1;
+        __syncthreads();
+        const bool over = *s_ovf != 0;
         // ... and the other end of fp16's range.  Below 2^-14 h is an fp16 SUBNORMAL (below 2^-25 it is zero): the split then
         // has an absolute floor of 2^-36 per value instead of 2^-22 relative.  That is harmless for small values BESIDE larger
         // ones of the same row (the floor stays below 2^-22 of the row's largest value as long as that one is a normal fp16),
@@ -728,6 +734,7 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
         }
         __syncthreads();
         run_x6 = *s_ovf != 0;
+        if (run_x6 && tid == 0) atomicAdd(&g_x6_redo[over ? 0 : 1], 1ull);
         if (run_x6) {                   // out of fp16's range: everything again, with the loop that has fp32's
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -883,6 +890,7 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
     return PCRCG_OK;
 }
 
+
 }  // namespace
 
 // Tile / split choice from the sweep of scripts/gemm_x6_bench.py over the path's shapes: the 64x64 tile wins or
@@ -942,6 +950,16 @@ static X6Plan x6_plan(int m, int n, int k, bool kmajor = false, bool reduce_rows
         if ((long)big.gx * ((rows + 127) / 128) * big.splits >= 240) return big;
     }
     return x6_plan_for((n <= 64 && m >= 32768) ? 1 : 3, m, n, k, reduce_rows);
+}
+
+// tiles the fp16 form handed to the bf16 redo since the last reset: out[0] beyond fp16's range, out[1] rows below it
+int gemm_x6_redo_counts(unsigned long long* out, int reset) {
+    if (out) PCRCG_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x6_redo), sizeof(unsigned long long) * 2));
+    if (reset) {
+        const unsigned long long z[2] = {0ull, 0ull};
+        PCRCG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_x6_redo), z, sizeof(z)));
+    }
+    return PCRCG_OK;
 }
 
 // the split-K factor gemm_x6_dispatch uses for an [m, n, k] product (> 1: it accumulates into a zeroed C)

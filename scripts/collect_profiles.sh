@@ -34,3 +34,17 @@ if [ "${2:-}" = "all" ]; then
   python3 $R/bench.py --pairs-per-forward 1 --steps 50 --warmup 5 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_one_pair_per_forward.json
 fi
 ls -la $O | grep ${TAG}
+# 5. the other workloads under the kernel tracer (kernel breakdown, front chain, concurrency) -- with the SAME library
+if [ "${2:-}" = "all" ]; then
+  cd /tmp
+  for W in K120k T30k; do
+    rm -rf /tmp/pw; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pw -o p -- python3 $R/bench.py --workload $W --steps 30 --warmup 5 --repeats 1 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_${W}_under_rocprof.json
+    python3 $R/scripts/prof_summary.py $(db /tmp/pw) $O/${TAG}_${W}_kernel_stats.csv 62
+    python3 $R/scripts/front_chain.py $(db /tmp/pw) > $O/${TAG}_${W}_front_chain.txt 2>&1
+    python3 $R/scripts/concurrency.py $(db /tmp/pw) > $O/${TAG}_${W}_concurrency.txt 2>&1
+  done
+  bash $R/scripts/collect_train_profile.sh $TAG > /dev/null 2>&1
+  bash $R/scripts/collect_forward_sequence.sh
+  mv $O/r05_forward_sequence.txt $O/${TAG}_forward_sequence.txt 2>/dev/null
+fi
+ls -la $O | grep ${TAG}

@@ -113,3 +113,4 @@ def test_model_with_small_input_features(cuda, golden_dir, scale):
     for key in ("feats_f", "scores_overlap", "scores_saliency"):
         assert MR.rel_err(out[key].cpu(), ref[key]) < 1e-4, (key, MR.rel_err(out[key].cpu(), ref[key]))
         assert MR.rel_err(out_ops[key].cpu(), ref[key]) < 1e-4, (key, "forward_ops")
+
