@@ -271,7 +271,12 @@ TT kpconv(Tape& t, const pcrcg_batch& b, const pcrcg_block& blk, Wt w, const TT&
     if (t.live()) {
         t.check(pcrcg_kpconv_aggregate(q, nq, b.points[l], ns, tab.idx, tab.cols, tab.ld, x.p, cin, blk.kp, blk.extent, wf,
                                        inv_n, ws, wsb, t.st));
-        t.check(gemm_general(wf, kc, 0, w.p, cout, 0, y.p, y.ld, nq, cout, kc, inv_n, nullptr, false, t.st));
+        // the contraction: with the caller's K-contiguous copy of the weights (pcrcg_block.kp_wt, [cout, 15 cin]) the
+        // C = A B^T form with both operands k-contiguous -- the inference runner's product; without it the k-major form
+        if (blk.kp_wt && kc % 4 == 0)
+            t.check(gemm_general(wf, kc, 0, blk.kp_wt, kc, 1, y.p, y.ld, nq, cout, kc, inv_n, nullptr, false, t.st));
+        else
+            t.check(gemm_general(wf, kc, 0, w.p, cout, 0, y.p, y.ld, nq, cout, kc, inv_n, nullptr, false, t.st));
     }
     t.need_scratch(fbytes(nq, kc));
     float* dys = static_cast<float*>(t.value_bytes(fbytes(nq, cout)));          // dy / n: read by the off-path dW product

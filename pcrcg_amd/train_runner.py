@@ -116,6 +116,12 @@ class TrainRunner:
             keep.append(kp.kernel_points.data)
             bv.kp = kp.kernel_points.data.contiguous().data_ptr()
             direct(bv, bg, "kp_w", kp.weights, lambda t: t.reshape(-1, t.shape[-1]))
+            # a K-contiguous copy [cout, 15 cin] for the FORWARD contraction (value only: the gradient belongs to kp_w); one
+            # small transpose per KPConv and step buys the k-contiguous product instead of the k-major one
+            if (kp.weights.shape[0] * kp.weights.shape[1]) % 4 == 0:
+                wt = kp.weights.data.reshape(-1, kp.weights.shape[-1]).t().contiguous()
+                keep.append(wt)
+                bv.kp_wt = wt.data_ptr()
 
         for i, mod in enumerate(m.encoder_blocks):
             bv, bg = v.enc[i], g.enc[i]
