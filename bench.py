@@ -752,7 +752,7 @@ def main():
         traffic, traffic_detail, traffic_offline = None, {"skipped": "--no-pmc / --no-extras / N > 1 / not the S30k fp32 line"}, None
         if not args.no_pmc and not args.no_extras and world == 1 and RECIPE == "S30k" and not BF16:
             traffic, traffic_detail = live_pmc_traffic()
-        for name in ("r04_pmc_kpconv.json", "r03_pmc_kpconv.json", "r02_pmc_kpconv.json"):
+        for name in ("r05_pmc_kpconv.json", "r04_pmc_kpconv.json", "r03_pmc_kpconv.json"):
             pmc_path = os.path.join(REPO, "profiles", name)
             if os.path.exists(pmc_path):
                 traffic_offline = {"hbm_bytes_per_launch": json.load(open(pmc_path)).get("hbm_bytes_per_launch"),
