@@ -57,9 +57,9 @@ int pcrcg_abi_version(void);
  *   att_tq=16                                                                              attention tile
  *   gemm_log=0 x6_tile=-1 x6_splitk=0 x6_t1=32 x6_t2=128 x6_order=-1 x6_big=0 x6_h2=1 gemm_tile=-1 gemm_splitk=0 gemm_split_target=768   GEMM plans
  *   train_side_stream=1                                                                    train-step backward
- *   deterministic=0    1: bit-reproducible results -- no floating-point atomics (no split-K, InstanceNorm statistics from
- *                      stored partials, fixed-point scatter sums in the train step); implies stat_sums=0 x6_splitk=1
- *                      gemm_splitk=1.  Together with a fixed pairing of the pair engine (PairStreams(adaptive_jobs=False))
+ *   deterministic=0    1: bit-reproducible results -- no floating-point atomics (split-K partial tiles stored and added in
+ *                      split order by a second pass, InstanceNorm statistics from stored partials, fixed-point scatter sums
+ *                      in the train step); implies stat_sums=0 gemm_splitk=1; allocates its scratch itself.  Together with a fixed pairing of the pair engine (PairStreams(adaptive_jobs=False))
  *                      outputs are a function of the inputs alone.
  * Returns PCRCG_EBADARG (and changes nothing) on an unknown name. */
 int pcrcg_debug_set(const char* spec);

@@ -148,10 +148,11 @@ struct DebugOpts {
     int train_side_stream = 1; // train-step backward: weight-gradient products on a second stream
     int gemm_tile = -1, gemm_splitk = 0, gemm_split_target = 768;        // fp32-MFMA GEMM plan overrides
     // deterministic=1: results that are a function of the inputs alone, bit for bit, run after run -- no floating-point
-    // atomics anywhere on the path: the products never split K over workgroups (x6_splitk = gemm_splitk = 1), InstanceNorm
-    // statistics come from stored partials and a fixed-order finishing pass (stat_sums = 0), and the train step's scatter
-    // kernels accumulate in 64-bit fixed point (integer addition is associative; trainops.hip).  Slower (DESIGN.md has the
-    // price); the default keeps the atomics.  Setting it overrides the three switches it implies.
+    // atomics anywhere on the path: split-K products store their partial tiles and add them in split order (a second pass,
+    // gemm_x6.hip; the fp32-MFMA kernel does not split: gemm_splitk = 1), InstanceNorm statistics come from stored partials
+    // and a fixed-order finishing pass (stat_sums = 0), and the train step's scatter kernels accumulate in 64-bit fixed
+    // point (integer addition is associative; trainops.hip).  Slower (DESIGN.md has the price); the default keeps the
+    // atomics.  Setting it overrides the two switches it implies.
     int deterministic = 0;
 };
 const DebugOpts& debug_opts();

@@ -28,6 +28,8 @@
 // prefetch), and two or more co-resident blocks per CU overlap one block's split/write phase with the
 // others' MFMA phase.
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 #include <hip/hip_ext.h>
@@ -206,7 +208,7 @@ constexpr int x6_threads() { return (BM == 128 && BN == 128) ? 512 : 256; }
 // picks the cheaper.  Tall products (many row tiles per XCD) keep order 0: A streams once, B's few blocks stay cached.
 // Short, wide ones (the coarse levels: 381 .. 763 rows against 512 .. 2048 output columns) take order 1: every XCD then
 // owns a few column tiles of the weights instead of reading all of them (measured before: fetch = A + 8 B).
-struct TileMap { int gx, gy, gs, order; };
+struct TileMap { int gx, gy, gs, order; long split_stride; };   // split_stride != 0: split s writes its partial tile to C + s * split_stride (no atomics)
 static int x6_tile_order(int gx, int gy, int gs, int bm, int bn, int k_per_split) {
     const int forced = debug_opts().x6_order;
     if (forced >= 0 && forced <= 2) return forced;
@@ -306,6 +308,7 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
     }
     const int k_begin = split * k_per_split;
     const int k_end = min(Kdim, k_begin + k_per_split);
+    C += (long)split * tm.split_stride;          // the deterministic mode's two-pass reduction (gemm_x6_dispatch)
 
     f32x16 acc[TM][TN];
     f32x16 acc_lo[H2 ? TM : 1][H2 ? TN : 1];       // H2: the cross terms ha lb + la hb (worth 2^-11 of acc's units)
@@ -860,6 +863,41 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
     }
 }
 
+// set by gemm_x6_dispatch around a launch whose splits store partial tiles (deterministic mode), 0 / false otherwise
+thread_local long g_split_stride = 0;
+thread_local bool g_det_pass = false;
+// the deterministic mode's partial-tile buffer: one per stream, grown on demand (a debugging mode: synchronous allocation)
+float* det_partials(hipStream_t st, size_t floats) {
+    struct Buf { float* p = nullptr; size_t n = 0; };
+    static std::mutex mu;
+    static std::map<hipStream_t, Buf> bufs;
+    std::lock_guard<std::mutex> g(mu);
+    Buf& b = bufs[st];
+    if (b.n < floats) {
+        if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr;
+        b.n = 0;
+        const size_t want = floats + floats / 4;
+        if (hipMalloc(&b.p, want * sizeof(float)) != hipSuccess) { b.p = nullptr; return nullptr; }
+        b.n = want;
+    }
+    return b.p;
+}
+
+// C (+)= sum over the splits' partial tiles, in split order: the second pass of the deterministic mode's split-K
+__global__ void __launch_bounds__(256) k_split_reduce(const float* __restrict__ part, long stride, int splits, float* __restrict__ c,
+                                                      int ldc, int m, int n, int accumulate) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)m * n) return;
+    const long r = t / n;
+    const int col = (int)(t - r * n);
+    float sum = part[t];
+    for (int s = 1; s < splits; ++s) sum += part[(long)s * stride + t];
+    float* dst = c + r * ldc + col;
+    *dst = accumulate ? *dst + sum : sum;
+}
+
 template <int BM, int BN, int MINB, int ATERMS, int ALAY, int BLAY, int ANORM = 0, int KNOCK = 0, int H2 = 0>
 int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n,
               int k, const float* row_scale, const float* bias, int k_per_split, int vec_a, int vec_b, int atomic_out,
@@ -868,6 +906,7 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
               float a_slope = 1.f, GemmPairArgs pr = GemmPairArgs(), float h2_sa = 1.f, float h2_sb = 1.f) {
     // grid = (column tiles, row tiles, splits) as the caller counts them; launched 1-D (see the kernel's tile order)
     TileMap tm;
+    tm.split_stride = g_split_stride;
     tm.gx = (int)grid.x;
     tm.gy = (int)grid.y;
     tm.gs = (int)grid.z;
@@ -1006,7 +1045,50 @@ int gemm_x6_dispatch(const float* a, int lda, const float* b, int ldb, float* c,
         set_error("gemm_x6: normalise-on-load is built for the 64 x 64 tile of k-contiguous fp32 operands");
         return PCRCG_EBADARG;
     }
-    const int atomic_out = splits > 1 || accumulate;
+    // ---- deterministic mode (PCRCG_DEBUG=deterministic=1): split-K WITHOUT atomics.  The splits store their partial tiles
+    // to a scratch buffer (this very function once more, with C redirected and g_det_pass set: plain stores, split s at
+    // s * split_stride), and k_split_reduce adds them up in split order -- onto C when the product accumulates.  Costs one
+    // extra pass over splits x M x N floats; the scratch is the library's own (per stream, grown on demand).
+    if (splits > 1 && debug_opts().deterministic && !g_det_pass) {
+        const size_t rows_all = (size_t)m_total;
+        float* part = det_partials(st, (size_t)splits * rows_all * (size_t)n);
+        if (!part) { set_error("gemm_x6: no memory for the deterministic mode's partial tiles"); return PCRCG_ELAUNCH; }
+        GemmExtra ex2;
+        if (ex) ex2 = *ex;
+        ex2.accumulate = 0;
+        GemmGroup grp2;
+        size_t row = (size_t)m;
+        if (grp) {
+            grp2 = *grp;
+            for (int e = 0; e < n_extra; ++e) {
+                grp2.p[e].c = part + row * (size_t)n;
+                grp2.p[e].c_zeroed = true;
+                grp2.p[e].colstats = nullptr;
+                if (grp->p[e].h_chunks) *grp->p[e].h_chunks = 0;
+                grp2.p[e].h_chunks = nullptr;
+                row += (size_t)grp->p[e].m;
+            }
+        }
+        g_det_pass = true;
+        g_split_stride = (long)(rows_all * (size_t)n);
+        const int rc = gemm_x6_dispatch(a, lda, b, ldb, part, n, m, n, k, row_scale, bias, nullptr, 0, nullptr, st, a_bf16, true,
+                                        a_kmajor, b_kmajor, false, ex ? &ex2 : nullptr, grp ? &grp2 : nullptr);
+        g_det_pass = false;
+        g_split_stride = 0;
+        if (rc != PCRCG_OK) return rc;
+        row = 0;
+        for (int e = -1; e < n_extra; ++e) {
+            const int me = e < 0 ? m : grp->p[e].m;
+            float* ce = e < 0 ? c : grp->p[e].c;
+            const long total = (long)me * n;
+            hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part + row * (size_t)n,
+                               (long)(rows_all * (size_t)n), splits, ce, ldc, me, n, accumulate ? 1 : 0);
+            row += (size_t)me;
+        }
+        PCRCG_CHECK_LAUNCH();
+        return PCRCG_OK;
+    }
+    const int atomic_out = g_det_pass ? 0 : (splits > 1 || accumulate);
     if (splits > 1 && !c_zeroed && !accumulate) {
         if (ldc == n) PCRCG_CHECK_HIP(hipMemsetAsync(c, 0, (size_t)m * n * sizeof(float), st));
         else PCRCG_CHECK_HIP(hipMemset2DAsync(c, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), m, st));

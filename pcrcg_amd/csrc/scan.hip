@@ -253,8 +253,7 @@ bool debug_parse(const char* spec, const DebugOpts* base) {
     }
     if (d.deterministic) {           // what the switch implies (common.h)
         d.stat_sums = 0;
-        d.x6_splitk = 1;
-        d.gemm_splitk = 1;
+        d.gemm_splitk = 1;       // (the split-bf16 / fp16 family keeps its split-K plans and reduces them in two passes)
     }
     g_debug.store(new DebugOpts(d), std::memory_order_release);
     return true;
