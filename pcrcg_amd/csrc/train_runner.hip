@@ -32,6 +32,9 @@ namespace pcrcg {
 // grad_operand: 1 = A holds gradients, 2 = B does, 0 = neither (see GemmExtra::grad_operand, common.h)
 int gemm_general(const float* a, int lda, int trans_a, const float* b, int ldb, int trans_b, float* c, int ldc, int m, int n,
                  int k, const float* row_scale, const float* bias, bool accumulate, hipStream_t st, int grad_operand = 0);
+int gemm_bt_colstats(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k,
+                     const float* row_scale, const float* bias, void* colstats, size_t colstats_bytes, int* h_chunks,
+                     hipStream_t st, bool c_zeroed, bool colstats_sums);
 int tr_scale_rows(const float* src, int ld_src, const float* s, float* dst, int rows, int cols, hipStream_t st);
 int tr_add_lrelu(const float* a, int lda, const float* b, int ldb, float slope, float* y, int ldy, int rows, int cols,
                  hipStream_t st);
@@ -146,6 +149,19 @@ struct Tape {
         return t;
     }
     void* value_bytes(size_t bytes) { void* q = val.take(bytes); fits(); return q; }
+    // [2][c] fp64 column-sum accumulators for a product whose epilogue leaves its output's InstanceNorm statistics (round 5):
+    // carved from the head of the SCRATCH region, which only the backward uses and which the forward clears once up to
+    // kSumsBytes; NULL when that head is used up (the norm then makes its own pass, as before)
+    static constexpr size_t kSumsBytes = 1 << 20;
+    size_t sums_off = 0;
+    double* sums_slot(int c) {
+        const size_t bytes = ((size_t)2 * c * sizeof(double) + 255) & ~size_t(255);
+        if (dry || !scratch.base || !debug_opts().stat_sums || sums_off + bytes > kSumsBytes || sums_off + bytes > scratch.cap)
+            return nullptr;              // (stat_sums = 0 -- the deterministic mode -- keeps the atomics-free statistics pass)
+        double* q = reinterpret_cast<double*>(scratch.base + sums_off);
+        sums_off += bytes;
+        return q;
+    }
     void need_scratch(size_t bytes) { if (bytes > bw_scratch) bw_scratch = bytes; }
     template <typename F> void record(F&& f) { if (!dry) bw.emplace_back(std::forward<F>(f)); }
     // backward-time scratch (stack discipline inside one operator)
@@ -178,10 +194,22 @@ inline size_t fbytes(long rows, long cols) { return sizeof(float) * (size_t)(row
 // ---- operators: forward now, backward recorded ---------------------------------------------------------------------
 
 // y = x @ W^T (+ bias); W [out, in] with leading dimension ldw   (nn.Linear / 1x1 convolution on row-major features)
-TT linear(Tape& t, const TT& x, Wt w, int ldw, Wt bias, int out, TT* into = nullptr) {
+// sums_out (optional): receives fp64 column sums [2][out] of y left by the product's epilogue (for the InstanceNorm that
+// follows), or NULL when this product could not leave them (split over K, no slot)
+TT linear(Tape& t, const TT& x, Wt w, int ldw, Wt bias, int out, TT* into = nullptr, const double** sums_out = nullptr) {
     TT y = into ? *into : t.tensor(x.rows, out);
-    if (t.live())
-        t.check(gemm_general(x.p, x.ld, 0, w.p, ldw, 1, y.p, y.ld, x.rows, out, x.cols, nullptr, bias.p, false, t.st));
+    if (sums_out) *sums_out = nullptr;
+    if (t.live()) {
+        double* slot = sums_out ? t.sums_slot(out) : nullptr;
+        if (slot) {
+            int chunks = 0;
+            t.check(gemm_bt_colstats(x.p, x.ld, w.p, ldw, y.p, y.ld, x.rows, out, x.cols, nullptr, bias.p, slot,
+                                     (size_t)2 * out * sizeof(double), &chunks, t.st, false, true));
+            if (chunks == -1) *sums_out = slot;
+        } else {
+            t.check(gemm_general(x.p, x.ld, 0, w.p, ldw, 1, y.p, y.ld, x.rows, out, x.cols, nullptr, bias.p, false, t.st));
+        }
+    }
     t.record([x, y, w, ldw, bias, out](Tape& b) {
         if (x.g)     // dx += dy @ W
             b.check(gemm_general(y.g, y.ld, 0, w.p, ldw, 0, x.g, x.ld, x.rows, x.cols, out, nullptr, nullptr, true, b.st, 1));
@@ -220,13 +248,15 @@ TT matmul_nn(Tape& t, const TT& p, const TT& v, TT* into = nullptr) {
 }
 
 // InstanceNorm over the rows + LeakyReLU(slope)  (ref:models/blocks.py:448-462); x has this one consumer
-TT instnorm_lrelu(Tape& t, const TT& x, float slope, TT* into = nullptr) {
+// sums: the producing product's column sums (linear / kpconv with sums_out), or NULL: the statistics take their own pass
+TT instnorm_lrelu(Tape& t, const TT& x, float slope, TT* into = nullptr, const double* sums = nullptr) {
     TT y = into ? *into : t.tensor(x.rows, x.cols);
     float* stats = static_cast<float*>(t.value_bytes(sizeof(float) * 2 * x.cols));
     const size_t wsb = pcrcg_instnorm_ws_bytes(x.cols), bwb = pcrcg_instnorm_backward_ws_bytes(x.cols);
     void* ws = t.value_bytes(wsb);
     if (t.live()) {
-        t.check(pcrcg_instnorm_stats(x.p, x.rows, x.cols, x.ld, 1e-5f, stats, ws, wsb, t.st));
+        if (sums) t.check(pcrcg_instnorm_stats_from_partials(sums, 1, x.cols, (double)x.rows, 1e-5f, stats, t.st));
+        else t.check(pcrcg_instnorm_stats(x.p, x.rows, x.cols, x.ld, 1e-5f, stats, ws, wsb, t.st));
         t.check(pcrcg_instnorm_apply(x.p, x.rows, x.cols, x.ld, stats, nullptr, 0, nullptr, slope, y.p, y.ld, t.st));
     }
     t.need_scratch(bwb + 256);
@@ -257,7 +287,8 @@ void copy_into(Tape& t, const TT& src, const TT& dst_slice) {
 }
 
 // KPConv.forward (ref:models/blocks.py:229-374): aggregate, contract, divide by the neighbour count
-TT kpconv(Tape& t, const pcrcg_batch& b, const pcrcg_block& blk, Wt w, const TT& x) {
+TT kpconv(Tape& t, const pcrcg_batch& b, const pcrcg_block& blk, Wt w, const TT& x, const double** sums_out = nullptr) {
+    if (sums_out) *sums_out = nullptr;
     const int l = blk.layer;
     const pcrcg_table& tab = blk.strided ? b.pools[l] : b.neighbors[l];
     const float* q = blk.strided ? b.points[l + 1] : b.points[l];
@@ -273,7 +304,13 @@ TT kpconv(Tape& t, const pcrcg_batch& b, const pcrcg_block& blk, Wt w, const TT&
                                        inv_n, ws, wsb, t.st));
         // the contraction: with the caller's K-contiguous copy of the weights (pcrcg_block.kp_wt, [cout, 15 cin]) the
         // C = A B^T form with both operands k-contiguous -- the inference runner's product; without it the k-major form
-        if (blk.kp_wt && kc % 4 == 0)
+        double* slot = (sums_out && blk.kp_wt && kc % 4 == 0) ? t.sums_slot(cout) : nullptr;
+        if (slot) {
+            int chunks = 0;
+            t.check(gemm_bt_colstats(wf, kc, blk.kp_wt, kc, y.p, y.ld, nq, cout, kc, inv_n, nullptr, slot,
+                                     (size_t)2 * cout * sizeof(double), &chunks, t.st, false, true));
+            if (chunks == -1) *sums_out = slot;
+        } else if (blk.kp_wt && kc % 4 == 0)
             t.check(gemm_general(wf, kc, 0, blk.kp_wt, kc, 1, y.p, y.ld, nq, cout, kc, inv_n, nullptr, false, t.st));
         else
             t.check(gemm_general(wf, kc, 0, w.p, cout, 0, y.p, y.ld, nq, cout, kc, inv_n, nullptr, false, t.st));
@@ -337,18 +374,25 @@ TT softmax_rows(Tape& t, const TT& s, float scale, float* scale_grad = nullptr) 
 
 // ---- blocks (ref:models/blocks.py) ---------------------------------------------------------------------------------
 TT unary(Tape& t, const TT& x, Wt w, int ldw, int out, float slope) {
-    TT y = linear(t, x, w, ldw, Wt(), out);
-    return instnorm_lrelu(t, y, slope);
+    const double* sums = nullptr;
+    TT y = linear(t, x, w, ldw, Wt(), out, nullptr, &sums);
+    return instnorm_lrelu(t, y, slope, nullptr, sums);
 }
 
 Wt wt(const float* p, const float* g) { Wt w; w.p = p; w.g = const_cast<float*>(g); return w; }
 
 TT encoder_block(Tape& t, const pcrcg_batch& b, const pcrcg_block& blk, const pcrcg_block& gb, const TT& x) {
-    if (blk.type == PCRCG_BLK_SIMPLE)                                            // :579-590
-        return instnorm_lrelu(t, kpconv(t, b, blk, wt(blk.kp_w, gb.kp_w), x), 0.1f);
+    const double* ksums = nullptr;
+    if (blk.type == PCRCG_BLK_SIMPLE) {                                          // :579-590
+        TT c0 = kpconv(t, b, blk, wt(blk.kp_w, gb.kp_w), x, &ksums);
+        return instnorm_lrelu(t, c0, 0.1f, nullptr, ksums);
+    }
     TT y = x;                                                                    // resnetb :650-678
     if (blk.unary1) y = unary(t, x, wt(blk.unary1, gb.unary1), x.cols, blk.mid_dim, 0.1f);
-    y = instnorm_lrelu(t, kpconv(t, b, blk, wt(blk.kp_w, gb.kp_w), y), 0.1f);
+    {
+        TT c1 = kpconv(t, b, blk, wt(blk.kp_w, gb.kp_w), y, &ksums);
+        y = instnorm_lrelu(t, c1, 0.1f, nullptr, ksums);
+    }
     y = unary(t, y, wt(blk.unary2, gb.unary2), blk.mid_dim, blk.out_dim, 1.0f);  // no_relu
     TT sc = blk.strided ? max_pool(t, x, b.pools[blk.layer]) : x;
     if (blk.shortcut) sc = unary(t, sc, wt(blk.shortcut, gb.shortcut), sc.cols, blk.out_dim, 1.0f);
@@ -548,6 +592,14 @@ int pcrcg_kpfcnn_train_forward(const pcrcg_model* model, const pcrcg_model* grad
     t->grad.cap = grad_bytes;
     t->scratch.base = base + value_bytes + grad_bytes;
     t->scratch.cap = scratch_bytes;
+    {   // the column-sum slots of the forward's products (Tape::sums_slot)
+        const size_t head = scratch_bytes < Tape::kSumsBytes ? scratch_bytes : Tape::kSumsBytes;
+        if (head && hipMemsetAsync(t->scratch.base, 0, head, t->st) != hipSuccess) {
+            delete t;
+            set_error("pcrcg_kpfcnn_train_forward: clearing the statistics slots failed");
+            return PCRCG_ELAUNCH;
+        }
+    }
     forward(*t, *model, *grads, *batch);
     if (t->rc == PCRCG_OK) {
         // heads (:571-582): L2-normalised descriptors, sigmoid scores

@@ -13,7 +13,10 @@ _real = pyramid.NativePyramid.build
 
 
 def cached_build(self, points, lengths, fresh_arena=False, defer_restore=False, group=0):
-    key = (int(points.shape[0]) // 1000, int(lengths.shape[0]), bool(defer_restore), int(group))
+    if isinstance(points, (list, tuple)):            # a grouped build hands its pairs over as parts
+        key = (sum(int(p.shape[0]) for p in points) // 1000, sum(int(l.shape[0]) for l in lengths), bool(defer_restore), int(group))
+    else:
+        key = (int(points.shape[0]) // 1000, int(lengths.shape[0]), bool(defer_restore), int(group))
     cache = self.__dict__.setdefault("_knock_cache", {})
     if key not in cache:
         cache[key] = _real(self, points, lengths, fresh_arena, defer_restore, group)
