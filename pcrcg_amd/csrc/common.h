@@ -106,6 +106,19 @@ int kpconv_aggregate_bf16(const float* q_pts, int nq, const float* s_pts, int ns
                           const float* x, unsigned short* x_bf16, int cin, const float* kp, float extent,
                           unsigned short* wf_bf16, float* inv_n, void* ws, size_t ws_bytes, hipStream_t st);
 
+// InstanceNorm + LeakyReLU from fp64 column sums for up to four tensors of one width in one launch (pointops.hip)
+struct NormJob {
+    const float* x; const double* sums; const float* res; const double* res_sums; float* y;
+    const float* s_pts; float4* pk;      // pack form only: the KPConv support records of the output rows
+    int n; double count;
+};
+int instnorm_apply_sums_multi(const NormJob* jobs, int count, int c, int ldx, float eps, int ldr, float slope, int ldy, bool pack,
+                              hipStream_t st);
+
+int copy2d_multi(const float* const* src, float* const* dst, const int* rows, int count, int ld_src, int ld_dst, int cols,
+                 hipStream_t st);
+int instnorm_colsums_multi(const float* const* x, double* const* sums, const int* n, int count, int c, int ldx, hipStream_t st);
+
 // DGCNN edge convolution (gnn.hip): emax + InstanceNorm2d statistics of up to four clouds in one launch (k_edgeconv_rows)
 struct EdgeCloud {
     const float* ctr; const float* nbr; const int* idx; float* emax; double* sums; int n, k;

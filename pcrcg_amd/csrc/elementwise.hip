@@ -6,8 +6,11 @@
 namespace pcrcg {
 namespace {
 
-__global__ void __launch_bounds__(256) k_copy2d(const float* __restrict__ src, int ld_src, float* __restrict__ dst,
-                                                 int ld_dst, int rows, int cols) {
+struct CopyMulti { const float* src[4]; float* dst[4]; int rows[4]; };      // up to four copies of one width per launch (blockIdx.y)
+__global__ void __launch_bounds__(256) k_copy2d(CopyMulti mm, int ld_src, int ld_dst, int cols) {
+    const float* __restrict__ src = mm.src[blockIdx.y];
+    float* __restrict__ dst = mm.dst[blockIdx.y];
+    const int rows = mm.rows[blockIdx.y];
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long)rows * cols) return;
     const long r = e / cols;
@@ -73,6 +76,27 @@ __global__ void __launch_bounds__(256) k_inject_image(const float* __restrict__ 
 }
 
 }  // namespace
+
+// dst_g[r, :cols] = src_g[r, :cols] for up to four (src, dst, rows) of one width and one pair of leading dimensions: one launch
+int copy2d_multi(const float* const* src, float* const* dst, const int* rows, int count, int ld_src, int ld_dst, int cols,
+                 hipStream_t st) {
+    PCRCG_CHECK_ARG(count >= 1 && count <= 4 && cols >= 0 && ld_src >= cols && ld_dst >= cols);
+    CopyMulti mm;
+    int rmax = 0;
+    for (int g = 0; g < 4; ++g) {
+        const int k = g < count ? g : 0;
+        mm.src[g] = src[k]; mm.dst[g] = dst[k]; mm.rows[g] = g < count ? rows[k] : 0;
+        if (g < count) {
+            PCRCG_CHECK_ARG(rows[k] >= 0 && (rows[k] == 0 || (src[k] && dst[k])));
+            rmax = rows[k] > rmax ? rows[k] : rmax;
+        }
+    }
+    if (rmax == 0 || cols == 0) return PCRCG_OK;
+    const long total = (long)rmax * cols;
+    hipLaunchKernelGGL(k_copy2d, dim3((unsigned)((total + 255) / 256), count), dim3(256), 0, st, mm, ld_src, ld_dst, cols);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
 }  // namespace pcrcg
 
 using namespace pcrcg;
@@ -107,11 +131,7 @@ int pcrcg_copy2d(const float* src, int ld_src, float* dst, int ld_dst, int rows,
     PCRCG_CHECK_ARG(rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= cols);
     if (rows == 0 || cols == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(src && dst);
-    const long total = (long)rows * cols;
-    hipLaunchKernelGGL(k_copy2d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), src, ld_src,
-                       dst, ld_dst, rows, cols);
-    PCRCG_CHECK_LAUNCH();
-    return PCRCG_OK;
+    return pcrcg::copy2d_multi(&src, &dst, &rows, 1, ld_src, ld_dst, cols, as_stream(stream));
 }
 
 int pcrcg_add(const float* a, const float* b, float* dst, long n, void* stream) {

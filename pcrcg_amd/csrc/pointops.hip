@@ -67,9 +67,12 @@ __global__ void __launch_bounds__(256) k_gather_first(const float* __restrict__ 
 // ---- InstanceNorm statistics: deterministic two-stage column reduction in fp64 -----------------
 constexpr int kStatChunks = 128;   // row chunks (= partial sums per channel)
 
+struct ColsMulti { const float* x[4]; double* partial[4]; int n[4]; };      // up to four tensors per launch (blockIdx.z)
 template <bool ATOMIC>      // ATOMIC: add the chunk's sums into zeroed [2][c] accumulators instead of storing partials
-__global__ void __launch_bounds__(256) k_colstats_partial(const float* __restrict__ x, int n, int c, int ldx,
-                                                           double* __restrict__ partial /* [2][c][chunks] */) {
+__global__ void __launch_bounds__(256) k_colstats_partial(ColsMulti mm, int c, int ldx) {
+    const float* __restrict__ x = mm.x[blockIdx.z];
+    double* __restrict__ partial = mm.partial[blockIdx.z];    /* [2][c][chunks] */
+    const int n = mm.n[blockIdx.z];
     __shared__ double s_sum[4][64], s_sq[4][64];
     const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int ch = blockIdx.y * 64 + lane;
@@ -197,12 +200,24 @@ __device__ __forceinline__ void stats4_from_sums(const double* __restrict__ sums
 // k_instnorm_apply4 with the statistics taken from fp64 column SUMS (what the GEMM epilogue's sums mode leaves): no
 // finishing launch in between.  A thread keeps four channels and walks rows, so the fp64 arithmetic is paid once per
 // thread.  RES: 0 none, 1 residual as is, 2 residual normalised by its own sums.
+// (round 5: up to four tensors of one shape class per launch -- blockIdx.y -- the pairs of one forward call)
+struct NormMulti {
+    const float* x[4]; const double* sums[4]; const float* res[4]; const double* res_sums[4]; float* y[4];
+    const float* s_pts[4]; float4* pk[4];
+    int n[4]; double count[4];
+};
 template <int RES>
-__global__ void __launch_bounds__(256) k_instnorm_apply4_sums(const float* __restrict__ x, int n, int c4, int ldx,
-                                                               const double* __restrict__ sums, double count, float eps,
-                                                               const float* __restrict__ res, int ldr,
-                                                               const double* __restrict__ res_sums, float slope,
-                                                               float* __restrict__ y, int ldy, int rows_per_block) {
+__global__ void __launch_bounds__(256) k_instnorm_apply4_sums(NormMulti mm, int c4, int ldx, float eps, int ldr, float slope, int ldy,
+                                                               int rows_per_block) {
+    const int g = blockIdx.y;
+    const float* __restrict__ x = mm.x[g];
+    const double* __restrict__ sums = mm.sums[g];
+    const float* __restrict__ res = mm.res[g];
+    const double* __restrict__ res_sums = mm.res_sums[g];
+    float* __restrict__ y = mm.y[g];
+    const int n = mm.n[g];
+    const double count = mm.count[g];
+    if ((long)blockIdx.x * rows_per_block >= n) return;
     const int cb = c4 < 256 ? c4 : 256;          // channel groups per pass (c4 is a power of two times ... see host check)
     const int rp = 256 / cb;                     // rows handled at once
     const int r_lo = blockIdx.x * rows_per_block, r_hi = min(n, r_lo + rows_per_block);
@@ -267,11 +282,17 @@ __global__ void __launch_bounds__(256) k_instnorm_apply4_pack(const float* __res
     if (q == 0) pk[r] = make_float4(s_pts[3 * r], s_pts[3 * r + 1], s_pts[3 * r + 2], part > 0.0f ? 1.f : 0.f);
 }
 
-__global__ void __launch_bounds__(256) k_instnorm_apply4_sums_pack(const float* __restrict__ x, int n, int c4, int ldx,
-                                                                    const double* __restrict__ sums, double count, float eps,
-                                                                    float slope, float* __restrict__ y, int ldy,
-                                                                    int rows_per_block, const float* __restrict__ s_pts,
-                                                                    float4* __restrict__ pk) {
+__global__ void __launch_bounds__(256) k_instnorm_apply4_sums_pack(NormMulti mm, int c4, int ldx, float eps, float slope, int ldy,
+                                                                    int rows_per_block) {
+    const int g = blockIdx.y;
+    const float* __restrict__ x = mm.x[g];
+    const double* __restrict__ sums = mm.sums[g];
+    float* __restrict__ y = mm.y[g];
+    const float* __restrict__ s_pts = mm.s_pts[g];
+    float4* __restrict__ pk = mm.pk[g];
+    const int n = mm.n[g];
+    const double count = mm.count[g];
+    if ((long)blockIdx.x * rows_per_block >= n) return;
     const int rp = 256 / c4;                           // c4 <= 64 divides 64: one pass over the channel groups
     const int r_lo = blockIdx.x * rows_per_block, r_hi = min(n, r_lo + rows_per_block);
     const int q = (int)(threadIdx.x % c4);
@@ -293,6 +314,9 @@ __global__ void __launch_bounds__(256) k_instnorm_apply4_sums_pack(const float* 
 
 }  // namespace
 
+int instnorm_apply_sums_multi(const NormJob* jobs, int count, int c, int ldx, float eps, int ldr, float slope, int ldy, bool pack,
+                              hipStream_t st);
+
 // Normalise + LeakyReLU (no residual) and leave the KPConv support records of the output rows in `pk` (see the kernels).
 // Statistics as (mean, rstd) pairs (`stats`) or as fp64 column sums (`sums`, `count`); exactly one of the two.
 bool instnorm_pack_ok(int c, int ldx, int ldy) {
@@ -310,12 +334,45 @@ int instnorm_apply_pack(const float* x, int n, int c, int ldx, const float* stat
         hipLaunchKernelGGL(k_instnorm_apply4_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, n, c4, ldx, stats,
                            slope, y, ldy, s_pts, pk);
     } else {
-        const int rp = 256 / c4;
-        int rows_per_block = rp * 8;
-        while (rows_per_block > rp && (long)(n + rows_per_block - 1) / rows_per_block < 256) rows_per_block -= rp;
-        hipLaunchKernelGGL(k_instnorm_apply4_sums_pack, dim3((unsigned)((n + rows_per_block - 1) / rows_per_block)), dim3(256), 0,
-                           st, x, n, c4, ldx, sums, count, eps, slope, y, ldy, rows_per_block, s_pts, pk);
+        NormJob one{x, sums, nullptr, nullptr, y, s_pts, pk, n, count};
+        return instnorm_apply_sums_multi(&one, 1, c, ldx, eps, 0, slope, ldy, true, st);
     }
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+// lrelu(IN(x) [+ res | + IN(res)]) for up to four tensors of one width in ONE launch (the pairs of a forward call); pack: also
+// leave the KPConv support records (instnorm_apply_pack).  The caller has checked the layout rules of the single-tensor entry.
+int instnorm_apply_sums_multi(const NormJob* jobs, int count, int c, int ldx, float eps, int ldr, float slope, int ldy, bool pack,
+                              hipStream_t st) {
+    PCRCG_CHECK_ARG(jobs && count >= 1 && count <= 4 && c >= 4 && c % 4 == 0);
+    const int c4 = c / 4;
+    NormMulti mm;
+    int nmax = 0;
+    for (int g = 0; g < 4; ++g) {
+        const NormJob& j = jobs[g < count ? g : 0];
+        mm.x[g] = j.x; mm.sums[g] = j.sums; mm.res[g] = j.res; mm.res_sums[g] = j.res_sums; mm.y[g] = j.y;
+        mm.s_pts[g] = j.s_pts; mm.pk[g] = j.pk; mm.n[g] = g < count ? j.n : 0; mm.count[g] = j.count;
+        if (g < count) {
+            PCRCG_CHECK_ARG(j.n >= 0 && j.x && j.sums && j.y && j.count >= 1.0);
+            PCRCG_CHECK_ARG((j.res != nullptr) == (jobs[0].res != nullptr) && (j.res_sums != nullptr) == (jobs[0].res_sums != nullptr));
+            nmax = j.n > nmax ? j.n : nmax;
+        }
+    }
+    if (nmax == 0) return PCRCG_OK;
+    const int rp = 256 / (c4 < 256 ? c4 : 256);
+    // ~8 rows per thread, but at least ~256 workgroups' worth of parallelism on small inputs
+    int rows_per_block = rp * 8;
+    while (rows_per_block > rp && (long)(nmax + rows_per_block - 1) / rows_per_block * count < 256) rows_per_block -= rp;
+    const dim3 grid((unsigned)((nmax + rows_per_block - 1) / rows_per_block), count);
+    if (pack)
+        hipLaunchKernelGGL(k_instnorm_apply4_sums_pack, grid, dim3(256), 0, st, mm, c4, ldx, eps, slope, ldy, rows_per_block);
+    else if (!jobs[0].res)
+        hipLaunchKernelGGL(k_instnorm_apply4_sums<0>, grid, dim3(256), 0, st, mm, c4, ldx, eps, ldr, slope, ldy, rows_per_block);
+    else if (!jobs[0].res_sums)
+        hipLaunchKernelGGL(k_instnorm_apply4_sums<1>, grid, dim3(256), 0, st, mm, c4, ldx, eps, ldr, slope, ldy, rows_per_block);
+    else
+        hipLaunchKernelGGL(k_instnorm_apply4_sums<2>, grid, dim3(256), 0, st, mm, c4, ldx, eps, ldr, slope, ldy, rows_per_block);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -330,6 +387,25 @@ int colstats_finalize(const double* partial, int nchunks, int c, double count, f
     return PCRCG_OK;
 }
 int colstats_chunks() { return kStatChunks; }
+
+// column sums (sum, sum of squares) of up to four [n_g, c] tensors added into their zeroed [2][c] fp64 accumulators, one launch
+int instnorm_colsums_multi(const float* const* x, double* const* sums, const int* n, int count, int c, int ldx, hipStream_t st) {
+    PCRCG_CHECK_ARG(count >= 1 && count <= 4 && c >= 1 && ldx >= c);
+    ColsMulti mm;
+    int nmax = 0;
+    for (int g = 0; g < 4; ++g) {
+        const int k = g < count ? g : 0;
+        PCRCG_CHECK_ARG(n[k] >= 1 && x[k] && sums[k]);
+        mm.x[g] = x[k]; mm.partial[g] = sums[k]; mm.n[g] = n[k];
+        if (g < count) nmax = n[k] > nmax ? n[k] : nmax;
+    }
+    // enough row chunks to fill the chip on tall inputs, few on short ones (each adds 2 atomics per channel)
+    int chunks = (nmax + 63) / 64;
+    if (chunks > kStatChunks) chunks = kStatChunks;
+    hipLaunchKernelGGL(k_colstats_partial<true>, dim3(chunks, (c + 63) / 64, count), dim3(256), 0, st, mm, c, ldx);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
 
 }  // namespace pcrcg
 
@@ -385,19 +461,19 @@ int pcrcg_instnorm_stats(const float* x, int n, int c, int ldx, float eps, float
     double* partial = cv.take<double>((size_t)kStatChunks * 2 * c);
     PCRCG_CHECK_WS(cv);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(k_colstats_partial<false>, dim3(kStatChunks, (c + 63) / 64), dim3(256), 0, st, x, n, c, ldx, partial);
+    {
+        ColsMulti mm;
+        for (int g = 0; g < 4; ++g) { mm.x[g] = x; mm.partial[g] = partial; mm.n[g] = n; }
+        hipLaunchKernelGGL(k_colstats_partial<false>, dim3(kStatChunks, (c + 63) / 64, 1), dim3(256), 0, st, mm, c, ldx);
+    }
     return colstats_finalize(partial, kStatChunks, c, (double)n, eps, stats, st);
 }
 
 int pcrcg_instnorm_colsums(const float* x, int n, int c, int ldx, void* sums, void* stream) {
     PCRCG_CHECK_ARG(n >= 1 && c >= 1 && ldx >= c && x && sums);
-    // enough row chunks to fill the chip on tall inputs, few on short ones (each adds 2 atomics per channel)
-    int chunks = (n + 63) / 64;
-    if (chunks > kStatChunks) chunks = kStatChunks;
-    hipLaunchKernelGGL(k_colstats_partial<true>, dim3(chunks, (c + 63) / 64), dim3(256), 0, as_stream(stream), x, n, c, ldx,
-                       static_cast<double*>(sums));
-    PCRCG_CHECK_LAUNCH();
-    return PCRCG_OK;
+    const float* xs[1] = {x};
+    double* ss[1] = {static_cast<double*>(sums)};
+    return instnorm_colsums_multi(xs, ss, &n, 1, c, ldx, as_stream(stream));
 }
 
 int pcrcg_instnorm_apply_sums(const float* x, int n, int c, int ldx, const void* sums, double count, float eps,
@@ -411,25 +487,8 @@ int pcrcg_instnorm_apply_sums(const float* x, int n, int c, int ldx, const void*
     // the kernel's thread -> channel-group map needs the groups to tile 256 threads (or be a multiple of 256)
     PCRCG_CHECK_ARG((c4 <= 256 ? 256 % c4 == 0 : c4 % 256 == 0) && ldx % 4 == 0 && ldy % 4 == 0 && al16(x) && al16(y) &&
                     (!res || (ldr % 4 == 0 && al16(res))));
-    const int rp = 256 / (c4 < 256 ? c4 : 256);
-    // ~8 rows per thread, but at least ~256 workgroups' worth of parallelism on small inputs
-    int rows_per_block = rp * 8;
-    while (rows_per_block > rp && (long)(n + rows_per_block - 1) / rows_per_block < 256) rows_per_block -= rp;
-    const unsigned blocks = (unsigned)((n + rows_per_block - 1) / rows_per_block);
-    hipStream_t st = as_stream(stream);
-    const double* s = static_cast<const double*>(sums);
-    const double* rs = static_cast<const double*>(res_sums);
-    if (!res)
-        hipLaunchKernelGGL(k_instnorm_apply4_sums<0>, dim3(blocks), dim3(256), 0, st, x, n, c4, ldx, s, count, eps, res, ldr, rs,
-                           slope, y, ldy, rows_per_block);
-    else if (!res_sums)
-        hipLaunchKernelGGL(k_instnorm_apply4_sums<1>, dim3(blocks), dim3(256), 0, st, x, n, c4, ldx, s, count, eps, res, ldr, rs,
-                           slope, y, ldy, rows_per_block);
-    else
-        hipLaunchKernelGGL(k_instnorm_apply4_sums<2>, dim3(blocks), dim3(256), 0, st, x, n, c4, ldx, s, count, eps, res, ldr, rs,
-                           slope, y, ldy, rows_per_block);
-    PCRCG_CHECK_LAUNCH();
-    return PCRCG_OK;
+    NormJob one{x, static_cast<const double*>(sums), res, static_cast<const double*>(res_sums), y, nullptr, nullptr, n, count};
+    return instnorm_apply_sums_multi(&one, 1, c, ldx, eps, ldr, slope, ldy, false, as_stream(stream));
 }
 
 int pcrcg_instnorm_apply(const float* x, int n, int c, int ldx, const float* stats, const float* res,

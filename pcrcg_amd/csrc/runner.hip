@@ -186,6 +186,15 @@ void col_stats(Ctx& c, const Mat& x, int g, const Stat* s, float* stats, void* w
 // sums-mode statistics the producing product could not leave (a split-K product): one pass into the same accumulators
 void fill_sums(Ctx& c, const Mat& x, Stat* xs) {
     if (!c.live() || !xs || !xs->sums) return;
+    {   // the pairs whose product left nothing: one launch for all of them
+        const float* xp[GMAX]; double* sp[GMAX]; int np[GMAX]; int idx[GMAX]; int cnt = 0;
+        for (int g = 0; g < c.G && cnt < 4; ++g)
+            if (xs->chunks[g] == 0 && x.rows[g] >= 1) { xp[cnt] = x.p[g]; sp[cnt] = static_cast<double*>(xs->partials[g]); np[cnt] = x.rows[g]; idx[cnt++] = g; }
+        if (cnt >= 2) {
+            c.check(instnorm_colsums_multi(xp, sp, np, cnt, x.cols, x.ld, c.st));
+            for (int i = 0; i < cnt; ++i) xs->chunks[idx[i]] = -1;
+        }
+    }
     for (int g = 0; g < c.G; ++g)
         if (xs->chunks[g] == 0) {
             c.check(pcrcg_instnorm_colsums(x.p[g], x.rows[g], x.cols, x.ld, xs->partials[g], c.st));
@@ -205,6 +214,20 @@ void norm_act(Ctx& c, const Mat& x, float slope, const Mat& y, Stat* xs = nullpt
     fill_sums(c, x, xs);
     if (res && norm_res) fill_sums(c, *res, rs);
     if (c.live() && all_sums(c, xs) && (!res || !norm_res || all_sums(c, rs)) && sums_apply_ok(x, y, res)) {
+        // every pair of the call in ONE launch (round 5: a launch per pair cost the stream ~5 us of queue time each)
+        NormJob jobs[GMAX];
+        bool al = true;
+        for (int g = 0; g < c.G; ++g) {
+            jobs[g] = NormJob{x.p[g], static_cast<const double*>(xs->partials[g]), res ? res->p[g] : nullptr,
+                              (res && norm_res) ? static_cast<const double*>(rs->partials[g]) : nullptr, y.p[g], nullptr, nullptr,
+                              x.rows[g], (double)(x.rows[g] > 0 ? x.rows[g] : 1)};
+            al = al && ((reinterpret_cast<uintptr_t>(x.p[g]) | reinterpret_cast<uintptr_t>(y.p[g]) |
+                         reinterpret_cast<uintptr_t>(res ? res->p[g] : nullptr)) & 15) == 0;
+        }
+        if (al && c.G <= 4) {
+            c.check(instnorm_apply_sums_multi(jobs, c.G, x.cols, x.ld, 1e-5f, res ? res->ld : 0, slope, y.ld, false, c.st));
+            return;
+        }
         for (int g = 0; g < c.G; ++g)
             c.check(pcrcg_instnorm_apply_sums(x.p[g], x.rows[g], x.cols, x.ld, xs->partials[g], (double)x.rows[g], 1e-5f,
                                               res ? res->p[g] : nullptr, res ? res->ld : 0,
@@ -451,6 +474,21 @@ bool norm_act_pack(Ctx& c, const Batches& B, int layer, const Mat& t, float slop
     const size_t wsb = pcrcg_instnorm_ws_bytes(t.cols);
     void* ws = c.raw(wsb);
     fill_sums(c, t, ts);              // a split-K product left nothing: one pass into the accumulators
+    if (c.live() && all_sums(c, ts) && c.G <= 4) {          // every pair of the call in one launch
+        NormJob jobs[GMAX];
+        bool ok = true;
+        for (int g = 0; g < c.G; ++g) {
+            float4* pk = kpconv_pk_ptr(kp_ws[g], kp_ws_bytes[g], t.rows[g]);
+            ok = ok && pk != nullptr && ((reinterpret_cast<uintptr_t>(t.p[g]) | reinterpret_cast<uintptr_t>(u.p[g])) & 15) == 0;
+            jobs[g] = NormJob{t.p[g], static_cast<const double*>(ts->partials[g]), nullptr, nullptr, u.p[g], B.b[g]->points[layer], pk,
+                              t.rows[g], (double)(t.rows[g] > 0 ? t.rows[g] : 1)};
+        }
+        if (ok) {
+            c.check(instnorm_apply_sums_multi(jobs, c.G, t.cols, t.ld, 1e-5f, 0, slope, u.ld, true, c.st));
+            c.release(m);
+            return true;
+        }
+    }
     if (c.live())
         for (int g = 0; g < c.G; ++g) {
             const float* s_pts = B.b[g]->points[layer];
@@ -550,6 +588,17 @@ void edge_norm_all(Ctx& c, const Mat& cn, int cw, int* const* idx, const int* n,
     }
     if (multi && edgeconv_rows_ok(cl, c.G, cn.ld, cn.ld, e.ld, cw)) {
         c.check(edgeconv_rows_multi(cl, c.G, cn.ld, cn.ld, e.ld, cw, true, nullptr, c.st));
+        NormJob jobs[GMAX];
+        bool al = c.G <= 4;
+        for (int g = 0; g < c.G; ++g) {
+            jobs[g] = NormJob{e.p[g], static_cast<const double*>(sums[g]), nullptr, nullptr, out.p[g], nullptr, nullptr, n[g],
+                              (double)n[g] * (double)k[g]};
+            al = al && ((reinterpret_cast<uintptr_t>(e.p[g]) | reinterpret_cast<uintptr_t>(out.p[g])) & 15) == 0 && n[g] > 0 && k[g] > 0;
+        }
+        if (al) {
+            c.check(instnorm_apply_sums_multi(jobs, c.G, cw, e.ld, 1e-5f, 0, 0.2f, out.ld, false, c.st));
+            return;
+        }
         for (int g = 0; g < c.G; ++g)
             c.check(pcrcg_instnorm_apply_sums(e.p[g], n[g], cw, e.ld, sums[g], (double)n[g] * (double)k[g], 1e-5f, nullptr, 0, nullptr,
                                               0.2f, out.p[g], out.ld, c.st));
@@ -587,10 +636,10 @@ Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, co
     Mat cat1 = cols(cat, ch, ch), cat2 = cols(cat, 2 * ch, 2 * ch);
     const bool ok1 = sums_apply_ok(e1, cat1, nullptr), ok2 = sums_apply_ok(e2, cat2, nullptr);
     if (c.live()) {
-        for (int g = 0; g < c.G; ++g) {
-            c.check(pcrcg_knn(coords[g], f.rows[g], kq[g], idx[g], c.st));
-            c.check(pcrcg_copy2d(f.p[g], f.ld, cat.p[g], cat.ld, f.rows[g], ch, c.st));                     // x0
-        }
+        for (int g = 0; g < c.G; ++g) c.check(pcrcg_knn(coords[g], f.rows[g], kq[g], idx[g], c.st));
+        if (c.G <= 4) c.check(copy2d_multi(f.p, cat.p, f.rows, c.G, f.ld, cat.ld, ch, c.st));                // x0, every cloud
+        else
+            for (int g = 0; g < c.G; ++g) c.check(pcrcg_copy2d(f.p[g], f.ld, cat.p[g], cat.ld, f.rows[g], ch, c.st));
         // x1 = max_k lrelu(IN2d(conv1(cat(f_i, f_j - f_i))))  (:121-125)
         linear(c, f, gl.edge1, ch, nullptr, cn1);
         edge_norm_all(c, cn1, ch, idx, f.rows, kq, e1, cat1, sums1, ok1, stats, ws, wsb);
@@ -666,8 +715,10 @@ Mat cross_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, c
                                            c.st));
                 }
             }
-            c.check(pcrcg_copy2d(x.p[g], x.ld, cat.p[g], cat.ld, n, ch, c.st));
         }
+    if (c.live() && c.G <= 4) c.check(copy2d_multi(x.p, cat.p, x.rows, c.G, x.ld, cat.ld, ch, c.st));
+    else if (c.live())
+        for (int g = 0; g < c.G; ++g) c.check(pcrcg_copy2d(x.p[g], x.ld, cat.p[g], cat.ld, x.rows[g], ch, c.st));
     linear(c, msg, gl.wm, ch, gl.bm, cols(cat, ch, ch));       // merge, written next to x: cat([x, message])
     Stat h0s = stat_buffer(c, r2, 2 * ch);
     linear(c, cat, gl.w0, 2 * ch, gl.b0, h0, &h0s);
