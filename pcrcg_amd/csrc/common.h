@@ -115,6 +115,10 @@ struct NormJob {
 int instnorm_apply_sums_multi(const NormJob* jobs, int count, int c, int ldx, float eps, int ldr, float slope, int ldy, bool pack,
                               hipStream_t st);
 
+struct GatherJob { const float* x; const int64_t* idx; float* out; int ns, nq, h, ld_idx; };
+int gather_max_multi(const GatherJob* jobs, int count, int c, hipStream_t st);
+int heads_multi(const float* const* x, const int* rows, int count, int ld, int fd, float* const* feats, float* const* s_ov,
+                float* const* s_sal, hipStream_t st);
 int copy2d_multi(const float* const* src, float* const* dst, const int* rows, int count, int ld_src, int ld_dst, int cols,
                  hipStream_t st);
 int instnorm_colsums_multi(const float* const* x, double* const* sums, const int* n, int count, int c, int ldx, hipStream_t st);

@@ -51,6 +51,33 @@ __global__ void __launch_bounds__(256) k_sigmoid_scores(const float* __restrict_
     dst[r] = v;
 }
 
+// The three heads of the network's last matrix for up to four pairs in ONE launch (round 5; ref:models/architectures.py:571-582):
+// feats_f = F.normalize(x[:, :fd]), scores = clamp(sigmoid(x[:, fd]), 0, 1) and the same of x[:, fd + 1], non-finite -> 0 --
+// the arithmetic of k_l2norm_rows and k_sigmoid_scores, one wavefront per row
+struct HeadsMulti { const float* x[4]; float* feats[4]; float* s_ov[4]; float* s_sal[4]; int rows[4]; };
+__global__ void __launch_bounds__(256) k_heads(HeadsMulti mm, int ld, int fd) {
+    const int g = blockIdx.y, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= mm.rows[g]) return;
+    const float* src = mm.x[g] + (long)r * ld;
+    float s = 0.f;
+    for (int c = lane; c < fd; c += 64) {
+        const float v = src[c];
+        s += v * v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    float* dst = mm.feats[g] + (long)r * fd;
+    for (int c = lane; c < fd; c += 64) dst[c] = src[c] * inv;
+    if (lane < 2) {
+        float v = 1.0f / (1.0f + expf(-src[fd + lane]));
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        if (isnan(v) || isinf(v)) v = 0.0f;
+        (lane == 0 ? mm.s_ov[g] : mm.s_sal[g])[r] = v;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_fill2d(float* __restrict__ dst, int ld, int rows, int cols, float v) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long)rows * cols) return;
@@ -76,6 +103,23 @@ __global__ void __launch_bounds__(256) k_inject_image(const float* __restrict__ 
 }
 
 }  // namespace
+
+int heads_multi(const float* const* x, const int* rows, int count, int ld, int fd, float* const* feats, float* const* s_ov,
+                float* const* s_sal, hipStream_t st) {
+    PCRCG_CHECK_ARG(count >= 1 && count <= 4 && fd >= 1 && ld >= fd + 2);
+    HeadsMulti mm;
+    int rmax = 0;
+    for (int g = 0; g < 4; ++g) {
+        const int k = g < count ? g : 0;
+        PCRCG_CHECK_ARG(x[k] && feats[k] && s_ov[k] && s_sal[k] && rows[k] >= 0);
+        mm.x[g] = x[k]; mm.feats[g] = feats[k]; mm.s_ov[g] = s_ov[k]; mm.s_sal[g] = s_sal[k]; mm.rows[g] = g < count ? rows[k] : 0;
+        if (g < count) rmax = rows[k] > rmax ? rows[k] : rmax;
+    }
+    if (rmax == 0) return PCRCG_OK;
+    hipLaunchKernelGGL(k_heads, dim3((rmax + 3) / 4, count), dim3(256), 0, st, mm, ld, fd);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
 
 // dst_g[r, :cols] = src_g[r, :cols] for up to four (src, dst, rows) of one width and one pair of leading dimensions: one launch
 int copy2d_multi(const float* const* src, float* const* dst, const int* rows, int count, int ld_src, int ld_dst, int cols,

@@ -14,10 +14,15 @@ namespace {
 constexpr int kWavesPerBlock = 4;
 
 // one wavefront per (query row, block of 64 lanes x float4 | float channels)
+// (round 5: up to four (features, table, output) triples of one width per launch -- blockIdx.y -- the pairs of a forward call)
+struct GatherMulti { const float* x[4]; const long long* idx[4]; float* out[4]; int ns[4], nq[4], h[4], ld_idx[4]; };
 template <bool VEC4>
-__global__ void __launch_bounds__(kWavesPerBlock * 64) k_gather_max(const float* __restrict__ x, int ns, int c,
-                                                                     const long long* __restrict__ idx, int nq, int h,
-                                                                     int ld_idx, float* __restrict__ out, int nchunk) {
+__global__ void __launch_bounds__(kWavesPerBlock * 64) k_gather_max(GatherMulti mm, int c, int nchunk) {
+    const int g = blockIdx.y;
+    const float* __restrict__ x = mm.x[g];
+    const long long* __restrict__ idx = mm.idx[g];
+    float* __restrict__ out = mm.out[g];
+    const int ns = mm.ns[g], nq = mm.nq[g], h = mm.h[g], ld_idx = mm.ld_idx[g];
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (item >= (long)nq * nchunk) return;
@@ -388,6 +393,33 @@ int colstats_finalize(const double* partial, int nchunks, int c, double count, f
 }
 int colstats_chunks() { return kStatChunks; }
 
+// out_g[q, :] = max over the table row's neighbours of x_g[., :] for up to four triples of one width in ONE launch
+int gather_max_multi(const GatherJob* jobs, int count, int c, hipStream_t st) {
+    PCRCG_CHECK_ARG(jobs && count >= 1 && count <= 4 && c >= 1);
+    GatherMulti mm;
+    bool vec = c % 4 == 0;
+    int nq_max = 0;
+    for (int g = 0; g < 4; ++g) {
+        const GatherJob& j = jobs[g < count ? g : 0];
+        mm.x[g] = j.x; mm.idx[g] = reinterpret_cast<const long long*>(j.idx); mm.out[g] = j.out;
+        mm.ns[g] = j.ns; mm.nq[g] = g < count ? j.nq : 0; mm.h[g] = j.h; mm.ld_idx[g] = j.ld_idx;
+        if (g < count) {
+            PCRCG_CHECK_ARG(j.ns >= 0 && j.nq >= 0 && j.h >= 1 && j.ld_idx >= j.h && (j.nq == 0 || (j.x && j.idx && j.out)));
+            vec = vec && ((reinterpret_cast<uintptr_t>(j.x) | reinterpret_cast<uintptr_t>(j.out)) & 15) == 0;
+            nq_max = j.nq > nq_max ? j.nq : nq_max;
+        }
+    }
+    if (nq_max == 0) return PCRCG_OK;
+    const int per_wave = vec ? 256 : 64;
+    const int nchunk = (c + per_wave - 1) / per_wave;
+    const long items = (long)nq_max * nchunk;
+    const dim3 grid((unsigned)((items + kWavesPerBlock - 1) / kWavesPerBlock), count);
+    if (vec) hipLaunchKernelGGL(k_gather_max<true>, grid, dim3(kWavesPerBlock * 64), 0, st, mm, c, nchunk);
+    else hipLaunchKernelGGL(k_gather_max<false>, grid, dim3(kWavesPerBlock * 64), 0, st, mm, c, nchunk);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
 // column sums (sum, sum of squares) of up to four [n_g, c] tensors added into their zeroed [2][c] fp64 accumulators, one launch
 int instnorm_colsums_multi(const float* const* x, double* const* sums, const int* n, int count, int c, int ldx, hipStream_t st) {
     PCRCG_CHECK_ARG(count >= 1 && count <= 4 && c >= 1 && ldx >= c);
@@ -418,21 +450,8 @@ int pcrcg_gather_max(const float* x, int ns, int c, const int64_t* idx, int nq, 
     PCRCG_CHECK_ARG(ns >= 0 && c >= 1 && nq >= 0 && h >= 1 && ld_idx >= h);
     if (nq == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(x && idx && out);
-    const long long* idx_ll = reinterpret_cast<const long long*>(idx);
-    const bool vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    const int per_wave = vec ? 256 : 64;
-    const int nchunk = (c + per_wave - 1) / per_wave;
-    const long items = (long)nq * nchunk;
-    const unsigned blocks = (unsigned)((items + kWavesPerBlock - 1) / kWavesPerBlock);
-    if (vec)
-        hipLaunchKernelGGL(k_gather_max<true>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, as_stream(stream), x, ns, c,
-                           idx_ll, nq, h, ld_idx, out, nchunk);
-    else
-        hipLaunchKernelGGL(k_gather_max<false>, dim3(blocks), dim3(kWavesPerBlock * 64), 0, as_stream(stream), x, ns,
-                           c, idx_ll, nq, h, ld_idx, out, nchunk);
-    PCRCG_CHECK_LAUNCH();
-    return PCRCG_OK;
+    const GatherJob one{x, idx, out, ns, nq, h, ld_idx};
+    return gather_max_multi(&one, 1, c, as_stream(stream));
 }
 
 int pcrcg_gather_first(const float* x, int ns, int c, const int64_t* idx, int nq, int ld_idx, float* out,

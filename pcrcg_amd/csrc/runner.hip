@@ -545,7 +545,14 @@ Mat resnet_block(Ctx& c, const Batches& B, const pcrcg_block& blk, const Mat& fe
     Mat sc = feats;
     if (blk.strided) {   // max_pool shortcut (:672-673)
         sc = c.mat(nq, feats.cols);
-        if (c.live())
+        if (c.live() && c.G <= 4) {          // every pair's pool in one launch
+            GatherJob jobs[GMAX];
+            for (int g = 0; g < c.G; ++g) {
+                const pcrcg_table& t = B.b[g]->pools[blk.layer];
+                jobs[g] = GatherJob{feats.p[g], t.idx, sc.p[g], feats.rows[g], nq[g], t.cols, t.ld};
+            }
+            c.check(gather_max_multi(jobs, c.G, feats.cols, c.st));
+        } else if (c.live())
             for (int g = 0; g < c.G; ++g) {
                 const pcrcg_table& t = B.b[g]->pools[blk.layer];
                 c.check(pcrcg_gather_max(feats.p[g], feats.rows[g], feats.cols, t.idx, nq[g], t.cols, t.ld, sc.p[g], c.st));
@@ -609,7 +616,10 @@ void edge_norm_all(Ctx& c, const Mat& cn, int cw, int* const* idx, const int* n,
 }
 
 // SelfAttention.forward (ref:models/gcn.py:110-134) on row-major [n, ch]: one cloud of every pair
-Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, const float* const* coords, const Mat& f) {
+// knn_given: the clouds' kNN tables when the caller has them already (they depend on the coordinates only, which no layer
+// changes: the forward computes them once for all self-attention layers), or NULL
+Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, const float* const* coords, const Mat& f,
+                   int* const* knn_given = nullptr) {
     const int ch = f.cols;
     Mat y = c.mat(f.rows, ch);
     const size_t m = c.mark();
@@ -618,7 +628,7 @@ Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, co
     for (int g = 0; g < c.G; ++g) {
         const int n = f.rows[g];
         kq[g] = mdl.knn_k < n - 1 ? mdl.knn_k : n - 1;
-        idx[g] = static_cast<int*>(c.raw(sizeof(int) * (size_t)n * (kq[g] > 0 ? kq[g] : 1)));
+        idx[g] = knn_given ? knn_given[g] : static_cast<int*>(c.raw(sizeof(int) * (size_t)n * (kq[g] > 0 ? kq[g] : 1)));
     }
     Mat cat = c.mat(f.rows, 4 * ch);
     const size_t wsb = pcrcg_edgeconv_ws_bytes(2 * ch);
@@ -636,7 +646,8 @@ Mat self_attention(Ctx& c, const pcrcg_model& mdl, const pcrcg_gnn_layer& gl, co
     Mat cat1 = cols(cat, ch, ch), cat2 = cols(cat, 2 * ch, 2 * ch);
     const bool ok1 = sums_apply_ok(e1, cat1, nullptr), ok2 = sums_apply_ok(e2, cat2, nullptr);
     if (c.live()) {
-        for (int g = 0; g < c.G; ++g) c.check(pcrcg_knn(coords[g], f.rows[g], kq[g], idx[g], c.st));
+        if (!knn_given)
+            for (int g = 0; g < c.G; ++g) c.check(pcrcg_knn(coords[g], f.rows[g], kq[g], idx[g], c.st));
         if (c.G <= 4) c.check(copy2d_multi(f.p, cat.p, f.rows, c.G, f.ld, cat.ld, ch, c.st));                // x0, every cloud
         else
             for (int g = 0; g < c.G; ++g) c.check(pcrcg_copy2d(f.p[g], f.ld, cat.p[g], cat.ld, f.rows[g], ch, c.st));
@@ -762,6 +773,23 @@ void forward(Ctx& c, const pcrcg_model& mdl, const Batches& B, const pcrcg_outpu
     Mat fc = c.gemm_out(nc, gd, mdl.enc_out_dim);
     linear(c, x, mdl.bottle_w, mdl.enc_out_dim, mdl.bottle_b, fc);
     Mat d0 = rows(fc, zero, ns), d1 = rows(fc, ns, nt);
+    // the kNN graphs of the coarse clouds: geometry only (ref:models/gcn.py:48-51 builds them from the coordinates in every
+    // self-attention layer: the same tables each time) -- once per forward (round 5), order [source clouds | target clouds]
+    int* knn0[GMAX] = {};
+    int* knn1[GMAX] = {};
+    int n_self = 0;
+    for (int i = 0; i < mdl.n_gnn; ++i) n_self += mdl.gnn[i].cross ? 0 : 1;
+    const bool knn_once = n_self >= 2 && debug_opts().gnn_merge;
+    if (knn_once)
+        for (int g = 0; g < c.G; ++g) {
+            const int k0 = mdl.knn_k < ns[g] - 1 ? mdl.knn_k : ns[g] - 1, k1 = mdl.knn_k < nt[g] - 1 ? mdl.knn_k : nt[g] - 1;
+            knn0[g] = static_cast<int*>(c.raw(sizeof(int) * (size_t)ns[g] * (k0 > 0 ? k0 : 1)));
+            knn1[g] = static_cast<int*>(c.raw(sizeof(int) * (size_t)nt[g] * (k1 > 0 ? k1 : 1)));
+            if (c.live()) {
+                c.check(pcrcg_knn(c0[g], ns[g], k0, knn0[g], c.st));
+                c.check(pcrcg_knn(c1[g], nt[g], k1, knn1[g], c.st));
+            }
+        }
     for (int i = 0; i < mdl.n_gnn; ++i) {
         const pcrcg_gnn_layer& gl = mdl.gnn[i];
         if (gl.cross && 2 * c.G <= GMAX && c.paired_ok() && debug_opts().gnn_merge) {
@@ -795,13 +823,14 @@ void forward(Ctx& c, const pcrcg_model& mdl, const Batches& B, const pcrcg_outpu
             const int G0 = c.G;
             Mat f2;
             const float* cc[GMAX];
+            int* kk[GMAX];
             f2.cols = d0.cols; f2.ld = d0.ld;
             for (int g = 0; g < G0; ++g) {
-                f2.p[g] = d0.p[g]; f2.rows[g] = d0.rows[g]; cc[g] = c0[g];
-                f2.p[G0 + g] = d1.p[g]; f2.rows[G0 + g] = d1.rows[g]; cc[G0 + g] = c1[g];
+                f2.p[g] = d0.p[g]; f2.rows[g] = d0.rows[g]; cc[g] = c0[g]; kk[g] = knn0[g];
+                f2.p[G0 + g] = d1.p[g]; f2.rows[G0 + g] = d1.rows[g]; cc[G0 + g] = c1[g]; kk[G0 + g] = knn1[g];
             }
             c.G = 2 * G0;
-            const Mat y2 = self_attention(c, mdl, gl, cc, f2);
+            const Mat y2 = self_attention(c, mdl, gl, cc, f2, knn_once ? kk : nullptr);
             c.G = G0;
             d0 = y2; d1 = y2;
             for (int g = 0; g < GMAX; ++g) {
@@ -809,8 +838,8 @@ void forward(Ctx& c, const pcrcg_model& mdl, const Batches& B, const pcrcg_outpu
                 d1.p[g] = g < G0 ? y2.p[G0 + g] : nullptr; d1.rows[g] = g < G0 ? y2.rows[G0 + g] : 0;
             }
         } else {
-            d0 = self_attention(c, mdl, gl, c0, d0);
-            d1 = self_attention(c, mdl, gl, c1, d1);
+            d0 = self_attention(c, mdl, gl, c0, d0, knn_once ? knn0 : nullptr);
+            d1 = self_attention(c, mdl, gl, c1, d1, knn_once ? knn1 : nullptr);
         }
     }
     // coarse features [score | saliency | proj_gnn feats] (:538-565), rows 16-byte aligned
@@ -932,6 +961,11 @@ void forward(Ctx& c, const pcrcg_model& mdl, const Batches& B, const pcrcg_outpu
     // heads (:571-582)
     if (c.live()) {
         const int fd = mdl.final_dim;
+        if (c.G <= 4) {           // the three heads of every pair in one launch
+            float *ff[GMAX], *so[GMAX], *ss[GMAX];
+            for (int g = 0; g < c.G; ++g) { ff[g] = out[g].feats_f; so[g] = out[g].scores_overlap; ss[g] = out[g].scores_saliency; }
+            c.check(heads_multi(x.p, x.rows, c.G, x.ld, fd, ff, so, ss, c.st));
+        } else
         for (int g = 0; g < c.G; ++g) {
             c.check(pcrcg_l2norm_rows(x.p[g], x.ld, out[g].feats_f, fd, x.rows[g], fd, c.st));
             c.check(pcrcg_sigmoid_scores(x.p[g] + fd, x.ld, out[g].scores_overlap, x.rows[g], c.st));
