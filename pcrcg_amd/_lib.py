@@ -171,6 +171,11 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `make -C pcrcg_amd/csrc` "
                 "(or __graft_entry__.build()).  pcrcg_amd has no CPU or PyTorch fallback.")
+        # torch first: its wheel bundles its own libamdhip64, and the library must bind to THAT copy of the HIP runtime (the
+        # one that owns the device memory and streams it is handed).  Loaded the other way round -- this library first,
+        # pulling in the system's libamdhip64, torch afterwards -- the process holds two runtimes and every call in here
+        # fails with "no ROCm-capable device is detected" (seen with build() and smoke() in one process).
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the library does not export it
