@@ -17,8 +17,9 @@
 //
 // Since round 4 the forward products (k-contiguous fp32 operands) run the fp16 TWO-term form instead -- three matrix
 // instructions per chunk, two LDS planes, the same loop structure; see split2h and the H2 kernels below -- and fall back to
-// the three-term form above, inside the kernel, for any tile whose operands leave fp16's range.  The training rows'
-// k-major products and bf16-stored operands use the three-term form directly.
+// the three-term form above, inside the kernel, for any tile whose operands leave fp16's normal range at EITHER end
+// (round 5: rows whose values are all below 2^-14 as well as values beyond 65504).  The training rows' k-major products
+// without a named gradient operand and bf16-stored operands use the three-term form directly.
 //
 // Structure: 256 threads = 4 wavefronts (2 x 2), block tile BM x BN x 32.  Operand tiles are loaded as
 // float4 pairs (8 consecutive k of one row per thread and pass), split on the VALU and written to LDS as
@@ -172,12 +173,14 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigne
 //     a b = ha hb + 2^-11 (ha lb + la hb) + [2^-22 la lb]
 // with the bracket and the representation error both at 2^-22 |ab|: three v_mfma_f32_32x32x16_f16 per 16-deep k-chunk
 // (fp16 x fp16 products are exact in the matrix core's fp32 accumulation, fp16 subnormals are kept: scripts/micro/
-// mfma_f16_denormal.hip) instead of six bf16 ones, two LDS planes instead of three, 8 instead of 11 VALU operations per
+// mfma_f16_denormal.hip) instead of six bf16 ones, two LDS planes instead of three, 4 instead of 11 VALU operations per
 // operand pair.  Measured on the path's shapes: 4.5-5.8e-7 of a float64 product, a plain fp32 GEMM's error (the
-// three-term bf16 form: 2.4e-7).  The ONE thing the form cannot do is hold |x| >= 65520: such an operand leaves a
-// non-finite partial sum behind (see the check after the loop), and a workgroup that finds one throws its sums away and
-// runs its tile again with the three-term bf16 loop, which has fp32's range -- no flag for the host, no different
-// result contract.
+// three-term bf16 form: 2.4e-7).  What the form cannot do is hold values outside fp16's NORMAL range, at either end:
+// |x| >= 65520 becomes +-inf and leaves a non-finite partial sum behind; below 2^-14 h is a subnormal (below 2^-25: zero)
+// and the split's error is an absolute 2^-36 instead of a relative 2^-22 -- harmless beside larger values of the same row,
+// fatal for a row whose values are ALL that small.  Both are caught per tile after the loop (see the checks there), and a
+// workgroup that finds either throws its sums away and runs its tile again with the three-term bf16 loop, which has fp32's
+// range -- no flag for the host, no different result contract.
 constexpr float kH2Scale = 2048.0f;          // 2^11
 // Four VALU instructions per operand pair (round 5; the compiler's own code for the same arithmetic takes six): h by
 // v_cvt_pk_f16_f32, y = 2^11 x by one packed multiply, and l = fp16_rn(y - 2^11 h) by the mixed-precision FMAs, which read
