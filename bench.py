@@ -485,9 +485,11 @@ def main():
                     help="pairs built together that share one pcrcg_kpfcnn_forward_group call (weight products once for all)")
     ap.add_argument("--pairs-per-build", type=int, default=2, choices=[1, 2, 3, 4],
                     help="pairs one front-end kernel chain (pcrcg_pyramid_build call) carries")
+    ap.add_argument("--adaptive-jobs", action="store_true",
+                    help="engine: decide from queue / stream state whether the pairs of a build share a forward call (round 4's "
+                         "default; timing-dependent grouping, no throughput gain any more)")
     ap.add_argument("--fixed-jobs", action="store_true",
-                    help="A/B aid: forward jobs always carry --pairs-per-forward pairs (default: one pair each while model "
-                         "streams stand idle or nothing else is queued -- an engine filling up or running empty)")
+                    help="(the default since round 5, kept for old command lines) forward jobs always carry --pairs-per-forward pairs")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs behind roofline.traffic (traffic: null, ~30 s less)")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -645,7 +647,7 @@ def main():
     # ---- headline: the reference's batch contract inside the engine too (full [N, limit] upsample tables) ----------
     pipe = PairStreams(net, cfg, limits, dev, model_streams=WORKERS, front_threads=FRONTS, up_nearest=False,
                        pairs_per_forward=args.pairs_per_forward, pairs_per_build=args.pairs_per_build,
-                       adaptive_jobs=not args.fixed_jobs)
+                       adaptive_jobs=args.adaptive_jobs and not args.fixed_jobs)
     # engine priming (untimed, before the W warm-up steps): every model stream's first call allocates its workspace
     # and every front-end arena its tables; a handful of pairs per stream gets that out of the way
     run_pairs(pipe, 4 * WORKERS * args.pairs_per_forward)

@@ -57,7 +57,7 @@ class PairStreams:
 
     def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=1, tie_order=None,
                  pairs_per_build=2, up_nearest=False, front_streams=1, front_priority=0, pairs_per_forward=2,
-                 adaptive_jobs=True):
+                 adaptive_jobs=False):
         """pairs_per_forward = 2 .. 4: pairs that were built together also go through the network together, up to that
         many per pcrcg_kpfcnn_forward_group call on one model stream, in which every product with a weight matrix runs
         once for all of them (the pairs never mix; outputs equal separate forwards up to summation order).  1: one call
@@ -66,13 +66,14 @@ class PairStreams:
         column KPFCNN.forward reads, ref:models/blocks.py:77-87) instead of the batch contract's [N, limit] tables:
         ~1 % less front-end work, same outputs.  Off by default: the tables are then exactly what build_pyramid()
         hands to any other consumer.
-        adaptive_jobs (default on): whether two pairs of one build share a forward call is decided from the state of the
-        queues and of the model streams at that moment, i.e. from host and GPU TIMING.  Grouping changes the summation
-        order of the weight products (split-K plans, row tiles), so with it on the low-order bits of a pair's outputs
-        can differ from run to run (never beyond the 1e-5 the grouped and the single forward differ by).  Parity and
-        regression tests, and anyone who needs run-to-run identical bits, construct the engine with
-        adaptive_jobs=False (bench.py --fixed-jobs) -- together with PCRCG_DEBUG=deterministic=1 (atomics-free sums)
-        the outputs are then a function of the inputs alone."""
+        adaptive_jobs (default OFF since round 5): when on, whether two pairs of one build share a forward call is
+        decided from the state of the queues and of the model streams at that moment, i.e. from host and GPU TIMING --
+        grouping changes the summation order of the weight products, so the low-order bits of a pair's outputs then differ
+        from run to run (never beyond the 1e-5 the grouped and the single forward differ by).  It bought 1.5 % on 20-step
+        regions in round 4 and buys nothing any more (profiles/r05_ab_adaptive_jobs_20_step.txt: 510-515 pairs/s either way,
+        as does building an empty engine's first pair alone), so the default is the fixed grouping: which pairs share a
+        call depends on the configuration only, and together with PCRCG_DEBUG=deterministic=1 (atomics-free sums) the
+        outputs are a function of the inputs alone."""
         self.net, self.config, self.limits = net, config, neighborhood_limits
         self.device = torch.device(device if device is not None else "cuda")
         if not getattr(net, "use_runner", False):
@@ -185,9 +186,8 @@ class PairStreams:
                 if items[-1] is None:
                     self._in.put(None)         # pass the shutdown token on to the other front threads
                     items.pop()
-                # the pairs' forward jobs, in submission order: consecutive pairs of this build, up to per_forward each --
-                # one pair each while model streams stand idle (an engine filling up) or when nothing else is queued (an
-                # engine running empty): two streams then start / finish a pair each instead of one carrying both
+                # the pairs' forward jobs, in submission order: consecutive pairs of this build, up to per_forward each; with
+                # adaptive_jobs (off by default) one pair each while model streams stand idle or nothing else is queued
                 sizes = self.job_sizes(len(items), self._per_forward, self._adaptive and len(items) > 1 and
                                        (self._in.empty() or self._idle_models() >= 2))
                 job0 = self._jobs
