@@ -114,3 +114,29 @@ def test_model_with_small_input_features(cuda, golden_dir, scale):
         assert MR.rel_err(out[key].cpu(), ref[key]) < 1e-4, (key, MR.rel_err(out[key].cpu(), ref[key]))
         assert MR.rel_err(out_ops[key].cpu(), ref[key]) < 1e-4, (key, "forward_ops")
 
+
+def test_redo_counters_report_which_range_end_was_left(cuda):
+    """include/pcrcg.h pcrcg_gemm_redo_counts: a product on ordinary operands redoes no tile, one with a value beyond 65504
+    counts under [0], one whose A rows sit at 1e-9 under [1] -- the diagnostic bench.py / scripts/redo_probe.py read."""
+    import ctypes
+    from pcrcg_amd import _lib
+    L = _lib.lib()
+    out = (ctypes.c_ulonglong * 2)()
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(512, 256, generator=g).to(cuda)
+    w = (torch.randn(128, 256, generator=g) * 0.05).to(cuda)
+
+    def counts(aa):
+        _lib.check(L.pcrcg_gemm_redo_counts(None, 1), "pcrcg_gemm_redo_counts")
+        ops.gemm(aa, w.t())
+        torch.cuda.synchronize()
+        _lib.check(L.pcrcg_gemm_redo_counts(out, 1), "pcrcg_gemm_redo_counts")
+        return int(out[0]), int(out[1])
+
+    assert counts(a) == (0, 0)
+    big = a.clone()
+    big[3, 5] = 1.0e6
+    over, under = counts(big)
+    assert over >= 1 and under == 0
+    over, under = counts(a * 1e-9)
+    assert over == 0 and under == (512 // 64) * (128 // 64)          # every tile of the product
