@@ -281,10 +281,14 @@ __global__ void __launch_bounds__(256) k_knn_reg(const float* __restrict__ coord
 //              D/32 output tiles; the four wavefronts' partial tiles meet in LDS and leave as one store, scaled by 1 / sum.
 // Needs D % 32 == 0 and the scores of a 32-query tile in LDS: ms <= 1024 (the larger clouds take the per-head GEMM path).
 struct AttCloud { const float* q; const float* k; const float* v; float* out; int n, ms; };
-struct AttMulti { AttCloud cl[4]; int ldq, ldk, ldv, ldo; float scale; int ms_max; };
+struct AttMulti { AttCloud cl[4]; int ldq, ldk, ldv, ldo; float scale; int chunk_blocks; };   // chunk_blocks: 32-key blocks per LDS chunk
 
 typedef float attf16 __attribute__((ext_vector_type(16)));
 
+// Clouds whose scores do not fit LDS at once (K120k: 1936 keys) are walked in CHUNKS of chunk_blocks key blocks with the
+// running row maximum / row sum of the online softmax: per chunk the scores tile, then m' = max(m, chunk max),
+// alpha = exp(m - m'), P = exp(S - m'), l = l alpha + sum P, and every wavefront's partial output is scaled by alpha (row by
+// row) before the chunk's P V is added.  One chunk (every indoor cloud) is the plain three-phase form.
 template <int D>
 __global__ void __launch_bounds__(256) k_attention_mfma(AttMulti a) {
     constexpr int DH = D / 2, NT = D / 32;
@@ -296,12 +300,14 @@ __global__ void __launch_bounds__(256) k_attention_mfma(AttMulti a) {
     const int head = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int l31 = lane & 31, half = lane >> 5;
-    const int sld = ((a.ms_max + 31) / 32) * 32 + 1;          // odd row stride: a column of S walks all banks
+    const int sld = a.chunk_blocks * 32 + 1;                  // odd row stride: a column of S walks all banks
     float* const S = att2_lds;                                 // [32][sld]
-    float* const rinv = S + 32 * sld;                          // [32] 1 / row sum
-    float* const red = rinv + 32;                              // [3][32][D] partial output tiles of wavefronts 1..3
+    float* const m_run = S + 32 * sld;                         // [32] running row maximum
+    float* const l_run = m_run + 32;                           // [32] running row sum
+    float* const alpha = l_run + 32;                           // [32] this chunk's rescale of what was accumulated before
+    float* const red = alpha + 32;                             // [3][32][D] partial output tiles of wavefronts 1..3
     const int nkb = (ms + 31) / 32;
-    // ---- 1: scores
+    if (threadIdx.x < 32) { m_run[threadIdx.x] = -INFINITY; l_run[threadIdx.x] = 0.f; }
     float qr[DH];
     {
         const float* qrow = cl.q + (long)min(q0 + l31, n - 1) * a.ldq + head * D + half * DH;
@@ -311,71 +317,90 @@ __global__ void __launch_bounds__(256) k_attention_mfma(AttMulti a) {
             qr[4 * c] = t.x; qr[4 * c + 1] = t.y; qr[4 * c + 2] = t.z; qr[4 * c + 3] = t.w;
         }
     }
-    for (int kb = wave; kb < nkb; kb += 4) {
-        const int key = kb * 32 + l31;
-        const float* krow = cl.k + (long)min(key, ms - 1) * a.ldk + head * D + half * DH;
-        float kr[DH];
-#pragma unroll
-        for (int c = 0; c < DH / 4; ++c) {
-            const float4 t = *reinterpret_cast<const float4*>(krow + 4 * c);
-            kr[4 * c] = t.x; kr[4 * c + 1] = t.y; kr[4 * c + 2] = t.z; kr[4 * c + 3] = t.w;
-        }
-        attf16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < DH; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[kk], kr[kk], acc, 0, 0, 0);
-        // C/D layout: column = l31 (the key), rows (r & 3) + 8 (r >> 2) + 4 half
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            S[row * sld + kb * 32 + l31] = key < ms ? acc[r] * a.scale : -INFINITY;
-        }
-    }
-    __syncthreads();
-    // ---- 2: softmax, rows 8 wave .. 8 wave + 7
-    for (int rr = 0; rr < 8; ++rr) {
-        const int row = wave * 8 + rr;
-        float* const srow = S + row * sld;
-        float mx = -INFINITY;
-        for (int j = lane; j < nkb * 32; j += 64) mx = fmaxf(mx, srow[j]);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        float sum = 0.f;
-        for (int j = lane; j < nkb * 32; j += 64) {
-            const float e = expf(srow[j] - mx);                 // exp(-inf) = 0 for the padded keys
-            srow[j] = e;
-            sum += e;
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        if (lane == 0) rinv[row] = 1.0f / sum;
-    }
-    __syncthreads();
-    // ---- 3: P V, wavefront w takes the key blocks [w * per, (w + 1) * per)
     attf16 o[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-    {
-        const int per = (nkb + 3) / 4;
-        const int kb0 = min(wave * per, nkb), kb1 = min(kb0 + per, nkb);
-        // within a block of 32 keys, half 0 takes keys 0..15 and half 1 keys 16..31: step j multiplies key (16 half + j)
-        for (int kb = kb0; kb < kb1; ++kb) {
-            float pv[16], vv[NT][16];
+    for (int kb_lo = 0; kb_lo < nkb; kb_lo += a.chunk_blocks) {
+        const int kb_hi = min(nkb, kb_lo + a.chunk_blocks), cb = kb_hi - kb_lo;      // this chunk: key blocks [kb_lo, kb_hi)
+        __syncthreads();                                       // the previous chunk's P is no longer read (and m / l are set)
+        // ---- 1: scores of the chunk
+        for (int kb = kb_lo + wave; kb < kb_hi; kb += 4) {
+            const int key = kb * 32 + l31;
+            const float* krow = cl.k + (long)min(key, ms - 1) * a.ldk + head * D + half * DH;
+            float kr[DH];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int key = kb * 32 + 16 * half + j;
-                pv[j] = S[l31 * sld + key];                      // A[row = l31][k]: P of this lane's query row
-                const float* vrow = cl.v + (long)min(key, ms - 1) * a.ldv + head * D;
+            for (int c = 0; c < DH / 4; ++c) {
+                const float4 t = *reinterpret_cast<const float4*>(krow + 4 * c);
+                kr[4 * c] = t.x; kr[4 * c + 1] = t.y; kr[4 * c + 2] = t.z; kr[4 * c + 3] = t.w;
+            }
+            attf16 acc;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) vv[t][j] = key < ms ? vrow[t * 32 + l31] : 0.f;     // B[k][col = l31]
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < DH; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[kk], kr[kk], acc, 0, 0, 0);
+            // C/D layout: column = l31 (the key), rows (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                S[row * sld + (kb - kb_lo) * 32 + l31] = key < ms ? acc[r] * a.scale : -INFINITY;
+            }
+        }
+        __syncthreads();
+        // ---- 2: online softmax, rows 8 wave .. 8 wave + 7
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr;
+            float* const srow = S + row * sld;
+            float mx = -INFINITY;
+            for (int j = lane; j < cb * 32; j += 64) mx = fmaxf(mx, srow[j]);
+#pragma unroll
+            for (int s2 = 32; s2 >= 1; s2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s2, 64));
+            const float m_old = m_run[row], m_new = fmaxf(m_old, mx);       // finite: every chunk holds at least one key
+            float sum = 0.f;
+            for (int j = lane; j < cb * 32; j += 64) {
+                const float e = expf(srow[j] - m_new);                        // exp(-inf) = 0 for the padded keys
+                srow[j] = e;
+                sum += e;
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
+            for (int s2 = 32; s2 >= 1; s2 >>= 1) sum += __shfl_xor(sum, s2, 64);
+            if (lane == 0) {
+                const float al = expf(m_old - m_new);                         // 0 on the first chunk (m_old = -inf)
+                alpha[row] = al;
+                l_run[row] = l_run[row] * al + sum;
+                m_run[row] = m_new;
+            }
+        }
+        __syncthreads();
+        // ---- 3: o = o alpha + P V over this chunk's keys; wavefront w takes the blocks [w * per, (w + 1) * per) of the chunk
+        if (kb_lo > 0) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[j], vv[t][j], o[t], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) {
+                const float al = alpha[(r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) o[t][r] *= al;
+            }
+        }
+        {
+            const int per = (cb + 3) / 4;
+            const int b0 = min(wave * per, cb), b1 = min(b0 + per, cb);
+            // within a block of 32 keys, half 0 takes keys 0..15 and half 1 keys 16..31: step j multiplies key (16 half + j)
+            for (int bi = b0; bi < b1; ++bi) {
+                float pv[16], vv[NT][16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int kloc = bi * 32 + 16 * half + j, key = kb_lo * 32 + kloc;
+                    pv[j] = S[l31 * sld + kloc];                 // A[row = l31][k]: P of this lane's query row
+                    const float* vrow = cl.v + (long)min(key, ms - 1) * a.ldv + head * D;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) vv[t][j] = key < ms ? vrow[t * 32 + l31] : 0.f;     // B[k][col = l31]
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[j], vv[t][j], o[t], 0, 0, 0);
+            }
         }
     }
     if (wave > 0) {
@@ -395,7 +420,7 @@ __global__ void __launch_bounds__(256) k_attention_mfma(AttMulti a) {
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int at = row * D + t * 32 + l31;
-                const float v = ((o[t][r] + red[at]) + (red[32 * D + at] + red[64 * D + at])) * rinv[row];
+                const float v = ((o[t][r] + red[at]) + (red[32 * D + at] + red[64 * D + at])) / l_run[row];
                 if (q0 + row < n) cl.out[(long)(q0 + row) * a.ldo + head * D + t * 32 + l31] = v;
             }
     }
@@ -683,13 +708,18 @@ int edgeconv_rows_multi(const EdgeCloud* cl, int count, int ld_ctr, int ld_nbr, 
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
+// 32-key blocks of scores a workgroup keeps in LDS beside its partial output tiles (160 KB per CU, one workgroup of this
+// kernel per CU is enough: it is a latency chain, not a throughput kernel)
+static int attention_chunk_blocks(int d) {
+    const size_t fixed = sizeof(float) * (96 + (size_t)96 * d);
+    const size_t budget = 156 * 1024 - fixed;
+    return (int)((budget / (32 * sizeof(float)) - 1) / 32);
+}
 bool attention_mfma_ok(const AttnCloud* cl, int count, int ldq, int ldk, int ldv, int d) {
     if (!debug_opts().att_mfma || count < 1 || count > 4 || (d != 32 && d != 64 && d != 128)) return false;
     if (ldq % 4 != 0 || ldk % 4 != 0 || ldv % 4 != 0) return false;
     for (int i = 0; i < count; ++i) {
-        // the scores of a 32-query tile + the partial output tiles must fit the CU's 160 KB of LDS
-        const size_t sld = (size_t)((cl[i].ms + 31) / 32) * 32 + 1;
-        if (cl[i].n < 1 || cl[i].ms < 1 || sizeof(float) * (32 * sld + 32 + (size_t)96 * d) > 160 * 1024) return false;
+        if (cl[i].n < 1 || cl[i].ms < 1) return false;
         if ((reinterpret_cast<uintptr_t>(cl[i].q) | reinterpret_cast<uintptr_t>(cl[i].k)) & 15) return false;
     }
     return true;
@@ -704,9 +734,11 @@ int attention_mfma_multi(const AttnCloud* cl, int count, int ldq, int ldk, int l
         a.cl[i] = AttCloud{c.q, c.k, c.v, c.out, c.n, c.ms};
         if (i < count) { nmax = c.n > nmax ? c.n : nmax; msmax = c.ms > msmax ? c.ms : msmax; }
     }
-    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale; a.ms_max = msmax;
-    const int sld = ((msmax + 31) / 32) * 32 + 1;
-    const size_t lds = sizeof(float) * ((size_t)32 * sld + 32 + (size_t)3 * 32 * d);
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+    const int nkb = (msmax + 31) / 32, cap = attention_chunk_blocks(d);
+    a.chunk_blocks = nkb < cap ? nkb : cap;
+    const size_t sld = (size_t)a.chunk_blocks * 32 + 1;
+    const size_t lds = sizeof(float) * (32 * sld + 96 + (size_t)3 * 32 * d);
     const dim3 grid((nmax + 31) / 32, heads, count);
 #define ATT2(DD)                                                                                                          \
     do {                                                                                                                  \

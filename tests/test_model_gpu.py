@@ -335,7 +335,9 @@ def test_softmax_rows(cuda):
 
 @pytest.mark.parametrize("n,ms,heads,d", [(381, 382, 4, 128), (381, 382, 4, 64), (1, 1, 1, 16), (17, 65, 2, 32), (100, 64, 3, 48), (763, 700, 4, 64),
                                           (33, 1500, 4, 16), (382, 381, 2, 128), (50, 860, 2, 128), (1, 1, 1, 32), (40, 1050, 3, 64),
-                                          (31, 33, 1, 64)])
+                                          (31, 33, 1, 64),
+                                          # more keys than one LDS chunk of scores holds (832 at d = 128): the online-softmax walk
+                                          (70, 833, 2, 128), (100, 1936, 4, 128), (64, 3000, 2, 64), (33, 5000, 1, 32), (1936, 1936, 4, 128)])
 def test_attention_one_launch(cuda, n, ms, heads, d):
     """pcrcg_attention against the reference formulation (ref:models/gcn.py:151-155) in float64, and against the
     per-head GEMM / softmax / GEMM path it replaces in the runner."""
