@@ -43,7 +43,8 @@ const char* pcrcg_last_error(void);
  *   2 (round 3)  forward groups, train-step runner, correspondences, debug switches; one-kernel KPConv entries removed
  *   3 (round 4/5) cell-grid workspace: 64-bit run cursor, 16-byte slots, compact cell list and ticket block (a grid built
  *                by a version-2 library cannot be walked); new entries pcrcg_radius_query_cells,
- *                pcrcg_pyramid_build_parts, pcrcg_gemm_f32_grad, pcrcg_thread_shares_gpu; pcrcg_profile_kpconv flag bits;
+ *                pcrcg_pyramid_build_parts, pcrcg_gemm_f32_grad, pcrcg_thread_shares_gpu, pcrcg_gather_jobs;
+ *                pcrcg_profile_kpconv flag bits;
  *                forward products in the fp16 two-term form with both range ends handled in the kernel (see
  *                pcrcg_gemm_set_mode); deterministic=1 debug switch */
 #define PCRCG_ABI_VERSION 3

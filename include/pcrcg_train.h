@@ -59,6 +59,24 @@ int pcrcg_sgd_step(float* params, float* grads, float* momentum_buf, long n, flo
                    int zero_grads, void* stream);
 int pcrcg_weighted_bce(const float* prediction, const float* gt, int n, float* out3, float* grad, void* ws, size_t ws_bytes,
                        void* stream);
+/* The train step's re-packed weight layouts in ONE launch, and the way back for their gradients in one more (the host side
+ * of pcrcg_kpfcnn_train_forward keeps K-contiguous KPConv weights, the DGCNN edge convolutions' [Wa - Wb ; Wb] split
+ * (ref:models/gcn.py:31-60 applied to cat(x_i, x_j - x_i)), head-major attention projections (ref:models/gcn.py:139-160) and
+ * row-padded decoder weights beside the parameters as the reference stores them; every step they follow the parameters).
+ * jobs: n_jobs records IN DEVICE MEMORY; job j computes, for i < n,  dst[i] = src[m1[i]] + s2 * src[m2[i]]   (an index of -1
+ * contributes zero, m2 may be NULL), or adds that to dst[i] when accumulate != 0.  The maps make every dst element the
+ * target of exactly one i, so the result is a function of the inputs alone.  max_n = the largest n of the table. */
+typedef struct pcrcg_gather_job {
+    const float* src;
+    float* dst;
+    const int* m1;
+    const int* m2;
+    int n;
+    float s2;
+    int accumulate;
+    int pad_;
+} pcrcg_gather_job;
+int pcrcg_gather_jobs(const void* jobs, int n_jobs, int max_n, void* stream);
 
 /* pcrcg_gemm_f32 with an optionally transposed A:  C = (Aop * Bop) * row_scale[m] + bias[n],
  * Aop = A ([M,K] row-major, lda >= K) or A^T (A stored [K,M] row-major, lda >= M) when trans_a.

@@ -2,6 +2,7 @@
 // of torch.cat), residual add, row L2 normalisation (F.normalize, ref:models/architectures.py:541,582)
 // and the score head (sigmoid + clamp + NaN/Inf scrub, ref:models/architectures.py:176-179,576-579).
 #include "common.h"
+#include "pcrcg_train.h"
 
 namespace pcrcg {
 namespace {
@@ -141,6 +142,21 @@ int copy2d_multi(const float* const* src, float* const* dst, const int* rows, in
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
+// Re-packed weight layouts of the train step and the way back for their gradients (include/pcrcg_train.h pcrcg_gather_jobs):
+// job j fills dst[i] = src[m1[i]] + s2 src[m2[i]] (an index of -1 contributes zero; m2 may be NULL), or adds that to dst[i].
+struct GatherJobs { const float* src; float* dst; const int* m1; const int* m2; int n; float s2; int accumulate; int pad; };
+__global__ void __launch_bounds__(256) k_gather_jobs(const GatherJobs* __restrict__ jobs) {
+    const GatherJobs jb = jobs[blockIdx.y];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < jb.n; i += (long)gridDim.x * 256) {
+        const int a = jb.m1[i];
+        float v = a >= 0 ? jb.src[a] : 0.f;
+        if (jb.m2) {
+            const int b = jb.m2[i];
+            if (b >= 0) v += jb.s2 * jb.src[b];
+        }
+        jb.dst[i] = jb.accumulate ? jb.dst[i] + v : v;
+    }
+}
 }  // namespace pcrcg
 
 using namespace pcrcg;
@@ -176,6 +192,17 @@ int pcrcg_copy2d(const float* src, int ld_src, float* dst, int ld_dst, int rows,
     if (rows == 0 || cols == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(src && dst);
     return pcrcg::copy2d_multi(&src, &dst, &rows, 1, ld_src, ld_dst, cols, as_stream(stream));
+}
+
+int pcrcg_gather_jobs(const void* jobs, int n_jobs, int max_n, void* stream) {
+    static_assert(sizeof(GatherJobs) == sizeof(pcrcg_gather_job), "pcrcg_gather_job layout");
+    PCRCG_CHECK_ARG(n_jobs >= 0 && max_n >= 0);
+    if (n_jobs == 0 || max_n == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(jobs != nullptr);
+    const int gx = (max_n + 1023) / 1024 < 512 ? (max_n + 1023) / 1024 : 512;
+    hipLaunchKernelGGL(k_gather_jobs, dim3(gx, n_jobs), dim3(256), 0, as_stream(stream), static_cast<const GatherJobs*>(jobs));
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
 }
 
 int pcrcg_add(const float* a, const float* b, float* dst, long n, void* stream) {

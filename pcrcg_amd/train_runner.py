@@ -26,6 +26,12 @@ class TrainOutputs(ctypes.Structure):
                 ("d_inv_temperature", ctypes.c_void_p), ("n_points", ctypes.c_int), ("final_dim", ctypes.c_int)]
 
 
+class GatherJob(ctypes.Structure):
+    """pcrcg_gather_job (include/pcrcg_train.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("m1", ctypes.c_void_p), ("m2", ctypes.c_void_p),
+                ("n", ctypes.c_int), ("s2", ctypes.c_float), ("accumulate", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
 class _Tape:
     """Owner of one C++ tape: frees it exactly once (after the backward, or when the autograd node is dropped without
     one) and tells the runner that its cached workspace is free again."""
@@ -72,15 +78,39 @@ class TrainRunner:
         """(value pointer, gradient pointer) of one weight; both tensors are kept alive."""
         if value.dtype != torch.float32 or not value.is_cuda or not value.is_contiguous():
             raise RuntimeError("pcrcg_amd.train_runner: weights must be contiguous float32 tensors on a HIP device")
+        if grad is not None and not grad.is_contiguous():
+            raise RuntimeError("pcrcg_amd.train_runner: parameter gradients must be contiguous")
         keep.append(value)
         keep.append(grad)
         return value.data_ptr(), (grad.data_ptr() if grad is not None else None)
 
-    def _descriptors(self):
-        """-> (values Model, gradients Model, keep-alive list, fold-back closures run after the backward)."""
+    def _plan_key(self):
+        """What the cached plan depends on: where every parameter and its gradient live, and which of them train."""
+        key = []
+        for p in self.model.parameters():
+            g = _grad(p) if p.requires_grad else None
+            key.append((p.data_ptr(), g.data_ptr() if g is not None else 0))
+        return tuple(key)
+
+    def _plan(self):
+        """-> the step's descriptors, built once and reused while no parameter or gradient has moved: the two Model
+        structs (values, gradient twins), the arena of re-packed weight layouts with the device job table that refreshes it
+        from the parameters (ONE launch per step, pcrcg_gather_jobs), and the arena their gradients land in with the table
+        that adds those back to the parameters' gradients (one launch after the backward)."""
+        key = self._plan_key()
+        if self._lent is not None:                # an earlier forward still awaits its backward: it owns the cached arenas
+            return self._build_plan()
+        plan = getattr(self, "_cached_plan", None)
+        if plan is None or plan["key"] != key:
+            plan = self._cached_plan = self._build_plan()
+            plan["key"] = key
+        return plan
+
+    def _build_plan(self):
         m = self.model
         v, g = Model(), Model()
-        keep, fold = [], []
+        keep, specs = [], []
+        dev = m.epsilon.device
         v.n_enc, v.n_dec, v.n_gnn = len(m.encoder_blocks), len(m.decoder_blocks), len(m.gnn.layers)
         if v.n_enc > MAX_BLOCKS or v.n_dec > MAX_BLOCKS or v.n_gnn > MAX_GNN:
             raise RuntimeError("pcrcg_amd.train_runner: architecture too deep for the descriptor")
@@ -96,18 +126,16 @@ class TrainRunner:
             setattr(dst_v, name, pv)
             setattr(dst_g, name, pg)
 
-        def derived(dst_v, dst_g, name, value, fold_back, *sources):
-            """A re-packed copy of one or more parameters (`sources`): its gradient lands in a zeroed buffer of the same
-            shape and fold_back(buffer) adds it to the parameters' gradients after the backward.  All sources frozen:
-            no buffer, a NULL gradient pointer."""
-            value = value.contiguous()
-            trainable = any(p.requires_grad for p in sources) if sources else True
-            buf = torch.zeros_like(value) if trainable else None
-            pv, pg = self._pair(keep, value, buf)
-            setattr(dst_v, name, pv)
-            setattr(dst_g, name, pg)
-            if trainable:
-                fold.append(lambda: fold_back(buf))
+        def index_of(param):
+            return torch.arange(param.numel(), dtype=torch.int32, device=dev).view(param.shape)
+
+        def derived(dst_v, dst_g, name, param, m1, m2=None, with_grad=True):
+            """A re-packed copy of `param`:  derived.flat[i] = param.flat[m1[i]] - param.flat[m2[i]]  (-1: nothing).  It
+            lives in the plan's arena and follows the parameter every step; its gradient (with_grad, and the parameter
+            trains) lands in the twin arena and is added back through the inverse maps."""
+            specs.append(dict(dst_v=dst_v, dst_g=dst_g, name=name, param=param, m1=m1.reshape(-1).contiguous(),
+                              m2=None if m2 is None else m2.reshape(-1).contiguous(),
+                              grad=bool(with_grad and param.requires_grad)))
 
         def kp_block(bv, bg, kp):
             if kp.in_channels != 1 and kp.in_channels % 4 != 0:
@@ -116,12 +144,10 @@ class TrainRunner:
             keep.append(kp.kernel_points.data)
             bv.kp = kp.kernel_points.data.contiguous().data_ptr()
             direct(bv, bg, "kp_w", kp.weights, lambda t: t.reshape(-1, t.shape[-1]))
-            # a K-contiguous copy [cout, 15 cin] for the FORWARD contraction (value only: the gradient belongs to kp_w); one
-            # small transpose per KPConv and step buys the k-contiguous product instead of the k-major one
+            # a K-contiguous copy [cout, 15 cin] for the FORWARD contraction (value only: the gradient belongs to kp_w): the
+            # k-contiguous product instead of the k-major one
             if (kp.weights.shape[0] * kp.weights.shape[1]) % 4 == 0:
-                wt = kp.weights.data.reshape(-1, kp.weights.shape[-1]).t().contiguous()
-                keep.append(wt)
-                bv.kp_wt = wt.data_ptr()
+                derived(bv, bg, "kp_wt", kp.weights, index_of(kp.weights).reshape(-1, kp.weights.shape[-1]).t(), with_grad=False)
 
         for i, mod in enumerate(m.encoder_blocks):
             bv, bg = v.enc[i], g.enc[i]
@@ -160,9 +186,9 @@ class TrainRunner:
                     bv.mlp_ld = k
                 else:                               # rows padded to 16 bytes (decoder widths 1538 and 769)
                     kp4 = (k + 3) // 4 * 4
-                    padded = torch.zeros((w.shape[0], kp4), dtype=w.dtype, device=w.device)
-                    padded[:, :k].copy_(w.data)
-                    derived(bv, bg, "mlp", padded, lambda buf, w=w, k=k: _grad(w).add_(buf[:, :k]), w)
+                    padded = torch.full((w.shape[0], kp4), -1, dtype=torch.int32, device=dev)
+                    padded[:, :k] = index_of(w)
+                    derived(bv, bg, "mlp", w, padded)
                     bv.mlp_ld = kp4
             elif isinstance(mod, NearestUpsampleBlock):
                 bv.type, bv.layer = BLK_UPSAMPLE, mod.layer_ind
@@ -174,36 +200,24 @@ class TrainRunner:
             if isinstance(layer, SelfAttention):
                 lv.cross = 0
                 v.knn_k = layer.k
-
-                def packed(name, conv):
+                for name, conv in (("edge1", layer.conv1), ("edge2", layer.conv2)):
+                    # conv(cat(x_i, x_j - x_i)) = (Wa - Wb) x_i + Wb x_j: the packed rows [Wa - Wb ; Wb]
                     w = conv.weight
-                    w2 = w.data.flatten(1)
-                    cin = w2.shape[1] // 2
-                    wa, wb = w2[:, :cin], w2[:, cin:]
-
-                    def back(buf, w=w, cin=cin):
-                        gw = _grad(w).flatten(1)
-                        cout = gw.shape[0]
-                        gw[:, :cin].add_(buf[:cout])                       # d(Wa - Wb) -> Wa
-                        gw[:, cin:].add_(buf[cout:] - buf[:cout])          # Wb sits in both terms
-                    derived(lv, lg, name, torch.cat([wa - wb, wb], 0), back, w)
-                packed("edge1", layer.conv1)
-                packed("edge2", layer.conv2)
+                    ix = index_of(w).flatten(1)
+                    cin = ix.shape[1] // 2
+                    ia, ib = ix[:, :cin], ix[:, cin:]
+                    derived(lv, lg, name, w, torch.cat([ia, ib], 0), torch.cat([ib, torch.full_like(ib, -1)], 0))
                 direct(lv, lg, "conv3", layer.conv3.weight, lambda t: t.flatten(1))
             elif isinstance(layer, AttentionalPropagation):
                 lv.cross = 1
                 att = layer.attn
                 h, d = att.num_heads, att.dim
                 heads = h
-                dev = att.merge.weight.device
                 perm = (torch.arange(h, device=dev)[:, None] + h * torch.arange(d, device=dev)[None, :]).reshape(-1)
                 for name, proj in zip("qkv", att.proj):
-                    derived(lv, lg, "w" + name, proj.weight.data.squeeze(-1)[perm],
-                            lambda buf, p=proj.weight: _grad(p).squeeze(-1).index_add_(0, perm, buf), proj.weight)
-                    derived(lv, lg, "b" + name, proj.bias.data[perm],
-                            lambda buf, p=proj.bias: _grad(p).index_add_(0, perm, buf), proj.bias)
-                derived(lv, lg, "wm", att.merge.weight.data.squeeze(-1)[:, perm],
-                        lambda buf, p=att.merge.weight: _grad(p).squeeze(-1).index_add_(1, perm, buf), att.merge.weight)
+                    derived(lv, lg, "w" + name, proj.weight, index_of(proj.weight).squeeze(-1)[perm])
+                    derived(lv, lg, "b" + name, proj.bias, index_of(proj.bias)[perm])
+                derived(lv, lg, "wm", att.merge.weight, index_of(att.merge.weight).squeeze(-1)[:, perm])
                 direct(lv, lg, "bm", att.merge.bias)
                 direct(lv, lg, "w0", layer.mlp[0].weight, lambda t: t.squeeze(-1))
                 direct(lv, lg, "b0", layer.mlp[0].bias)
@@ -216,11 +230,73 @@ class TrainRunner:
         for name, conv in (("bottle", m.bottle), ("proj_gnn", m.proj_gnn), ("proj_score", m.proj_score)):
             direct(v, g, name + "_w", conv.weight, lambda t: t.squeeze(-1))
             direct(v, g, name + "_b", conv.bias)
-        v.temperature = float(torch.exp(m.epsilon.detach()).item()) + 0.03
+        # ---- the arenas of the re-packed layouts and of their gradients, and the two job tables
+        def rounded(n):
+            return (n + 63) // 64 * 64
+        total = sum(rounded(sp["m1"].numel()) for sp in specs)
+        total_g = sum(rounded(sp["m1"].numel()) for sp in specs if sp["grad"])
+        values = torch.zeros(max(total, 1), dtype=torch.float32, device=dev)
+        grads = torch.zeros(max(total_g, 1), dtype=torch.float32, device=dev)
+        derive, fold = [], []
+        off = off_g = 0
+        for sp in specs:
+            p, n = sp["param"], sp["m1"].numel()
+            if p.dtype != torch.float32 or not p.is_cuda or not p.data.is_contiguous():
+                raise RuntimeError("pcrcg_amd.train_runner: weights must be contiguous float32 tensors on a HIP device")
+            setattr(sp["dst_v"], sp["name"], values.data_ptr() + 4 * off)
+            keep += [sp["m1"], sp["m2"], p.data]
+            derive.append(GatherJob(p.data_ptr(), values.data_ptr() + 4 * off, sp["m1"].data_ptr(),
+                                    sp["m2"].data_ptr() if sp["m2"] is not None else None, n, -1.0, 0, 0))
+            off += rounded(n)
+            if not sp["grad"]:
+                setattr(sp["dst_g"], sp["name"], None)
+                continue
+            setattr(sp["dst_g"], sp["name"], grads.data_ptr() + 4 * off_g)
+            # the way back: parameter element q collects the gradient of every packed element it went into
+            ar = torch.arange(n, dtype=torch.int32, device=dev)
+            inv = []
+            for mp in (sp["m1"], sp["m2"]):
+                if mp is None:
+                    inv.append(None)
+                    continue
+                back = torch.full((p.numel(),), -1, dtype=torch.int32, device=dev)
+                ok = mp >= 0
+                back[mp[ok].long()] = ar[ok]
+                inv.append(back)
+            gp = _grad(p)
+            if not gp.is_contiguous():
+                raise RuntimeError("pcrcg_amd.train_runner: parameter gradients must be contiguous")
+            keep += inv + [gp]
+            fold.append(GatherJob(grads.data_ptr() + 4 * off_g, gp.data_ptr(), inv[0].data_ptr(),
+                                  inv[1].data_ptr() if inv[1] is not None else None, p.numel(), -1.0, 1, 0))
+            off_g += rounded(n)
+
+        def table(jobs):
+            if not jobs:
+                return None, 0, 0
+            arr = (GatherJob * len(jobs))(*jobs)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            return host.to(dev), len(jobs), max(j.n for j in jobs)
+        return {"v": v, "g": g, "keep": keep, "values": values, "grads": grads, "derive": table(derive), "fold": table(fold),
+                "has_grads": total_g > 0}
+
+    def _descriptors(self):
+        """-> (values Model, gradients Model, keep-alive list, plan) for this step: the cached plan with the re-packed
+        layouts refreshed from the parameters (one launch), their gradient arena cleared (one more) and the temperature
+        read back from epsilon."""
+        plan = self._plan()
+        v, g = plan["v"], plan["g"]
+        stream = torch.cuda.current_stream().cuda_stream
+        tab, n_jobs, max_n = plan["derive"]
+        if n_jobs:
+            _lib.check(_lib.lib().pcrcg_gather_jobs(tab.data_ptr(), n_jobs, max_n, stream), "pcrcg_gather_jobs")
+        if plan["has_grads"]:
+            plan["grads"].zero_()
+        v.temperature = float(torch.exp(self.model.epsilon.detach()).item()) + 0.03
         # the gradient twin only needs its pointers; copy the integer layout so that validation sees the same model
         for f in ("n_enc", "n_dec", "n_gnn", "enc_out_dim", "gnn_dim", "heads", "knn_k", "final_dim", "temperature"):
             setattr(g, f, getattr(v, f))
-        return v, g, keep, fold
+        return v, g, plan["keep"], plan
 
     # ---- forward / backward --------------------------------------------------------------------------------------
     def forward(self, batch):
@@ -242,7 +318,7 @@ class TrainRunner:
 
     def _forward(self, batch):
         L = _lib.lib()
-        v, g, keep, fold = self._descriptors()
+        v, g, keep, plan = self._descriptors()
         b, bkeep, dev = self._batch_helper.batch_struct(batch)
         sizes = [ctypes.c_size_t() for _ in range(3)]
         _lib.check(L.pcrcg_kpfcnn_train_ws_bytes(ctypes.byref(v), ctypes.byref(g), ctypes.byref(b), *[ctypes.byref(s) for s in sizes]),
@@ -271,7 +347,7 @@ class TrainRunner:
             return ws[off:off + 4 * n].view(torch.float32).view(*shape)
         n0, fd = out.n_points, out.final_dim
         outs = (view(out.feats_f, n0, fd), view(out.scores_overlap, n0), view(out.scores_saliency, n0))
-        state = {"tape": _Tape(tape, self, ws), "keep": (keep, bkeep, v, g, b), "fold": fold,
+        state = {"tape": _Tape(tape, self, ws), "keep": (keep, bkeep, v, g, b, plan), "plan": plan,
                  "d_inv_t": view(out.d_inv_temperature, 1), "inv_t": 1.0 / v.temperature, "ws": ws}
         return outs, state
 
@@ -294,8 +370,10 @@ class TrainRunner:
                                                      torch.cuda.current_stream().cuda_stream), "pcrcg_kpfcnn_train_backward")
         finally:
             tape.release()
-        for f in state["fold"]:
-            f()
+        tab, n_jobs, max_n = state["plan"]["fold"]
+        if n_jobs:       # the re-packed layouts' gradients, added to the parameters' (one launch)
+            _lib.check(L.pcrcg_gather_jobs(tab.data_ptr(), n_jobs, max_n, torch.cuda.current_stream().cuda_stream),
+                       "pcrcg_gather_jobs")
         # temperature = exp(epsilon) + 0.03 and the library reports dL/d(1/temperature)
         eps = self.model.epsilon.detach()
         return state["d_inv_t"].reshape(()) * (-(state["inv_t"] ** 2)) * torch.exp(eps)
