@@ -65,7 +65,8 @@ int pcrcg_weighted_bce(const float* prediction, const float* gt, int n, float* o
  * row-padded decoder weights beside the parameters as the reference stores them; every step they follow the parameters).
  * jobs: n_jobs records IN DEVICE MEMORY; job j computes, for i < n,  dst[i] = src[m1[i]] + s2 * src[m2[i]]   (an index of -1
  * contributes zero, m2 may be NULL), or adds that to dst[i] when accumulate != 0.  The maps make every dst element the
- * target of exactly one i, so the result is a function of the inputs alone.  max_n = the largest n of the table. */
+ * target of exactly one i, so the result is a function of the inputs alone.  A job with m1 == NULL is a plain transpose:
+ * src [n / cols][cols] -> dst [cols][n / cols].  max_n = the largest n of the table. */
 typedef struct pcrcg_gather_job {
     const float* src;
     float* dst;
@@ -74,7 +75,7 @@ typedef struct pcrcg_gather_job {
     int n;
     float s2;
     int accumulate;
-    int pad_;
+    int cols; /* transpose jobs only */
 } pcrcg_gather_job;
 int pcrcg_gather_jobs(const void* jobs, int n_jobs, int max_n, void* stream);
 

@@ -111,6 +111,7 @@ struct NormJob {
     const float* x; const double* sums; const float* res; const double* res_sums; float* y;
     const float* s_pts; float4* pk;      // pack form only: the KPConv support records of the output rows
     int n; double count;
+    float* stats_out = nullptr;          // optional: receives the (mean, rstd) pairs [c][2] the sums stand for (the train tape keeps them)
 };
 int instnorm_apply_sums_multi(const NormJob* jobs, int count, int c, int ldx, float eps, int ldr, float slope, int ldy, bool pack,
                               hipStream_t st);
@@ -171,6 +172,7 @@ struct DebugOpts {
     // point (integer addition is associative; trainops.hip).  Slower (DESIGN.md has the price); the default keeps the
     // atomics.  Setting it overrides the two switches it implies.
     int deterministic = 0;
+    int bwd_mfma = 1;               // KPConv backward's scatter on the matrix cores (k_kpconv_bwd_dx_mfma); 0: the VALU kernel
 };
 const DebugOpts& debug_opts();
 

@@ -144,10 +144,37 @@ int copy2d_multi(const float* const* src, float* const* dst, const int* rows, in
 }
 // Re-packed weight layouts of the train step and the way back for their gradients (include/pcrcg_train.h pcrcg_gather_jobs):
 // job j fills dst[i] = src[m1[i]] + s2 src[m2[i]] (an index of -1 contributes zero; m2 may be NULL), or adds that to dst[i].
-struct GatherJobs { const float* src; float* dst; const int* m1; const int* m2; int n; float s2; int accumulate; int pad; };
+// m1 == NULL: a plain transpose, src [n / cols][cols] -> dst [cols][n / cols], through 32 x 32 LDS tiles (a map whose
+// consecutive entries are a whole row apart would send every lane of a load to the same memory channel).
+struct GatherJobs { const float* src; float* dst; const int* m1; const int* m2; int n; float s2; int accumulate; int cols; };
 __global__ void __launch_bounds__(256) k_gather_jobs(const GatherJobs* __restrict__ jobs) {
     const GatherJobs jb = jobs[blockIdx.y];
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < jb.n; i += (long)gridDim.x * 256) {
+    if (!jb.m1) {
+        __shared__ float tile[32][33];
+        const int cols = jb.cols, rows = jb.n / cols;
+        const int tx = (cols + 31) / 32, ty = (rows + 31) / 32;
+        const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;          // 32 x 8 threads, four rows each
+        for (int t = blockIdx.x; t < tx * ty; t += gridDim.x) {
+            const int r0 = (t / tx) * 32, c0 = (t % tx) * 32;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + ly + 8 * u, c = c0 + lx;
+                tile[ly + 8 * u][lx] = (r < rows && c < cols) ? jb.src[(long)r * cols + c] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + ly + 8 * u, r = r0 + lx;              // dst row c, column r
+                if (c < cols && r < rows) {
+                    float* d = jb.dst + (long)c * rows + r;
+                    *d = jb.accumulate ? *d + tile[lx][ly + 8 * u] : tile[lx][ly + 8 * u];
+                }
+            }
+        }
+        return;
+    }
+    auto one = [&](long i) {
         const int a = jb.m1[i];
         float v = a >= 0 ? jb.src[a] : 0.f;
         if (jb.m2) {
@@ -155,7 +182,29 @@ __global__ void __launch_bounds__(256) k_gather_jobs(const GatherJobs* __restric
             if (b >= 0) v += jb.s2 * jb.src[b];
         }
         jb.dst[i] = jb.accumulate ? jb.dst[i] + v : v;
+    };
+    // four elements per thread and pass: their index loads, then their gathers, are in flight together
+    const bool vec = ((reinterpret_cast<uintptr_t>(jb.dst) | reinterpret_cast<uintptr_t>(jb.m1) | reinterpret_cast<uintptr_t>(jb.m2)) & 15) == 0;
+    if (!vec) {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < jb.n; i += (long)gridDim.x * 256) one(i);
+        return;
     }
+    const long n4 = jb.n & ~3;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n4; i += (long)gridDim.x * 1024) {
+        const int4 a = *reinterpret_cast<const int4*>(jb.m1 + i);
+        int4 b = make_int4(-1, -1, -1, -1);
+        if (jb.m2) b = *reinterpret_cast<const int4*>(jb.m2 + i);
+        float4 v = make_float4(a.x >= 0 ? jb.src[a.x] : 0.f, a.y >= 0 ? jb.src[a.y] : 0.f, a.z >= 0 ? jb.src[a.z] : 0.f,
+                               a.w >= 0 ? jb.src[a.w] : 0.f);
+        if (b.x >= 0) v.x += jb.s2 * jb.src[b.x];
+        if (b.y >= 0) v.y += jb.s2 * jb.src[b.y];
+        if (b.z >= 0) v.z += jb.s2 * jb.src[b.z];
+        if (b.w >= 0) v.w += jb.s2 * jb.src[b.w];
+        float4* d = reinterpret_cast<float4*>(jb.dst + i);
+        if (jb.accumulate) { const float4 o = *d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *d = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (jb.n & 3)) one(n4 + threadIdx.x);
 }
 }  // namespace pcrcg
 
@@ -199,7 +248,7 @@ int pcrcg_gather_jobs(const void* jobs, int n_jobs, int max_n, void* stream) {
     PCRCG_CHECK_ARG(n_jobs >= 0 && max_n >= 0);
     if (n_jobs == 0 || max_n == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(jobs != nullptr);
-    const int gx = (max_n + 1023) / 1024 < 512 ? (max_n + 1023) / 1024 : 512;
+    const int gx = (max_n + 1023) / 1024 < 1024 ? (max_n + 1023) / 1024 : 1024;
     hipLaunchKernelGGL(k_gather_jobs, dim3(gx, n_jobs), dim3(256), 0, as_stream(stream), static_cast<const GatherJobs*>(jobs));
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;

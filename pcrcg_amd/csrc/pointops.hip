@@ -210,6 +210,7 @@ struct NormMulti {
     const float* x[4]; const double* sums[4]; const float* res[4]; const double* res_sums[4]; float* y[4];
     const float* s_pts[4]; float4* pk[4];
     int n[4]; double count[4];
+    float* stats_out[4];
 };
 template <int RES>
 __global__ void __launch_bounds__(256) k_instnorm_apply4_sums(NormMulti mm, int c4, int ldx, float eps, int ldr, float slope, int ldy,
@@ -231,6 +232,11 @@ __global__ void __launch_bounds__(256) k_instnorm_apply4_sums(NormMulti mm, int 
         float4 m0, s0, m1 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = make_float4(1.f, 1.f, 1.f, 1.f);
         stats4_from_sums(sums, 4 * c4, 4 * q, count, eps, m0, s0);
         if (RES == 2) stats4_from_sums(res_sums, 4 * c4, 4 * q, count, eps, m1, s1);
+        if (blockIdx.x == 0 && threadIdx.x < cb && mm.stats_out[g]) {       // the pairs k_colstats_final would have left
+            float4* so = reinterpret_cast<float4*>(mm.stats_out[g] + 8 * q);
+            so[0] = make_float4(m0.x, s0.x, m0.y, s0.y);
+            so[1] = make_float4(m0.z, s0.z, m0.w, s0.w);
+        }
         auto finish = [&](const float4& xv, float4 rv, long r) {
             float4 v = make_float4((xv.x - m0.x) * s0.x, (xv.y - m0.y) * s0.y, (xv.z - m0.z) * s0.z, (xv.w - m0.w) * s0.w);
             if (RES) {
@@ -358,6 +364,7 @@ int instnorm_apply_sums_multi(const NormJob* jobs, int count, int c, int ldx, fl
         const NormJob& j = jobs[g < count ? g : 0];
         mm.x[g] = j.x; mm.sums[g] = j.sums; mm.res[g] = j.res; mm.res_sums[g] = j.res_sums; mm.y[g] = j.y;
         mm.s_pts[g] = j.s_pts; mm.pk[g] = j.pk; mm.n[g] = g < count ? j.n : 0; mm.count[g] = j.count;
+        mm.stats_out[g] = g < count ? j.stats_out : nullptr;
         if (g < count) {
             PCRCG_CHECK_ARG(j.n >= 0 && j.x && j.sums && j.y && j.count >= 1.0);
             PCRCG_CHECK_ARG((j.res != nullptr) == (jobs[0].res != nullptr) && (j.res_sums != nullptr) == (jobs[0].res_sums != nullptr));

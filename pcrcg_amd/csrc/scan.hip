@@ -217,7 +217,8 @@ const DebugName kDebugNames[] = {
     {"kd_spin_limit", &DebugOpts::kd_spin_limit}, {"gemm_log", &DebugOpts::gemm_log}, {"x6_tile", &DebugOpts::x6_tile}, {"x6_order", &DebugOpts::x6_order}, {"x6_big", &DebugOpts::x6_big}, {"x6_h2", &DebugOpts::x6_h2}, {"train_side_stream", &DebugOpts::train_side_stream},
     {"x6_splitk", &DebugOpts::x6_splitk}, {"x6_t1", &DebugOpts::x6_t1}, {"x6_t2", &DebugOpts::x6_t2},
     {"gemm_tile", &DebugOpts::gemm_tile}, {"gemm_splitk", &DebugOpts::gemm_splitk},
-    {"gemm_split_target", &DebugOpts::gemm_split_target}, {"deterministic", &DebugOpts::deterministic}};
+    {"gemm_split_target", &DebugOpts::gemm_split_target}, {"deterministic", &DebugOpts::deterministic},
+    {"bwd_mfma", &DebugOpts::bwd_mfma}};
 // The options are IMMUTABLE snapshots behind one atomic pointer: the engine's front and model threads read them
 // concurrently (their library calls hold no lock), pcrcg_debug_set publishes a new snapshot and never frees an old one
 // (a handful of 100-byte objects per process), so a reader's reference stays valid and no field is ever seen half

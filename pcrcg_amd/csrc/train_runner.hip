@@ -255,9 +255,20 @@ TT instnorm_lrelu(Tape& t, const TT& x, float slope, TT* into = nullptr, const d
     const size_t wsb = pcrcg_instnorm_ws_bytes(x.cols), bwb = pcrcg_instnorm_backward_ws_bytes(x.cols);
     void* ws = t.value_bytes(wsb);
     if (t.live()) {
-        if (sums) t.check(pcrcg_instnorm_stats_from_partials(sums, 1, x.cols, (double)x.rows, 1e-5f, stats, t.st));
-        else t.check(pcrcg_instnorm_stats(x.p, x.rows, x.cols, x.ld, 1e-5f, stats, ws, wsb, t.st));
-        t.check(pcrcg_instnorm_apply(x.p, x.rows, x.cols, x.ld, stats, nullptr, 0, nullptr, slope, y.p, y.ld, t.st));
+        const int c4 = x.cols / 4;
+        const bool tiles = x.cols % 4 == 0 && c4 >= 1 && (c4 <= 256 ? 256 % c4 == 0 : c4 % 256 == 0) && x.ld % 4 == 0 && y.ld % 4 == 0 &&
+                           ((reinterpret_cast<uintptr_t>(x.p) | reinterpret_cast<uintptr_t>(y.p)) & 15) == 0;
+        if (sums && tiles && x.rows > 0) {
+            // statistics straight from the product's column sums inside the normalising kernel, which also leaves the
+            // (mean, rstd) pairs for the backward: one launch
+            NormJob one{x.p, sums, nullptr, nullptr, y.p, nullptr, nullptr, x.rows, (double)x.rows};
+            one.stats_out = stats;
+            t.check(instnorm_apply_sums_multi(&one, 1, x.cols, x.ld, 1e-5f, 0, slope, y.ld, false, t.st));
+        } else {
+            if (sums) t.check(pcrcg_instnorm_stats_from_partials(sums, 1, x.cols, (double)x.rows, 1e-5f, stats, t.st));
+            else t.check(pcrcg_instnorm_stats(x.p, x.rows, x.cols, x.ld, 1e-5f, stats, ws, wsb, t.st));
+            t.check(pcrcg_instnorm_apply(x.p, x.rows, x.cols, x.ld, stats, nullptr, 0, nullptr, slope, y.p, y.ld, t.st));
+        }
     }
     t.need_scratch(bwb + 256);
     t.record([x, y, stats, slope, bwb](Tape& b) {

@@ -194,6 +194,85 @@ __global__ void __launch_bounds__(256) k_kpconv_bwd_dx(const float* __restrict__
 // ---- pooling backward ---------------------------------------------------------------------------
 // max_pool: the gradient of y[q,c] = max_h x[idx[q,h],c] goes to the FIRST neighbour attaining the maximum
 // (shadow neighbours contribute the value 0 and swallow the gradient when they win, ref:models/blocks.py:95).
+// The same scatter on the matrix cores (round 5).  Per query the contribution of its H neighbours is the small product
+//   G[h, c] = sum_k w[h, k] d_wf[q, k, c]        (w: the H x 15 influence weights, ref:models/blocks.py:300-340)
+// and row h of G is added to dx[idx[q, h], :].  One wavefront per (query, 64-channel chunk) takes 16 neighbours at a time
+// through v_mfma_f32_16x16x4_f32: A = w (lane (j, hsub): neighbour j of the tile, kernel point 4 step + hsub), B = d_wf rows
+// (lane (j, hsub): channel 16 t + j, the same kernel point; loaded once per query), D register r of lane (j, hsub) = neighbour
+// 4 hsub + r, channel 16 t + j -- so one atomic instruction covers four neighbours' 64-byte runs.  fp32 in, fp32 out: the
+// products are the VALU kernel's up to summation order.
+typedef float bw_f32x4 __attribute__((ext_vector_type(4)));
+template <bool DET>
+__global__ void __launch_bounds__(256) k_kpconv_bwd_dx_mfma(const float* __restrict__ q_pts, int nq,
+                                                             const float* __restrict__ s_pts, int ns,
+                                                             const long long* __restrict__ idx, int H, int ld_idx,
+                                                             const float* __restrict__ d_wf, int cin,
+                                                             const float* __restrict__ kp, float extent,
+                                                             float* __restrict__ dx, int nchunk, FixAcc fx) {
+    const int lane = threadIdx.x & 63;
+    const int hsub = lane >> 4, j = lane & 15;
+    const float fscale = DET ? fix_scale(fx) : 1.0f;
+    const long item = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (item >= (long)nq * nchunk) return;
+    const int q = (int)(item / nchunk), chunk = (int)(item - (long)q * nchunk);
+    const int c0 = chunk * 64;
+    const int nt = (cin - c0 + 15) / 16 < 4 ? (cin - c0 + 15) / 16 : 4;       // 16-channel groups of this chunk (wave-uniform)
+    const float inv_extent = 1.0f / extent;
+    const float qx = q_pts[3 * (long)q], qy = q_pts[3 * (long)q + 1], qz = q_pts[3 * (long)q + 2];
+    float kx[4], ky[4], kz[4], d[4][4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int k = 4 * st + hsub;                    // this lane's kernel point of step st (15: the padding row)
+        const int kc = k < K ? k : K - 1;
+        kx[st] = kp[3 * kc]; ky[st] = kp[3 * kc + 1]; kz[st] = kp[3 * kc + 2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = c0 + 16 * t + j;
+            const float v = d_wf[((long)q * K + kc) * cin + (c < cin ? c : cin - 1)];
+            d[st][t] = (k < K && c < cin) ? v : 0.f;
+        }
+    }
+    for (int hc = 0; hc < H; hc += 64) {
+        // lanes = neighbours: index + centred coordinates, once per 64 neighbours
+        const int h = hc + lane;
+        const long long iv = idx[(long)q * ld_idx + (h < H ? h : H - 1)];
+        const int i = (h < H && iv >= 0 && iv < ns) ? (int)iv : -1;
+        const long ic = i >= 0 ? i : 0;
+        const float px = s_pts[3 * ic] - qx, py = s_pts[3 * ic + 1] - qy, pz = s_pts[3 * ic + 2] - qz;
+        const int hn = H - hc < 64 ? H - hc : 64;
+        for (int h0 = 0; h0 < hn; h0 += 16) {
+            const int ii = __shfl(i, h0 + j, 64);
+            const float nx = __shfl(px, h0 + j, 64), ny = __shfl(py, h0 + j, 64), nz = __shfl(pz, h0 + j, 64);
+            if (__ballot(ii >= 0) == 0) continue;
+            float w[4];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const float ddx = nx - kx[st], ddy = ny - ky[st], ddz = nz - kz[st];
+                const float wv = fmaxf(1.0f - __builtin_amdgcn_sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) * inv_extent, 0.0f);
+                w[st] = (ii >= 0 && 4 * st + hsub < K) ? wv : 0.f;
+            }
+            bw_f32x4 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = (bw_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t >= nt) break;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[st], d[st][t], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ir = __shfl(i, h0 + 4 * hsub + r, 64);
+                if (ir < 0) continue;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int c = c0 + 16 * t + j;
+                    if (t < nt && c < cin) scatter_add<DET>(dx, (long)ir * cin + c, acc[t][r], fx, fscale);
+                }
+            }
+        }
+    }
+}
 template <bool DET>
 __global__ void __launch_bounds__(256) k_gather_max_bwd(const float* __restrict__ x, int ns, int c,
                                                          const long long* __restrict__ idx, int nq, int h, int ld_idx,
@@ -507,13 +586,21 @@ extern "C" int pcrcg_kpconv_backward_dx(const float* q_pts, int nq, const float*
     if (debug_opts().deterministic) {       // |contribution| <= 15 max|d_wf| (influence weights <= 1), at most nq of them per element
         FixAcc fx;
         PCRCG_PROPAGATE(det_begin(as_stream(stream), (size_t)ns * cin, d_wf, nq, PCRCG_KPOINTS * cin, (long)PCRCG_KPOINTS * cin, 22, &fx));
-        hipLaunchKernelGGL(k_kpconv_bwd_dx<true>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), q_pts, nq,
-                           s_pts, ns, reinterpret_cast<const long long*>(idx), h, ld_idx, d_wf, cin, kp, extent, dx, nchunk, fx);
+        if (debug_opts().bwd_mfma)
+            hipLaunchKernelGGL(k_kpconv_bwd_dx_mfma<true>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), q_pts,
+                               nq, s_pts, ns, reinterpret_cast<const long long*>(idx), h, ld_idx, d_wf, cin, kp, extent, dx, nchunk, fx);
+        else
+            hipLaunchKernelGGL(k_kpconv_bwd_dx<true>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), q_pts, nq,
+                               s_pts, ns, reinterpret_cast<const long long*>(idx), h, ld_idx, d_wf, cin, kp, extent, dx, nchunk, fx);
         PCRCG_CHECK_LAUNCH();
         return det_end(as_stream(stream), fx, dx, (size_t)ns * cin);
     }
-    hipLaunchKernelGGL(k_kpconv_bwd_dx<false>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), q_pts, nq,
-                       s_pts, ns, reinterpret_cast<const long long*>(idx), h, ld_idx, d_wf, cin, kp, extent, dx, nchunk, kNoFix);
+    if (debug_opts().bwd_mfma)
+        hipLaunchKernelGGL(k_kpconv_bwd_dx_mfma<false>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), q_pts, nq,
+                           s_pts, ns, reinterpret_cast<const long long*>(idx), h, ld_idx, d_wf, cin, kp, extent, dx, nchunk, kNoFix);
+    else
+        hipLaunchKernelGGL(k_kpconv_bwd_dx<false>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), q_pts, nq,
+                           s_pts, ns, reinterpret_cast<const long long*>(idx), h, ld_idx, d_wf, cin, kp, extent, dx, nchunk, kNoFix);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }

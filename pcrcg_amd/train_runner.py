@@ -29,7 +29,7 @@ class TrainOutputs(ctypes.Structure):
 class GatherJob(ctypes.Structure):
     """pcrcg_gather_job (include/pcrcg_train.h)."""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("m1", ctypes.c_void_p), ("m2", ctypes.c_void_p),
-                ("n", ctypes.c_int), ("s2", ctypes.c_float), ("accumulate", ctypes.c_int), ("pad_", ctypes.c_int)]
+                ("n", ctypes.c_int), ("s2", ctypes.c_float), ("accumulate", ctypes.c_int), ("cols", ctypes.c_int)]
 
 
 class _Tape:
@@ -129,13 +129,16 @@ class TrainRunner:
         def index_of(param):
             return torch.arange(param.numel(), dtype=torch.int32, device=dev).view(param.shape)
 
-        def derived(dst_v, dst_g, name, param, m1, m2=None, with_grad=True):
+        def derived(dst_v, dst_g, name, param, m1, m2=None, with_grad=True, transpose_cols=0):
             """A re-packed copy of `param`:  derived.flat[i] = param.flat[m1[i]] - param.flat[m2[i]]  (-1: nothing).  It
             lives in the plan's arena and follows the parameter every step; its gradient (with_grad, and the parameter
-            trains) lands in the twin arena and is added back through the inverse maps."""
-            specs.append(dict(dst_v=dst_v, dst_g=dst_g, name=name, param=param, m1=m1.reshape(-1).contiguous(),
+            trains) lands in the twin arena and is added back through the inverse maps.  transpose_cols: the copy is the
+            plain transpose of the parameter seen as [numel / cols, cols] (value only, m1 unused)."""
+            specs.append(dict(dst_v=dst_v, dst_g=dst_g, name=name, param=param, cols=int(transpose_cols),
+                              n=param.numel() if transpose_cols else m1.numel(),
+                              m1=None if transpose_cols else m1.reshape(-1).contiguous(),
                               m2=None if m2 is None else m2.reshape(-1).contiguous(),
-                              grad=bool(with_grad and param.requires_grad)))
+                              grad=bool(with_grad and param.requires_grad and not transpose_cols)))
 
         def kp_block(bv, bg, kp):
             if kp.in_channels != 1 and kp.in_channels % 4 != 0:
@@ -147,7 +150,7 @@ class TrainRunner:
             # a K-contiguous copy [cout, 15 cin] for the FORWARD contraction (value only: the gradient belongs to kp_w): the
             # k-contiguous product instead of the k-major one
             if (kp.weights.shape[0] * kp.weights.shape[1]) % 4 == 0:
-                derived(bv, bg, "kp_wt", kp.weights, index_of(kp.weights).reshape(-1, kp.weights.shape[-1]).t(), with_grad=False)
+                derived(bv, bg, "kp_wt", kp.weights, None, with_grad=False, transpose_cols=kp.weights.shape[-1])
 
         for i, mod in enumerate(m.encoder_blocks):
             bv, bg = v.enc[i], g.enc[i]
@@ -233,20 +236,20 @@ class TrainRunner:
         # ---- the arenas of the re-packed layouts and of their gradients, and the two job tables
         def rounded(n):
             return (n + 63) // 64 * 64
-        total = sum(rounded(sp["m1"].numel()) for sp in specs)
-        total_g = sum(rounded(sp["m1"].numel()) for sp in specs if sp["grad"])
+        total = sum(rounded(sp["n"]) for sp in specs)
+        total_g = sum(rounded(sp["n"]) for sp in specs if sp["grad"])
         values = torch.zeros(max(total, 1), dtype=torch.float32, device=dev)
         grads = torch.zeros(max(total_g, 1), dtype=torch.float32, device=dev)
         derive, fold = [], []
         off = off_g = 0
         for sp in specs:
-            p, n = sp["param"], sp["m1"].numel()
+            p, n = sp["param"], sp["n"]
             if p.dtype != torch.float32 or not p.is_cuda or not p.data.is_contiguous():
                 raise RuntimeError("pcrcg_amd.train_runner: weights must be contiguous float32 tensors on a HIP device")
             setattr(sp["dst_v"], sp["name"], values.data_ptr() + 4 * off)
             keep += [sp["m1"], sp["m2"], p.data]
-            derive.append(GatherJob(p.data_ptr(), values.data_ptr() + 4 * off, sp["m1"].data_ptr(),
-                                    sp["m2"].data_ptr() if sp["m2"] is not None else None, n, -1.0, 0, 0))
+            derive.append(GatherJob(p.data_ptr(), values.data_ptr() + 4 * off, sp["m1"].data_ptr() if sp["m1"] is not None else None,
+                                    sp["m2"].data_ptr() if sp["m2"] is not None else None, n, -1.0, 0, sp["cols"]))
             off += rounded(n)
             if not sp["grad"]:
                 setattr(sp["dst_g"], sp["name"], None)

@@ -72,6 +72,48 @@ def test_kpconv_grads(cuda, mini, level, strided, cin, cout):
     assert rel(x1.grad, x0.grad) < TOL
 
 
+@pytest.mark.parametrize("level,strided,cin", [(0, False, 32), (0, True, 40), (1, False, 129), (2, False, 256), (0, False, 1)])
+def test_kpconv_backward_dx_matrix_core_kernel_against_the_valu_kernel(cuda, mini, level, strided, cin):
+    """pcrcg_kpconv_backward_dx (include/pcrcg_train.h): the 16-neighbour MFMA tiles (round 5, bwd_mfma=1) and the
+    wavefront-per-neighbour VALU kernel they replace scatter the same sums up to order, and both match the float64 oracle's
+    d x of sum(wf * d_wf)."""
+    from pcrcg_amd import _lib, ops
+    from pcrcg_amd.kernel_points import load_kernels
+    g = torch.Generator().manual_seed(level * 7 + cin)
+    s_pts = mini["points"][level]
+    q_pts = mini["points"][level + 1] if strided else s_pts
+    idx = (mini["pools"][level] if strided else mini["neighbors"][level]).to(cuda).contiguous()
+    radius, extent = 0.0625 * 2 ** level, 0.05 * 2 ** level
+    kp = torch.tensor(load_kernels(radius, 15, dimension=3, fixed="center"), dtype=torch.float32)
+    nq, ns, h = q_pts.shape[0], s_pts.shape[0], idx.shape[1]
+    d_wf = torch.randn(nq, 15 * cin, generator=g)
+    L = _lib.lib()
+    q_d, s_d, g_d, kp_d = q_pts.to(cuda).contiguous(), s_pts.to(cuda).contiguous(), d_wf.to(cuda), kp.to(cuda)
+
+    def run(spec):
+        dx = torch.zeros(ns, cin, device=cuda)
+        try:
+            _lib.check(L.pcrcg_debug_set(spec), "pcrcg_debug_set")
+            _lib.check(L.pcrcg_kpconv_backward_dx(q_d.data_ptr(), nq, s_d.data_ptr(), ns, idx.data_ptr(), h, h, g_d.data_ptr(), cin,
+                                                  kp_d.data_ptr(), extent, dx.data_ptr(), ops._stream()), "pcrcg_kpconv_backward_dx")
+            torch.cuda.synchronize()
+        finally:
+            _lib.check(L.pcrcg_debug_set(None), "pcrcg_debug_set")
+        return dx
+    new, old = run(b"bwd_mfma=1"), run(b"bwd_mfma=0")
+    # float64: dx[i] = sum over (q, h) with idx[q, h] == i of sum_k w[q, h, k] d_wf[q, k, :]
+    idc = idx.cpu()
+    valid = idc < ns
+    nb = s_pts.double()[idc.clamp(max=ns - 1)] - q_pts.double()[:, None, :]
+    w = (1.0 - (nb[:, :, None, :] - kp.double()[None, None]).norm(dim=-1) / extent).clamp(min=0.0) * valid[:, :, None]
+    contrib = torch.einsum("qhk,qkc->qhc", w, d_wf.double().view(nq, 15, cin))
+    want = torch.zeros(ns + 1, cin, dtype=torch.float64)
+    want.index_add_(0, idc.clamp(max=ns).reshape(-1), contrib.reshape(-1, cin))
+    assert rel(old, want[:ns]) < TOL, ("valu", rel(old, want[:ns]))
+    assert rel(new, want[:ns]) < TOL, ("mfma", rel(new, want[:ns]))
+    assert rel(new, old) < 1e-5
+
+
 @pytest.mark.parametrize("n,c,slope", [(500, 64, 0.1), (1000, 130, 1.0), (37, 8, 0.0), (4000, 32, 0.2)])
 def test_instnorm_lrelu_grads(cuda, n, c, slope):
     g = torch.Generator().manual_seed(n + c)
