@@ -299,6 +299,55 @@ __global__ void __launch_bounds__(256) k_gather_max_bwd(const float* __restrict_
 }
 
 // closest_pool: dx[idx[q,0], :] += dy[q, :]
+// four channels per lane (c % 4 == 0): the neighbours' rows are read as float4, as the forward reads them
+template <bool DET>
+__global__ void __launch_bounds__(256) k_gather_max_bwd4(const float* __restrict__ x, int ns, int c,
+                                                          const long long* __restrict__ idx, int nq, int h, int ld_idx,
+                                                          const float* __restrict__ y, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int nchunk, FixAcc fx) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (item >= (long)nq * nchunk) return;
+    const int q = (int)(item / nchunk), chunk = (int)(item - (long)q * nchunk);
+    const int cb = chunk * 64 + lane;
+    if (cb >= (c >> 2)) return;
+    const float fscale = DET ? fix_scale(fx) : 1.0f;
+    const float4 m = reinterpret_cast<const float4*>(y + (long)q * c)[cb], gq = reinterpret_cast<const float4*>(dy + (long)q * c)[cb];
+    const long long* row = idx + (long)q * ld_idx;
+    // where each channel meets its maximum FIRST (that row takes the gradient); the adds are issued after the walk, whole
+    // wavefront at once: an atomic inside the walk would go out once per neighbour with a handful of lanes active
+    int open = 15;
+    long long at[4] = {-1, -1, -1, -1};
+    const float me[4] = {m.x, m.y, m.z, m.w};
+    for (int j0 = 0; j0 < h && open; j0 += 4) {            // four rows in flight (clamped, branch-free loads), then in order
+        long long iv[4];
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) iv[u] = row[j0 + u < h ? j0 + u : h - 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool real = iv[u] >= 0 && iv[u] < ns;
+            const float4 t = reinterpret_cast<const float4*>(x + (real ? iv[u] : 0) * c)[cb];
+            v[u] = real ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!real) iv[u] = -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + u >= h) break;
+            const float ve[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((open >> k & 1) && ve[k] == me[k]) {
+                    open &= ~(1 << k);
+                    at[k] = iv[u];
+                }
+        }
+    }
+    const float ge[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (at[k] >= 0) scatter_add<DET>(dx, at[k] * c + 4 * cb + k, ge[k], fx, fscale);
+}
 template <bool DET>
 __global__ void __launch_bounds__(256) k_gather_first_bwd(const float* __restrict__ dy, int ld_dy, int c,
                                                            const long long* __restrict__ idx, int nq, int ld_idx, int ns,
@@ -610,18 +659,21 @@ extern "C" int pcrcg_gather_max_backward(const float* x, int ns, int c, const in
     PCRCG_CHECK_ARG(ns >= 0 && c >= 1 && nq >= 0 && h >= 1 && ld_idx >= h);
     if (nq == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(x && idx && y && dy && dx);
-    const int nchunk = (c + 63) / 64;
+    const bool vec = c % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+    const int nchunk = vec ? (c / 4 + 63) / 64 : (c + 63) / 64;
     const long items = (long)nq * nchunk;
+    const dim3 grid((unsigned)((items + 3) / 4));
+    const long long* ix = reinterpret_cast<const long long*>(idx);
     if (debug_opts().deterministic) {
         FixAcc fx;
         PCRCG_PROPAGATE(det_begin(as_stream(stream), (size_t)ns * c, dy, nq, c, c, 20, &fx));
-        hipLaunchKernelGGL(k_gather_max_bwd<true>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), x, ns, c,
-                           reinterpret_cast<const long long*>(idx), nq, h, ld_idx, y, dy, dx, nchunk, fx);
+        if (vec) hipLaunchKernelGGL(k_gather_max_bwd4<true>, grid, dim3(256), 0, as_stream(stream), x, ns, c, ix, nq, h, ld_idx, y, dy, dx, nchunk, fx);
+        else hipLaunchKernelGGL(k_gather_max_bwd<true>, grid, dim3(256), 0, as_stream(stream), x, ns, c, ix, nq, h, ld_idx, y, dy, dx, nchunk, fx);
         PCRCG_CHECK_LAUNCH();
         return det_end(as_stream(stream), fx, dx, (size_t)ns * c);
     }
-    hipLaunchKernelGGL(k_gather_max_bwd<false>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), x, ns, c,
-                       reinterpret_cast<const long long*>(idx), nq, h, ld_idx, y, dy, dx, nchunk, kNoFix);
+    if (vec) hipLaunchKernelGGL(k_gather_max_bwd4<false>, grid, dim3(256), 0, as_stream(stream), x, ns, c, ix, nq, h, ld_idx, y, dy, dx, nchunk, kNoFix);
+    else hipLaunchKernelGGL(k_gather_max_bwd<false>, grid, dim3(256), 0, as_stream(stream), x, ns, c, ix, nq, h, ld_idx, y, dy, dx, nchunk, kNoFix);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -660,7 +712,8 @@ extern "C" int pcrcg_instnorm_backward(const float* x, int n, int c, int ldx, co
     float* means = cv.take<float>(2 * (size_t)c);
     PCRCG_CHECK_WS(cv);
     hipStream_t st = as_stream(stream);
-    int chunks = (n + 255) / 256;
+    // row chunks of >= 32 rows (8 per thread): the few-hundred-row tensors of the coarse levels are latency chains otherwise
+    int chunks = (n + 31) / 32;
     if (chunks > kBwdChunks) chunks = kBwdChunks;
     if (chunks < 1) chunks = 1;
     hipLaunchKernelGGL(k_in_bwd_partial, dim3(chunks, (c + 63) / 64), dim3(256), 0, st, x, n, c, ldx, stats, dy, ld_dy,
@@ -820,6 +873,46 @@ __global__ void __launch_bounds__(256) k_add_lrelu(const float* __restrict__ a, 
     const float v = a[r * lda + c] + b[r * ldb + c];
     y[r * ldy + c] = v >= 0.f ? v : v * slope;
 }
+// float4 forms of the element-wise kernels below (widths and leading dimensions multiples of 4, 16-byte aligned bases):
+// one thread per four channels of a row
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__global__ void __launch_bounds__(256) k_add_lrelu4(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                     float slope, float* __restrict__ y, int ldy, long total4, int c4) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total4) return;
+    const long r = t / c4;
+    const int c = 4 * (int)(t - r * c4);
+    const float4 u = ld4(a + r * lda + c), w = ld4(b + r * ldb + c);
+    float4 v = make_float4(u.x + w.x, u.y + w.y, u.z + w.z, u.w + w.w);
+    v.x = v.x >= 0.f ? v.x : v.x * slope; v.y = v.y >= 0.f ? v.y : v.y * slope;
+    v.z = v.z >= 0.f ? v.z : v.z * slope; v.w = v.w >= 0.f ? v.w : v.w * slope;
+    st4(y + r * ldy + c, v);
+}
+__global__ void __launch_bounds__(256) k_add_lrelu_bwd4(const float* __restrict__ y, int ldy, const float* __restrict__ dy,
+                                                         int ld_dy, float slope, float* __restrict__ ga, int lga,
+                                                         float* __restrict__ gb, int lgb, long total4, int c4) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total4) return;
+    const long r = t / c4;
+    const int c = 4 * (int)(t - r * c4);
+    const float4 yv = ld4(y + r * ldy + c), d = ld4(dy + r * ld_dy + c);
+    const float4 g = make_float4(d.x * (yv.x > 0.f ? 1.0f : slope), d.y * (yv.y > 0.f ? 1.0f : slope),
+                                 d.z * (yv.z > 0.f ? 1.0f : slope), d.w * (yv.w > 0.f ? 1.0f : slope));
+    if (ga) { float4 o = ld4(ga + r * lga + c); o.x += g.x; o.y += g.y; o.z += g.z; o.w += g.w; st4(ga + r * lga + c, o); }
+    if (gb) { float4 o = ld4(gb + r * lgb + c); o.x += g.x; o.y += g.y; o.z += g.z; o.w += g.w; st4(gb + r * lgb + c, o); }
+}
+__global__ void __launch_bounds__(256) k_add2d4(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst,
+                                                 long total4, int c4) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total4) return;
+    const long r = t / c4;
+    const int c = 4 * (int)(t - r * c4);
+    const float4 v = ld4(src + r * ld_src + c);
+    float4 o = ld4(dst + r * ld_dst + c);
+    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+    st4(dst + r * ld_dst + c, o);
+}
 // g = dy * (y > 0 ? 1 : slope), added to ga and gb (either may be NULL).  lrelu keeps the sign, so y > 0 <=> a + b > 0;
 // at exactly 0 torch's leaky_relu_backward takes the slope (x > 0 ? 1 : slope), and so does this.
 __global__ void __launch_bounds__(256) k_add_lrelu_bwd(const float* __restrict__ y, int ldy, const float* __restrict__ dy,
@@ -901,6 +994,7 @@ __global__ void __launch_bounds__(256) k_dot_acc(const float* __restrict__ a, co
     if (threadIdx.x == 0) atomicAdd(out, (float)(s[0] * (double)scale));
 }
 inline unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 }  // namespace
 
 int tr_scale_rows(const float* src, int ld_src, const float* s, float* dst, int rows, int cols, hipStream_t st) {
@@ -912,14 +1006,20 @@ int tr_scale_rows(const float* src, int ld_src, const float* s, float* dst, int 
 int tr_add_lrelu(const float* a, int lda, const float* b, int ldb, float slope, float* y, int ldy, int rows, int cols,
                  hipStream_t st) {
     const long total = (long)rows * cols;
-    if (total > 0) hipLaunchKernelGGL(k_add_lrelu, dim3(blocks_for(total)), dim3(256), 0, st, a, lda, b, ldb, slope, y, ldy, total, cols);
+    if (total > 0 && cols % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldy % 4 == 0 && al16(a) && al16(b) && al16(y))
+        hipLaunchKernelGGL(k_add_lrelu4, dim3(blocks_for(total / 4)), dim3(256), 0, st, a, lda, b, ldb, slope, y, ldy, total / 4, cols / 4);
+    else if (total > 0) hipLaunchKernelGGL(k_add_lrelu, dim3(blocks_for(total)), dim3(256), 0, st, a, lda, b, ldb, slope, y, ldy, total, cols);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
 int tr_add_lrelu_bwd(const float* y, int ldy, const float* dy, int ld_dy, float slope, float* ga, int lga, float* gb, int lgb,
                      int rows, int cols, hipStream_t st) {
     const long total = (long)rows * cols;
-    if (total > 0)
+    if (total > 0 && cols % 4 == 0 && ldy % 4 == 0 && ld_dy % 4 == 0 && (!ga || lga % 4 == 0) && (!gb || lgb % 4 == 0) && al16(y) &&
+        al16(dy) && al16(ga) && al16(gb))
+        hipLaunchKernelGGL(k_add_lrelu_bwd4, dim3(blocks_for(total / 4)), dim3(256), 0, st, y, ldy, dy, ld_dy, slope, ga, lga, gb, lgb,
+                           total / 4, cols / 4);
+    else if (total > 0)
         hipLaunchKernelGGL(k_add_lrelu_bwd, dim3(blocks_for(total)), dim3(256), 0, st, y, ldy, dy, ld_dy, slope, ga, lga, gb, lgb,
                            total, cols);
     PCRCG_CHECK_LAUNCH();
@@ -927,7 +1027,9 @@ int tr_add_lrelu_bwd(const float* y, int ldy, const float* dy, int ld_dy, float 
 }
 int tr_add2d(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t st) {
     const long total = (long)rows * cols;
-    if (total > 0) hipLaunchKernelGGL(k_add2d, dim3(blocks_for(total)), dim3(256), 0, st, src, ld_src, dst, ld_dst, total, cols);
+    if (total > 0 && cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && al16(src) && al16(dst))
+        hipLaunchKernelGGL(k_add2d4, dim3(blocks_for(total / 4)), dim3(256), 0, st, src, ld_src, dst, ld_dst, total / 4, cols / 4);
+    else if (total > 0) hipLaunchKernelGGL(k_add2d, dim3(blocks_for(total)), dim3(256), 0, st, src, ld_src, dst, ld_dst, total, cols);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
