@@ -133,6 +133,16 @@ int pcrcg_gather_first_backward(const float* dy, int ld_dy, int c, const int64_t
 size_t pcrcg_instnorm_backward_ws_bytes(int c);
 int pcrcg_instnorm_backward(const float* x, int n, int c, int ldx, const float* stats, const float* dy, int ld_dy,
                             float slope, float* dx, int ld_dx, void* ws, size_t ws_bytes, void* stream);
+/* Multi-head attention backward in ONE launch (round 5; forward: pcrcg_attention, include/pcrcg.h; ref:models/gcn.py:151-155,
+ * out[:, h d:(h+1) d] = softmax(scale q_h k_h^T) v_h with head-major column blocks).  Given q [n, heads d], k / v [ms, heads d],
+ * the forward's out and d_out = dL/d out, ADDS dL/dq, dL/dk, dL/dv to dq / dk / dv (float atomics: the caller zeroes them
+ * or holds other contributions there).  pcrcg_attention_backward_supported: head widths 32 / 64 / 128, ms <= 1216 (the score
+ * tile of a 32-query workgroup in LDS), leading dimensions multiples of 4, not under deterministic=1 -- the train tape keeps
+ * the per-head product path (pcrcg_gemm_f32_ex, pcrcg_softmax_rows_backward) for everything else. */
+int pcrcg_attention_backward_supported(int n, int ms, int d, int ldq, int ldk, int ldv, int ld_do);
+int pcrcg_attention_backward(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* out, int ldo,
+                             const float* d_out, int ld_do, float* dq, int ld_dq, float* dk, int ld_dk, float* dv, int ld_dv,
+                             int n, int ms, int heads, int d, float scale, void* stream);
 /* Row softmax p = softmax(s * scale): ds = scale * p * (dp - sum_j p*dp) (ref:models/gcn.py:151-155). */
 int pcrcg_softmax_rows_backward(const float* p, int ld_p, const float* dp, int ld_dp, int rows, int cols, float scale,
                                 float* ds, int ld_ds, void* stream);

@@ -135,6 +135,10 @@ SIGNATURES = {
     "pcrcg_instnorm_backward_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_instnorm_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p,
                                         c_int, c_void_p, c_size_t, c_void_p]),
+    "pcrcg_attention_backward_supported": (c_int, [c_int] * 7),
+    "pcrcg_attention_backward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                         c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                         c_void_p]),
     "pcrcg_softmax_rows_backward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
                                             c_void_p]),
     "pcrcg_edgeconv_backward_ws_bytes": (c_size_t, [c_int]),

@@ -137,6 +137,12 @@ struct AttnCloud { const float* q; const float* k; const float* v; float* out; i
 bool attention_mfma_ok(const AttnCloud* cl, int count, int ldq, int ldk, int ldv, int d);
 int attention_mfma_multi(const AttnCloud* cl, int count, int ldq, int ldk, int ldv, int ldo, int heads, int d, float scale,
                          hipStream_t st);
+// its backward (train step): gradients ADDED to dq / dk / dv by float atomics; false: keys beyond what the score tile of a
+// 32-query workgroup holds in LDS (1216), head widths other than 32 / 64 / 128, deterministic=1
+bool attention_bwd_mfma_ok(int n, int ms, int d, int ldq, int ldk, int ldv, int ld_do);
+int attention_bwd_mfma(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+                       const float* d_o, int ld_do, float* dq, int ld_dq, float* dk, int ld_dk, float* dv, int ld_dv, int n, int ms,
+                       int heads, int d, float scale, hipStream_t st);
 
 // Tuning / A-B switches of the library, in ONE place.  Every field defaults to the product behaviour; they are set by
 // pcrcg_debug_set("name=value,name=value") or, once at first use, from the environment variable PCRCG_DEBUG (same

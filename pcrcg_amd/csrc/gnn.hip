@@ -11,6 +11,7 @@
 //                         InstanceNorm2d statistics over all (i,j).
 //   pcrcg_softmax_rows    attention / saliency softmax (:151-155; ref:models/architectures.py:562-563).
 #include "common.h"
+#include "pcrcg_train.h"
 
 namespace pcrcg {
 
@@ -426,6 +427,210 @@ __global__ void __launch_bounds__(256) k_attention_mfma(AttMulti a) {
     }
 }
 
+// ---- the attention's backward on the same tiles (train step) --------------------------------------------------------------
+// out_h = softmax(scale q_h k_h^T) v_h (ref:models/gcn.py:151-155).  With P the softmax and D_i = sum_c dO_ic O_ic (= sum_j
+// P_ij dP_ij, so P need not be kept from the forward):
+//     dP = dO v^T,   dS = scale P o (dP - D),   dq = dS k,   dk = dS^T q,   dv = P^T dO.
+// A workgroup takes 32 queries of one head: it re-forms S and P for them in LDS (as the forward does), then dS in its place,
+// and its four wavefronts split the key blocks for dP, for dk / dv (contractions over the tile's 32 queries, partial over
+// the query tiles: float atomics into the zeroed gradients) and for dq (partial over a wavefront's keys: atomics as well).
+// fp32 operands on v_mfma_f32_32x32x2_f32 throughout.  The score tile must fit LDS (dS overwrites P once dv has read it):
+// ms <= 1216 keys (the indoor coarse clouds have 350-800); the tape keeps the per-head product path for anything larger
+// and for deterministic=1.
+struct AttBwd {
+    const float* q; const float* k; const float* v; const float* o; const float* d_o;
+    float* dq; float* dk; float* dv;
+    int n, ms, ldq, ldk, ldv, ldo, ld_do, ld_dq, ld_dk, ld_dv;
+    float scale;
+};
+template <int D>
+__global__ void __launch_bounds__(256) k_attention_bwd_mfma(AttBwd a) {
+    constexpr int DH = D / 2, NT = D / 32;
+    extern __shared__ __attribute__((aligned(16))) float attb_lds[];
+    const int n = a.n, ms = a.ms;
+    const int q0 = blockIdx.x * 32;
+    if (q0 >= n) return;
+    const int head = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int l31 = lane & 31, half = lane >> 5;
+    const int nkb = (ms + 31) / 32;
+    const int sld = nkb * 32 + 1;
+    float* const P = attb_lds;                     // [32][sld]: scores, then P, then (in place) dS
+    float* const dS = P;
+    float* const Di = P + 32 * sld;                // [32]
+    const int qrow = min(q0 + l31, n - 1);
+    // ---- 1: scores
+    {
+        float qr[DH];
+        const float* qp = a.q + (long)qrow * a.ldq + head * D + half * DH;
+#pragma unroll
+        for (int c = 0; c < DH / 4; ++c) {
+            const float4 t = *reinterpret_cast<const float4*>(qp + 4 * c);
+            qr[4 * c] = t.x; qr[4 * c + 1] = t.y; qr[4 * c + 2] = t.z; qr[4 * c + 3] = t.w;
+        }
+        for (int kb = wave; kb < nkb; kb += 4) {
+            const int key = kb * 32 + l31;
+            const float* krow = a.k + (long)min(key, ms - 1) * a.ldk + head * D + half * DH;
+            float kr[DH];
+#pragma unroll
+            for (int c = 0; c < DH / 4; ++c) {
+                const float4 t = *reinterpret_cast<const float4*>(krow + 4 * c);
+                kr[4 * c] = t.x; kr[4 * c + 1] = t.y; kr[4 * c + 2] = t.z; kr[4 * c + 3] = t.w;
+            }
+            attf16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < DH; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[kk], kr[kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                P[row * sld + key] = key < ms ? acc[r] * a.scale : -INFINITY;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2: P = softmax rows (rows past the cloud: zeros, so that they add nothing to dk / dv), D_i
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr;
+        float* const prow = P + row * sld;
+        const bool real = q0 + row < n;
+        float mx = -INFINITY;
+        for (int j = lane; j < nkb * 32; j += 64) mx = fmaxf(mx, prow[j]);
+#pragma unroll
+        for (int s2 = 32; s2 >= 1; s2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s2, 64));
+        float sum = 0.f;
+        for (int j = lane; j < nkb * 32; j += 64) {
+            const float e = expf(prow[j] - mx);
+            prow[j] = e;
+            sum += e;
+        }
+#pragma unroll
+        for (int s2 = 32; s2 >= 1; s2 >>= 1) sum += __shfl_xor(sum, s2, 64);
+        const float inv = real ? 1.0f / sum : 0.f;
+        for (int j = lane; j < nkb * 32; j += 64) prow[j] *= inv;
+        float dd = 0.f;
+        const long ro = (long)min(q0 + row, n - 1);
+        for (int c = lane; c < D; c += 64) dd = fmaf(a.d_o[ro * a.ld_do + head * D + c], a.o[ro * a.ldo + head * D + c], dd);
+#pragma unroll
+        for (int s2 = 32; s2 >= 1; s2 >>= 1) dd += __shfl_xor(dd, s2, 64);
+        if (lane == 0) Di[row] = dd;
+    }
+    __syncthreads();
+    // ---- 3: dv += P^T dO over this tile's 32 queries; wavefront w takes key blocks w, w + 4, ...
+    for (int kb = wave; kb < nkb; kb += 4) {
+        const int key_lo = kb * 32;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            attf16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int qi = 2 * s + half;                                   // the contraction index: a query of the tile
+                const long ro = (long)min(q0 + qi, n - 1);
+                const float av = P[qi * sld + key_lo + l31];                                      // A[row = key][k = query]
+                const float bv = a.d_o[ro * a.ld_do + head * D + 32 * t + l31];                        // B[k = query][col = channel]
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key_lo + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key < ms) atomicAdd(a.dv + (long)key * a.ld_dv + head * D + 32 * t + l31, acc[r]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 4: dP = dO v^T per key block, dS = scale P (dP - D) IN PLACE of P (an element is read and written by one lane)
+    {
+        float gr[DH];
+        const float* gp = a.d_o + (long)qrow * a.ld_do + head * D + half * DH;
+#pragma unroll
+        for (int c = 0; c < DH / 4; ++c) {
+            const float4 t = *reinterpret_cast<const float4*>(gp + 4 * c);
+            gr[4 * c] = t.x; gr[4 * c + 1] = t.y; gr[4 * c + 2] = t.z; gr[4 * c + 3] = t.w;
+        }
+        for (int kb = wave; kb < nkb; kb += 4) {
+            const int key = kb * 32 + l31;
+            const float* vrow = a.v + (long)min(key, ms - 1) * a.ldv + head * D + half * DH;
+            float vr[DH];
+#pragma unroll
+            for (int c = 0; c < DH / 4; ++c) {
+                const float4 t = *reinterpret_cast<const float4*>(vrow + 4 * c);
+                vr[4 * c] = t.x; vr[4 * c + 1] = t.y; vr[4 * c + 2] = t.z; vr[4 * c + 3] = t.w;
+            }
+            attf16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < DH; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gr[kk], vr[kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                dS[row * sld + key] = a.scale * P[row * sld + key] * (acc[r] - Di[row]);      // P = 0 on padded keys and rows
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 5: dk += dS^T q, the same contraction with dS and the queries
+    for (int kb = wave; kb < nkb; kb += 4) {
+        const int key_lo = kb * 32;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            attf16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int qi = 2 * s + half;                                   // the contraction index: a query of the tile
+                const long ro = (long)min(q0 + qi, n - 1);
+                const float av = dS[qi * sld + key_lo + l31];                                      // A[row = key][k = query]
+                const float bv = a.q[ro * a.ldq + head * D + 32 * t + l31];                        // B[k = query][col = channel]
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key_lo + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key < ms) atomicAdd(a.dk + (long)key * a.ld_dk + head * D + 32 * t + l31, acc[r]);
+            }
+        }
+    }
+    // ---- 6: dq += dS k over a wavefront's quarter of the key blocks
+    {
+        attf16 o[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+        const int per = (nkb + 3) / 4;
+        const int b0 = min(wave * per, nkb), b1 = min(b0 + per, nkb);
+        for (int bi = b0; bi < b1; ++bi) {
+            float pv[16], kv[NT][16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int key = bi * 32 + 16 * half + j;
+                pv[j] = dS[l31 * sld + key];
+                const float* krow = a.k + (long)min(key, ms - 1) * a.ldk + head * D;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) kv[t][j] = key < ms ? krow[t * 32 + l31] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[j], kv[t][j], o[t], 0, 0, 0);
+        }
+        if (b1 > b0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (q0 + row < n) atomicAdd(a.dq + (long)(q0 + row) * a.ld_dq + head * D + t * 32 + l31, o[t][r]);
+                }
+        }
+    }
+}
+
 // Round 5: the same reduction with the ROWS in parallel.  k_edgeconv_reduce below walks its rows with one 4-byte load per
 // lane and neighbour (a dependent chain of rows_per_chunk / 4 x (index -> k loads): 20 us for 381 x 10 x 512 values that
 // fit L2 ten times over).  Here a wavefront takes one row at a time: lanes 0 .. k-1 load the row's neighbour indices, which
@@ -757,6 +962,40 @@ int attention_mfma_multi(const AttnCloud* cl, int count, int ldq, int ldk, int l
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
+// attention backward on the matrix cores (k_attention_bwd_mfma): gradients ADDED to dq / dk / dv
+bool attention_bwd_mfma_ok(int n, int ms, int d, int ldq, int ldk, int ldv, int ld_do) {
+    if (!debug_opts().att_mfma || debug_opts().deterministic || n < 1 || ms < 1 || (d != 32 && d != 64 && d != 128)) return false;
+    if (ldq % 4 != 0 || ldk % 4 != 0 || ldv % 4 != 0 || ld_do % 4 != 0) return false;
+    const size_t sld = (size_t)((ms + 31) / 32) * 32 + 1;
+    return sizeof(float) * (32 * sld + 32) <= 156 * 1024;
+}
+int attention_bwd_mfma(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+                       const float* d_o, int ld_do, float* dq, int ld_dq, float* dk, int ld_dk, float* dv, int ld_dv, int n, int ms,
+                       int heads, int d, float scale, hipStream_t st) {
+    PCRCG_CHECK_ARG(attention_bwd_mfma_ok(n, ms, d, ldq, ldk, ldv, ld_do) && q && k && v && o && d_o && dq && dk && dv);
+    PCRCG_CHECK_ARG(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
+                      reinterpret_cast<uintptr_t>(d_o)) & 15) == 0);
+    AttBwd a{q, k, v, o, d_o, dq, dk, dv, n, ms, ldq, ldk, ldv, ldo, ld_do, ld_dq, ld_dk, ld_dv, scale};
+    const size_t sld = (size_t)((ms + 31) / 32) * 32 + 1;
+    const size_t lds = sizeof(float) * (32 * sld + 32);
+    const dim3 grid((n + 31) / 32, heads);
+#define ATTB(DD)                                                                                                          \
+    do {                                                                                                                  \
+        static size_t configured = 0;                                                                                     \
+        if (lds > configured) {                                                                                           \
+            PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_bwd_mfma<DD>),                  \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+            configured = lds;                                                                                             \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((k_attention_bwd_mfma<DD>), grid, dim3(256), lds, st, a);                                      \
+    } while (0)
+    if (d == 128) ATTB(128);
+    else if (d == 64) ATTB(64);
+    else ATTB(32);
+#undef ATTB
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
 }  // namespace pcrcg
 
 using namespace pcrcg;
@@ -817,6 +1056,20 @@ int pcrcg_edgeconv_reduce_sums(const float* ctr, int ld_ctr, const float* nbr, i
                        nbr, ld_nbr, idx, n, k, c, emax, ld_emax, static_cast<double*>(sums));
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
+}
+
+int pcrcg_attention_backward_supported(int n, int ms, int d, int ldq, int ldk, int ldv, int ld_do) {
+    return attention_bwd_mfma_ok(n, ms, d, ldq, ldk, ldv, ld_do) ? 1 : 0;
+}
+int pcrcg_attention_backward(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* out, int ldo,
+                             const float* d_out, int ld_do, float* dq, int ld_dq, float* dk, int ld_dk, float* dv, int ld_dv,
+                             int n, int ms, int heads, int d, float scale, void* stream) {
+    PCRCG_CHECK_ARG(n >= 0 && ms >= 1 && heads >= 1);
+    if (n == 0) return PCRCG_OK;
+    PCRCG_CHECK_ARG(ldq >= heads * d && ldk >= heads * d && ldv >= heads * d && ldo >= heads * d && ld_do >= heads * d &&
+                    ld_dq >= heads * d && ld_dk >= heads * d && ld_dv >= heads * d);
+    return attention_bwd_mfma(q, ldq, k, ldk, v, ldv, out, ldo, d_out, ld_do, dq, ld_dq, dk, ld_dk, dv, ld_dv, n, ms, heads, d, scale,
+                              as_stream(stream));
 }
 
 int pcrcg_attention_supported(int d) { return d == 16 || d == 32 || d == 48 || d == 64 || d == 128; }

@@ -463,11 +463,24 @@ TT cross_attention(Tape& t, const pcrcg_model& m, const pcrcg_gnn_layer& g, cons
     TT kk = linear(t, src, wt(g.wk, gg.wk), ch, wt(g.bk, gg.bk), ch);
     TT v = linear(t, src, wt(g.wv, gg.wv), ch, wt(g.bv, gg.bv), ch);
     TT msg = t.tensor(n, ch);
-    for (int i = 0; i < h; ++i) {
-        TT qi = cols(q, i * d, d), ki = cols(kk, i * d, d), vi = cols(v, i * d, d), mi = cols(msg, i * d, d);
-        TT prob = softmax_rows(t, matmul_bt(t, qi, ki), 1.0f / sqrtf((float)d));
-        (void)ms;
-        matmul_nn(t, prob, vi, &mi);
+    const float scale = 1.0f / sqrtf((float)d);
+    AttnCloud one{q.p, kk.p, v.p, msg.p, n, ms};
+    // every head in ONE launch each way on the fp32 matrix cores (round 5; the sizing pass keeps the per-head path's
+    // workspace, which is the larger one)
+    const bool fused = !t.dry && q.g && kk.g && v.g && attention_mfma_ok(&one, 1, q.ld, kk.ld, v.ld, d) &&
+                       attention_bwd_mfma_ok(n, ms, d, q.ld, kk.ld, v.ld, msg.ld);
+    if (fused) {
+        if (t.live()) t.check(attention_mfma_multi(&one, 1, q.ld, kk.ld, v.ld, msg.ld, h, d, scale, t.st));
+        t.record([q, kk, v, msg, n, ms, h, d, scale](Tape& b) {
+            b.check(attention_bwd_mfma(q.p, q.ld, kk.p, kk.ld, v.p, v.ld, msg.p, msg.ld, msg.g, msg.ld, q.g, q.ld, kk.g, kk.ld, v.g,
+                                       v.ld, n, ms, h, d, scale, b.st));
+        });
+    } else {
+        for (int i = 0; i < h; ++i) {
+            TT qi = cols(q, i * d, d), ki = cols(kk, i * d, d), vi = cols(v, i * d, d), mi = cols(msg, i * d, d);
+            TT prob = softmax_rows(t, matmul_bt(t, qi, ki), scale);
+            matmul_nn(t, prob, vi, &mi);
+        }
     }
     TT cat = t.tensor(n, 2 * ch);
     copy_into(t, x, cols(cat, 0, ch));

@@ -114,6 +114,44 @@ def test_kpconv_backward_dx_matrix_core_kernel_against_the_valu_kernel(cuda, min
     assert rel(new, old) < 1e-5
 
 
+@pytest.mark.parametrize("n,ms,heads,d", [(381, 382, 4, 128), (382, 381, 4, 128), (33, 65, 2, 64), (100, 1216, 1, 32), (1, 3, 1, 32), (500, 700, 4, 128),
+                                          (450, 31, 3, 64)])
+def test_attention_backward_one_launch(cuda, n, ms, heads, d):
+    """pcrcg_attention_backward (include/pcrcg_train.h): dq, dk, dv of out_h = softmax(q_h k_h^T / sqrt(d)) v_h
+    (ref:models/gcn.py:151-155) against float64 autograd, ADDED to what the buffers hold; strided operands as the train
+    tape has them (column slices of wider matrices); shapes beyond the kernel are refused."""
+    from pcrcg_amd import _lib, ops
+    g = torch.Generator().manual_seed(n * 3 + ms + d)
+    ch = heads * d
+    wide_q = torch.randn(n, ch + 8, generator=g) * 1.3
+    wide_kv = torch.randn(ms, 2 * ch + 4, generator=g) * 1.3
+    d_out = torch.randn(n, ch, generator=g)
+    q64 = wide_q[:, 4:4 + ch].double().clone().requires_grad_(True)
+    k64 = wide_kv[:, :ch].double().clone().requires_grad_(True)
+    v64 = wide_kv[:, ch + 4:].double().clone().requires_grad_(True)
+    outs = []
+    for h in range(heads):
+        sl = slice(h * d, (h + 1) * d)
+        outs.append(torch.softmax(q64[:, sl] @ k64[:, sl].t() / d ** 0.5, 1) @ v64[:, sl])
+    out64 = torch.cat(outs, 1)
+    out64.backward(d_out.double())
+    L = _lib.lib()
+    wq, wkv, do = wide_q.to(cuda), wide_kv.to(cuda), d_out.to(cuda)
+    qd, kd, vd = wq[:, 4:4 + ch], wkv[:, :ch], wkv[:, ch + 4:]
+    out = ops.attention(qd, kd, vd, heads)
+    assert rel(out, out64.detach()) < 5e-6
+    assert L.pcrcg_attention_backward_supported(n, ms, d, wq.stride(0), wkv.stride(0), wkv.stride(0), ch) == 1
+    base = torch.randn(n, ch, generator=g).to(cuda)                     # dq already holds something: the kernel adds
+    dq, dk, dv = base.clone(), torch.zeros(ms, ch, device=cuda), torch.zeros(ms, ch, device=cuda)
+    _lib.check(L.pcrcg_attention_backward(qd.data_ptr(), wq.stride(0), kd.data_ptr(), wkv.stride(0), vd.data_ptr(), wkv.stride(0),
+                                          out.data_ptr(), ch, do.data_ptr(), ch, dq.data_ptr(), ch, dk.data_ptr(), ch, dv.data_ptr(), ch,
+                                          n, ms, heads, d, d ** -0.5, ops._stream()), "pcrcg_attention_backward")
+    torch.cuda.synchronize()
+    assert rel(dq - base, q64.grad) < 2e-5 and rel(dk, k64.grad) < 2e-5 and rel(dv, v64.grad) < 2e-5
+    assert L.pcrcg_attention_backward_supported(n, 1217, d, ch, ch, ch, ch) == 0       # the score tile no longer fits LDS
+    assert L.pcrcg_attention_backward_supported(n, ms, 48, ch, ch, ch, ch) == 0
+
+
 @pytest.mark.parametrize("n,c,slope", [(500, 64, 0.1), (1000, 130, 1.0), (37, 8, 0.0), (4000, 32, 0.2)])
 def test_instnorm_lrelu_grads(cuda, n, c, slope):
     g = torch.Generator().manual_seed(n + c)
