@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(256) k_attention_mfma(AttMulti a) {
 // P_ij dP_ij, so P need not be kept from the forward):
 //     dP = dO v^T,   dS = scale P o (dP - D),   dq = dS k,   dk = dS^T q,   dv = P^T dO.
 // A workgroup takes 32 queries of one head: it re-forms S and P for them in LDS (as the forward does), then dS in its place,
-// and its four wavefronts split the key blocks for dP, for dk / dv (contractions over the tile's 32 queries, partial over
+// and its eight wavefronts split the key blocks for dP, for dk / dv (contractions over the tile's 32 queries, partial over
 // the query tiles: float atomics into the zeroed gradients) and for dq (partial over a wavefront's keys: atomics as well).
 // fp32 operands on v_mfma_f32_32x32x2_f32 throughout.  The score tile must fit LDS (dS overwrites P once dv has read it):
 // ms <= 1216 keys (the indoor coarse clouds have 350-800); the tape keeps the per-head product path for anything larger
@@ -444,8 +444,8 @@ struct AttBwd {
     float scale;
 };
 template <int D>
-__global__ void __launch_bounds__(256) k_attention_bwd_mfma(AttBwd a) {
-    constexpr int DH = D / 2, NT = D / 32;
+__global__ void __launch_bounds__(512) k_attention_bwd_mfma(AttBwd a) {
+    constexpr int DH = D / 2, NT = D / 32, NW = 8;          // eight wavefronts: the workgroups are few (n / 32 x heads), their key loops long
     extern __shared__ __attribute__((aligned(16))) float attb_lds[];
     const int n = a.n, ms = a.ms;
     const int q0 = blockIdx.x * 32;
@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(256) k_attention_bwd_mfma(AttBwd a) {
             const float4 t = *reinterpret_cast<const float4*>(qp + 4 * c);
             qr[4 * c] = t.x; qr[4 * c + 1] = t.y; qr[4 * c + 2] = t.z; qr[4 * c + 3] = t.w;
         }
-        for (int kb = wave; kb < nkb; kb += 4) {
+        for (int kb = wave; kb < nkb; kb += NW) {
             const int key = kb * 32 + l31;
             const float* krow = a.k + (long)min(key, ms - 1) * a.ldk + head * D + half * DH;
             float kr[DH];
@@ -491,8 +491,8 @@ __global__ void __launch_bounds__(256) k_attention_bwd_mfma(AttBwd a) {
     }
     __syncthreads();
     // ---- 2: P = softmax rows (rows past the cloud: zeros, so that they add nothing to dk / dv), D_i
-    for (int rr = 0; rr < 8; ++rr) {
-        const int row = wave * 8 + rr;
+    for (int rr = 0; rr < 32 / NW; ++rr) {
+        const int row = wave * (32 / NW) + rr;
         float* const prow = P + row * sld;
         const bool real = q0 + row < n;
         float mx = -INFINITY;
@@ -517,8 +517,8 @@ __global__ void __launch_bounds__(256) k_attention_bwd_mfma(AttBwd a) {
         if (lane == 0) Di[row] = dd;
     }
     __syncthreads();
-    // ---- 3: dv += P^T dO over this tile's 32 queries; wavefront w takes key blocks w, w + 4, ...
-    for (int kb = wave; kb < nkb; kb += 4) {
+    // ---- 3: dv += P^T dO over this tile's 32 queries; wavefront w takes key blocks w, w + 8, ...
+    for (int kb = wave; kb < nkb; kb += NW) {
         const int key_lo = kb * 32;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(256) k_attention_bwd_mfma(AttBwd a) {
             const float4 t = *reinterpret_cast<const float4*>(gp + 4 * c);
             gr[4 * c] = t.x; gr[4 * c + 1] = t.y; gr[4 * c + 2] = t.z; gr[4 * c + 3] = t.w;
         }
-        for (int kb = wave; kb < nkb; kb += 4) {
+        for (int kb = wave; kb < nkb; kb += NW) {
             const int key = kb * 32 + l31;
             const float* vrow = a.v + (long)min(key, ms - 1) * a.ldv + head * D + half * DH;
             float vr[DH];
@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(256) k_attention_bwd_mfma(AttBwd a) {
     }
     __syncthreads();
     // ---- 5: dk += dS^T q, the same contraction with dS and the queries
-    for (int kb = wave; kb < nkb; kb += 4) {
+    for (int kb = wave; kb < nkb; kb += NW) {
         const int key_lo = kb * 32;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(256) k_attention_bwd_mfma(AttBwd a) {
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-        const int per = (nkb + 3) / 4;
+        const int per = (nkb + NW - 1) / NW;
         const int b0 = min(wave * per, nkb), b1 = min(b0 + per, nkb);
         for (int bi = b0; bi < b1; ++bi) {
             float pv[16], kv[NT][16];
@@ -987,7 +987,7 @@ int attention_bwd_mfma(const float* q, int ldq, const float* k, int ldk, const f
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
             configured = lds;                                                                                             \
         }                                                                                                                 \
-        hipLaunchKernelGGL((k_attention_bwd_mfma<DD>), grid, dim3(256), lds, st, a);                                      \
+        hipLaunchKernelGGL((k_attention_bwd_mfma<DD>), grid, dim3(512), lds, st, a);                                      \
     } while (0)
     if (d == 128) ATTB(128);
     else if (d == 64) ATTB(64);

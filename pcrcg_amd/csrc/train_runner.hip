@@ -280,8 +280,8 @@ TT instnorm_lrelu(Tape& t, const TT& x, float slope, TT* into = nullptr, const d
 }
 
 // y = lrelu(a + b, slope)   (slope 1: a plain sum)
-TT add_lrelu(Tape& t, const TT& a, const TT& bb, float slope) {
-    TT y = t.tensor(a.rows, a.cols);
+TT add_lrelu(Tape& t, const TT& a, const TT& bb, float slope, TT* into = nullptr) {
+    TT y = into ? *into : t.tensor(a.rows, a.cols);
     if (t.live()) t.check(tr_add_lrelu(a.p, a.ld, bb.p, bb.ld, slope, y.p, y.ld, a.rows, a.cols, t.st));
     t.record([a, bb, y, slope](Tape& b) {
         b.check(tr_add_lrelu_bwd(y.p, y.ld, y.g, y.ld, slope, a.g, a.ld, bb.g, bb.ld, a.rows, a.cols, b.st));
@@ -412,18 +412,13 @@ TT encoder_block(Tape& t, const pcrcg_batch& b, const pcrcg_block& blk, const pc
 
 // ---- GNN head (ref:models/gcn.py) ----------------------------------------------------------------------------------
 // max_j lrelu(IN2d(ctr_i + nbr_idx[i,j]), 0.2), statistics over all n*k edges (:37-64, 121-129)
-TT edge_conv(Tape& t, const TT& f, Wt w_packed, int cout, const int* idx, int k, TT* into) {
-    // packed weight [2*cout, cin]: rows [0, cout) = Wa - Wb (centre term), rows [cout, 2 cout) = Wb (neighbour term)
-    const int cin = f.cols, n = f.rows;
-    Wt wc = w_packed, wn = w_packed;
-    wn.p = w_packed.p + (long)cout * cin;
-    wn.g = w_packed.g ? w_packed.g + (long)cout * cin : nullptr;
-    TT ctr = linear(t, f, wc, cin, Wt(), cout), nbr = linear(t, f, wn, cin, Wt(), cout);
+// the part behind the two weight products: ctr / nbr [n, cout] dense, y = *into (a column slice of the concatenation)
+void edge_conv_core(Tape& t, const TT& ctr, const TT& nbr, int cout, const int* idx, int k, const TT& y) {
+    const int n = ctr.rows;
     TT emax = t.tensor(n, cout, false);
     float* stats = static_cast<float*>(t.value_bytes(sizeof(float) * 2 * cout));
     const size_t wsb = pcrcg_edgeconv_ws_bytes(cout), bwb = pcrcg_edgeconv_backward_ws_bytes(cout);
     void* ws = t.value_bytes(wsb);
-    TT y = *into;
     if (t.live()) {
         t.check(pcrcg_edgeconv_reduce(ctr.p, ctr.ld, nbr.p, nbr.ld, idx, n, k, cout, 1e-5f, emax.p, emax.ld, stats, ws, wsb, t.st));
         t.check(pcrcg_instnorm_apply(emax.p, n, cout, emax.ld, stats, nullptr, 0, nullptr, 0.2f, y.p, y.ld, t.st));
@@ -437,27 +432,51 @@ TT edge_conv(Tape& t, const TT& f, Wt w_packed, int cout, const int* idx, int k,
         // dctr is written, dnbr accumulated (both gradients are zero before: single consumers)
         b.check(pcrcg_edgeconv_backward(ctr.p, nbr.p, idx, n, k, cout, stats, dy, 0.2f, ctr.g, nbr.g, w, bwb, b.st));
     });
-    return y;
+}
+// f holds the rows of `clouds` clouds one after the other (rows_of[c] each): the two weight products run ONCE over all rows,
+// the edge maxima and their statistics per cloud (idx[c]: that cloud's kNN graph, k[c] columns)
+void edge_conv(Tape& t, const TT& f, Wt w_packed, int cout, int clouds, const int* rows_of, int* const* idx, const int* k,
+               const TT& into) {
+    // packed weight [2*cout, cin]: rows [0, cout) = Wa - Wb (centre term), rows [cout, 2 cout) = Wb (neighbour term)
+    const int cin = f.cols;
+    Wt wc = w_packed, wn = w_packed;
+    wn.p = w_packed.p + (long)cout * cin;
+    wn.g = w_packed.g ? w_packed.g + (long)cout * cin : nullptr;
+    TT ctr = linear(t, f, wc, cin, Wt(), cout), nbr = linear(t, f, wn, cin, Wt(), cout);
+    for (int c = 0, r0 = 0; c < clouds; r0 += rows_of[c], ++c)
+        edge_conv_core(t, rows(ctr, r0, rows_of[c]), rows(nbr, r0, rows_of[c]), cout, idx[c], k[c], rows(into, r0, rows_of[c]));
 }
 
-TT self_attention(Tape& t, const pcrcg_model& m, const pcrcg_gnn_layer& g, const pcrcg_gnn_layer& gg, const float* coords,
-                  const TT& f) {
+// One DGCNN self-attention layer for the stacked rows of `clouds` clouds (round 5: the pair's two clouds share every weight
+// product -- one launch forward, one dX and one dW backward instead of two each; kNN graphs, edge maxima and InstanceNorm
+// statistics stay per cloud, so the clouds never mix)
+TT self_attention(Tape& t, const pcrcg_model& m, const pcrcg_gnn_layer& g, const pcrcg_gnn_layer& gg, int clouds,
+                  const float* const* coords, const int* rows_of, const TT& f) {
     const int n = f.rows, ch = f.cols;
-    const int k = m.knn_k < n - 1 ? m.knn_k : n - 1;
-    int* idx = static_cast<int*>(t.value_bytes(sizeof(int) * (size_t)n * (k > 0 ? k : 1) + 256));
+    int* idx[2];
+    int k[2];
+    for (int c = 0; c < clouds; ++c) {
+        k[c] = m.knn_k < rows_of[c] - 1 ? m.knn_k : rows_of[c] - 1;
+        idx[c] = static_cast<int*>(t.value_bytes(sizeof(int) * (size_t)rows_of[c] * (k[c] > 0 ? k[c] : 1) + 256));
+        if (t.live()) t.check(pcrcg_knn(coords[c], rows_of[c], k[c], idx[c], t.st));
+    }
     TT cat = t.tensor(n, 4 * ch);
-    if (t.live()) t.check(pcrcg_knn(coords, n, k, idx, t.st));
     copy_into(t, f, cols(cat, 0, ch));                                                           // x0
     TT s1 = cols(cat, ch, ch), s2 = cols(cat, 2 * ch, 2 * ch);
-    edge_conv(t, f, wt(g.edge1, gg.edge1), ch, idx, k, &s1);                                     // x1 :121-125
-    edge_conv(t, s1, wt(g.edge2, gg.edge2), 2 * ch, idx, k, &s2);                                // x2 :127-129
+    edge_conv(t, f, wt(g.edge1, gg.edge1), ch, clouds, rows_of, idx, k, s1);                     // x1 :121-125
+    edge_conv(t, s1, wt(g.edge2, gg.edge2), 2 * ch, clouds, rows_of, idx, k, s2);                // x2 :127-129
     TT x3 = linear(t, cat, wt(g.conv3, gg.conv3), 4 * ch, Wt(), ch);                             // :131-132
-    return instnorm_lrelu(t, x3, 0.2f);
+    TT out = t.tensor(n, ch);
+    for (int c = 0, r0 = 0; c < clouds; r0 += rows_of[c], ++c) {
+        TT oc = rows(out, r0, rows_of[c]);
+        instnorm_lrelu(t, rows(x3, r0, rows_of[c]), 0.2f, &oc);
+    }
+    return out;
 }
 
 // x + AttentionalPropagation(x, src)   (:151-185, 213-214); weights head-major (runner.py permutes them)
 TT cross_attention(Tape& t, const pcrcg_model& m, const pcrcg_gnn_layer& g, const pcrcg_gnn_layer& gg, const TT& x,
-                   const TT& src) {
+                   const TT& src, TT* into = nullptr) {
     const int n = x.rows, ms = src.rows, ch = x.cols, h = m.heads, d = ch / h;
     TT q = linear(t, x, wt(g.wq, gg.wq), ch, wt(g.bq, gg.bq), ch);
     TT kk = linear(t, src, wt(g.wk, gg.wk), ch, wt(g.bk, gg.bk), ch);
@@ -489,7 +508,7 @@ TT cross_attention(Tape& t, const pcrcg_model& m, const pcrcg_gnn_layer& g, cons
     TT h0 = linear(t, cat, wt(g.w0, gg.w0), 2 * ch, wt(g.b0, gg.b0), 2 * ch);
     TT h1 = instnorm_lrelu(t, h0, 0.0f);                                                        // InstanceNorm1d + ReLU
     TT delta = linear(t, h1, wt(g.w3, gg.w3), 2 * ch, wt(g.b3, gg.b3), ch);
-    return add_lrelu(t, x, delta, 1.0f);
+    return add_lrelu(t, x, delta, 1.0f, into);
 }
 
 void forward(Tape& t, const pcrcg_model& m, const pcrcg_model& gm, const pcrcg_batch& b) {
@@ -506,22 +525,23 @@ void forward(Tape& t, const pcrcg_model& m, const pcrcg_model& gm, const pcrcg_b
     // bottleneck + GNN (:527-536)
     const int nc = b.n_points[L - 1], ns = b.len_src_c, nt = nc - ns, g = m.gnn_dim;
     TT fc = linear(t, x, wt(m.bottle_w, gm.bottle_w), m.enc_out_dim, wt(m.bottle_b, gm.bottle_b), g);
-    TT d0 = rows(fc, 0, ns), d1 = rows(fc, ns, nt);
-    const float* c0 = b.points[L - 1];
-    const float* c1 = b.points[L - 1] + 3 * (long)ns;
+    // the GNN state of both clouds lives in ONE [ns + nt, g] tensor (source rows first): self-attention layers take it whole
+    TT dd = fc;
+    const float* coords[2] = {b.points[L - 1], b.points[L - 1] + 3 * (long)ns};
+    const int rows_of[2] = {ns, nt};
     for (int i = 0; i < m.n_gnn; ++i) {
         if (m.gnn[i].cross) {
-            d0 = cross_attention(t, m, m.gnn[i], gm.gnn[i], d0, d1);
-            d1 = cross_attention(t, m, m.gnn[i], gm.gnn[i], d1, d0);             // sees the updated d0 (:214)
+            TT nxt = t.tensor(nc, g);
+            TT n0 = rows(nxt, 0, ns), n1 = rows(nxt, ns, nt);
+            cross_attention(t, m, m.gnn[i], gm.gnn[i], rows(dd, 0, ns), rows(dd, ns, nt), &n0);
+            cross_attention(t, m, m.gnn[i], gm.gnn[i], rows(dd, ns, nt), n0, &n1);          // sees the updated source cloud (:214)
+            dd = nxt;
         } else {
-            d0 = self_attention(t, m, m.gnn[i], gm.gnn[i], c0, d0);
-            d1 = self_attention(t, m, m.gnn[i], gm.gnn[i], c1, d1);
+            dd = self_attention(t, m, m.gnn[i], gm.gnn[i], 2, coords, rows_of, dd);
         }
     }
     // coarse head (:538-565): x = [score | saliency | proj_gnn feats]
-    TT gcat = t.tensor(nc, g);
-    copy_into(t, d0, rows(gcat, 0, ns));
-    copy_into(t, d1, rows(gcat, ns, nt));
+    const TT& gcat = dd;
     const int wc = g + 2;
     TT xc = t.tensor(nc, wc);
     TT feats = cols(xc, 2, g), score = cols(xc, 0, 1), sal = cols(xc, 1, 1);
