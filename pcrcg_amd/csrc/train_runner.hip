@@ -61,6 +61,14 @@ struct Wt {                 // a weight and the buffer its gradient is accumulat
 struct Region {
     char* base = nullptr;
     size_t cap = 0, off = 0, peak = 0;
+    size_t top = 0;            // bytes handed out from the END of the region (take_top)
+    // from the end, growing downwards: the gradient region keeps there the tensors whose gradient the backward WRITES before
+    // anything reads it -- its one memset covers [0, off) only
+    void* take_top(size_t bytes) {
+        bytes = (bytes + 255) & ~size_t(255);
+        top += bytes;
+        return (base && top <= cap) ? base + ((cap - top) & ~size_t(255)) : nullptr;
+    }
     void* take(size_t bytes) {
         bytes = (bytes + 255) & ~size_t(255);
         void* q = base ? base + off : nullptr;
@@ -133,18 +141,19 @@ struct Tape {
     void check(int r) { if (r != PCRCG_OK && rc == PCRCG_OK) rc = r; }
     bool fits() {
         if (dry) return true;
-        if ((val.off > val.cap || grad.off > grad.cap) && rc == PCRCG_OK) {
+        if ((val.off > val.cap || grad.off + grad.top + 256 > grad.cap) && rc == PCRCG_OK) {
             set_error("pcrcg_kpfcnn_train_forward: workspace too small");
             rc = PCRCG_EWORKSPACE;
         }
         return rc == PCRCG_OK;
     }
-    TT tensor(int rows, int cols, bool want_grad = true, int ld = 0) {
+    // grad_written: the tensor's one consumer WRITES its gradient (an InstanceNorm behind a product): it need not be cleared
+    TT tensor(int rows, int cols, bool want_grad = true, int ld = 0, bool grad_written = false) {
         TT t;
         t.rows = rows; t.cols = cols; t.ld = ld ? ld : cols;
         const size_t bytes = sizeof(float) * (size_t)(rows > 0 ? rows : 1) * t.ld;
         t.p = static_cast<float*>(val.take(bytes));
-        if (want_grad) t.g = static_cast<float*>(grad.take(bytes));
+        if (want_grad) t.g = static_cast<float*>(grad_written ? grad.take_top(bytes) : grad.take(bytes));
         fits();
         return t;
     }
@@ -196,8 +205,10 @@ inline size_t fbytes(long rows, long cols) { return sizeof(float) * (size_t)(row
 // y = x @ W^T (+ bias); W [out, in] with leading dimension ldw   (nn.Linear / 1x1 convolution on row-major features)
 // sums_out (optional): receives fp64 column sums [2][out] of y left by the product's epilogue (for the InstanceNorm that
 // follows), or NULL when this product could not leave them (split over K, no slot)
-TT linear(Tape& t, const TT& x, Wt w, int ldw, Wt bias, int out, TT* into = nullptr, const double** sums_out = nullptr) {
-    TT y = into ? *into : t.tensor(x.rows, out);
+// y_grad_written: y goes into ONE InstanceNorm and nowhere else (its backward writes y's gradient: see Tape::tensor)
+TT linear(Tape& t, const TT& x, Wt w, int ldw, Wt bias, int out, TT* into = nullptr, const double** sums_out = nullptr,
+          bool y_grad_written = false) {
+    TT y = into ? *into : t.tensor(x.rows, out, true, 0, y_grad_written);
     if (sums_out) *sums_out = nullptr;
     if (t.live()) {
         double* slot = sums_out ? t.sums_slot(out) : nullptr;
@@ -305,7 +316,7 @@ TT kpconv(Tape& t, const pcrcg_batch& b, const pcrcg_block& blk, Wt w, const TT&
     const float* q = blk.strided ? b.points[l + 1] : b.points[l];
     const int nq = blk.strided ? b.n_points[l + 1] : b.n_points[l];
     const int ns = b.n_points[l], cin = x.cols, cout = blk.mid_dim, kc = PCRCG_KPOINTS * cin;
-    TT y = t.tensor(nq, cout);
+    TT y = t.tensor(nq, cout, true, 0, true);       // (every KPConv of the network feeds one InstanceNorm: encoder_block)
     float* wf = static_cast<float*>(t.value_bytes(fbytes(nq, kc)));
     float* inv_n = static_cast<float*>(t.value_bytes(fbytes(nq, 1)));
     const size_t wsb = pcrcg_kpconv_ws_bytes(ns);
@@ -386,7 +397,7 @@ TT softmax_rows(Tape& t, const TT& s, float scale, float* scale_grad = nullptr) 
 // ---- blocks (ref:models/blocks.py) ---------------------------------------------------------------------------------
 TT unary(Tape& t, const TT& x, Wt w, int ldw, int out, float slope) {
     const double* sums = nullptr;
-    TT y = linear(t, x, w, ldw, Wt(), out, nullptr, &sums);
+    TT y = linear(t, x, w, ldw, Wt(), out, nullptr, &sums, true);
     return instnorm_lrelu(t, y, slope, nullptr, sums);
 }
 
@@ -465,7 +476,7 @@ TT self_attention(Tape& t, const pcrcg_model& m, const pcrcg_gnn_layer& g, const
     TT s1 = cols(cat, ch, ch), s2 = cols(cat, 2 * ch, 2 * ch);
     edge_conv(t, f, wt(g.edge1, gg.edge1), ch, clouds, rows_of, idx, k, s1);                     // x1 :121-125
     edge_conv(t, s1, wt(g.edge2, gg.edge2), 2 * ch, clouds, rows_of, idx, k, s2);                // x2 :127-129
-    TT x3 = linear(t, cat, wt(g.conv3, gg.conv3), 4 * ch, Wt(), ch);                             // :131-132
+    TT x3 = linear(t, cat, wt(g.conv3, gg.conv3), 4 * ch, Wt(), ch, nullptr, nullptr, true);     // :131-132
     TT out = t.tensor(n, ch);
     for (int c = 0, r0 = 0; c < clouds; r0 += rows_of[c], ++c) {
         TT oc = rows(out, r0, rows_of[c]);
@@ -505,7 +516,7 @@ TT cross_attention(Tape& t, const pcrcg_model& m, const pcrcg_gnn_layer& g, cons
     copy_into(t, x, cols(cat, 0, ch));
     TT merged = cols(cat, ch, ch);
     linear(t, msg, wt(g.wm, gg.wm), ch, wt(g.bm, gg.bm), ch, &merged);
-    TT h0 = linear(t, cat, wt(g.w0, gg.w0), 2 * ch, wt(g.b0, gg.b0), 2 * ch);
+    TT h0 = linear(t, cat, wt(g.w0, gg.w0), 2 * ch, wt(g.b0, gg.b0), 2 * ch, nullptr, nullptr, true);
     TT h1 = instnorm_lrelu(t, h0, 0.0f);                                                        // InstanceNorm1d + ReLU
     TT delta = linear(t, h1, wt(g.w3, gg.w3), 2 * ch, wt(g.b3, gg.b3), ch);
     return add_lrelu(t, x, delta, 1.0f, into);
@@ -615,7 +626,7 @@ int pcrcg_kpfcnn_train_ws_bytes(const pcrcg_model* model, const pcrcg_model* gra
     forward(t, *model, *grads, *batch);
     const int n0 = batch->n_points[0];
     *value_bytes = t.val.peak + 3 * fbytes(n0, model->final_dim) + 4096;      // + the three outputs
-    *grad_bytes = t.grad.peak + 4096;
+    *grad_bytes = t.grad.peak + t.grad.top + 4096;
     *scratch_bytes = t.bw_scratch + 4096;
     return PCRCG_OK;
 }
