@@ -56,6 +56,69 @@ __global__ void __launch_bounds__(256) k_feature_argmax(const float* __restrict_
     if (row < n && jbeg < jend) atomicMax(&packed[row], pack_best(bv, bj));
 }
 
+// 32-wide descriptors on the fp32 matrix cores (round 5): a wavefront keeps 32 rows of A as its MFMA operand (lane (row,
+// half) holds A[row][16 half + s]) and walks the columns of its range 32 at a time -- lane (column, half) loads the same 16
+// entries of its B row as four float4 --, 16 v_mfma_f32_32x32x2_f32 per 32 x 32 block of scores; every lane keeps the best
+// score and column of its 16 rows over the columns it sees (= those congruent to its lane index), strictly-greater, so the
+// smaller column survives a tie; the 32 lanes of a row meet by shuffles at the end, and the column ranges (grid.y) through
+// the same 64-bit atomicMax as the VALU kernel.  fp32 operands, fp32 accumulation: the reference's torch.matmul arithmetic
+// up to summation order.
+typedef float fa_f16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) k_feature_argmax_mfma32(const float* __restrict__ a, int lda, int n,
+                                                                const float* __restrict__ b, int ldb, int m, int cols_per,
+                                                                unsigned long long* __restrict__ packed) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int row0 = (blockIdx.x * 4 + wave) * 32;
+    if (row0 >= n) return;
+    float av[16];
+    {
+        const float* ap = a + (long)min(row0 + l31, n - 1) * lda + 16 * half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(ap + 4 * q);
+            av[4 * q] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
+        }
+    }
+    float best[16];
+    int bj[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { best[r] = -INFINITY; bj[r] = 0; }
+    const int jbeg = blockIdx.y * cols_per, jend = min(m, jbeg + cols_per);
+    for (int j0 = jbeg; j0 < jend; j0 += 32) {
+        const int col = j0 + l31;
+        const float* bp = b + (long)min(col, m - 1) * ldb + 16 * half;
+        float bv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(bp + 4 * q);
+            bv[4 * q] = t.x; bv[4 * q + 1] = t.y; bv[4 * q + 2] = t.z; bv[4 * q + 3] = t.w;
+        }
+        fa_f16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
+        if (col < jend) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (acc[r] > best[r]) { best[r] = acc[r]; bj[r] = col; }
+        }
+    }
+    if (jbeg >= jend) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        unsigned long long p = pack_best(best[r], bj[r]);         // (-inf, 0) from a lane that saw no column loses to any score
+#pragma unroll
+        for (int sh = 16; sh >= 1; sh >>= 1) {
+            const unsigned long long o = __shfl_xor(p, sh, 64);
+            p = o > p ? o : p;
+        }
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (l31 == 0 && row < n) atomicMax(&packed[row], p);
+    }
+}
+
 // any width: A rows are re-read from memory (L1/L2 resident), one thread per row
 __global__ void __launch_bounds__(256) k_feature_argmax_any(const float* __restrict__ a, int lda, int n,
                                                              const float* __restrict__ b, int ldb, int m, int c,
@@ -609,6 +672,21 @@ extern "C" int pcrcg_feature_argmax(const float* a, int lda, int n, const float*
     hipStream_t st = as_stream(stream);
     PCRCG_CHECK_HIP(hipMemsetAsync(packed, 0, (size_t)n * 8, st));
     const int gx = (n + 255) / 256;
+    if (c == 32 && lda % 4 == 0 && ldb % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 &&
+        debug_opts().bwd_mfma) {
+        // the matrix-core kernel: 128 rows per workgroup, column ranges so that ~1k workgroups are in flight
+        const int gxm = (n + 127) / 128;
+        int splits = (1024 + gxm - 1) / gxm;
+        const int max_splits = (m + 255) / 256;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        const int cols_per = ((m + splits - 1) / splits + 31) / 32 * 32;
+        hipLaunchKernelGGL(k_feature_argmax_mfma32, dim3(gxm, (m + cols_per - 1) / cols_per), dim3(256), 0, st, a, lda, n, b, ldb, m,
+                           cols_per, packed);
+        hipLaunchKernelGGL(k_feature_argmax_unpack, dim3(gx), dim3(256), 0, st, packed, n, reinterpret_cast<long long*>(arg), best);
+        PCRCG_CHECK_LAUNCH();
+        return PCRCG_OK;
+    }
     int splits = (2048 + gx - 1) / gx;                      // ~2k blocks in flight
     const int max_splits = (m + 127) / 128;                 // at least one LDS tile of columns per block
     if (splits > max_splits) splits = max_splits;

@@ -174,6 +174,9 @@ class MetricLoss(torch.nn.Module):
         tgt_gt = torch.zeros(tgt_pcd.size(0), device=dev)
         tgt_gt[tgt_idx] = 1.
         p["overlap_labels"] = torch.cat((src_gt, tgt_gt))
+        # rows of the stacked score vector the saliency loss reads (unique by construction: one gather forward, one
+        # index_add backward instead of two indexing nodes whose backward sorts its indices)
+        p["saliency_rows"] = torch.cat((src_idx, tgt_idx + src_pcd.size(0)))
         p["src_pcd_sel"], p["tgt_pcd_sel"] = src_pcd[src_idx], tgt_pcd[tgt_idx]
         # correspondences closer than pos_radius, capped to max_points (:227-233)
         c_dist = torch.norm(src_pcd[correspondence[:, 0]] - tgt_pcd[correspondence[:, 1]], dim=1)
@@ -219,7 +222,8 @@ class MetricLoss(torch.nn.Module):
         distance_2 = torch.norm(tgt_pcd_sel - src_pcd_sel[idx21], p=2, dim=1)
         gt_labels = torch.cat(((distance_1 < self.matchability_radius).float(),
                                (distance_2 < self.matchability_radius).float()))
-        saliency = torch.cat((scores_saliency[:n_src][src_idx], scores_saliency[n_src:][tgt_idx]))
+        saliency = scores_saliency.index_select(0, p["saliency_rows"]) if "saliency_rows" in p else \
+            torch.cat((scores_saliency[:n_src][src_idx], scores_saliency[n_src:][tgt_idx]))
         class_loss, cls_precision, cls_recall = self.get_weighted_bce_loss(saliency, gt_labels)
         stats["saliency_loss"], stats["saliency_recall"], stats["saliency_precision"] = class_loss, cls_recall, cls_precision
 

@@ -17,7 +17,7 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
 
 
-@pytest.mark.parametrize("n,m,c", [(300, 257, 32), (1000, 3000, 32), (65, 129, 64), (40, 50, 20), (1, 1, 32)])
+@pytest.mark.parametrize("n,m,c", [(300, 257, 32), (1000, 3000, 32), (65, 129, 64), (40, 50, 20), (1, 1, 32), (6400, 28106, 32), (28106, 6318, 32), (33, 31, 32)])
 def test_feature_argmax_matches_matmul_max(cuda, n, m, c):
     g = torch.Generator().manual_seed(n + m)
     a = torch.randn(n, c, generator=g).to(cuda)
