@@ -85,15 +85,19 @@ __global__ void __launch_bounds__(256) k_feature_argmax_mfma32(const float* __re
 #pragma unroll
     for (int r = 0; r < 16; ++r) { best[r] = -INFINITY; bj[r] = 0; }
     const int jbeg = blockIdx.y * cols_per, jend = min(m, jbeg + cols_per);
+    auto load_b = [&](int j0, float4 (&t)[4]) {
+        const float* bp = b + (long)min(j0 + l31, m - 1) * ldb + 16 * half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const float4*>(bp + 4 * q);
+    };
+    float4 nxt[4];
+    if (jbeg < jend) load_b(jbeg, nxt);
     for (int j0 = jbeg; j0 < jend; j0 += 32) {
         const int col = j0 + l31;
-        const float* bp = b + (long)min(col, m - 1) * ldb + 16 * half;
         float bv[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 t = *reinterpret_cast<const float4*>(bp + 4 * q);
-            bv[4 * q] = t.x; bv[4 * q + 1] = t.y; bv[4 * q + 2] = t.z; bv[4 * q + 3] = t.w;
-        }
+        for (int q = 0; q < 4; ++q) { bv[4 * q] = nxt[q].x; bv[4 * q + 1] = nxt[q].y; bv[4 * q + 2] = nxt[q].z; bv[4 * q + 3] = nxt[q].w; }
+        if (j0 + 32 < jend) load_b(j0 + 32, nxt);           // the next block's rows are in flight behind this block's MFMAs
         fa_f16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
