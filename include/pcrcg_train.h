@@ -59,6 +59,9 @@ int pcrcg_sgd_step(float* params, float* grads, float* momentum_buf, long n, flo
                    int zero_grads, void* stream);
 int pcrcg_weighted_bce(const float* prediction, const float* gt, int n, float* out3, float* grad, void* ws, size_t ws_bytes,
                        void* stream);
+/* validate_gradient (ref:lib/utils.py:100-111: no NaN, no Inf in any parameter gradient) over a flat buffer of n floats
+ * (16-byte aligned) in one pass: flag[0] (device) = 1.0f when any value is not finite, else 0.0f. */
+int pcrcg_nonfinite_flag(const float* x, long n, float* flag, void* stream);
 /* The train step's re-packed weight layouts in ONE launch, and the way back for their gradients in one more (the host side
  * of pcrcg_kpfcnn_train_forward keeps K-contiguous KPConv weights, the DGCNN edge convolutions' [Wa - Wb ; Wb] split
  * (ref:models/gcn.py:31-60 applied to cat(x_i, x_j - x_i)), head-major attention projections (ref:models/gcn.py:139-160) and

@@ -158,6 +158,7 @@ SIGNATURES = {
     "pcrcg_circle_loss_ws_bytes": (c_size_t, [c_int]),
     "pcrcg_weighted_bce_ws_bytes": (c_size_t, []),
     "pcrcg_gather_jobs": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "pcrcg_nonfinite_flag": (c_int, [c_void_p, ctypes.c_long, c_void_p, c_void_p]),
     "pcrcg_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_float, c_float, c_float, c_int, c_void_p]),
     "pcrcg_weighted_bce": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pcrcg_feature_argmax_ws_bytes": (c_size_t, [c_int]),

@@ -235,6 +235,20 @@ __global__ void k_bce_final(const double* __restrict__ sums, int n, float* __res
     out[2] = sums[3] > 0 ? (float)(sums[1] / sums[3]) : 0.f;       // recall
 }
 
+// validate_gradient (ref:lib/utils.py:100-111) over the flat gradient bucket in ONE pass: flag[0] = 1 when any value is NaN or
+// +-Inf (every offending thread stores the same 1.0f: no atomics needed), else what the caller's memset left (0)
+__global__ void __launch_bounds__(256) k_nonfinite_flag(const float* __restrict__ x, long n, float* __restrict__ flag) {
+    bool bad = false;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const uint4 v = reinterpret_cast<const uint4*>(x)[i];
+        bad |= ((v.x & 0x7f800000u) == 0x7f800000u) | ((v.y & 0x7f800000u) == 0x7f800000u) | ((v.z & 0x7f800000u) == 0x7f800000u) |
+               ((v.w & 0x7f800000u) == 0x7f800000u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= (__float_as_uint(x[4 * n4 + threadIdx.x]) & 0x7f800000u) == 0x7f800000u;
+    if (bad) flag[0] = 1.0f;
+}
+
 // ---- SGD with momentum over flat buffers (torch.optim.SGD, dampening 0, no Nesterov; ref:main.py:59-66) ---------------------
 //   d = g + wd * p;  m = mu * m + d;  p = p - lr * m;  optionally g = 0 (the next step's accumulation starts from zero)
 __global__ void __launch_bounds__(256) k_sgd_step(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, long n,
@@ -299,6 +313,20 @@ int pcrcg_sgd_step(float* params, float* grads, float* momentum_buf, long n, flo
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(k_sgd_step, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), params, grads, momentum_buf, n, lr,
                            momentum, weight_decay, zero_grads);
+    }
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+
+int pcrcg_nonfinite_flag(const float* x, long n, float* flag, void* stream) {
+    PCRCG_CHECK_ARG(n >= 0 && flag && (n == 0 || x) && (uintptr_t)x % 16 == 0);
+    hipStream_t st = as_stream(stream);
+    PCRCG_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(float), st));
+    if (n > 0) {
+        long blocks = (n / 4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_nonfinite_flag, dim3((unsigned)blocks), dim3(256), 0, st, x, n, flag);
     }
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;

@@ -119,8 +119,15 @@ class GradientBucket:
         return bool(self.finite_tensor().item())
 
     def finite_tensor(self):
-        """The check as a 0-dim bool tensor on the bucket's device (no host round trip: Trainer.train_step reads it together
-        with the step's statistics)."""
+        """The check as a 0-dim tensor on the bucket's device, non-zero = all finite (no host round trip: Trainer.train_step
+        reads it together with the step's statistics).  On a HIP device ONE pass over the bucket (pcrcg_nonfinite_flag)
+        instead of torch's abs / compare / compare / all chain."""
+        if self.flat.is_cuda and self.flat.dtype == torch.float32 and self.flat.data_ptr() % 16 == 0:
+            from . import _lib
+            flag = torch.empty(1, dtype=torch.float32, device=self.flat.device)
+            _lib.check(_lib.lib().pcrcg_nonfinite_flag(self.flat.data_ptr(), self.flat.numel(), flag.data_ptr(),
+                                                       torch.cuda.current_stream().cuda_stream), "pcrcg_nonfinite_flag")
+            return flag[0] == 0
         return torch.isfinite(self.flat).all()
 
     def zero(self):
