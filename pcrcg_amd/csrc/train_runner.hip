@@ -45,6 +45,9 @@ int tr_bias_grad(const float* dy, int ld, int rows, int cols, float* db, hipStre
 int tr_l2norm_bwd(const float* x, int ldx, const float* dy, int ld_dy, float* dx, int ld_dx, int rows, int cols, hipStream_t st);
 int tr_sigmoid_bwd(const float* s, const float* ds, float* dx, int ld_dx, int rows, hipStream_t st);
 int tr_dot_acc(const float* a, const float* b, long n, float scale, float* out, hipStream_t st);
+bool instnorm_backward_sums_ok(const float* x, int n, int c, int ldx, const float* dy, int ld_dy, const float* dx, int ld_dx);
+int instnorm_backward_sums(const float* x, int n, int c, int ldx, const float* stats, const float* dy, int ld_dy, float slope,
+                           float* dx, int ld_dx, double* sums, hipStream_t st);
 
 namespace {
 
@@ -269,6 +272,18 @@ TT instnorm_lrelu(Tape& t, const TT& x, float slope, TT* into = nullptr, const d
         const int c4 = x.cols / 4;
         const bool tiles = x.cols % 4 == 0 && c4 >= 1 && (c4 <= 256 ? 256 % c4 == 0 : c4 % 256 == 0) && x.ld % 4 == 0 && y.ld % 4 == 0 &&
                            ((reinterpret_cast<uintptr_t>(x.p) | reinterpret_cast<uintptr_t>(y.p)) & 15) == 0;
+        if (!sums && tiles && x.rows > 0) {
+            // no sums from the producer (a product split over K, a row slice of a stacked tensor): ONE launch that leaves them
+            // in a zeroed slot (fp64 atomics of a few row chunks) instead of partial sums + a finishing launch
+            double* slot = t.sums_slot(x.cols);
+            const float* xs[1] = {x.p};
+            double* ss[1] = {slot};
+            const int ns[1] = {x.rows};
+            if (slot) {
+                t.check(instnorm_colsums_multi(xs, ss, ns, 1, x.cols, x.ld, t.st));
+                sums = slot;
+            }
+        }
         if (sums && tiles && x.rows > 0) {
             // statistics straight from the product's column sums inside the normalising kernel, which also leaves the
             // (mean, rstd) pairs for the backward: one launch
@@ -281,9 +296,17 @@ TT instnorm_lrelu(Tape& t, const TT& x, float slope, TT* into = nullptr, const d
             t.check(pcrcg_instnorm_apply(x.p, x.rows, x.cols, x.ld, stats, nullptr, 0, nullptr, slope, y.p, y.ld, t.st));
         }
     }
+    // few-row tensors (the coarse levels, the GNN): the backward's two column sums meet by atomics in a slot of the gradient
+    // region (cleared by the backward's one memset): no finishing launch
+    double* bw_sums = x.rows <= 32 * 32 ? static_cast<double*>(t.grad.take(sizeof(double) * 2 * x.cols)) : nullptr;
+    t.fits();
     t.need_scratch(bwb + 256);
-    t.record([x, y, stats, slope, bwb](Tape& b) {
+    t.record([x, y, stats, slope, bwb, bw_sums](Tape& b) {
         if (!x.g) return;
+        if (bw_sums && instnorm_backward_sums_ok(x.p, x.rows, x.cols, x.ld, y.g, y.ld, x.g, x.ld)) {
+            b.check(instnorm_backward_sums(x.p, x.rows, x.cols, x.ld, stats, y.g, y.ld, slope, x.g, x.ld, bw_sums, b.st));
+            return;
+        }
         void* w = b.tmp((bwb + 3) / 4);
         b.check(pcrcg_instnorm_backward(x.p, x.rows, x.cols, x.ld, stats, y.g, y.ld, slope, x.g, x.ld, w, bwb, b.st));
     });

@@ -434,6 +434,9 @@ __global__ void __launch_bounds__(256) k_gather_first_bwd(const float* __restric
 // Column sums in fp64, two deterministic stages (layout [2][c][chunks], as the forward statistics).
 constexpr int kBwdChunks = 128;
 
+// SUMS: the workgroups' partial sums meet in a ZEROED [2][c] buffer by fp64 atomics instead of being stored per chunk (few
+// row chunks: the coarse levels and the GNN -- no finishing launch; not under deterministic=1)
+template <bool SUMS>
 __global__ void __launch_bounds__(256) k_in_bwd_partial(const float* __restrict__ x, int n, int c, int ldx,
                                                          const float* __restrict__ stats, const float* __restrict__ dy,
                                                          int ld_dy, float slope, double* __restrict__ partial) {
@@ -473,8 +476,15 @@ __global__ void __launch_bounds__(256) k_in_bwd_partial(const float* __restrict_
     s_b[rl][lane] = b;
     __syncthreads();
     if (rl == 0 && ch < c) {
-        partial[(long)ch * nchunks + chunk] = (s_a[0][lane] + s_a[1][lane]) + (s_a[2][lane] + s_a[3][lane]);
-        partial[((long)c + ch) * nchunks + chunk] = (s_b[0][lane] + s_b[1][lane]) + (s_b[2][lane] + s_b[3][lane]);
+        const double ta = (s_a[0][lane] + s_a[1][lane]) + (s_a[2][lane] + s_a[3][lane]);
+        const double tb = (s_b[0][lane] + s_b[1][lane]) + (s_b[2][lane] + s_b[3][lane]);
+        if (SUMS) {
+            atomicAdd(&partial[ch], ta);
+            atomicAdd(&partial[c + ch], tb);
+        } else {
+            partial[(long)ch * nchunks + chunk] = ta;
+            partial[((long)c + ch) * nchunks + chunk] = tb;
+        }
     }
 }
 
@@ -533,6 +543,34 @@ __global__ void __launch_bounds__(256) k_in_bwd_apply4(const float* __restrict__
     };
     const float4 o = make_float4(one(xv.x, gv.x, s0.x, s0.y, m0.x, m0.y), one(xv.y, gv.y, s0.z, s0.w, m0.z, m0.w),
                                  one(xv.z, gv.z, s1.x, s1.y, m1.x, m1.y), one(xv.w, gv.w, s1.z, s1.w, m1.z, m1.w));
+    *reinterpret_cast<float4*>(dx + r * ld_dx + 4 * q) = o;
+}
+
+// k_in_bwd_apply4 with mean(g), mean(g xhat) taken from the [2][c] fp64 SUMS of k_in_bwd_partial<true>
+__global__ void __launch_bounds__(256) k_in_bwd_apply4_sums(const float* __restrict__ x, long total4, int c4, int ldx,
+                                                             const float* __restrict__ stats, const float* __restrict__ dy,
+                                                             int ld_dy, float slope, const double* __restrict__ sums,
+                                                             double inv_count, float* __restrict__ dx, int ld_dx) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total4) return;
+    const long r = t / c4;
+    const int q = (int)(t - r * c4), c = 4 * c4;
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + 4 * q);
+    const float4 gv = *reinterpret_cast<const float4*>(dy + r * ld_dy + 4 * q);
+    const float4 s0 = *reinterpret_cast<const float4*>(stats + 8 * q), s1 = *reinterpret_cast<const float4*>(stats + 8 * q + 4);
+    float mg[4], mgx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        mg[i] = (float)(sums[4 * q + i] * inv_count);
+        mgx[i] = (float)(sums[c + 4 * q + i] * inv_count);
+    }
+    auto one = [&](float xe, float ge, float mean, float rstd, float a, float b) {
+        const float xh = (xe - mean) * rstd;
+        const float g = ge * (xh > 0.f ? 1.0f : slope);
+        return rstd * (g - a - xh * b);
+    };
+    const float4 o = make_float4(one(xv.x, gv.x, s0.x, s0.y, mg[0], mgx[0]), one(xv.y, gv.y, s0.z, s0.w, mg[1], mgx[1]),
+                                 one(xv.z, gv.z, s1.x, s1.y, mg[2], mgx[2]), one(xv.w, gv.w, s1.z, s1.w, mg[3], mgx[3]));
     *reinterpret_cast<float4*>(dx + r * ld_dx + 4 * q) = o;
 }
 
@@ -798,7 +836,7 @@ extern "C" int pcrcg_instnorm_backward(const float* x, int n, int c, int ldx, co
     int chunks = (n + 31) / 32;
     if (chunks > kBwdChunks) chunks = kBwdChunks;
     if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL(k_in_bwd_partial, dim3(chunks, (c + 63) / 64), dim3(256), 0, st, x, n, c, ldx, stats, dy, ld_dy,
+    hipLaunchKernelGGL(k_in_bwd_partial<false>, dim3(chunks, (c + 63) / 64), dim3(256), 0, st, x, n, c, ldx, stats, dy, ld_dy,
                        slope, partial);
     hipLaunchKernelGGL(k_in_bwd_final, dim3((c + 3) / 4), dim3(256), 0, st, partial, chunks, c, (double)n, means);
     const long total = (long)n * c;
@@ -814,6 +852,28 @@ extern "C" int pcrcg_instnorm_backward(const float* x, int n, int c, int ldx, co
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
+
+namespace pcrcg {
+// InstanceNorm + LeakyReLU backward in TWO launches for tensors of few row chunks: `sums` is a ZEROED [2][c] fp64 buffer
+// (the train tape keeps it in its gradient region, which one memset clears) that the statistics kernel's workgroups add to
+bool instnorm_backward_sums_ok(const float* x, int n, int c, int ldx, const float* dy, int ld_dy, const float* dx, int ld_dx) {
+    return !debug_opts().deterministic && n >= 1 && n <= 32 * 32 && c % 4 == 0 && ldx % 4 == 0 && ld_dy % 4 == 0 && ld_dx % 4 == 0 &&
+           ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+}
+int instnorm_backward_sums(const float* x, int n, int c, int ldx, const float* stats, const float* dy, int ld_dy, float slope,
+                           float* dx, int ld_dx, double* sums, hipStream_t st) {
+    PCRCG_CHECK_ARG(instnorm_backward_sums_ok(x, n, c, ldx, dy, ld_dy, dx, ld_dx) && ldx >= c && ld_dy >= c && ld_dx >= c);
+    PCRCG_CHECK_ARG(x && stats && dy && dx && sums);
+    const int chunks = (n + 31) / 32;
+    hipLaunchKernelGGL(k_in_bwd_partial<true>, dim3(chunks, (c + 63) / 64), dim3(256), 0, st, x, n, c, ldx, stats, dy, ld_dy, slope,
+                       sums);
+    const long total4 = (long)n * (c / 4);
+    hipLaunchKernelGGL(k_in_bwd_apply4_sums, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, x, total4, c / 4, ldx, stats,
+                       dy, ld_dy, slope, sums, 1.0 / (double)n, dx, ld_dx);
+    PCRCG_CHECK_LAUNCH();
+    return PCRCG_OK;
+}
+}  // namespace pcrcg
 
 extern "C" int pcrcg_softmax_rows_backward(const float* p, int ld_p, const float* dp, int ld_dp, int rows, int cols,
                                            float scale, float* ds, int ld_ds, void* stream) {
