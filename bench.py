@@ -330,7 +330,7 @@ def secondary_k120k(dev, steps, warmup, workers, ppf, ppb):
     def run(count):
         sub = 0
         for i in range(count):
-            while sub < min(count, i + 8):
+            while sub < min(count, i + 4 * ppb):
                 hp, hl = pool[sub % len(pool)]
                 pipe.submit(hp.to(dev, non_blocking=True), hl.to(dev, non_blocking=True))
                 sub += 1
@@ -464,7 +464,7 @@ def live_pmc_traffic(timeout_s=90):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=48)      # (a multiple of the engine's group of four pairs and of its three model streams)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions of --steps steps each, run back to back; `value` is the median region")
@@ -480,11 +480,13 @@ def main():
                     help="experiment: Morton-sort each synthetic cloud (spatially coherent indices); recorded in config")
     ap.add_argument("--model-streams", type=int, default=3, help="engine: host threads / HIP streams enqueueing forwards")
     ap.add_argument("--front-threads", type=int, default=1, help="engine: host threads building pyramids")
-    ap.add_argument("--depth", type=int, default=8, help="pairs submitted ahead of the one being collected")
-    ap.add_argument("--pairs-per-forward", type=int, default=2, choices=[1, 2, 3, 4],
-                    help="pairs built together that share one pcrcg_kpfcnn_forward_group call (weight products once for all)")
-    ap.add_argument("--pairs-per-build", type=int, default=2, choices=[1, 2, 3, 4],
-                    help="pairs one front-end kernel chain (pcrcg_pyramid_build call) carries")
+    ap.add_argument("--depth", type=int, default=None,
+                    help="pairs submitted ahead of the one being collected (default: six builds' worth -- 24, K120k 12)")
+    ap.add_argument("--pairs-per-forward", type=int, default=None, choices=[1, 2, 3, 4],
+                    help="pairs built together that share one pcrcg_kpfcnn_forward_group call (weight products once for all); "
+                         "default 4 (K120k: 3), profiles/r05_ab_group_size.txt")
+    ap.add_argument("--pairs-per-build", type=int, default=None, choices=[1, 2, 3, 4],
+                    help="pairs one front-end kernel chain (pcrcg_pyramid_build call) carries; default 4 (K120k: 3)")
     ap.add_argument("--adaptive-jobs", action="store_true",
                     help="engine: decide from queue / stream state whether the pairs of a build share a forward call (round 4's "
                          "default; timing-dependent grouping, no throughput gain any more)")
@@ -507,6 +509,14 @@ def main():
     global RECIPE, INPUT_ORDER
     RECIPE = args.workload
     INPUT_ORDER = args.input_order
+    # group sizes of the engine: four pairs per front-end chain and per forward call, three for the 2 x 120 000-point slabs
+    group = 3 if RECIPE == "K120k" else 4
+    if args.pairs_per_forward is None:
+        args.pairs_per_forward = group
+    if args.pairs_per_build is None:
+        args.pairs_per_build = max(group, args.pairs_per_forward)
+    if args.depth is None:
+        args.depth = 6 * args.pairs_per_build
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -723,7 +733,7 @@ def main():
         del pipe
         torch.cuda.empty_cache()
         try:
-            extras["K120k"] = secondary_k120k(dev, 24, 4, WORKERS, args.pairs_per_forward, args.pairs_per_build)
+            extras["K120k"] = secondary_k120k(dev, 24, 4, WORKERS, 3, 3)
         except Exception as e:       # secondary figures never fail the headline
             extras["K120k"] = {"error": repr(e)}
         torch.cuda.empty_cache()

@@ -56,12 +56,15 @@ class PairStreams:
     ARENAS = 4        # per front thread: pairs whose tables may be alive at once (built, forward not yet passed)
 
     def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=1, tie_order=None,
-                 pairs_per_build=2, up_nearest=False, front_streams=1, front_priority=0, pairs_per_forward=2,
+                 pairs_per_build=4, up_nearest=False, front_streams=1, front_priority=0, pairs_per_forward=4,
                  adaptive_jobs=False):
         """pairs_per_forward = 2 .. 4: pairs that were built together also go through the network together, up to that
         many per pcrcg_kpfcnn_forward_group call on one model stream, in which every product with a weight matrix runs
         once for all of them (the pairs never mix; outputs equal separate forwards up to summation order).  1: one call
-        per pair.  pairs_per_build (1 .. 4): pairs one front-end kernel chain carries.
+        per pair.  pairs_per_build (1 .. 4): pairs one front-end kernel chain carries.  The defaults are four and four
+        since the end of round 5 (two and two before): +2.6 % on 30 000-point pairs, +5 % on the voxelised-scan-like ones
+        (profiles/r05_ab_group_size.txt); 2 x 120 000-point pairs run 1 % better with three and three.  Keep at least
+        three builds' worth of pairs submitted ahead (bench.py: 24).
         up_nearest: the engine's internal pyramids carry ONE-column upsample tables (the nearest coarse point: the only
         column KPFCNN.forward reads, ref:models/blocks.py:77-87) instead of the batch contract's [N, limit] tables:
         ~1 % less front-end work, same outputs.  Off by default: the tables are then exactly what build_pyramid()
