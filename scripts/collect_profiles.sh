@@ -5,10 +5,10 @@ TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --steps 50 --warmup 5 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json
+python3 $R/bench.py --steps 48 --warmup 5 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json
 db() { find "$1" -name "*results.db" | head -1; }
 # 1. the timed bench under the kernel tracer
-rm -rf /tmp/p1; rocprofv3 --kernel-trace --stats -d /tmp/p1 -o p -- python3 $R/bench.py --steps 50 --warmup 5 --repeats 1 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprof.json
+rm -rf /tmp/p1; rocprofv3 --kernel-trace --stats -d /tmp/p1 -o p -- python3 $R/bench.py --steps 48 --warmup 5 --repeats 1 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprof.json
 # pairs under the tracer: 24 priming (4 x model streams x pairs per forward) + 5 warm-up + 50 timed + 3 isolated forwards (+ 3 isolated pyramid builds)
 python3 $R/scripts/prof_summary.py $(db /tmp/p1) $O/${TAG}_kernel_stats.csv 82
 python3 $R/scripts/front_chain.py $(db /tmp/p1) > $O/${TAG}_front_chain.txt 2>&1
@@ -27,18 +27,19 @@ ls -la $O | grep ${TAG}
 # 4. secondary lines (no tracer): other workloads, index tie order, bf16 feature-storage variant
 if [ "${2:-}" = "all" ]; then
   for W in U30k K120k T30k; do
-    python3 $R/bench.py --workload $W --steps 30 --warmup 5 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_$W.json
+    S=48; [ $W = K120k ] && S=30          # (regions of whole groups: four pairs, K120k three)
+    python3 $R/bench.py --workload $W --steps $S --warmup 5 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_$W.json
   done
-  PCRCG_TIE_ORDER=index python3 $R/bench.py --steps 50 --warmup 5 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_tie_index.json
-  python3 $R/bench.py --variant bf16 --steps 50 --warmup 5 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_bf16_variant.json
-  python3 $R/bench.py --pairs-per-forward 1 --steps 50 --warmup 5 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_one_pair_per_forward.json
+  PCRCG_TIE_ORDER=index python3 $R/bench.py --steps 48 --warmup 5 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_tie_index.json
+  python3 $R/bench.py --variant bf16 --steps 48 --warmup 5 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_bf16_variant.json
+  python3 $R/bench.py --pairs-per-forward 1 --steps 48 --warmup 5 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_one_pair_per_forward.json
 fi
 ls -la $O | grep ${TAG}
 # 5. the other workloads under the kernel tracer (kernel breakdown, front chain, concurrency) -- with the SAME library
 if [ "${2:-}" = "all" ]; then
   cd /tmp
   for W in K120k T30k; do
-    rm -rf /tmp/pw; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pw -o p -- python3 $R/bench.py --workload $W --steps 30 --warmup 5 --repeats 1 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_${W}_under_rocprof.json
+    rm -rf /tmp/pw; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pw -o p -- python3 $R/bench.py --workload $W --steps $([ $W = K120k ] && echo 30 || echo 48) --warmup 5 --repeats 1 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_${W}_under_rocprof.json
     python3 $R/scripts/prof_summary.py $(db /tmp/pw) $O/${TAG}_${W}_kernel_stats.csv 62
     python3 $R/scripts/front_chain.py $(db /tmp/pw) > $O/${TAG}_${W}_front_chain.txt 2>&1
     python3 $R/scripts/concurrency.py $(db /tmp/pw) > $O/${TAG}_${W}_concurrency.txt 2>&1
