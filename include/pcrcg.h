@@ -50,14 +50,15 @@ const char* pcrcg_last_error(void);
 #define PCRCG_ABI_VERSION 3
 int pcrcg_abi_version(void);
 
-/* Tuning / A-B switches, for measurements only: "name=value,name=value" (NULL resets everything).  The same string is
+/* Tuning / A-B switches, for measurements only: "name=value,name=value" (NULL: back to what the process started with --
+ * the defaults, or what PCRCG_DEBUG made of them).  The same string is
  * read once from the environment variable PCRCG_DEBUG at first use; nothing else in the library reads the environment
  * except PCRCG_GEMM_MODE (pcrcg_gemm_set_mode).  Every switch defaults to the product behaviour:
  *   zero_arena=1 stat_sums=1 stat_sums_rows=2^30 fuse_norm=1 fuse_pack=1 fuse_upsample=1 gnn_merge=1 edge_rows=1 att_mfma=1   network runner fusions
  *   radius_blocks=0 radius_eager_redo=0 radius_cells=1 radius_prof=0 pyr_wait=1 pyr_trace=0 kd_spin_limit=0 kd_blocks=0   front end
  *   att_tq=16                                                                              attention tile
  *   gemm_log=0 x6_tile=-1 x6_splitk=0 x6_t1=32 x6_t2=128 x6_order=-1 x6_big=0 x6_h2=1 gemm_tile=-1 gemm_splitk=0 gemm_split_target=768   GEMM plans
- *   train_side_stream=1                                                                    train-step backward
+ *   train_side_stream=1 bwd_mfma=1                                                         train-step backward
  *   deterministic=0    1: bit-reproducible results -- no floating-point atomics (split-K partial tiles stored and added in
  *                      split order by a second pass, InstanceNorm statistics from stored partials, fixed-point scatter sums
  *                      in the train step); implies stat_sums=0 gemm_splitk=1; allocates its scratch itself.  Together with a fixed pairing of the pair engine (PairStreams(adaptive_jobs=False))

@@ -225,6 +225,7 @@ const DebugName kDebugNames[] = {
 // written.  The environment is read exactly once (std::call_once).  A multi-kernel call (a forward's sizing pass and
 // its live pass) reads the options several times: pcrcg_debug_set must not be called while calls are in flight.
 std::atomic<const DebugOpts*> g_debug{nullptr};
+std::atomic<const DebugOpts*> g_debug_env{nullptr};     // what PCRCG_DEBUG set at first use: pcrcg_debug_set(NULL) goes back to it
 std::once_flag g_debug_once;
 std::mutex g_debug_set_lock;
 const DebugOpts kDebugDefaults{};
@@ -266,6 +267,7 @@ const DebugOpts& debug_opts() {
         g_debug.store(&kDebugDefaults, std::memory_order_release);
         if (const char* e = getenv("PCRCG_DEBUG"))
             if (!debug_parse(e, &kDebugDefaults)) fprintf(stderr, "libpcrcg_hip: PCRCG_DEBUG ignored: %s\n", g_err);
+        g_debug_env.store(g_debug.load(std::memory_order_acquire), std::memory_order_release);
     });
     return *g_debug.load(std::memory_order_acquire);
 }
@@ -282,7 +284,10 @@ int pcrcg_debug_set(const char* spec) {
     const pcrcg::DebugOpts* cur = &pcrcg::debug_opts();   // the environment first, then this call on top of it
     std::lock_guard<std::mutex> hold(pcrcg::g_debug_set_lock);   // setters serialise; readers never block
     cur = pcrcg::g_debug.load(std::memory_order_acquire);
-    if (!spec) { pcrcg::g_debug.store(&pcrcg::kDebugDefaults, std::memory_order_release); return PCRCG_OK; }
+    if (!spec) {      // back to what the process started with: the defaults, or what PCRCG_DEBUG made of them
+        pcrcg::g_debug.store(pcrcg::g_debug_env.load(std::memory_order_acquire), std::memory_order_release);
+        return PCRCG_OK;
+    }
     return pcrcg::debug_parse(spec, cur) ? PCRCG_OK : PCRCG_EBADARG;
 }
 

@@ -121,6 +121,8 @@ def test_attention_backward_one_launch(cuda, n, ms, heads, d):
     (ref:models/gcn.py:151-155) against float64 autograd, ADDED to what the buffers hold; strided operands as the train
     tape has them (column slices of wider matrices); shapes beyond the kernel are refused."""
     from pcrcg_amd import _lib, ops
+    if "deterministic=1" in os.environ.get("PCRCG_DEBUG", ""):
+        pytest.skip("the one-launch backward adds by float atomics: the tape keeps the per-head path under deterministic=1")
     g = torch.Generator().manual_seed(n * 3 + ms + d)
     ch = heads * d
     wide_q = torch.randn(n, ch + 8, generator=g) * 1.3
