@@ -801,7 +801,7 @@ def main():
                                                         "experiment, not the headline workload]") + ", pyramid build + KPFCNN+GCN forward, random-init full-width weights, "
                                    "1 pair/GPU/step, " + ("inputs in pinned host memory, uploaded (two async copies, 720 KB) inside the "
                                    "timed region (SURVEY.md 8d)" if HEAD_FROM_HOST else "inputs resident in HBM") + "; pair engine: %d front thread(s) build pyramids "
-                                   "(pcrcg_pyramid_build, %.2f pairs per call on average: two waiting pairs share one kernel "
+                                   "(pcrcg_pyramid_build, %.2f pairs per call on average: the pairs that are waiting, up to four, share one kernel "
                                    "chain) on one front-end HIP stream, %d host threads enqueue the forwards "
                                    "(pcrcg_kpfcnn_forward_group: %s) on one model stream each; every table as the batch contract "
                                    "defines it ([N, limit] upsample tables included); every timed region starts and ends "
