@@ -286,3 +286,61 @@ def test_backward_products_keep_precision_for_tiny_gradients(cuda, scale):
     big[7, 3] = 300.0
     dxb = ops.gemm(big, w.t().contiguous().t(), grad_operand=1)
     assert torch.isfinite(dxb).all() and rel64(dxb, big.double() @ w.double()) < 2e-6
+
+
+def test_nonfinite_flag_over_a_flat_buffer(cuda):
+    """pcrcg_nonfinite_flag (include/pcrcg_train.h; validate_gradient, ref:lib/utils.py:100-111): 0 for finite values of
+    any magnitude (subnormals, the largest float), 1 for a NaN or an Inf anywhere -- including the last, unaligned elements."""
+    import ctypes
+    from pcrcg_amd import _lib
+    L = _lib.lib()
+    flag = torch.full((1,), 7.0, device=cuda)
+
+    def check(x):
+        _lib.check(L.pcrcg_nonfinite_flag(x.data_ptr(), x.numel(), flag.data_ptr(), ops._stream()), "pcrcg_nonfinite_flag")
+        torch.cuda.synchronize()
+        return float(flag[0])
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1_000_003, generator=g).to(cuda)
+    x[5], x[77], x[-1] = 3.4028234e38, 1e-45, -3.4028234e38
+    assert check(x) == 0.0
+    for pos, bad in ((0, float("nan")), (123_457, float("inf")), (x.numel() - 1, float("-inf")), (x.numel() - 2, float("nan"))):
+        y = x.clone()
+        y[pos] = bad
+        assert check(y) == 1.0, (pos, bad)
+    assert check(x[:0]) == 0.0 and check(x[:3]) == 0.0
+    from pcrcg_amd.trainer import GradientBucket
+    p = torch.nn.Parameter(torch.zeros(1000, device=cuda))
+    bucket = GradientBucket([p])
+    assert bucket.finite() is True
+    bucket.flat[17] = float("nan")
+    assert bucket.finite() is False
+
+
+def test_gather_jobs_maps_transposes_and_the_way_back(cuda):
+    """pcrcg_gather_jobs (include/pcrcg_train.h): dst[i] = src[m1[i]] + s2 src[m2[i]] with -1 = nothing, plain transposes
+    through LDS tiles (m1 = NULL), and the accumulate form that carries gradients back -- a table of jobs in one launch."""
+    import ctypes
+    from pcrcg_amd import _lib
+    from pcrcg_amd.train_runner import GatherJob
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(70, 33, generator=g).to(cuda)                       # transposed (odd sizes: partial tiles)
+    b = torch.randn(1000, generator=g).to(cuda)                         # mapped with a second, subtracted term and holes
+    m1 = torch.randint(-1, 1000, (1537,), generator=g, dtype=torch.int32).to(cuda)
+    m2 = torch.randint(-1, 1000, (1537,), generator=g, dtype=torch.int32).to(cuda)
+    out_t = torch.empty(33 * 70, device=cuda)
+    out_m = torch.empty(1537, device=cuda)
+    acc = torch.randn(1537, generator=g).to(cuda)
+    acc0 = acc.clone()
+    jobs = (GatherJob * 3)(GatherJob(a.data_ptr(), out_t.data_ptr(), None, None, a.numel(), -1.0, 0, 33),
+                           GatherJob(b.data_ptr(), out_m.data_ptr(), m1.data_ptr(), m2.data_ptr(), 1537, -1.0, 0, 0),
+                           GatherJob(b.data_ptr(), acc.data_ptr(), m1.data_ptr(), None, 1537, -1.0, 1, 0))
+    table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(cuda)
+    _lib.check(L.pcrcg_gather_jobs(table.data_ptr(), 3, a.numel(), ops._stream()), "pcrcg_gather_jobs")
+    torch.cuda.synchronize()
+    assert torch.equal(out_t.view(33, 70), a.t().contiguous())
+    pick = lambda m: torch.where(m >= 0, b[m.clamp(min=0).long()], torch.zeros((), device=cuda))
+    assert torch.equal(out_m, pick(m1) - pick(m2))
+    assert torch.equal(acc, acc0 + pick(m1))
+    _lib.check(L.pcrcg_gather_jobs(None, 0, 0, ops._stream()), "pcrcg_gather_jobs")          # an empty table is a no-op
