@@ -464,7 +464,7 @@ def live_pmc_traffic(timeout_s=90):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)      # (a multiple of the engine's group of four pairs and of its three model streams)
+    ap.add_argument("--steps", type=int, default=480)     # (whole groups of four pairs on three model streams; 0.8 s regions: fill and drain of the engine are ~1 % of them)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions of --steps steps each, run back to back; `value` is the median region")
@@ -733,7 +733,7 @@ def main():
         del pipe
         torch.cuda.empty_cache()
         try:
-            extras["K120k"] = secondary_k120k(dev, 24, 4, WORKERS, 3, 3)
+            extras["K120k"] = secondary_k120k(dev, 96, 6, WORKERS, 3, 3)
         except Exception as e:       # secondary figures never fail the headline
             extras["K120k"] = {"error": repr(e)}
         torch.cuda.empty_cache()

@@ -2,7 +2,7 @@
 # GPU box: in-engine A/B of whole library builds (scripts/build_variant.sh -> ab/NAME.so), interleaved so that box drift
 # shows: for each round, for each library, one bench.py run.  "cur" = the in-tree build.
 # usage: scripts/ab_lib.sh [-s STEPS] [-r ROUNDS] [-a "bench args"] cur base_gemm ...
-STEPS=48; ROUNDS=2; ARGS=""
+STEPS=480; ROUNDS=2; ARGS=""
 while [ "${1#-}" != "$1" ]; do case $1 in -s) STEPS=$2;; -r) ROUNDS=$2;; -a) ARGS=$2;; esac; shift 2; done
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cp $R/pcrcg_amd/libpcrcg_hip.so /tmp/cur.so

@@ -5,7 +5,8 @@ TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --steps 48 --warmup 5 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json
+python3 $R/bench.py 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json                       # (the default: 480-step regions)
+python3 $R/bench.py --steps 48 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_48_step_regions.json
 db() { find "$1" -name "*results.db" | head -1; }
 # 1. the timed bench under the kernel tracer
 rm -rf /tmp/p1; rocprofv3 --kernel-trace --stats -d /tmp/p1 -o p -- python3 $R/bench.py --steps 48 --warmup 5 --repeats 1 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprof.json
@@ -27,12 +28,12 @@ ls -la $O | grep ${TAG}
 # 4. secondary lines (no tracer): other workloads, index tie order, bf16 feature-storage variant
 if [ "${2:-}" = "all" ]; then
   for W in U30k K120k T30k; do
-    S=48; [ $W = K120k ] && S=30          # (regions of whole groups: four pairs, K120k three)
+    S=480; [ $W = K120k ] && S=120        # (regions of whole groups: four pairs, K120k three)
     python3 $R/bench.py --workload $W --steps $S --warmup 5 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_$W.json
   done
-  PCRCG_TIE_ORDER=index python3 $R/bench.py --steps 48 --warmup 5 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_tie_index.json
-  python3 $R/bench.py --variant bf16 --steps 48 --warmup 5 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_bf16_variant.json
-  python3 $R/bench.py --pairs-per-forward 1 --steps 48 --warmup 5 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_one_pair_per_forward.json
+  PCRCG_TIE_ORDER=index python3 $R/bench.py --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_tie_index.json
+  python3 $R/bench.py --variant bf16 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_bf16_variant.json
+  python3 $R/bench.py --pairs-per-forward 1 --repeats 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_one_pair_per_forward.json
 fi
 ls -la $O | grep ${TAG}
 # 5. the other workloads under the kernel tracer (kernel breakdown, front chain, concurrency) -- with the SAME library
