@@ -490,6 +490,8 @@ def main():
     ap.add_argument("--adaptive-jobs", action="store_true",
                     help="engine: decide from queue / stream state whether the pairs of a build share a forward call (round 4's "
                          "default; timing-dependent grouping, no throughput gain any more)")
+    ap.add_argument("--front-priority", type=int, default=0, help="engine: HIP priority of the front-end stream (< 0: ahead of the forwards)")
+    ap.add_argument("--front-streams", type=int, default=1, help="engine: front-end HIP streams (front threads take them in turn)")
     ap.add_argument("--fixed-jobs", action="store_true",
                     help="(the default since round 5, kept for old command lines) forward jobs always carry --pairs-per-forward pairs")
     ap.add_argument("--no-pmc", action="store_true",
@@ -657,6 +659,7 @@ def main():
     # ---- headline: the reference's batch contract inside the engine too (full [N, limit] upsample tables) ----------
     pipe = PairStreams(net, cfg, limits, dev, model_streams=WORKERS, front_threads=FRONTS, up_nearest=False,
                        pairs_per_forward=args.pairs_per_forward, pairs_per_build=args.pairs_per_build,
+                       front_priority=args.front_priority, front_streams=args.front_streams,
                        adaptive_jobs=args.adaptive_jobs and not args.fixed_jobs)
     # engine priming (untimed, before the W warm-up steps): every model stream's first call allocates its workspace
     # and every front-end arena its tables; a handful of pairs per stream gets that out of the way
