@@ -485,7 +485,7 @@ def main():
     ap.add_argument("--pairs-per-forward", type=int, default=None, choices=[1, 2, 3, 4],
                     help="pairs built together that share one pcrcg_kpfcnn_forward_group call (weight products once for all); "
                          "default 4 (K120k: 3), profiles/r05_ab_group_size.txt")
-    ap.add_argument("--pairs-per-build", type=int, default=None, choices=[1, 2, 3, 4],
+    ap.add_argument("--pairs-per-build", type=int, default=None, choices=[1, 2, 3, 4, 5, 6, 7, 8],
                     help="pairs one front-end kernel chain (pcrcg_pyramid_build call) carries; default 4 (K120k: 3)")
     ap.add_argument("--adaptive-jobs", action="store_true",
                     help="engine: decide from queue / stream state whether the pairs of a build share a forward call (round 4's "
@@ -661,6 +661,7 @@ def main():
                        pairs_per_forward=args.pairs_per_forward, pairs_per_build=args.pairs_per_build,
                        front_priority=args.front_priority, front_streams=args.front_streams,
                        adaptive_jobs=args.adaptive_jobs and not args.fixed_jobs)
+    ENGINE_PIPES = pipe.pipe_classes
     # engine priming (untimed, before the W warm-up steps): every model stream's first call allocates its workspace
     # and every front-end arena its tables; a handful of pairs per stream gets that out of the way
     run_pairs(pipe, 4 * WORKERS * args.pairs_per_forward)
@@ -819,6 +820,7 @@ def main():
                        "inputs": "pinned host memory, uploaded inside the timed region" if HEAD_FROM_HOST else "resident in HBM",
                        "tie_order": tie, "up_nearest": 0, "pairs_per_pyramid_build": round(ppb, 2),
                        "pairs_per_forward_call": args.pairs_per_forward,
+                       "engine_streams_by_dispatcher": ENGINE_PIPES,
                        "limits": limits, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
                        "lib_path": os.path.relpath(lib_path, REPO), "lib_sha16": lib_sha},
             "secondary": extras,

@@ -46,8 +46,11 @@ const char* pcrcg_last_error(void);
  *                pcrcg_pyramid_build_parts, pcrcg_gemm_f32_grad, pcrcg_thread_shares_gpu, pcrcg_gather_jobs;
  *                pcrcg_profile_kpconv flag bits;
  *                forward products in the fp16 two-term form with both range ends handled in the kernel (see
- *                pcrcg_gemm_set_mode); deterministic=1 debug switch */
-#define PCRCG_ABI_VERSION 3
+ *                pcrcg_gemm_set_mode); deterministic=1 debug switch
+ *   4 (round 6)  pyramid builder: levels sized from pcrcg_pyramid_cfg::shrink, ONE host round trip per call, the KD-forests
+ *                (level 0's, and one over the subsampled levels) on pcrcg_pyramid_cfg::side_stream (new cfg fields; pcrcg_pyramid_ws_bytes lost its `shrink`
+ *                argument; pcrcg_pyramid_restore and pcrcg_reorder_job changed layout) */
+#define PCRCG_ABI_VERSION 4
 int pcrcg_abi_version(void);
 
 /* Tuning / A-B switches, for measurements only: "name=value,name=value" (NULL: back to what the process started with --
@@ -187,6 +190,9 @@ typedef struct pcrcg_reorder_job {
     float radius;
     int group;            /* > 0: the nbq clouds are independent groups of `group` clouds (pcrcg_radius_query_groups):
                              indices relative to the group's first support, padding = the group's support count */
+    const float* sup;     /* version 4: forest != NULL: this job searches a forest of its OWN -- built over `sup` with */
+    const void* forest;   /*   pcrcg_kdforest_build(sup, forest_ns, .., forest_nb, ..) -- instead of the call's (the  */
+    int forest_ns, forest_nb; /* pyramid builder keeps one forest per level); NULL: the call's sup / forest / ns / nb */
 } pcrcg_reorder_job;
 size_t pcrcg_kdforest_ws_bytes(int ns, int nb);
 int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, void* forest, size_t forest_bytes,
@@ -548,9 +554,12 @@ int pcrcg_kpfcnn_forward_group(const pcrcg_model* model, const pcrcg_batch* batc
  *              groups of exactly equal distance, 1 = the reference's order (rows holding such groups are redone
  *              through the KD-forest, as pcrcg_radius_reorder_jobs documents).
  *   out        one pcrcg_batch (cfg->group == 0) or nb / cfg->group of them
- *   ws         arena of pcrcg_pyramid_ws_bytes(n0, nb, cfg, shrink) bytes; `shrink` in (0,1] is the caller's bound on
- *              rows(level l+1) / rows(level l) (1.0 = always enough; 3DMatch-like clouds keep about a quarter).  A
- *              too small arena is reported as PCRCG_EWORKSPACE -- nothing is corrupted, call again with a larger one.
+ *   ws         arena of pcrcg_pyramid_ws_bytes(n0, nb, cfg) bytes.  cfg->shrink in (0,1] is the caller's bound on
+ *              rows(level l+1) / rows(level l) (1.0 = always enough; 3DMatch-like clouds keep about a quarter): level l is
+ *              given room for n0 * shrink^l rows, and since round 6 that bound -- not a row count read back from the GPU --
+ *              sizes every buffer, table and launch of the level.  A cloud that keeps more rows than the bound allows is
+ *              reported as PCRCG_EWORKSPACE at the end of the call -- nothing is corrupted, call again with a larger
+ *              shrink (and the arena that goes with it).
  *   h_scratch  HOST scratch of >= 256 ints, pinned for best latency; h_lengths HOST [n_levels * nb] receives the
  *              per-level cloud lengths (stack_lengths); h_status HOST int (pinned; may be NULL) receives the tie-order
  *              restore status word ASYNCHRONOUSLY -- valid once `stream` has drained, 0 = fine, else as documented at
@@ -560,9 +569,12 @@ int pcrcg_kpfcnn_forward_group(const pcrcg_model* model, const pcrcg_batch* batc
  *              enqueues it with pcrcg_pyramid_restore_run on a stream of its choice that is ordered after `stream`'s
  *              work and before the first reader of the tables (the pair engine runs it on the pair's model stream:
  *              the front-end stream is the pipeline's bottleneck).
- * The call WAITS for `stream` once per pooled level (the subsampled row count sizes what follows) and once for the
- * tables' column counts; it holds no global state, so several host threads may build pyramids on several streams
- * concurrently.  The last launches (tie-order restore) are still in flight when it returns.
+ * The call WAITS for `stream` ONCE, at the end of the kernel chain, for the row counts of the levels and the tables'
+ * column counts (one copy of ~100 words): the levels are sized from cfg->shrink, every kernel takes its row count from
+ * the cloud lengths on the device.  (Rounds 2-5 read every subsampled level's row count back before sizing the next:
+ * four round trips per call, ~1.1 ms of idle front-end stream per four-pair chain.)  It holds no global state, so several
+ * host threads may build pyramids on several streams concurrently.  The last launches (tie-order restore) are still in
+ * flight when it returns.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct pcrcg_pyramid_cfg {
     int n_levels;
@@ -579,18 +591,26 @@ typedef struct pcrcg_pyramid_cfg {
                        (the reference's order among equidistant ones), which is all that the network reads of them
                        (closest_pool, ref:models/blocks.py:77-87): for hosts that feed pcrcg_kpfcnn_forward and nothing
                        else, the search keeps one candidate per row instead of sorting and writing `limit` of them */
+    double shrink;  /* bound on rows(level l+1) / rows(level l), in (0,1]; 0 or out of range = 1.0 (see `ws` above) */
+    void* side_stream;  /* NULL, or further streams (hipStream_t) of the caller's: the chain is a DAG -- a level's subsampling  */
+    void* side_stream2; /* needs only the level's points, as do its cell grid and conv search; a KD-forest of the restore step
+                       needs only its levels' points.  side_stream: the subsamplings run there, back to back from the moment
+                       the input is in place, beside the grids and searches on `stream`, which waits for each subsampled
+                       level when it first reads it.  side_stream2: the KD-forests (tie_order = 1) -- level 0's at once, the
+                       subsampled levels' when the last of them exists; NULL: behind the subsamplings on side_stream.
+                       `stream` waits for all of it before the call returns.  Both NULL: one stream, one line of kernels.
+                       Take streams that share `stream`'s hardware dispatcher (pcrcg_stream_pipe_classes): these are small
+                       latency-bound kernels whose dispatch is over at once, they do not hold each other up -- on a
+                       dispatcher that also serves a stream of large kernels they would stand behind every one of those. */
 } pcrcg_pyramid_cfg;
 typedef struct pcrcg_pyramid_restore {
     int njobs;                                   /* 0: no row holds a tie, nothing to do but post the status word */
-    pcrcg_reorder_job jobs[PCRCG_MAX_REORDER_JOBS];
-    const float* pts_all;                        /* rows of all levels, contiguous: the KD-forest's clouds */
-    const int* lens_all;                         /* [clouds_total] */
-    int rows_total, clouds_total;
-    void* forest;                                /* pcrcg_kdforest_ws_bytes(rows_total, clouds_total) bytes in the arena */
-    size_t forest_bytes;
+    pcrcg_reorder_job jobs[PCRCG_MAX_REORDER_JOBS]; /* every job names its forest (sup / forest / forest_ns / forest_nb): the
+                                                    builder keeps two, level 0's and one over the subsampled levels, and has
+                                                    enqueued their builds -- they exist once `stream`'s work has passed */
     int* tie_status;                             /* device status word */
 } pcrcg_pyramid_restore;
-size_t pcrcg_pyramid_ws_bytes(int n0, int nb, const pcrcg_pyramid_cfg* cfg, double shrink);
+size_t pcrcg_pyramid_ws_bytes(int n0, int nb, const pcrcg_pyramid_cfg* cfg);
 int pcrcg_pyramid_build(const float* pts, int n0, const int* len, int nb, const pcrcg_pyramid_cfg* cfg, void* ws,
                         size_t ws_bytes, int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status,
                         pcrcg_pyramid_restore* deferred, void* stream);
@@ -608,6 +628,15 @@ int pcrcg_pyramid_restore_run(const pcrcg_pyramid_restore* r, int* h_status, voi
  * default, -1 = high) for hosts that have no stream abstraction of their own; *stream receives a hipStream_t. */
 int pcrcg_stream_create(void** stream, int priority);
 int pcrcg_stream_destroy(void* stream);
+/* Which of the caller's n (<= 64) streams share a hardware dispatcher.  gfx950's command processor has four compute
+ * dispatchers; every stream's hardware queue belongs to one of them, and a dispatcher hands out the workgroups of one kernel
+ * at a time -- two busy streams on the same dispatcher take turns, kernel by kernel, instead of running side by side
+ * (profiles/r06_queue_pipes.txt).  cls[i] receives the class of streams[i] (0 = streams[0]'s class, then 1, 2, .. by first
+ * appearance).  The classes are MEASURED (~1.5 ms per test on an idle GPU: a dispatch-bound probe kernel on one stream, a
+ * one-workgroup kernel on the other); scratch = 16 bytes of device memory.  A host that runs several streams side by side
+ * (pcrcg_amd/pairstream.py) picks them from different classes, and puts streams of small, latency-bound kernels that should
+ * not wait for each other's resources -- the front-end chain and its KD-forests -- into one. */
+int pcrcg_stream_pipe_classes(void* const* streams, int n, int* cls, void* scratch);
 
 #ifdef __cplusplus
 }

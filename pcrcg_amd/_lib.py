@@ -18,7 +18,7 @@ def lib_identity():
     with open(LIB_PATH, "rb") as f:
         return LIB_PATH, hashlib.sha256(f.read()).hexdigest()[:16]
 
-ABI_VERSION = 3      # PCRCG_ABI_VERSION of the include/pcrcg.h these signatures were written against
+ABI_VERSION = 4      # PCRCG_ABI_VERSION of the include/pcrcg.h these signatures were written against
 
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
@@ -106,12 +106,13 @@ SIGNATURES = {
     "pcrcg_kpfcnn_group_ws_bytes": (c_size_t, [c_void_p, c_void_p, c_int]),
     "pcrcg_kpfcnn_forward_group": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "pcrcg_kpfcnn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "pcrcg_pyramid_ws_bytes": (c_size_t, [c_int, c_int, c_void_p, ctypes.c_double]),
+    "pcrcg_pyramid_ws_bytes": (c_size_t, [c_int, c_int, c_void_p]),
     "pcrcg_pyramid_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcrcg_pyramid_build_parts": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcrcg_pyramid_restore_run": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "pcrcg_stream_pipe_classes": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "pcrcg_thread_shares_gpu": (None, [c_int]),
     "pcrcg_stream_create": (c_int, [c_void_p, c_int]),
     "pcrcg_stream_destroy": (c_int, [c_void_p]),

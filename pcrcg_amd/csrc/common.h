@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 
 #include "pcrcg.h"
 
@@ -38,12 +39,22 @@ int exclusive_scan_i32(const int* in, int* out, int n, int* total, void* ws, hip
 
 constexpr int kWave = 64;
 
+// grid_subsample.hip: pcrcg_grid_subsample_batch with the number of points given as a host-side BOUND (the cloud
+// lengths on the device say how many there are) and room for out_cap output rows (more: *overflow = 1, output cut)
+int grid_subsample_bound(const float* pts, int n_bound, const int* len, int nb, float dl, int max_p, float* out_pts,
+                         int* out_len, int* out_m, int out_cap, int* overflow, void* ws, size_t ws_bytes, hipStream_t stream);
+
 // pointops.hip: InstanceNorm + LeakyReLU that also leaves the KPConv support records of its output (kpconv.hip: pk)
 bool instnorm_pack_ok(int c, int ldx, int ldy);
 int instnorm_apply_pack(const float* x, int n, int c, int ldx, const float* stats, const double* sums, double count, float eps,
                         float slope, float* y, int ldy, const float* s_pts, float4* pk, hipStream_t st);
 // kpconv.hip: where the support records live inside a pcrcg_kpconv_ws_bytes(ns) workspace
 float4* kpconv_pk_ptr(void* ws, size_t ws_bytes, int ns);
+
+// tieorder.hip: pcrcg_kdforest_build over clouds that are LEVELS of per_level clouds each, level l's rows starting at row
+// level_base[l] of sup (per_level = 0: one contiguous stack, the public entry point)
+int kdforest_build_levels(const float* sup, int ns, const int* slen, int nb, int per_level, const int* level_base, void* forest,
+                          size_t forest_bytes, hipStream_t stream);
 
 // radius.hip: pcrcg_radius_query_groups by pass (0 both kernels, 1 the first, 2 the redo of rows with > radius_fast_cap()
 // hits that the first one marked)
@@ -227,6 +238,27 @@ struct KpProfScope {
     } while (0)
 
 #define PCRCG_CHECK_LAUNCH() PCRCG_CHECK_HIP(hipGetLastError())
+
+// A kernel that may ask for more than 64 KB of dynamic LDS is granted, ONCE per kernel and under std::call_once, everything a
+// gfx950 workgroup can have (160 KB minus the kernel's static LDS).  The grant only lifts the launch-time limit -- what a
+// launch allocates is its own `lds` argument -- and it never shrinks, so host threads that launch the same kernel with
+// different sizes (the pair engine's model threads) cannot undo one another's setting.
+namespace pcrcg {
+inline hipError_t grant_max_dyn_lds(const void* kern) {
+    hipFuncAttributes at;
+    hipError_t e = hipFuncGetAttributes(&at, kern);
+    if (e != hipSuccess) return e;
+    const int cap = 160 * 1024 - (int)at.sharedSizeBytes;
+    return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+}
+}  // namespace pcrcg
+#define PCRCG_GRANT_LDS(kern)                                                                                   \
+    do {                                                                                                        \
+        static std::once_flag once_;                                                                            \
+        static hipError_t granted_ = hipSuccess;                                                                \
+        std::call_once(once_, [&] { granted_ = pcrcg::grant_max_dyn_lds(reinterpret_cast<const void*>(kern)); }); \
+        PCRCG_CHECK_HIP(granted_);                                                                              \
+    } while (0)
 
 #define PCRCG_PROPAGATE(expr)      \
     do {                           \

@@ -309,12 +309,7 @@ int launch_one(dim3 grid, hipStream_t st, const float* a, int lda, const float* 
                int atomic_out, double* colp, int colp_chunks) {
     constexpr size_t lds = 2 * sizeof(float) * stage_floats<BM, BN, TRANS_A, TRANS_B, BK>();
     auto kern = k_gemm_f32<BM, BN, WAVES_M, WAVES_N, TRANS_A, TRANS_B, BK>;
-    static bool configured = false;   // > 64 KiB of dynamic LDS must be requested once per kernel
-    if (!configured) {
-        PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
+    PCRCG_GRANT_LDS(kern);   // > 64 KiB of dynamic LDS must be requested once per kernel
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, lda, b, ldb, c, ldc, m, n, k, row_scale, bias, k_per_split,
                        vec_a, vec_b, atomic_out, colp, colp_chunks);
     PCRCG_CHECK_LAUNCH();

@@ -916,12 +916,7 @@ int launch_x6(dim3 grid, hipStream_t st, const float* a, int lda, const float* b
     tm.order = x6_tile_order(tm.gx, tm.gy, tm.gs, BM, BN, k_per_split);
     const size_t lds = lds_bytes<BM, BN>() + (ANORM ? 2 * sizeof(float) * (size_t)(((k_per_split + BK - 1) / BK) * BK) : 0) + (H2 ? 16 : 0);
     auto kern = k_gemm_x6<BM, BN, MINB, ATERMS, ALAY, BLAY, ANORM, KNOCK, H2>;
-    static size_t configured = 0;
-    if (lds > configured) {
-        PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    PCRCG_GRANT_LDS(kern);
     int m_all = m;                                             // a grouped launch's products all count
     for (int e = 0; e < pr.extra; ++e) m_all += pr.m[e];
     KpProfScope prof(st, m_all, n, k, (ATERMS == 1 || H2) ? 3 : 6, 3);  // bench.py's GEMM roofline: the kernel's own start / stop events

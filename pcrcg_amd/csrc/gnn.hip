@@ -947,12 +947,7 @@ int attention_mfma_multi(const AttnCloud* cl, int count, int ldq, int ldk, int l
     const dim3 grid((nmax + 31) / 32, heads, count);
 #define ATT2(DD)                                                                                                          \
     do {                                                                                                                  \
-        static size_t configured = 0;                                                                                     \
-        if (lds > configured) {                                                                                           \
-            PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_mfma<DD>),                      \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
-            configured = lds;                                                                                             \
-        }                                                                                                                 \
+        PCRCG_GRANT_LDS((k_attention_mfma<DD>));                                                            \
         hipLaunchKernelGGL((k_attention_mfma<DD>), grid, dim3(256), lds, st, a);                                          \
     } while (0)
     if (d == 128) ATT2(128);
@@ -981,12 +976,7 @@ int attention_bwd_mfma(const float* q, int ldq, const float* k, int ldk, const f
     const dim3 grid((n + 31) / 32, heads);
 #define ATTB(DD)                                                                                                          \
     do {                                                                                                                  \
-        static size_t configured = 0;                                                                                     \
-        if (lds > configured) {                                                                                           \
-            PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_bwd_mfma<DD>),                  \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
-            configured = lds;                                                                                             \
-        }                                                                                                                 \
+        PCRCG_GRANT_LDS((k_attention_bwd_mfma<DD>));                                                            \
         hipLaunchKernelGGL((k_attention_bwd_mfma<DD>), grid, dim3(512), lds, st, a);                                      \
     } while (0)
     if (d == 128) ATTB(128);
@@ -1090,12 +1080,7 @@ int pcrcg_attention(const float* q, int ldq, const float* k, int ldk, const floa
 #define ATT(DD, TQ)                                                                                                  \
     do {                                                                                                             \
         constexpr size_t lds = sizeof(float) * (64 * (DD + 4) + 64 * DD + TQ * 64);                                  \
-        static bool configured = false;                                                                              \
-        if (!configured && lds > 64 * 1024) {                                                                        \
-            PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention<DD, TQ>),                  \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
-            configured = true;                                                                                       \
-        }                                                                                                            \
+        if (lds > 64 * 1024) PCRCG_GRANT_LDS((k_attention<DD, TQ>));                              \
         hipLaunchKernelGGL((k_attention<DD, TQ>), dim3((n + TQ - 1) / TQ, heads), dim3(256), lds, st, q, ldq, k, ldk, v, \
                            ldv, out, ldo, n, ms, scale);                                                             \
     } while (0)

@@ -77,8 +77,12 @@ __global__ void __launch_bounds__(256) k_init(const int* __restrict__ len, int n
 // 235 workgroups whose every wavefront did so: ~5 600 atomics on six words serialised in one L2 channel, 33 us for
 // 60 000 points; 64 workgroups issue ~1 500).
 constexpr int kMinmaxBlocks = 64;
-__global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ pts, int n, const int* __restrict__ coff,
+// (Every kernel below takes the number of points from coff[nb] -- the sum of the cloud lengths, which live on the
+// device -- and its launch grid from a host-side BOUND: the pyramid builder sizes a level from the previous level's
+// bound, not from a row count read back from the GPU.)
+__global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ pts, const int* __restrict__ coff,
                                                  int nb, unsigned* __restrict__ mm) {
+    const int n = coff[nb];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // a workgroup walks a CONTIGUOUS slice of the points, so it sees at most a couple of clouds: the running
     // reduction is flushed whenever the cloud changes
@@ -138,13 +142,13 @@ __device__ __forceinline__ unsigned mix32(u64 x) {
     return (unsigned)x;
 }
 
-__global__ void __launch_bounds__(256) k_cell_insert(const float* __restrict__ pts, int n, const int* __restrict__ coff,
+__global__ void __launch_bounds__(256) k_cell_insert(const float* __restrict__ pts, const int* __restrict__ coff,
                                                       int nb, const unsigned* __restrict__ mm, float dl, float inv_dl,
                                                       u64* __restrict__ tkey, int* __restrict__ tfirst,
                                                       int* __restrict__ tcnt, int* __restrict__ slot_of,
                                                       u64* __restrict__ pkey) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= coff[nb]) return;
     const int b = cloud_of(coff, nb, i);
     const float mnx = dec_f32(mm[b * 6 + 0]), mny = dec_f32(mm[b * 6 + 1]), mnz = dec_f32(mm[b * 6 + 2]);
     const float mxx = dec_f32(mm[b * 6 + 3]), mxy = dec_f32(mm[b * 6 + 4]);
@@ -174,20 +178,22 @@ __global__ void __launch_bounds__(256) k_cell_insert(const float* __restrict__ p
     atomicAdd(&tcnt[slot], 1);
 }
 
-__global__ void __launch_bounds__(256) k_flag(int n, const int* __restrict__ slot_of, const int* __restrict__ tfirst,
-                                               int* __restrict__ flag) {
+// (positions between the point count and the bound get 0: the scan runs over the bound)
+__global__ void __launch_bounds__(256) k_flag(const int* __restrict__ n_dev, int n_bound, const int* __restrict__ slot_of,
+                                               const int* __restrict__ tfirst, int* __restrict__ flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = aload(&tfirst[slot_of[i]]) == i ? 1 : 0;
+    if (i < *n_dev) flag[i] = aload(&tfirst[slot_of[i]]) == i ? 1 : 0;
+    else if (i < n_bound) flag[i] = 0;
 }
 
 // rank = exclusive scan of flag.  A point with rank[i+1] != rank[i] (or the last one with total)
 // is the first occurrence of cell rank[i].
-__global__ void __launch_bounds__(256) k_cells(int n, const int* __restrict__ slot_of, const int* __restrict__ tfirst,
+__global__ void __launch_bounds__(256) k_cells(const int* __restrict__ n_dev, const int* __restrict__ slot_of, const int* __restrict__ tfirst,
                                                 const int* __restrict__ tcnt, const int* __restrict__ rank,
                                                 const u64* __restrict__ pkey, u64* __restrict__ ckey,
                                                 int* __restrict__ ccnt, int* __restrict__ trank) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= *n_dev) return;
     const int s = slot_of[i];
     if (aload(&tfirst[s]) == i) {
         const int c = rank[i];
@@ -197,11 +203,11 @@ __global__ void __launch_bounds__(256) k_cells(int n, const int* __restrict__ sl
     }
 }
 
-__global__ void __launch_bounds__(256) k_fill(int n, const int* __restrict__ slot_of, const int* __restrict__ trank,
+__global__ void __launch_bounds__(256) k_fill(const int* __restrict__ n_dev, const int* __restrict__ slot_of, const int* __restrict__ trank,
                                                const int* __restrict__ cstart, int* __restrict__ cfill,
                                                int* __restrict__ cidx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= *n_dev) return;
     const int c = trank[slot_of[i]];
     const int pos = cstart[c] + atomicAdd(&cfill[c], 1);
     cidx[pos] = i;
@@ -364,29 +370,36 @@ __device__ __forceinline__ UmapWs umap_carve(int* ebase, int* bbase, long estrid
 }
 
 // One workgroup per cloud: order the cloud's cells, cap at max_p, write rows and lengths.
-__global__ void __launch_bounds__(kUmapThreads) k_order_emit(int n, int nb, const int* __restrict__ coff,
+// out_cap rows fit behind out_pts: a cloud whose rows would not is cut there and *overflow is raised (the caller
+// reports PCRCG_EWORKSPACE; with out_cap >= the number of input points that cannot happen).
+__global__ void __launch_bounds__(kUmapThreads) k_order_emit(int nb, const int* __restrict__ coff,
                                                               const int* __restrict__ rank, const int* __restrict__ mtot,
                                                               const u64* __restrict__ ckey, const float* __restrict__ cbary,
                                                               int* __restrict__ ebase, int* __restrict__ bbase,
                                                               long estride, long bstride, int max_p,
                                                               float* __restrict__ out_pts, int* __restrict__ out_len,
-                                                              int* __restrict__ out_m) {
+                                                              int* __restrict__ out_m, int out_cap, int* __restrict__ overflow) {
     __shared__ int smem[kUmapThreads / 64];
     __shared__ int s_lds[11 * kUmapLds];
     const int b = blockIdx.x;
     const int mt = *mtot;
+    const int n = coff[nb];
     // cells of clouds < b precede this cloud's cells (first-occurrence order is input order)
     int out_off = 0, cell_lo = 0, cell_hi = 0;
     for (int bb = 0; bb <= b; ++bb) {
         const int lo = coff[bb] < n ? rank[coff[bb]] : mt;
         const int hi = coff[bb + 1] < n ? rank[coff[bb + 1]] : mt;
-        if (bb < b) out_off += min(hi - lo, max_p);
+        if (bb < b) out_off = min(out_off + min(hi - lo, max_p), out_cap);
         else { cell_lo = lo; cell_hi = hi; }
     }
     const int m = cell_hi - cell_lo;
     UmapWs w = umap_carve(ebase, bbase, estride, bstride, cell_lo, 3l * cell_lo + 16l * b);
     umap_order_block(ckey + cell_lo, m, w, smem, s_lds);
-    const int keep = min(m, max_p);                                         // :185-205
+    int keep = min(m, max_p);                                               // :185-205
+    if (out_off + keep > out_cap) {
+        keep = max(0, out_cap - out_off);
+        if (threadIdx.x == 0 && overflow) *overflow = 1;
+    }
     for (int j = threadIdx.x; j < keep; j += kUmapThreads) {
         const long c = cell_lo + w.ord_a[j];
         out_pts[3 * (long)(out_off + j)] = cbary[3 * c];
@@ -462,10 +475,20 @@ size_t pcrcg_grid_subsample_ws_bytes(int n, int nb) {
 int pcrcg_grid_subsample_batch(const float* pts, int n, const int* len, int nb, float dl, int max_p,
                                float* out_pts, int* out_len, int* out_m, void* ws, size_t ws_bytes,
                                void* stream) {
-    PCRCG_CHECK_ARG(n >= 0 && nb >= 1);
+    return pcrcg::grid_subsample_bound(pts, n, len, nb, dl, max_p, out_pts, out_len, out_m, n, nullptr, ws, ws_bytes,
+                                       as_stream(stream));
+}
+}
+
+// n = a BOUND on the number of points (the clouds' lengths, on the device, say how many there are); out_cap rows fit
+// behind out_pts (fewer than the result: *overflow = 1, the output is cut there).
+int pcrcg::grid_subsample_bound(const float* pts, int n, const int* len, int nb, float dl, int max_p, float* out_pts,
+                                int* out_len, int* out_m, int out_cap, int* overflow, void* ws, size_t ws_bytes,
+                                hipStream_t stream) {
+    PCRCG_CHECK_ARG(n >= 0 && nb >= 1 && out_cap >= 0);
     PCRCG_CHECK_ARG(pts && len && out_pts && out_len && out_m && ws);
     PCRCG_CHECK_ARG(dl > 0.0f);
-    hipStream_t st = as_stream(stream);
+    hipStream_t st = stream;
     if (max_p < 1) max_p = n;  // :134-135
     const size_t N = (size_t)n + 1;
     Carver cv(ws, ws_bytes);
@@ -498,20 +521,20 @@ int pcrcg_grid_subsample_batch(const float* pts, int n, const int* len, int nb, 
                        mtot, (long)N);
     if (n > 0) {
         const float inv_dl = 1 / dl;  // (1/sampleDl): int/float -> fp32 division on the host (:27)
-        hipLaunchKernelGGL(k_minmax, dim3(blocks < kMinmaxBlocks ? blocks : kMinmaxBlocks), dim3(256), 0, st, pts, n, coff, nb, mm);
-        hipLaunchKernelGGL(k_cell_insert, dim3(blocks), dim3(256), 0, st, pts, n, coff, nb, mm, dl, inv_dl, tkey,
+        const int* n_dev = coff + nb;
+        hipLaunchKernelGGL(k_minmax, dim3(blocks < kMinmaxBlocks ? blocks : kMinmaxBlocks), dim3(256), 0, st, pts, coff, nb, mm);
+        hipLaunchKernelGGL(k_cell_insert, dim3(blocks), dim3(256), 0, st, pts, coff, nb, mm, dl, inv_dl, tkey,
                            tfirst, tcnt, slot_of, pkey);
-        hipLaunchKernelGGL(k_flag, dim3(blocks), dim3(256), 0, st, n, slot_of, tfirst, rank);
+        hipLaunchKernelGGL(k_flag, dim3(blocks), dim3(256), 0, st, n_dev, n, slot_of, tfirst, rank);
         PCRCG_PROPAGATE(exclusive_scan_i32(rank, rank, n, mtot, scan_ws, st));
-        hipLaunchKernelGGL(k_cells, dim3(blocks), dim3(256), 0, st, n, slot_of, tfirst, tcnt, rank, pkey, ckey, ccnt,
+        hipLaunchKernelGGL(k_cells, dim3(blocks), dim3(256), 0, st, n_dev, slot_of, tfirst, tcnt, rank, pkey, ckey, ccnt,
                            trank);
         PCRCG_PROPAGATE(exclusive_scan_i32(ccnt, cstart, n, nullptr, scan_ws, st));
-        hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, st, n, slot_of, trank, cstart, cfill, cidx);
+        hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, st, n_dev, slot_of, trank, cstart, cfill, cidx);
         hipLaunchKernelGGL(k_barycentres, dim3(blocks), dim3(256), 0, st, pts, mtot, cstart, ccnt, cidx, cbary);
     }
-    hipLaunchKernelGGL(k_order_emit, dim3(nb), dim3(kUmapThreads), 0, st, n, nb, coff, rank, mtot, ckey, cbary, ebase,
-                       bbase, (long)es, (long)bs, max_p, out_pts, out_len, out_m);
+    hipLaunchKernelGGL(k_order_emit, dim3(nb), dim3(kUmapThreads), 0, st, nb, coff, rank, mtot, ckey, cbary, ebase,
+                       bbase, (long)es, (long)bs, max_p, out_pts, out_len, out_m, out_cap, overflow);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
-}
 }

@@ -19,6 +19,7 @@
 #include <sched.h>
 #include <time.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -57,6 +58,22 @@ inline double now_us() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
+// ---- which streams share a hardware dispatcher (pcrcg_stream_pipe_classes) ----
+// The command processor of gfx950 runs FOUR compute dispatchers ("pipes"); every HIP stream lives on a hardware queue of
+// one of them, and a dispatcher hands out the workgroups of ONE kernel at a time: while a kernel of many workgroups is
+// being dispatched -- for a GEMM beside other work that is most of its run time -- every other stream on the same dispatcher
+// stands still (profiles/r06_queue_pipes.txt: a one-workgroup kernel completes in 12 us beside such a dispatch on another
+// dispatcher and in ~470 us behind it on the same one; streams i and i + 4 share one, whatever GPU_MAX_HW_QUEUES says).
+// That is the pair engine's "concurrency wall" of rounds 3-5: a fifth busy stream does not add concurrency, it halves two.
+__global__ void k_probe_many(int* sink, int spin) {
+    int x = threadIdx.x;
+    for (int i = 0; i < spin; ++i) x = x * 1664525 + 1013904223;
+    if (x == 0x7fffffff) sink[0] = x;
+}
+__global__ void k_probe_tiny(int* sink) {
+    if (threadIdx.x == 1234567) sink[1] = 1;
 }
 
 int wait_mode() {
@@ -143,6 +160,17 @@ struct TableRec {
 
 using namespace pcrcg;
 
+// events of one call (stream fork / join); destroyed when the call returns -- a recorded wait keeps what it needs
+struct EventBox {
+    std::vector<hipEvent_t> ev;
+    int make(hipEvent_t* e) {
+        PCRCG_CHECK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        ev.push_back(*e);
+        return PCRCG_OK;
+    }
+    ~EventBox() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+};
+
 // The input clouds may come in several PARTS (the pairs of a grouped build, each where its caller left it): part i holds
 // n_parts[i] rows and nb_parts[i] cloud lengths; they are copied behind each other into the arena (the builder copies its
 // input anyway), so stacking pairs costs no concatenation kernel on the caller's side.
@@ -154,36 +182,61 @@ struct Parts {
     int count;
 };
 
+// Row bound of every level: level 0 holds n0 rows, a subsampled level at most `shrink` times the bound of the level it
+// comes from (the caller's promise, pcrcg_pyramid_cfg::shrink; a cloud that keeps more is reported as PCRCG_EWORKSPACE).
+// Everything on the device is SIZED by these bounds -- buffers, tables, launch grids -- and every kernel reads the
+// actual row counts from the cloud lengths, which never leave the device until the end of the chain.
+static void level_caps(int n0, const pcrcg_pyramid_cfg* cfg, int* cap) {
+    double shrink = cfg->shrink;
+    if (!(shrink > 0.0) || shrink > 1.0) shrink = 1.0;
+    cap[0] = n0;
+    for (int l = 1; l < cfg->n_levels; ++l) {
+        const double c = ceil((double)cap[l - 1] * shrink);
+        cap[l] = c < 1.0 ? 1 : (c > (double)cap[l - 1] ? cap[l - 1] : (int)c);
+    }
+}
+
 static int pyramid_run(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg* cfg, Arena& A,
                        int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status, pcrcg_pyramid_restore* deferred,
-                       double shrink, hipStream_t st) {
+                       hipStream_t st) {
     const int L = cfg->n_levels;
     const bool dry = A.dry;
     const bool want_ties = cfg->tie_order != 0;
     const int group = cfg->group > 0 ? cfg->group : 0;
     const int P = group > 0 ? nb / group : 1;          // output batches
     const int MS = P + 2;                              // ints of table metadata
-    // ---- persistent block 1: points of all levels, lengths, features, table metadata -----------------------
-    // level l+1 has at most as many rows as level l: L * n0 rows always suffice (12 bytes each)
-    float* pts_all = A.take<float>(3 * (size_t)L * ((size_t)n0 + 1));
+    int cap[PCRCG_MAX_LEVELS];
+    level_caps(n0, cfg, cap);
+    // ---- persistent block 1: points of all levels (level l at its own bound-sized place), lengths, features, metadata ----
+    // (one block, every level a whole number of ROWS behind the first: the upper levels' forest indexes them as one array)
+    float* level_pts[PCRCG_MAX_LEVELS];
+    {
+        size_t rows = 0;
+        for (int l = 0; l < L; ++l) rows += (size_t)cap[l] + 1;
+        float* pts_all = A.take<float>(3 * rows);
+        rows = 0;
+        for (int l = 0; l < L; ++l) { level_pts[l] = pts_all + 3 * rows; rows += (size_t)cap[l] + 1; }
+    }
     int* lens_all = A.take<int>((size_t)L * nb);
     float* feats = A.take<float>((size_t)n0);
     const int max_tables = 3 * L;
-    int* metas = A.take<int>((size_t)MS * max_tables + L);    // [MS per table] + subsample row counts [L]
+    // [MS per table] + subsampled row counts [L] + "a level outgrew its bound" [1] + the restore step's status word [1]
+    const size_t meta_ints = (size_t)MS * max_tables + L + 2;
+    int* metas = A.take<int>(meta_ints);
     int* m_dev = metas + MS * max_tables;
-    int* tie_status = A.take<int>(1);
+    int* overflow = m_dev + L;
+    int* tie_status = overflow + 1;
     if (!A.ok()) return PCRCG_EWORKSPACE;
 
     const bool eager = debug_opts().radius_eager_redo != 0;   // A/B aid
     std::vector<TableRec> tables;
     tables.reserve(max_tables);
     if (!dry) {
-        PCRCG_CHECK_HIP(hipMemsetAsync(metas, 0, sizeof(int) * ((size_t)MS * max_tables + L), st));
-        PCRCG_CHECK_HIP(hipMemsetAsync(tie_status, 0, sizeof(int), st));
+        PCRCG_CHECK_HIP(hipMemsetAsync(metas, 0, sizeof(int) * meta_ints, st));
         size_t row = 0, cloud = 0;
         for (int i = 0; i < in.count; ++i) {
             if (in.n[i] > 0)
-                PCRCG_CHECK_HIP(hipMemcpyAsync(pts_all + 3 * row, in.pts[i], sizeof(float) * 3 * (size_t)in.n[i], hipMemcpyDeviceToDevice, st));
+                PCRCG_CHECK_HIP(hipMemcpyAsync(level_pts[0] + 3 * row, in.pts[i], sizeof(float) * 3 * (size_t)in.n[i], hipMemcpyDeviceToDevice, st));
             PCRCG_CHECK_HIP(hipMemcpyAsync(lens_all + cloud, in.len[i], sizeof(int) * in.nb[i], hipMemcpyDeviceToDevice, st));
             row += (size_t)in.n[i];
             cloud += (size_t)in.nb[i];
@@ -191,7 +244,55 @@ static int pyramid_run(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg*
         PCRCG_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(feats), 0x3f800000, (size_t)(n0 > 0 ? n0 : 1), st));
     }
 
+    // ---- streams.  The chain is a DAG, not a line: a level's SUBSAMPLING needs only the level's points; the level's cell
+    // grid and its conv search need them too and nothing from the subsampling; only the pool / upsample searches and the
+    // next level need both.  And a KD-forest (restore step) needs only its levels' points.  With side streams from the
+    // caller (pcrcg_pyramid_cfg::side_stream / side_stream2) the three subsamplings run back to back on the first from the
+    // moment the input is in place -- beside grid 0 and the conv search of level 0, the longest kernel of the chain -- and
+    // the forests on the second (or behind the subsamplings on the first); `st` keeps the grids and the ten searches and
+    // waits, level by level, for the subsampled points.  Without side streams everything is enqueued on `st` in an order
+    // that is valid for one stream (what rounds 2-5 did).
+    // Two forests: level 0's, built as soon as the input is in place, and one over the subsampled levels, built when the
+    // last of them exists.  Level 0 holds three quarters of the rows and the deepest trees.  (One forest PER level, one
+    // launch each, was measured first: four persistent launches one after the other cost 3.9 ms of forest time per
+    // four-pair chain against 1.1 for one launch -- the levels' critical paths add up instead of overlapping.)
+    // Tie rows are the rule (every two-point cell of a subsampling puts one into the pool table), so the builds do not
+    // wait to be told that there are some.
+    hipStream_t sub_st = cfg->side_stream ? as_stream(cfg->side_stream) : st;
+    hipStream_t f_st = cfg->side_stream2 ? as_stream(cfg->side_stream2) : sub_st;
+    EventBox events;
+    // b waits for everything enqueued on a so far
+    auto order = [&](hipStream_t a, hipStream_t b) -> int {
+        if (a == b || dry) return PCRCG_OK;
+        hipEvent_t ev;
+        PCRCG_PROPAGATE(events.make(&ev));
+        PCRCG_CHECK_HIP(hipEventRecord(ev, a));
+        PCRCG_CHECK_HIP(hipStreamWaitEvent(b, ev, 0));
+        return PCRCG_OK;
+    };
+    void* forest[2] = {nullptr, nullptr};              // [0] level 0, [1] levels 1 .. L-1
+    size_t forest_b[2] = {0, 0};
+    int forest_ns[2] = {0, 0}, forest_nb[2] = {0, 0};
+    int upper_base[PCRCG_MAX_LEVELS] = {};               // row of level l (>= 1) relative to level 1's first row
+    auto build_forest = [&](int which) -> int {
+        if (!want_ties || (which == 1 && L < 2)) return PCRCG_OK;
+        if (which == 0) { forest_ns[0] = cap[0]; forest_nb[0] = nb; }
+        else {
+            for (int l = 1; l < L; ++l) upper_base[l - 1] = (int)((level_pts[l] - level_pts[1]) / 3);
+            forest_ns[1] = upper_base[L - 2] + cap[L - 1];
+            forest_nb[1] = (L - 1) * nb;
+        }
+        forest_b[which] = pcrcg_kdforest_ws_bytes(forest_ns[which], forest_nb[which]);
+        forest[which] = A.raw(forest_b[which]);
+        if (!A.ok()) return PCRCG_EWORKSPACE;
+        if (dry) return PCRCG_OK;
+        PCRCG_PROPAGATE(order(which == 0 ? st : sub_st, f_st));       // the input copies / the last subsampling
+        if (which == 0) return kdforest_build_levels(level_pts[0], cap[0], lens_all, nb, 0, nullptr, forest[0], forest_b[0], f_st);
+        return kdforest_build_levels(level_pts[1], forest_ns[1], lens_all + nb, forest_nb[1], nb, upper_base, forest[1], forest_b[1], f_st);
+    };
+
     const bool use_cells = debug_opts().radius_cells != 0;
+    // nq / ns are the BOUNDS of the query / support level (grids and tables are carved for them)
     auto add_table = [&](int kind, int level, int q_level, const void* grid, const void* qgrid, float radius, const float* q,
                          const int* qlen, int nq, int ns, const int* slen, int limit, int sup_level) -> int {
         TableRec t;
@@ -223,49 +324,49 @@ static int pyramid_run(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg*
         return PCRCG_OK;
     };
 
-    float* pts = pts_all;
-    int* lens = lens_all;
-    int n = n0;
-    float* level_pts[PCRCG_MAX_LEVELS];
-    int level_n[PCRCG_MAX_LEVELS];
+    // the subsamplings' scratch: ONE block for all levels (they run one after the other on one stream; level 0 needs the
+    // most).  It is NOT handed back to the arena: beside the searches on another stream nothing may share its memory.
+    const size_t sub_wsb = L > 1 ? pcrcg_grid_subsample_ws_bytes(cap[0], nb) : 0;
+    void* sub_ws = L > 1 ? A.raw(sub_wsb) : nullptr;
+    if (!A.ok()) return PCRCG_EWORKSPACE;
+
     void* carried = nullptr;
     float carried_r = 0.f;
+    PCRCG_PROPAGATE(order(st, sub_st));                  // the input is in place: the subsamplings may start
+    PCRCG_PROPAGATE(build_forest(0));
     for (int l = 0; l < L; ++l) {
         const int limit = cfg->limit[l];
         const float r_conv = cfg->r_conv[l], r_pool = cfg->r_pool[l];
-        level_pts[l] = pts;
-        level_n[l] = n;
+        float* pts = level_pts[l];
+        int* lens = lens_all + (size_t)l * nb;
+        const int n = cap[l];
         void* grid = nullptr;
         float grid_r = 0.f;
+        const bool pooled = cfg->pooled[l] && l + 1 < L;
+        if (!pooled && l + 1 < L) {
+            set_error("pcrcg_pyramid_build: level %d of %d is not pooled", l, L);
+            return PCRCG_EBADARG;
+        }
+        // the level's subsampling first: on its own stream it runs beside the grid and the conv search below
+        if (pooled && !dry)
+            PCRCG_PROPAGATE(grid_subsample_bound(pts, n, lens, nb, cfg->dl[l], 0, level_pts[l + 1], lens + nb, m_dev + l, cap[l + 1],
+                                                 overflow, sub_ws, sub_wsb, sub_st));
+        if (pooled && l + 2 == L) PCRCG_PROPAGATE(build_forest(1));      // the last subsampled level exists: the upper levels' forest
         if (cfg->has_conv[l]) {
             if (carried && carried_r == r_conv) { grid = carried; grid_r = carried_r; }
             else { PCRCG_PROPAGATE(build_grid(pts, n, lens, r_conv, &grid)); grid_r = r_conv; }
             PCRCG_PROPAGATE(add_table(0, l, l, grid, grid, r_conv, pts, lens, n, n, lens, limit, l));
         }
         carried = nullptr;
-        if (cfg->pooled[l] && l + 1 < L) {
-            float* sub = pts + 3 * (size_t)n;               // next level's rows directly behind this level's
+        if (pooled) {
+            float* sub = level_pts[l + 1];
             int* sub_len = lens + nb;
-            int m = 0;
-            {
-                const size_t mark = A.off;
-                const size_t wsb = pcrcg_grid_subsample_ws_bytes(n, nb);
-                void* ws = A.raw(wsb);
-                if (!A.ok()) return PCRCG_EWORKSPACE;
-                if (!dry) {
-                    PCRCG_PROPAGATE(pcrcg_grid_subsample_batch(pts, n, lens, nb, cfg->dl[l], 0, sub, sub_len, m_dev + l, ws, wsb, st));
-                    // host round trip: the row count sizes everything that follows
-                    PCRCG_PROPAGATE(fetch(h_scratch, m_dev + l, 1, nullptr, 0, st));
-                    m = h_scratch[1];
-                } else {
-                    m = (int)((double)n * shrink);
-                }
-                A.off = mark;                                // scratch is free again (stream order protects it)
-            }
+            const int m = cap[l + 1];
             if (grid == nullptr || grid_r != r_pool) {
                 PCRCG_PROPAGATE(build_grid(pts, n, lens, r_pool, &grid));
                 grid_r = r_pool;
             }
+            PCRCG_PROPAGATE(order(sub_st, st));          // from here on `st` reads the subsampled level
             // the coarse level's grid first: it is the upsample table's support grid, the next level's conv grid AND the
             // query grid of the pool table (every query set of the pyramid walks a grid of its own, cell by cell)
             void* up_grid = nullptr;
@@ -274,21 +375,33 @@ static int pyramid_run(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg*
             PCRCG_PROPAGATE(add_table(2, l, l, up_grid, grid, 2 * r_pool, pts, lens, n, m, sub_len, cfg->up_nearest ? 1 : limit, l + 1));
             carried = up_grid;
             carried_r = 2 * r_pool;
-            pts = sub;
-            lens = sub_len;
-            n = m;
-        } else if (l + 1 < L) {
-            set_error("pcrcg_pyramid_build: level %d of %d is not pooled", l, L);
-            return PCRCG_EBADARG;
         }
     }
     if (dry) return PCRCG_OK;
-    const size_t rows_total = (size_t)(pts - pts_all) / 3 + (size_t)n;
+    hipEvent_t forests_done = nullptr;
+    if (want_ties && f_st != st) {
+        PCRCG_PROPAGATE(events.make(&forests_done));
+        PCRCG_CHECK_HIP(hipEventRecord(forests_done, f_st));
+    }
 
-    // ---- one round trip for all tables: column counts, capacity status, rows holding ties, cloud lengths --
+    // ---- the ONE round trip of the call: column counts, capacity status, rows holding ties, row counts, cloud lengths ----
     const int nt = (int)tables.size();
-    PCRCG_PROPAGATE(fetch(h_scratch, metas, MS * nt, lens_all, L * nb, st));
+    const int meta_words = MS * max_tables + L + 1;
+    PCRCG_PROPAGATE(fetch(h_scratch, metas, meta_words, lens_all, L * nb, st));
+    // whatever follows on `st` (the reorder step, the caller's readers, a second attempt in the same arena) comes after the forests
+    if (forests_done) PCRCG_CHECK_HIP(hipStreamWaitEvent(st, forests_done, 0));
     const int* hm = h_scratch + 1;
+    if (hm[MS * max_tables + L] != 0) {
+        set_error("pcrcg_pyramid_build: a level keeps more rows than pcrcg_pyramid_cfg::shrink = %.3f allows -- call again with a "
+                  "larger bound (1.0 always fits)", cfg->shrink);
+        return PCRCG_EWORKSPACE;
+    }
+    for (int i = 0; i < L * nb; ++i) h_lengths[i] = hm[meta_words + i];
+    int level_n[PCRCG_MAX_LEVELS];
+    for (int l = 0; l < L; ++l) {
+        level_n[l] = 0;
+        for (int c = 0; c < nb; ++c) level_n[l] += h_lengths[(size_t)l * nb + c];
+    }
     {   // tables with a row of more hits than the first pass stages (128 in the cell search, 256 in the per-query kernel): redo pass now, then the metadata once more (it appends tie rows)
         int redone = 0;
         for (int i = 0; i < nt; ++i) {
@@ -302,9 +415,8 @@ static int pyramid_run(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg*
                                               2));
             ++redone;
         }
-        if (redone) PCRCG_PROPAGATE(fetch(h_scratch, metas, MS * nt, lens_all, L * nb, st));
+        if (redone) PCRCG_PROPAGATE(fetch(h_scratch, metas, meta_words, lens_all, L * nb, st));
     }
-    for (int i = 0; i < L * nb; ++i) h_lengths[i] = hm[MS * nt + i];
     // rows of group p at level l: [row0, row0 + rows)
     auto group_rows = [&](int l, int p, int* row0, int* rows) {
         const int c0 = group > 0 ? p * group : 0, c1 = group > 0 ? c0 + group : nb;
@@ -356,36 +468,28 @@ static int pyramid_run(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg*
         }
         if (want_ties && widest > 0 && tie_rows > 0 && R.njobs < PCRCG_MAX_REORDER_JOBS) {
             pcrcg_reorder_job& j = R.jobs[R.njobs++];
+            const int fi = t.sup_level == 0 ? 0 : 1;
             j.q = t.q; j.qlen = t.qlen; j.rows = t.ties; j.count = t.counts; j.idx = t.idx;
-            j.nq = t.nq; j.nbq = nb; j.cloud0 = nb * t.sup_level; j.nrows = tie_rows; j.max_count = widest < 8192 ? widest : 8192;   // (tieorder.hip stages at most 8192 hits per row)
+            j.nq = level_n[t.q_level]; j.nbq = nb; j.cloud0 = fi == 0 ? 0 : (t.sup_level - 1) * nb; j.nrows = tie_rows;
+            j.max_count = widest < 8192 ? widest : 8192;   // (tieorder.hip stages at most 8192 hits per row)
             j.cols = t.limit; j.radius = t.radius; j.group = group;
+            j.sup = level_pts[fi]; j.forest = forest[fi]; j.forest_ns = forest_ns[fi]; j.forest_nb = forest_nb[fi];
         }
     }
     // ---- the reference's order inside groups of exactly equal distance (tieorder.hip) ----------------------
-    R.pts_all = pts_all; R.lens_all = lens_all; R.rows_total = (int)rows_total; R.clouds_total = L * nb;
-    R.forest = nullptr; R.forest_bytes = 0; R.tie_status = tie_status;
-    if (R.njobs > 0) {
-        R.forest_bytes = pcrcg_kdforest_ws_bytes((int)rows_total, L * nb);
-        R.forest = A.raw(R.forest_bytes);
-        if (!A.ok()) return PCRCG_EWORKSPACE;
-    }
+    R.tie_status = tie_status;
     if (!deferred) return pcrcg_pyramid_restore_run(&R, h_status, st);
     return PCRCG_OK;
 }
 
 extern "C" {
 
-size_t pcrcg_pyramid_ws_bytes(int n0, int nb, const pcrcg_pyramid_cfg* cfg, double shrink) {
+size_t pcrcg_pyramid_ws_bytes(int n0, int nb, const pcrcg_pyramid_cfg* cfg) {
     if (!cfg || n0 < 0 || nb < 1 || cfg->n_levels < 1 || cfg->n_levels > PCRCG_MAX_LEVELS) return 0;
-    if (!(shrink > 0.0) || shrink > 1.0) shrink = 1.0;
     Arena A(nullptr, 0, true);
     const Parts none{nullptr, nullptr, nullptr, nullptr, 0};
-    if (pyramid_run(none, n0, nb, cfg, A, nullptr, nullptr, nullptr, nullptr, nullptr, shrink, nullptr) != PCRCG_OK) return 0;
-    // the KD-forest of the restore step over all levels' rows
-    size_t rows = 0;
-    double r = n0;
-    for (int l = 0; l < cfg->n_levels; ++l) { rows += (size_t)r + 1; r *= shrink; }
-    return A.peak + (cfg->tie_order != 0 ? ((pcrcg_kdforest_ws_bytes((int)rows, cfg->n_levels * nb) + 255) & ~size_t(255)) : 0) + 4096;
+    if (pyramid_run(none, n0, nb, cfg, A, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != PCRCG_OK) return 0;
+    return A.peak + 4096;
 }
 
 // A non-blocking HIP stream (hipStreamNonBlocking) with an optional priority (0 = default, -1 = high).
@@ -397,6 +501,62 @@ int pcrcg_stream_create(void** stream, int priority) {
     return PCRCG_OK;
 }
 
+// cls[i] = dispatcher class of streams[i]: 0 for streams[0]'s, then 1, 2, ... in order of first appearance.  Measured, not
+// looked up (the runtime does not say): a dispatch-bound kernel (2 M one-wavefront workgroups, ~0.9 ms of dispatching) on a
+// class representative, a one-workgroup kernel on the candidate 150 us later, host-timed; "same dispatcher" = the tiny
+// kernel took more than a third of what is left of the big dispatch.  Every candidate is tested against one representative
+// per known class (at most four exist), each test twice; ~1.5 ms per test.  Call it on an otherwise idle GPU.
+// scratch: >= 16 bytes of device memory.
+int pcrcg_stream_pipe_classes(void* const* streams, int n, int* cls, void* scratch) {
+    PCRCG_CHECK_ARG(streams && cls && scratch && n >= 1 && n <= 64);
+    int* sink = static_cast<int*>(scratch);
+    PCRCG_CHECK_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_probe_tiny, dim3(1), dim3(64), 0, as_stream(streams[i]), sink);   // warm every queue
+    PCRCG_CHECK_HIP(hipDeviceSynchronize());
+    const int blocks = 2000000;
+    double t0 = now_us();
+    hipLaunchKernelGGL(k_probe_many, dim3(blocks), dim3(64), 0, as_stream(streams[0]), sink, 64);
+    PCRCG_CHECK_HIP(hipStreamSynchronize(as_stream(streams[0])));
+    const double big_us = now_us() - t0;
+    if (big_us < 400.0) {      // the probe needs a dispatch that outlasts the launch of the tiny kernel
+        set_error("pcrcg_stream_pipe_classes: the dispatch-bound probe kernel took only %.0f us", big_us);
+        return PCRCG_ELAUNCH;
+    }
+    int reps[8], nrep = 0;
+    auto shares = [&](int a, int b, bool* out) -> int {      // does streams[b] wait for a dispatch on streams[a]?
+        int votes = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL(k_probe_many, dim3(blocks), dim3(64), 0, as_stream(streams[a]), sink, 64);
+            const double start = now_us();
+            while (now_us() - start < 150.0) {}
+            const double a0 = now_us();
+            hipLaunchKernelGGL(k_probe_tiny, dim3(1), dim3(64), 0, as_stream(streams[b]), sink);
+            PCRCG_CHECK_HIP(hipStreamSynchronize(as_stream(streams[b])));
+            const double d = now_us() - a0;
+            PCRCG_CHECK_HIP(hipDeviceSynchronize());
+            votes += d > (big_us - 150.0) / 3.0 ? 1 : 0;
+        }
+        *out = votes == 2;
+        return PCRCG_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+        cls[i] = -1;
+        for (int j = 0; j < i && cls[i] < 0; ++j)
+            if (streams[j] == streams[i]) cls[i] = cls[j];
+        for (int r = 0; r < nrep && cls[i] < 0; ++r) {
+            bool same = false;
+            PCRCG_PROPAGATE(shares(reps[r], i, &same));
+            if (same) cls[i] = r;
+        }
+        if (cls[i] < 0) {
+            if (nrep == 8) { set_error("pcrcg_stream_pipe_classes: more than 8 dispatcher classes -- the probe is not measuring what it should"); return PCRCG_ELAUNCH; }
+            reps[nrep] = i;
+            cls[i] = nrep++;
+        }
+    }
+    return PCRCG_OK;
+}
+
 int pcrcg_stream_destroy(void* stream) {
     PCRCG_CHECK_HIP(hipStreamDestroy(as_stream(stream)));
     return PCRCG_OK;
@@ -405,13 +565,7 @@ int pcrcg_stream_destroy(void* stream) {
 int pcrcg_pyramid_restore_run(const pcrcg_pyramid_restore* r, int* h_status, void* stream) {
     PCRCG_CHECK_ARG(r && r->tie_status && r->njobs >= 0 && r->njobs <= PCRCG_MAX_REORDER_JOBS);
     hipStream_t st = as_stream(stream);
-    if (r->njobs > 0) {
-        PCRCG_CHECK_ARG(r->forest && r->pts_all && r->lens_all);
-        PCRCG_PROPAGATE(pcrcg_kdforest_build(r->pts_all, r->rows_total, r->lens_all, r->clouds_total, r->forest,
-                                             r->forest_bytes, st));
-        PCRCG_PROPAGATE(pcrcg_radius_reorder_jobs(r->jobs, r->njobs, r->pts_all, r->rows_total, r->clouds_total, r->forest,
-                                                  r->tie_status, st));
-    }
+    if (r->njobs > 0) PCRCG_PROPAGATE(pcrcg_radius_reorder_jobs(r->jobs, r->njobs, nullptr, 0, 1, nullptr, r->tie_status, st));
     if (h_status) PCRCG_CHECK_HIP(hipMemcpyAsync(h_status, r->tie_status, sizeof(int), hipMemcpyDeviceToHost, st));
     return PCRCG_OK;
 }
@@ -429,10 +583,10 @@ static int pyramid_build_checked(const Parts& in, int n0, int nb, const pcrcg_py
     Arena A(ws, ws_bytes, false);
     hipStream_t st = as_stream(stream);
     const double t0 = g_trace.on ? now_us() : 0.0, w0 = g_trace.wait;
-    const int rc = pyramid_run(in, n0, nb, cfg, A, h_scratch, out, h_lengths, h_status, deferred, 1.0, st);
+    const int rc = pyramid_run(in, n0, nb, cfg, A, h_scratch, out, h_lengths, h_status, deferred, st);
     if (g_trace.on) { g_trace.enq += now_us() - t0 - (g_trace.wait - w0); g_trace.calls += 1; }
     if (rc == PCRCG_EWORKSPACE)
-        set_error("pcrcg_pyramid_build: arena too small (%zu needed so far, %zu given): size it with a larger `shrink`", A.off, ws_bytes);
+        if (A.off > ws_bytes) set_error("pcrcg_pyramid_build: arena too small (%zu needed so far, %zu given): size it with pcrcg_pyramid_ws_bytes for this cfg", A.off, ws_bytes);
     return rc;
 }
 

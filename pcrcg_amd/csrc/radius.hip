@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) k_grid_init(GridView g, const int* __rest
         for (int b = 0; b < nb; ++b) { g.soff[b] = s; s += slen[b]; }
         g.soff[nb] = s;
         g.hdr->inv_cell = inv_cell;
-        g.hdr->ns = ns;
+        g.hdr->ns = s;          // (the kernel argument is the caller's bound; the lengths say how many supports there are)
         g.hdr->nb = nb;
         g.hdr->cursor = 0ull;
         g.hdr->overflow = 0;
@@ -162,9 +162,9 @@ __global__ void __launch_bounds__(256) k_grid_init(GridView g, const int* __rest
         *reinterpret_cast<uint4*>(&g.tab[i]) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
 }
 
-__global__ void __launch_bounds__(256) k_grid_insert(const float* __restrict__ sup, int ns, int nb, GridView g) {
+__global__ void __launch_bounds__(256) k_grid_insert(const float* __restrict__ sup, int nb, GridView g) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ns) return;
+    if (i >= g.soff[nb]) return;
     const int b = cloud_of(g.soff, nb, i);
     int cx, cy, cz;
     if (!cell_coords(sup[3 * (long)i], sup[3 * (long)i + 1], sup[3 * (long)i + 2], g.hdr->inv_cell, &cx, &cy, &cz))
@@ -198,9 +198,9 @@ __global__ void __launch_bounds__(256) k_grid_starts(int nslots, int nb, GridVie
     }
 }
 
-__global__ void __launch_bounds__(256) k_grid_scatter(const float* __restrict__ sup, int ns, GridView g) {
+__global__ void __launch_bounds__(256) k_grid_scatter(const float* __restrict__ sup, int nb, GridView g) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ns) return;
+    if (i >= g.soff[nb]) return;
     const int dst = g.tab[g.slot_of[i]].start + g.pos_in[i];
     g.spts[dst] = make_float4(sup[3 * (long)i], sup[3 * (long)i + 1], sup[3 * (long)i + 2], __int_as_float(i));
 }
@@ -395,6 +395,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_radius_query(
         wave_max = nhit > wave_max ? nhit : wave_max;
         __builtin_amdgcn_wave_barrier();
     };
+    // nq is the caller's BOUND on the rows (what its launch and its buffers were sized for); the query lengths, on the
+    // device, say how many rows there are
+    {
+        int have = 0;
+        for (int b = 0; b < nb; ++b) have += qlen[b];
+        nq = nq < have ? nq : have;
+    }
     if (!REDO) {
         for (int qi = gw; qi < nq; qi += nw) one_query(qi);
     } else {
@@ -992,9 +999,9 @@ int pcrcg_cellgrid_build(const float* sup, int ns, const int* slen, int nb, floa
     hipLaunchKernelGGL(k_grid_init, dim3(init_blocks), dim3(256), 0, st, g, slen, ns, nb, inv_cell, (long)(2 * N));
     if (ns > 0) {
         const int blocks = (ns + 255) / 256;
-        hipLaunchKernelGGL(k_grid_insert, dim3(blocks), dim3(256), 0, st, sup, ns, nb, g);
+        hipLaunchKernelGGL(k_grid_insert, dim3(blocks), dim3(256), 0, st, sup, nb, g);
         hipLaunchKernelGGL(k_grid_starts, dim3((2 * ns + 255) / 256), dim3(256), 0, st, 2 * ns, nb, g);
-        hipLaunchKernelGGL(k_grid_scatter, dim3(blocks), dim3(256), 0, st, sup, ns, g);
+        hipLaunchKernelGGL(k_grid_scatter, dim3(blocks), dim3(256), 0, st, sup, nb, g);
     }
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;

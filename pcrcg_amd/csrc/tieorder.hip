@@ -125,7 +125,14 @@ inline KdView forest_view(void* ws, size_t bytes, int ns, int nb, bool* ok) {
 // ------------------------------------------------------------------------------------------------
 // forest build
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_kd_init(const int* __restrict__ slen, int ns, int nb, KdView v) {
+// bases.per_level > 0: the clouds are LEVELS of bases.per_level clouds each, level l's rows starting at row bases.base[l] of
+// `sup` (the pyramid builder keeps every level at a place sized by its row BOUND, so the levels are not contiguous); a
+// cloud's end is its root node's `right`, never the next cloud's start.
+struct KdBases {
+    int per_level;
+    int base[PCRCG_MAX_LEVELS];
+};
+__global__ void __launch_bounds__(256) k_kd_init(const int* __restrict__ slen, int ns, int nb, KdView v, KdBases bases) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         KdCtl* c = v.ctl;
         c->node_count = nb;
@@ -134,6 +141,7 @@ __global__ void __launch_bounds__(256) k_kd_init(const int* __restrict__ slen, i
         int s = 0, tasks = 0;
         for (int b = 0; b < nb; ++b) {
             const int n = slen[b];
+            if (bases.per_level > 0 && b % bases.per_level == 0) s = bases.base[b / bases.per_level];
             KdNode nd;
             nd.left = s;
             nd.right = s + n;
@@ -737,6 +745,8 @@ __device__ __forceinline__ void stable_sort_wave(const u64* a, u64* out, int n, 
 // ------------------------------------------------------------------------------------------------
 struct ReorderJobs {
     pcrcg_reorder_job job[PCRCG_MAX_REORDER_JOBS];
+    KdView view[PCRCG_MAX_REORDER_JOBS];          // the forest a job searches (its own, or the call's) ...
+    const float* sup[PCRCG_MAX_REORDER_JOBS];     // ... and that forest's points
     int row_begin[PCRCG_MAX_REORDER_JOBS + 1];
     int njobs;
 };
@@ -744,8 +754,7 @@ struct ReorderJobs {
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ float unif(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
-__global__ void __launch_bounds__(kReorderWaves * 64) k_reorder(ReorderJobs jobs, const float* __restrict__ sup, KdView v,
-                                                                 int W, int* __restrict__ status) {
+__global__ void __launch_bounds__(kReorderWaves * 64) k_reorder(const ReorderJobs jobs, int W, int* __restrict__ status) {
     extern __shared__ u64 s_dyn[];
     // per wavefront: W staged hits, then a region that holds the traversal stack (node, mindistsq, dists[3] per
     // entry) first and the sorted row afterwards
@@ -758,22 +767,25 @@ __global__ void __launch_bounds__(kReorderWaves * 64) k_reorder(ReorderJobs jobs
     float* st_min = reinterpret_cast<float*>(st_node + kTravStack);
     float* st_d = st_min + kTravStack;      // [kTravStack][3]
     const int t = blockIdx.x * waves + wave;
-    if (t == 0 && lane == 0 && v.ctl->status && status) *status = v.ctl->status;
     if (t >= jobs.row_begin[jobs.njobs]) return;
     int ji = 0;
     while (ji + 1 < jobs.njobs && t >= jobs.row_begin[ji + 1]) ++ji;
     const pcrcg_reorder_job& jb = jobs.job[ji];
+    const KdView& v = jobs.view[ji];
+    const float* __restrict__ sup = jobs.sup[ji];
     const int local = t - jobs.row_begin[ji];
+    if (local == 0 && lane == 0 && v.ctl->status && status) *status = v.ctl->status;
     const int qi = jb.rows ? uni(jb.rows[local]) : local;
     const float* q = jb.q;
     int b = 0, qacc = 0;
     while (b < jb.nbq - 1 && qi >= qacc + jb.qlen[b]) { qacc += jb.qlen[b]; ++b; }
     const int root = jb.cloud0 + b;
-    int seg = v.soff[jb.cloud0], pad = v.soff[jb.cloud0 + jb.nbq] - seg;
+    // (a cloud ends at its root's `right`: the next cloud may start elsewhere -- levels at places of their own, KdBases)
+    int seg = v.soff[jb.cloud0], pad = v.nodes[jb.cloud0 + jb.nbq - 1].right - seg;
     if (jb.group > 0) {   // independent groups of clouds: relative to the query's own group
         const int g0 = jb.cloud0 + (b / jb.group) * jb.group, g1 = min(g0 + jb.group, jb.cloud0 + jb.nbq);
         seg = v.soff[g0];
-        pad = v.soff[g1] - seg;
+        pad = v.nodes[g1 - 1].right - seg;
     }
     const float r2 = jb.radius * jb.radius;      // neighbors.cpp:226
     const float vx = q[3 * (long)qi], vy = q[3 * (long)qi + 1], vz = q[3 * (long)qi + 2];
@@ -882,9 +894,21 @@ size_t pcrcg_kdforest_ws_bytes(int ns, int nb) { return forest_bytes(ns, nb < 1 
 
 int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, void* forest, size_t forest_bytes_,
                          void* stream) {
+    return pcrcg::kdforest_build_levels(sup, ns, slen, nb, 0, nullptr, forest, forest_bytes_, as_stream(stream));
+}
+}
+
+// per_level > 0: nb / per_level levels of per_level clouds, level l's rows from row level_base[l] of `sup`; ns = a bound on
+// the rows `sup` spans (what the workspace was sized for)
+int pcrcg::kdforest_build_levels(const float* sup, int ns, const int* slen, int nb, int per_level, const int* level_base,
+                                 void* forest, size_t forest_bytes_, hipStream_t stream) {
     PCRCG_CHECK_ARG(ns >= 0 && nb >= 1 && slen && forest);
+    PCRCG_CHECK_ARG(per_level == 0 || (per_level > 0 && nb % per_level == 0 && nb / per_level <= PCRCG_MAX_LEVELS && level_base));
+    KdBases bases;
+    bases.per_level = per_level;
+    for (int l = 0; l < PCRCG_MAX_LEVELS; ++l) bases.base[l] = per_level > 0 && l < nb / per_level ? level_base[l] : 0;
     PCRCG_CHECK_ARG(ns == 0 || sup);
-    hipStream_t st = as_stream(stream);
+    hipStream_t st = stream;
     bool ok;
     KdView v = forest_view(forest, forest_bytes_, ns, nb, &ok);
     if (!ok) {
@@ -893,7 +917,7 @@ int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, void
     }
     int init_blocks = (v.qcap + 255) / 256;
     init_blocks = init_blocks < 1 ? 1 : (init_blocks > 1024 ? 1024 : init_blocks);
-    hipLaunchKernelGGL(k_kd_init, dim3(init_blocks), dim3(256), 0, st, slen, ns, nb, v);
+    hipLaunchKernelGGL(k_kd_init, dim3(init_blocks), dim3(256), 0, st, slen, ns, nb, v, bases);
     if (ns > 0) {
         // one workgroup per ~1024 points can be busy at the deepest level of big nodes / the LDS subtrees
         int blocks = ns / (2 * kSubMax) + nb;
@@ -906,20 +930,29 @@ int pcrcg_kdforest_build(const float* sup, int ns, const int* slen, int nb, void
     return PCRCG_OK;
 }
 
+extern "C" {
+
 int pcrcg_radius_reorder_jobs(const pcrcg_reorder_job* jobs, int njobs, const float* sup, int ns, int nb,
                               const void* forest, int* status, void* stream) {
-    PCRCG_CHECK_ARG(njobs >= 0 && njobs <= PCRCG_MAX_REORDER_JOBS && (njobs == 0 || jobs) && forest && nb >= 1 && ns >= 0);
+    PCRCG_CHECK_ARG(njobs >= 0 && njobs <= PCRCG_MAX_REORDER_JOBS && (njobs == 0 || jobs) && nb >= 1 && ns >= 0);
     ReorderJobs pack;
     int total = 0, width = 1;
     pack.njobs = 0;
     for (int i = 0; i < njobs; ++i) {
         const pcrcg_reorder_job& j = jobs[i];
-        PCRCG_CHECK_ARG(j.nq >= 0 && j.nbq >= 1 && j.cloud0 >= 0 && j.cloud0 + j.nbq <= nb && j.qlen && j.idx);
+        // a job searches its own forest (j.forest, over j.sup: the pyramid builder keeps one forest per level) or the call's
+        const bool own = j.forest != nullptr;
+        const int fnb = own ? j.forest_nb : nb, fns = own ? j.forest_ns : ns;
+        PCRCG_CHECK_ARG(own || forest);
+        PCRCG_CHECK_ARG(j.nq >= 0 && j.nbq >= 1 && j.cloud0 >= 0 && j.cloud0 + j.nbq <= fnb && fns >= 0 && j.qlen && j.idx);
         PCRCG_CHECK_ARG(j.cols >= 1 && j.max_count >= 0 && j.max_count <= kMaxRow && j.radius > 0.0f);
         const int nrows = j.rows ? j.nrows : j.nq;
-        PCRCG_CHECK_ARG(nrows >= 0 && nrows <= j.nq && (j.nq == 0 || (j.q && sup)));
+        PCRCG_CHECK_ARG(nrows >= 0 && nrows <= j.nq && (j.nq == 0 || (j.q && (own ? j.sup : sup))));
         if (nrows == 0) continue;
+        bool vok;
         pack.job[pack.njobs] = j;
+        pack.view[pack.njobs] = forest_view(const_cast<void*>(own ? j.forest : forest), forest_bytes(fns, fnb), fns, fnb, &vok);
+        pack.sup[pack.njobs] = own ? j.sup : sup;
         pack.row_begin[pack.njobs] = total;
         ++pack.njobs;
         total += nrows;
@@ -928,18 +961,14 @@ int pcrcg_radius_reorder_jobs(const pcrcg_reorder_job* jobs, int njobs, const fl
     pack.row_begin[pack.njobs] = total;
     if (total == 0) return PCRCG_OK;
     hipStream_t st = as_stream(stream);
-    bool ok;
-    KdView v = forest_view(const_cast<void*>(forest), forest_bytes(ns, nb), ns, nb, &ok);
     const size_t second = (size_t)width > (size_t)kTravStack * 5 / 2 ? (size_t)width : (size_t)kTravStack * 5 / 2;
     const size_t per_wave = (size_t)width + second + 1;
     // 64 KB of dynamic LDS per workgroup while that holds the widest row; beyond, one wavefront per workgroup with up to
     // 2 * 8192 * 8 B + 8 B = 128 KB (gfx950: 160 KB per CU), which the kernel has to be granted explicitly
     const int waves = width > 2000 ? 1 : (width > 512 ? 2 : kReorderWaves);
     const size_t lds = per_wave * waves * sizeof(u64);
-    if (lds > 64 * 1024)
-        PCRCG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reorder), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds));
-    hipLaunchKernelGGL(k_reorder, dim3((total + waves - 1) / waves), dim3(waves * 64), lds, st, pack, sup, v, width, status);
+    if (lds > 64 * 1024) PCRCG_GRANT_LDS(k_reorder);
+    hipLaunchKernelGGL(k_reorder, dim3((total + waves - 1) / waves), dim3(waves * 64), lds, st, pack, width, status);
     PCRCG_CHECK_LAUNCH();
     return PCRCG_OK;
 }
@@ -961,6 +990,9 @@ int pcrcg_radius_reorder(const float* q, int nq, const int* qlen, int nbq, const
     j.cols = cols;
     j.radius = radius;
     j.group = 0;
+    j.sup = nullptr;
+    j.forest = nullptr;
+    j.forest_ns = j.forest_nb = 0;
     return pcrcg_radius_reorder_jobs(&j, 1, sup, ns, nb, forest, status, stream);
 }
 }

@@ -198,6 +198,20 @@ class CellGrid:
         return out
 
 
+def stream_pipe_classes(streams):
+    """Dispatcher class of every torch stream in `streams` (pcrcg_stream_pipe_classes: measured, ~1.5 ms per test, on an
+    idle GPU): streams of one class share one of gfx950's four compute dispatchers and take turns kernel by kernel."""
+    L = _lib.lib()
+    n = len(streams)
+    ptrs = (ctypes.c_void_p * n)(*[s.cuda_stream for s in streams])
+    cls = (ctypes.c_int * n)()
+    scratch = torch.zeros(16, dtype=torch.int32, device=streams[0].device)
+    torch.cuda.synchronize(streams[0].device)
+    with torch.cuda.device(streams[0].device):
+        _lib.check(L.pcrcg_stream_pipe_classes(ptrs, n, cls, scratch.data_ptr()), "pcrcg_stream_pipe_classes")
+    return [int(c) for c in cls]
+
+
 MAX_REORDER_JOBS = 12     # PCRCG_MAX_REORDER_JOBS
 
 
@@ -206,7 +220,8 @@ class ReorderJob(ctypes.Structure):
     _fields_ = [("q", ctypes.c_void_p), ("qlen", ctypes.c_void_p), ("rows", ctypes.c_void_p), ("count", ctypes.c_void_p),
                 ("idx", ctypes.c_void_p), ("nq", ctypes.c_int), ("nbq", ctypes.c_int), ("cloud0", ctypes.c_int),
                 ("nrows", ctypes.c_int), ("max_count", ctypes.c_int), ("cols", ctypes.c_int), ("radius", ctypes.c_float),
-                ("group", ctypes.c_int)]
+                ("group", ctypes.c_int), ("sup", ctypes.c_void_p), ("forest", ctypes.c_void_p), ("forest_ns", ctypes.c_int),
+                ("forest_nb", ctypes.c_int)]
 
 
 class KdForest:

@@ -25,6 +25,7 @@ before the first HIP call (bench.py does).  ONE engine per process and device: t
 which this engine's four streams use up; a second engine -- even the closed, not yet collected one of an earlier
 measurement -- puts more streams on the same queues and both slow down (measured: a fresh engine 453 pairs/s, the third
 one created in the same process 355).  Reuse the engine (set_up_nearest() exists for that reason)."""
+import os
 import queue
 import threading
 import time
@@ -57,7 +58,7 @@ class PairStreams:
 
     def __init__(self, net, config, neighborhood_limits, device=None, model_streams=3, front_threads=1, tie_order=None,
                  pairs_per_build=4, up_nearest=False, front_streams=1, front_priority=0, pairs_per_forward=4,
-                 adaptive_jobs=False):
+                 adaptive_jobs=False, forest_stream=None, pipes=None):
         """pairs_per_forward = 2 .. 4: pairs that were built together also go through the network together, up to that
         many per pcrcg_kpfcnn_forward_group call on one model stream, in which every product with a weight matrix runs
         once for all of them (the pairs never mix; outputs equal separate forwards up to summation order).  1: one call
@@ -86,9 +87,13 @@ class PairStreams:
             self.runner.descriptor()           # built once, here, before any worker thread can race for it
         # front_streams / front_priority (< 0: the front-end chain ahead of the forwards) exist for measurements: more
         # than one front-end stream, and a prioritised one, both measured slower
-        self.fronts = [torch.cuda.Stream(device=self.device, priority=int(front_priority))
-                       for _ in range(max(1, int(front_streams)))]
-        self.models = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(model_streams)))]
+        # side streams of the front end (round 6: the chain is a DAG -- the subsamplings and the KD-forests of the tie-order
+        # restore step need nothing from the searches): forest_stream = 2 (default; PCRCG_FOREST_STREAM) one stream for the
+        # subsamplings and one for the forests, 1 both on one, 0 everything in line on the front-end stream
+        if forest_stream is None:
+            forest_stream = int(os.environ.get("PCRCG_FOREST_STREAM", "2"))
+        self._pick_streams(max(1, int(front_streams)), max(1, int(model_streams)), int(forest_stream), int(front_priority),
+                           os.environ.get("PCRCG_ENGINE_PIPES", "auto") if pipes is None else pipes)
         self.front = self.fronts[0]
         nf = max(1, int(front_threads))
         # every front thread owns a ring of builders (arena + pinned scratch each)
@@ -98,13 +103,17 @@ class PairStreams:
                      for _ in range(nf)]
         # per arena: a one-slot queue holding the event after which it may be overwritten (None: never used); the
         # front thread TAKES it before building into the arena, the model thread puts the forward's event back
+        if self.sides:
+            for f, ring in enumerate(self._pyr):
+                for pyr in ring:
+                    pyr.set_side_streams(*self.sides[f % len(self.sides)])
         self._free = [[queue.Queue() for _ in range(self.ARENAS)] for _ in range(nf)]
         for ring in self._free:
             for q in ring:
                 q.put(None)
         self._in = queue.Queue()               # one queue: a front thread takes up to `pairs_per_build` consecutive pairs
         self._take = threading.Lock()
-        self._per_build = min(4, max(1, int(pairs_per_build)))
+        self._per_build = min(8, max(1, int(pairs_per_build)))     # (pcrcg_pyramid_build: at most 16 clouds)
         self._users = [[1] * self.ARENAS for _ in range(nf)]   # forwards that read the arena's current contents
         self._per_forward = min(4, max(1, int(pairs_per_forward)))
         self._adaptive = bool(adaptive_jobs)
@@ -129,6 +138,60 @@ class PairStreams:
             t = threading.Thread(target=self._serve_model, args=(m,), name=f"pcrcg-model-{m}", daemon=True)
             t.start()
             self._threads.append(t)
+
+    def _pick_streams(self, n_front, n_model, want_side, front_priority, pipes):
+        """The engine's streams by hardware DISPATCHER (round 6).  gfx950's command processor has four compute dispatchers;
+        a stream's hardware queue belongs to one, and a dispatcher hands out the workgroups of one kernel at a time -- two
+        busy streams on one dispatcher take turns kernel by kernel (profiles/r06_queue_pipes.txt; this is the wall rounds
+        3-5 ran into with a fourth model stream: it shared the front-end stream's dispatcher, and the front-end chain stood
+        behind every GEMM's dispatch).  pipes="auto": a dozen candidate streams are classified by measurement
+        (ops.stream_pipe_classes, ~50 ms once) and the engine takes the front-end stream and its KD-forest stream from
+        ONE class -- both run small latency-bound kernels whose dispatch is over at once -- and the model streams from the
+        other classes, in turn.  pipes="off" (or PCRCG_ENGINE_PIPES=off): streams in creation order, as rounds 1-5 did.
+        self.pipe_classes records what was chosen."""
+        dev = self.device
+        if pipes == "off":
+            self.fronts = [torch.cuda.Stream(device=dev, priority=front_priority) for _ in range(n_front)]
+            self.sides = [(torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev) if want_side > 1 else None)
+                          for _ in self.fronts] if want_side else []
+            self.models = [torch.cuda.Stream(device=dev) for _ in range(n_model)]
+            self.pipe_classes = None
+            return
+        from . import ops
+        cands = [torch.cuda.Stream(device=dev) for _ in range(12)]
+        fcands = cands if front_priority == 0 else [torch.cuda.Stream(device=dev, priority=front_priority) for _ in range(4)]
+        cls = ops.stream_pipe_classes(cands + (fcands if fcands is not cands else []))
+        ccls, fcls = cls[:len(cands)], (cls[len(cands):] if fcands is not cands else cls[:len(cands)])
+        by = {}
+        for s_, c in zip(cands, ccls):
+            by.setdefault(c, []).append(s_)
+        front_class = fcls[0]
+        self.fronts, used = [], set()
+        for s_, c in zip(fcands, fcls):                       # front-end streams: all from the first one's class
+            if c == front_class and len(self.fronts) < n_front:
+                self.fronts.append(s_)
+                used.add(id(s_))
+        while len(self.fronts) < n_front:
+            self.fronts.append(self.fronts[-1])
+        free_front = [s_ for s_ in by.get(front_class, []) if id(s_) not in used]
+        self.sides = []
+        if want_side:                                         # (beyond what the class offers: whatever torch hands out)
+            spare = iter(free_front + [torch.cuda.Stream(device=dev) for _ in range(2 * len(self.fronts))])
+            for i in range(len(self.fronts)):
+                self.sides.append((next(spare), next(spare) if want_side > 1 else None))
+        others = [c for c in sorted(by) if c != front_class] or [front_class]
+        if pipes == "front4":                                 # measurement aid: model streams on ALL classes, the front end's too
+            others = sorted(by)
+        take = {c: 0 for c in by}
+        self.models = []
+        for m in range(n_model):
+            c = others[m % len(others)]
+            taken = [x for pair in self.sides for x in pair if x is not None]
+            pool = [s_ for s_ in by[c] if id(s_) not in used and all(s_ is not x for x in taken)]
+            self.models.append(pool[take[c] % len(pool)] if pool else torch.cuda.Stream(device=dev))
+            take[c] += 1
+        self.pipe_classes = {"candidates": ccls, "front": front_class, "model": [others[m % len(others)] for m in range(n_model)],
+                             "side_streams": want_side, "side_class": front_class if want_side else None}
 
     def set_up_nearest(self, on):
         """Switch the engine's internal upsample tables between the batch contract's [N, limit] form (off) and the
@@ -382,7 +445,7 @@ class PairStreams:
         self.synchronize()
 
     def synchronize(self):
-        for s in self.fronts + self.models:
+        for s in self.fronts + [x for pair in self.sides for x in pair if x is not None] + self.models:
             s.synchronize()
         self._check_status(wait=True)
 

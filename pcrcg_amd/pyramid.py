@@ -225,7 +225,8 @@ def _restore_reference_order(redo, level_points, level_lens, all_rows):
 
 class NativePyramid:
     """Front end of one pair through pcrcg_pyramid_build (csrc/pyramid.hip): ONE call into the library enqueues the
-    whole pyramid (the call waits for its four host round trips itself, with the GIL released).  One instance owns
+    whole pyramid (levels sized from the bound `shrink`; the call waits for its one host round trip itself, with the GIL
+    released).  One instance owns
     an arena, pinned scratch and a ring of status words; it serves one host thread / one stream at a time
     (pcrcg_amd/pairstream.py gives every worker its own).  tie_order "auto" or "index"; "reference" (every row
     through the KD-forest, a cross-check) and want_counts stay with the Python mirror pyramid_steps."""
@@ -256,6 +257,15 @@ class NativePyramid:
         self.scratch = torch.empty(512, dtype=_I32, pin_memory=True)
         self.status = torch.zeros(self.STATUS_RING, dtype=_I32, pin_memory=True)
         self.arena, self.shrink, self.calls = None, 0.5, 0
+        self.side = None        # set_side_stream(): a second stream for the KD-forests of the restore step
+
+    def set_side_streams(self, sub=None, forest=None):
+        """Further torch streams of the caller's for the parts of the chain that need nothing from the searches
+        (pcrcg_pyramid_cfg.side_stream / side_stream2): `sub` runs the three subsamplings back to back, `forest` the
+        KD-forests of the tie-order restore step (None: behind the subsamplings on `sub`).  Both None: one stream."""
+        self.side = (sub, forest)
+        self.cfg.side_stream = sub.cuda_stream if sub is not None else None
+        self.cfg.side_stream2 = forest.cuda_stream if forest is not None else None
 
     def restore(self, deferred, slot):
         """Enqueue a deferred tie-order restore step (build(..., defer_restore=True)) on the CURRENT stream."""
@@ -293,7 +303,8 @@ class NativePyramid:
         slot = self.calls % self.STATUS_RING
         self.calls += 1
         while True:
-            need = L.pcrcg_pyramid_ws_bytes(n0, nb, ct.byref(self.cfg), ct.c_double(self.shrink))
+            self.cfg.shrink = float(self.shrink)
+            need = L.pcrcg_pyramid_ws_bytes(n0, nb, ct.byref(self.cfg))
             if need == 0:
                 raise RuntimeError("pcrcg_pyramid_ws_bytes rejected the configuration")
             arena = self.arena

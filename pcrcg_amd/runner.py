@@ -66,21 +66,16 @@ class PyramidCfg(ctypes.Structure):
     _fields_ = [("n_levels", ctypes.c_int), ("r_conv", ctypes.c_float * MAX_LEVELS), ("r_pool", ctypes.c_float * MAX_LEVELS),
                 ("dl", ctypes.c_float * MAX_LEVELS), ("has_conv", ctypes.c_int * MAX_LEVELS),
                 ("pooled", ctypes.c_int * MAX_LEVELS), ("limit", ctypes.c_int * MAX_LEVELS), ("tie_order", ctypes.c_int),
-                ("group", ctypes.c_int), ("up_nearest", ctypes.c_int)]
+                ("group", ctypes.c_int), ("up_nearest", ctypes.c_int), ("shrink", ctypes.c_double), ("side_stream", _fp),
+                ("side_stream2", _fp)]
 
 
-class ReorderJobC(ctypes.Structure):
-    """pcrcg_reorder_job (include/pcrcg.h)."""
-    _fields_ = [("q", _fp), ("qlen", _fp), ("rows", _fp), ("count", _fp), ("idx", _fp), ("nq", ctypes.c_int),
-                ("nbq", ctypes.c_int), ("cloud0", ctypes.c_int), ("nrows", ctypes.c_int), ("max_count", ctypes.c_int),
-                ("cols", ctypes.c_int), ("radius", ctypes.c_float), ("group", ctypes.c_int)]
+from .ops import ReorderJob as ReorderJobC   # pcrcg_reorder_job (include/pcrcg.h): ONE mirror of the struct
 
 
 class PyramidRestore(ctypes.Structure):
     """pcrcg_pyramid_restore (include/pcrcg.h)."""
-    _fields_ = [("njobs", ctypes.c_int), ("jobs", ReorderJobC * 12), ("pts_all", _fp), ("lens_all", _fp),
-                ("rows_total", ctypes.c_int), ("clouds_total", ctypes.c_int), ("forest", _fp),
-                ("forest_bytes", ctypes.c_size_t), ("tie_status", _fp)]
+    _fields_ = [("njobs", ctypes.c_int), ("jobs", ReorderJobC * 12), ("tie_status", _fp)]
 
 
 class Outputs(ctypes.Structure):

@@ -22,7 +22,27 @@ for sid, ks in streams.items():
     busy = sum(e - s for _, s, e in ks)
     print(f"stream {sid}: {len(ks)} kernels, busy {busy / 1e6:.2f} ms = {100.0 * busy / (b - a):.1f}% of the window")
 sid, front = max(streams.items(), key=lambda kv: sum(1 for k in kv[1] if ("k_radius_query" in k[0] or "k_radius_cells" in k[0])))
-pairs = max(sum(1 for k in front if "k_order_emit" in k[0]) / 3.0, 1)      # kernel CHAINS (three subsampled levels each); a chain carries up to four pairs
+# kernel CHAINS (three subsampled levels each; round 6: the subsamplings may run on a side stream); a chain carries up to four pairs
+pairs = max(sum(1 for ks in streams.values() for k in ks if "k_order_emit" in k[0]) / 3.0, 1)
+# chain latency on the front-end stream: first kernel after the previous chain's k_reorder .. this chain's k_reorder end
+spans, first = [], None
+for n, s, e in front:
+    if first is None:
+        first = s
+    if "k_reorder" in n:
+        spans.append((e - first) / 1e6)
+        first = None
+if spans:
+    sp = sorted(spans)
+    print(f"chain latency (first kernel .. k_reorder end) over {len(sp)} chains: median {sp[len(sp) // 2]:.2f} ms, min {sp[0]:.2f}, max {sp[-1]:.2f}")
+for osid, ks in streams.items():      # side streams of the front end
+    if osid != sid and any(("k_order_emit" in k[0] or "k_kd_forest" in k[0]) for k in ks):
+        agg = {}
+        for n, s, e in ks:
+            d = agg.setdefault(n, [0, 0.0])
+            d[0] += 1
+            d[1] += e - s
+        print(f"side stream {osid}: per chain " + ", ".join(f"{n} {v[0] / pairs:.1f}x{v[1] / v[0] / 1e3:.0f}us" for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]))
 print(f"front-end stream {sid}: window {(b - a) / 1e6:.1f} ms, {pairs:.1f} front-end chains (up to four pairs each) -> {(b - a) / 1e6 / pairs:.3f} ms per chain; the columns below are per CHAIN")
 stat = {}
 prev_end = None
