@@ -53,5 +53,15 @@ def kitti_config(**over):
     return cfg
 
 
+def modelnet_config(**over):
+    """ModelNet40 configuration (ref:configs/test/modelnet.yaml:12-35): three levels, the `modelnet` block list with two
+    consecutive unary blocks in the decoder (ref:configs/models.py:42-57)."""
+    cfg = Config(_COMMON, dataset="modelnet", num_layers=3, first_feats_dim=512, final_feats_dim=96, first_subsampling_dl=0.06,
+                 conv_radius=2.75, gnn_feats_dim=256, overlap_radius=0.04)
+    cfg.update(over)
+    cfg["architecture"] = list(architectures[cfg["dataset"]])
+    return cfg
+
+
 def as_config(cfg):
     return cfg if isinstance(cfg, Config) else Config(cfg)

@@ -1,10 +1,9 @@
 """Pair engine: independent fragment pairs through two stages of host threads, each stage a call into
 libpcrcg_hip.so that releases the GIL.
 
-  front stage   F threads share ONE front-end HIP stream.  A thread builds the pyramid of its pair with
-                pcrcg_pyramid_build (the whole front end in one call; the call waits for its four host round trips
-                itself, by event, so it only waits for its OWN kernels): the kernels of F pairs interleave on the
-                stream and keep it busy while one pair waits for a row count.  One stream on purpose: the front-end
+  front stage   F threads share ONE front-end HIP stream (+ its side streams).  A thread builds the pyramid of its pairs with
+                pcrcg_pyramid_build (the whole front end in one call; levels are sized from a row bound, the call waits
+                ONCE, at the end of the chain, for the row and column counts).  One stream on purpose: the front-end
                 kernels are latency-bound and partly persistent (the KD-forest's task queue); several pyramids side
                 by side, or pyramids on the model streams, slow everything down (measured: every pair on its own
                 stream, 4 streams: 217 pairs/s; this topology: see DESIGN.md).
@@ -20,11 +19,16 @@ worker spent 1.7 ms of interpreter time per pair.
     eng = PairStreams(net, config, limits, device)
     eng.submit(points, lengths); ...; out = eng.result()      # results come back in submission order
 
-The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): set GPU_MAX_HW_QUEUES=8
-before the first HIP call (bench.py does).  ONE engine per process and device: the GPU schedules four queues at a time,
-which this engine's four streams use up; a second engine -- even the closed, not yet collected one of an earlier
-measurement -- puts more streams on the same queues and both slow down (measured: a fresh engine 453 pairs/s, the third
-one created in the same process 355).  Reuse the engine (set_up_nearest() exists for that reason)."""
+Streams and hardware (round 6): gfx950's command processor has FOUR compute dispatchers; a stream's hardware queue belongs
+to one, and a dispatcher hands out the workgroups of one kernel at a time, so two busy streams on one dispatcher take turns
+kernel by kernel (profiles/r06_queue_pipes.txt).  The engine therefore CHOOSES its streams: it classifies a dozen
+candidates by measurement (pcrcg_stream_pipe_classes, ~50 ms at construction) and takes the front-end streams from one
+class and the three model streams from the other three (_pick_streams; `pipe_classes` records the choice, a
+RuntimeWarning says when it could not be made).  That holds with the runtime's default of four hardware queues and with
+GPU_MAX_HW_QUEUES=8 alike; rounds 1-5 took streams in creation order and needed the variable set before the first HIP
+call.  ONE engine per process and device: a second engine -- even the closed, not yet collected one of an earlier
+measurement -- puts more busy streams on the same four dispatchers and both slow down.  Reuse the engine
+(set_up_nearest() exists for that reason)."""
 import os
 import queue
 import threading
@@ -190,8 +194,22 @@ class PairStreams:
             pool = [s_ for s_ in by[c] if id(s_) not in used and all(s_ is not x for x in taken)]
             self.models.append(pool[take[c] % len(pool)] if pool else torch.cuda.Stream(device=dev))
             take[c] += 1
-        self.pipe_classes = {"candidates": ccls, "front": front_class, "model": [others[m % len(others)] for m in range(n_model)],
-                             "side_streams": want_side, "side_class": front_class if want_side else None}
+        mcls = [others[m % len(others)] for m in range(n_model)]
+        # the engine's premise, verified: the front end and every model stream on a dispatcher of its own (with up to three
+        # model streams).  It holds with the runtime's default of four hardware queues as well as with GPU_MAX_HW_QUEUES=8
+        # (tests/test_pairstream_gpu.py runs both in fresh processes) -- the streams are CHOSEN by class, not taken in creation
+        # order, which is what made rounds 1-5 depend on that variable (448 against 536 pairs/s).  If the probe finds fewer
+        # classes than the engine needs streams, two of them will take turns: say so instead of running slowly in silence.
+        distinct = len(set(mcls)) == min(n_model, 3) and front_class not in mcls
+        if not distinct:
+            import warnings
+            warnings.warn("pcrcg_amd.PairStreams: the probe found dispatcher classes %s among its candidate streams; the front-end "
+                          "stream (class %d) and the model streams (classes %s) share a hardware dispatcher and will take turns "
+                          "kernel by kernel (pcrcg_stream_pipe_classes, profiles/r06_queue_pipes.txt)"
+                          % (sorted(by), front_class, mcls), RuntimeWarning)
+        self.pipe_classes = {"candidates": ccls, "front": front_class, "model": mcls, "distinct": bool(distinct),
+                             "side_streams": want_side, "side_class": front_class if want_side else None,
+                             "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "(unset: the runtime's default, 4)")}
 
     def set_up_nearest(self, on):
         """Switch the engine's internal upsample tables between the batch contract's [N, limit] form (off) and the

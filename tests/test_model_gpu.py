@@ -612,3 +612,38 @@ def test_tie_rich_pair_against_reference(cuda, golden_dir):
     # limits of this pair by the reference's calibration formula, reproduced on the device
     from pcrcg_amd.pyramid import calibrate_neighbors
     assert list(calibrate_neighbors([(pts, lens)], cfg, samples_threshold=0)) == ties["limits"]
+
+
+def test_modelnet_block_list_against_the_reference(cuda, golden_dir):
+    """ref:configs/models.py:42-57 (`modelnet`): three levels, two consecutive unary blocks in the decoder.  The reference's
+    own collate dict and state_dict (tests/golden/modelnet_mini.pt) through the C++ runner and the op-by-op mirror against
+    the reference model's outputs; and this path's pyramid of the raw clouds equals the reference's tables entry for entry."""
+    from pcrcg_amd import modelnet_config
+    mm = torch.load(os.path.join(golden_dir, "modelnet_mini.pt"))
+    cfg = modelnet_config(first_feats_dim=32, gnn_feats_dim=64, final_feats_dim=32)
+    net = KPFCNN(cfg)
+    net.load_state_dict(mm["state_dict"], strict=True)
+    net = net.to(cuda).eval()
+    dbatch = _to(mm["batch"], cuda)
+    with torch.no_grad():
+        out_ops = net.forward_ops(dbatch)
+        out = net(dbatch)
+    assert net.use_runner
+    for k in ("feats_f", "scores_overlap", "scores_saliency"):
+        assert out[k].shape == mm["outputs"][k].shape
+        assert rel(out[k], mm["outputs"][k]) < TOL, k
+        assert rel(out_ops[k], mm["outputs"][k]) < TOL, k
+        assert rel(out[k], out_ops[k]) < 1e-5, k
+    pts = torch.cat([mm["src"], mm["tgt"]]).to(cuda)
+    lens = torch.tensor([mm["src"].shape[0], mm["tgt"].shape[0]], dtype=torch.int32, device=cuda)
+    mine = build_pyramid(pts, lens, cfg, mm["limits"])
+    assert len(mine["points"]) == 3
+    for l in range(3):
+        assert torch.equal(mine["points"][l].cpu().view(torch.int32), mm["batch"]["points"][l].view(torch.int32)), l
+        for key in ("neighbors", "pools", "upsamples"):
+            assert mine[key][l].shape == mm["batch"][key][l].shape, (key, l)
+            assert torch.equal(mine[key][l].cpu(), mm["batch"][key][l]), (key, l)
+    with torch.no_grad():
+        out2 = net(mine)
+    for k in ("feats_f", "scores_overlap", "scores_saliency"):
+        assert rel(out2[k], mm["outputs"][k]) < TOL, k

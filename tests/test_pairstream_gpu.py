@@ -260,3 +260,80 @@ def test_one_column_upsample_tables_are_column_zero(cuda, recipe):
         if l + 1 < cfg.num_layers:
             assert got["upsamples"][l].shape == (full["upsamples"][l].shape[0], 1)
             assert torch.equal(got["upsamples"][l][:, 0], full["upsamples"][l][:, 0]), l
+
+
+def test_side_streams_leave_the_tables_unchanged(cuda):
+    """pcrcg_pyramid_cfg.side_stream / side_stream2 (round 6: the subsamplings and the KD-forests beside the searches): the
+    same tables, entry for entry, as the one-stream build -- for a single pair and for a grouped build of three pairs."""
+    cfg = indoor_config()
+    limits = synthetic.LIMITS["C1"]
+    sub, forest = torch.cuda.Stream(device=cuda), torch.cuda.Stream(device=cuda)
+    for recipes in (("C1",), ("T8k", "C1", "mini")):
+        parts = [_pair(r, i, cuda) for i, r in enumerate(recipes)]
+        pts, lens = torch.cat([p for p, _ in parts]), torch.cat([l for _, l in parts])
+        group = 2 if len(parts) > 1 else 0
+        outs = []
+        for side in (None, (sub, None), (sub, forest)):
+            nat = NativePyramid(cfg, limits, "auto")
+            if side is not None:
+                nat.set_side_streams(*side)
+            b, arena, lens_h, slot = nat.build(pts, lens, group=group)
+            torch.cuda.synchronize()
+            assert int(nat.status[slot]) == 0
+            bs = list(b) if group else [b]
+            outs.append([nat.as_dict(bb, arena, lens_h, part=(2 * i, 2) if group else None) for i, bb in enumerate(bs)])
+        for other in outs[1:]:
+            for got, want in zip(other, outs[0]):
+                assert got["stack_lengths_host"] == want["stack_lengths_host"]
+                for l in range(cfg.num_layers):
+                    assert torch.equal(got["points"][l].view(torch.int32), want["points"][l].view(torch.int32))
+                    for key in ("neighbors", "pools", "upsamples"):
+                        assert torch.equal(got[key][l], want[key][l]), (recipes, key, l)
+
+
+_ENGINE_PROBE = r"""
+import json, sys, warnings
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from pcrcg_amd import indoor_config, synthetic
+from pcrcg_amd.architectures import KPFCNN
+from pcrcg_amd.pairstream import PairStreams
+dev = torch.device("cuda:0")
+cfg = indoor_config(first_feats_dim=32, gnn_feats_dim=64)
+torch.manual_seed(0); np.random.seed(0)
+net = KPFCNN(cfg).to(dev).eval()
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    eng = PairStreams(net, cfg, [20, 26, 30, 32], dev)
+src, tgt = synthetic.pair("mini", 0)
+pts = torch.from_numpy(np.concatenate([src, tgt])).to(dev)
+lens = torch.tensor([len(src), len(tgt)], dtype=torch.int32, device=dev)
+for _ in range(6):
+    eng.submit(pts, lens)
+outs = [eng.result() for _ in range(6)]
+eng.drain(); eng.close()
+print(json.dumps({"classes": eng.pipe_classes, "warnings": [str(x.message)[:80] for x in w],
+                  "finite": bool(all(torch.isfinite(o["feats_f"]).all() for o in outs))}))
+"""
+
+
+@pytest.mark.parametrize("queues", [None, "8"])
+def test_engine_streams_sit_on_distinct_dispatchers(cuda, queues):
+    """The engine picks its streams by hardware dispatcher class (pcrcg_stream_pipe_classes), so its premise -- the front end
+    and each of the three model streams on a dispatcher of its own -- holds in a process with the runtime's default of four
+    hardware queues and in one with GPU_MAX_HW_QUEUES=8 alike (rounds 1-5 needed the variable set before the first HIP
+    call and lost 16 % silently without it).  Fresh processes: the variable is read once, when HIP starts."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    if queues:
+        env["GPU_MAX_HW_QUEUES"] = queues
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _ENGINE_PROBE, repo], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    c = rec["classes"]
+    assert rec["finite"] and c["distinct"] and not rec["warnings"], rec
+    assert len(set([c["front"]] + c["model"])) == 4, c
+    assert c["side_class"] == c["front"]
