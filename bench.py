@@ -358,6 +358,103 @@ def secondary_k120k(dev, steps, warmup, workers, ppf, ppb):
             "radius_search_in_engine": radius_roofline(ev, steps)}
 
 
+def secondary_image129(dev, steps, warmup, workers, ppf, ppb, isolated=6):
+    """PCR-CG's SHIPPED configuration (ref:configs/test/indoor.yaml:21-34: image_feature True, img_num 2, in_feats_dim 129;
+    injection ref:models/architectures.py:195-514) through the same engine: S30k pairs with synthetic 2-D inputs
+    (pcrcg_amd.synthetic.image_inputs: two 128 x 120 x 160 feature maps per cloud, 45 % of the points projected per image,
+    valid masks; the ResUNet that produces the maps on real data is the caller's and outside the clock -- the maps are
+    resident in HBM like the ResUNet's outputs would be).  Inside the clock: points uploaded from pinned host memory,
+    pyramid build, injection of the [N, 129] input, KPFCNN+GCN forward.  Reported with it: the FIRST KPConv's gather kernel
+    (60 000 queries x 43 neighbours x 129 channels, rows of 132 floats) against the HBM roofline, alone and in the engine
+    -- the dominant kernel of this configuration (1.38 GB by the SURVEY.md 8d formula against 2.37 GB for the whole
+    geometry-only pair)."""
+    cfg = indoor_config(image_feature=True, img_num=2, in_feats_dim=129)
+    limits = synthetic.LIMITS["S30k"]
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = KPFCNN(cfg).eval().to(dev)
+    cout_of = {blk.KPConv.in_channels: blk.KPConv.out_channels for blk in net.encoder_blocks}
+
+    def real_width(ev):      # the first layer's launches report the row width (132 floats); the algorithmic bytes count 129 channels
+        return [(e[0], e[1], e[2], 129 if e[3] == 132 else e[3], e[4], e[5]) for e in ev]
+    pool = []
+    for s_ in range(4):
+        a, b = synthetic.pair("S30k", s_)
+        im = synthetic.image_inputs(len(a), len(b), s_, img_num=2)
+        batch_like = {k: torch.from_numpy(v).to(dev) for k, v in im.items()}
+        batch_like["points"] = [torch.empty(len(a) + len(b), 3, device=dev)]
+        batch_like["src_pcd_raw"] = torch.empty(len(a), 3)
+        _, _, images = net.image_list(batch_like)
+        pool.append((torch.from_numpy(np.concatenate([a, b])).pin_memory(), torch.tensor([len(a), len(b)], dtype=torch.int32).pin_memory(),
+                     images))
+
+    def first_layer(ev):
+        rows = [e for e in ev if e[5] == 0 and e[3] == 132]
+        if not rows:
+            return None
+        ms = sum(e[0] for e in rows) / len(rows)
+        by = kpconv_algorithmic_bytes(rows[0][1], rows[0][2], 129, cout_of[129], 4)
+        return {"nq": rows[0][1], "h": rows[0][2], "cin": 129, "row_floats": 132, "cout": cout_of[129], "launches": len(rows),
+                "avg_launch_us": round(1e3 * ms, 1), "algorithmic_MB": round(by / 1e6, 1), "achieved_GBs": round(by / (ms * 1e-3) / 1e9, 1),
+                "frac_of_hbm_peak": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # the forward alone on one stream: what the first layer's gather does with the GPU to itself
+    from pcrcg_amd.pyramid import build_pyramid
+    hp, hl, images = pool[0]
+    b0 = build_pyramid(hp.to(dev), hl.to(dev), cfg, limits)
+    b0["features"] = ops.inject_image_features(int(hp.shape[0]), int(hl[0]), images, channels=128, width=net.IMAGE_WIDTH)
+    runner = net.runner()
+    with torch.no_grad():
+        for _ in range(2):
+            runner.forward(b0)
+        torch.cuda.synchronize()
+        ops.kpconv_profile_start()
+        t0 = time.perf_counter()
+        for _ in range(isolated):
+            runner.forward(b0)
+        torch.cuda.synchronize()
+        iso_ms = 1e3 * (time.perf_counter() - t0) / isolated
+    ev_iso = ops.kpconv_profile_stop()
+    g_iso, _ = kpconv_roofline(real_width(ev_iso), cout_of)
+    del b0
+    pipe = PairStreams(net, cfg, limits, dev, model_streams=workers, front_threads=1, up_nearest=False,
+                       pairs_per_forward=ppf, pairs_per_build=ppb)
+
+    def run(count):
+        sub = 0
+        for i in range(count):
+            while sub < min(count, i + 6 * ppb):
+                hp, hl, images = pool[sub % len(pool)]
+                pipe.submit(hp.to(dev, non_blocking=True), hl.to(dev, non_blocking=True), images=images)
+                sub += 1
+            pipe.result(wait=False)
+
+    run(3 * workers * ppf)
+    pipe.drain()
+    run(warmup)
+    pipe.drain()
+    torch.cuda.synchronize()
+    ops.kpconv_profile_start()
+    t0 = time.perf_counter()
+    run(steps)
+    pipe.drain()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ev = ops.kpconv_profile_stop()
+    pipe.close()
+    g, _ = kpconv_roofline(real_width(ev), cout_of)
+    gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0
+    return {"workload": "S30k-img129 (secondary; PCR-CG's shipped configuration): S30k pairs + synthetic 2-D inputs (2 images per cloud, "
+                        "128 x 120 x 160 maps resident in HBM, 45 % of the points projected per image), image_feature=True, img_num=2, "
+                        "in_feats_dim=129; pyramid build + feature injection + KPFCNN+GCN forward",
+            "steps": steps, "value": round(steps / dt, 2), "unit": "fragment-pairs/s", "ms_per_step": round(1e3 * dt / steps, 3),
+            "forward_alone_ms": round(iso_ms, 3),
+            "first_kpconv_gather": {"alone": first_layer(ev_iso), "in_engine": first_layer(ev)},
+            "kpconv_gathers_all_layers": {"alone_GBs": round(g_iso["bytes"] / (g_iso["ms"] * 1e-3) / 1e9, 1) if g_iso["ms"] > 0 else None,
+                                          "in_engine_GBs": round(gbs, 1), "in_engine_frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                                          "algorithmic_bytes_per_pair": int(g["bytes"] / max(steps, 1))}}
+
+
 def dry_run_main(args, rank, world):
     """--launcher-dry-run: the N-rank protocol of this file -- process group from the launcher's environment, fences,
     EXACTLY --steps steps per region, MAX over ranks, rank 0's single line with `ranks_seen` and per-rank values --
@@ -504,6 +601,8 @@ def main():
     ap.add_argument("--variant", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: the bf16 feature-storage VARIANT (pcrcg_model.feature_bf16) -- a separate line with its "
                          "measured error against the fp32 path; never the headline")
+    ap.add_argument("--image129-only", action="store_true",
+                    help="run only the S30k-img129 secondary leg (PCR-CG's shipped 129-channel configuration) and print its record")
     ap.add_argument("--launcher-dry-run", action="store_true",
                     help="the N-rank protocol (launcher, process group, fences, MAX over ranks, rank 0's line) over gloo "
                          "on the CPU with a stand-in workload: what tests/test_launcher_cpu.py runs; never a measurement")
@@ -588,6 +687,10 @@ def main():
     assert all(cout_of[blk.KPConv.in_channels] == blk.KPConv.out_channels for blk in net.encoder_blocks)
     per_pair = len(net.encoder_blocks)
 
+    if args.image129_only:
+        print(json.dumps(secondary_image129(dev, args.steps, args.warmup, args.model_streams, args.pairs_per_forward,
+                                            args.pairs_per_build)), flush=True)
+        return
     if args.isolated_only:
         from pcrcg_amd.pyramid import build_pyramid
         batch_iso = build_pyramid(*pool[seeds[0] % 16], cfg, limits)
@@ -740,6 +843,11 @@ def main():
             extras["K120k"] = secondary_k120k(dev, 96, 6, WORKERS, 3, 3)
         except Exception as e:       # secondary figures never fail the headline
             extras["K120k"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            extras["S30k_img129"] = secondary_image129(dev, 96, 8, WORKERS, 4, 4)
+        except Exception as e:
+            extras["S30k_img129"] = {"error": repr(e)}
         torch.cuda.empty_cache()
         try:
             extras["train_step"] = secondary_train_step(dev, 12)

@@ -109,10 +109,10 @@ class KPFCNN(nn.Module):
     def _conv1x1(layer, x):
         return ops.gemm(x, layer.weight.data.squeeze(-1).t(), bias=layer.bias.data)
 
-    def image_features(self, batch, backbone2d=None):
-        """ref:models/architectures.py:195-514: x = ones [N, 129] with the 2-D features of the projected points
-        scattered in (pcrcg_inject_image_features).  The 2-D feature maps come from `backbone2d` applied to
-        batch['{src,tgt}_color{i}'] as in the reference, or -- precomputed -- from batch['{src,tgt}{i}_feature2d']."""
+    IMAGE_WIDTH = 132      # the 129-channel input as the runners take it: rows of whole float4s, three zero columns
+
+    def image_list(self, batch, backbone2d=None):
+        """The projections of a batch as ops.inject_image_features takes them, in the reference's write order."""
         n = int(batch["points"][0].shape[0])
         len_src = int(batch["src_pcd_raw"].shape[0])
         dev = batch["points"][0].device
@@ -131,13 +131,25 @@ class KPFCNN(nn.Module):
                 images.append(dict(fmap=fmap.detach().to(dev, torch.float32), inds2d=batch[f"{side}{i}_inds2d"].to(dev),
                                    inds3d=batch[f"{side}{i}_inds3d"].to(dev), target=side == "tgt",
                                    valid=None if valid is None else valid.to(dev)))
-        return ops.inject_image_features(n, len_src, images, channels=128)
+        return n, len_src, images
+
+    def image_features(self, batch, backbone2d=None, width=None):
+        """ref:models/architectures.py:195-514: x = ones [N, 129] with the 2-D features of the projected points
+        scattered in (pcrcg_inject_image_features).  The 2-D feature maps come from `backbone2d` applied to
+        batch['{src,tgt}_color{i}'] as in the reference, or -- precomputed -- from batch['{src,tgt}{i}_feature2d'].
+        width=IMAGE_WIDTH: rows padded with zero columns (what the C++ runners take)."""
+        n, len_src, images = self.image_list(batch, backbone2d)
+        return ops.inject_image_features(n, len_src, images, channels=128, width=width)
 
     def forward(self, batch, backbone2d=None):
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if self.image_feature:
+            # the C++ runners (inference and train step) take the 129 channels in rows of 132 floats -- the first KPConv's
+            # gather kernel reads whole float4s -- against weights padded with zero rows; the op-by-op paths take [N, 129]
+            wide = self.use_runner
             batch = dict(batch)
-            batch["features"] = self.image_features(batch, backbone2d)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            batch["features"] = self.image_features(batch, backbone2d, width=self.IMAGE_WIDTH if wide else None)
+        if training:
             # training: forward with a tape + backward in C++ (pcrcg_amd/train_runner.py, one autograd node whose backward
             # accumulates every parameter's gradient into p.grad); configurations it does not cover take the op-by-op
             # autograd composition of the same kernels (pcrcg_amd/train_forward.py)
@@ -164,8 +176,9 @@ class KPFCNN(nn.Module):
     def train_runner(self):
         """The (lazily created) C++ train-step runner (pcrcg_amd/train_runner.py): forward with a tape + backward, one
         library call each.  None when this configuration needs the op-by-op autograd path (pcrcg_amd/train_forward.py):
-        no InstanceNorm (use_batch_norm False) or the 129-channel image-feature input."""
-        if not self.use_runner or self.image_feature:
+        no InstanceNorm (use_batch_norm False).  (Round 6: PCR-CG's shipped configuration -- the 129-channel
+        image-feature input -- goes through it too, its first KPConv against zero-padded weights.)"""
+        if not self.use_runner:
             return None
         if getattr(self, "_train_runner", None) is None:
             with _RUNNER_LOCK:

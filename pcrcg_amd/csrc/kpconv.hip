@@ -104,7 +104,12 @@ __device__ __forceinline__ float4 load4(const unsigned short* p) {
                        __uint_as_float(u.y & 0xffff0000u));
 }
 
-template <int NB, bool NT_STORE, typename FT>  // 64-channel blocks handled per wavefront (one float4 per lane and block)
+// TAIL (round 6, PCR-CG's 129-channel input in rows of 132 floats): cin = 64 NB + 4 with ONE wavefront per query -- the last
+// float4 of a row does not get a 64-channel block of its own (a third wavefront per query that repeats the index loads,
+// the shuffles and the 15 square roots for four channels: what the plain plan gave this width) but rides along on the vector
+// units: every lane multiplies its influence weight with its neighbour's last float4 (the 16 lanes of a neighbour read one
+// address), the four neighbour groups meet by two shuffles at the end.
+template <int NB, bool NT_STORE, typename FT, bool TAIL = false>  // 64-channel blocks handled per wavefront (one float4 per lane and block)
 __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
     const float* __restrict__ q_pts, int nq, const float* __restrict__ s_pts, int ns,
     const long long* __restrict__ idx, int H, int ld_idx, const FT* __restrict__ x, int cin,
@@ -136,6 +141,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[b][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int npos = 0;
+        float ta0 = 0.f, ta1 = 0.f, ta2 = 0.f, ta3 = 0.f;             // TAIL: this lane's (kernel point j, neighbour group hsub) share
         for (int hc = 0; hc < H; hc += 64) {
             // lanes = neighbours: index + centred coordinates, once per 64 neighbours
             const int h = hc + lane;
@@ -151,6 +157,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
             for (int h0 = 0; h0 < hn; h0 += 4 * STEPS) {
                 float w[STEPS];
                 float4 v[STEPS][NB];
+                float4 vt[STEPS];
 #pragma unroll
                 for (int s = 0; s < STEPS; ++s) {
                     const int src = h0 + 4 * s + hsub;            // <= 63
@@ -172,6 +179,10 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
                         const bool ok = real && c < cin;
                         v[s][b] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
                     }
+                    if constexpr (TAIL) {
+                        const float4 t = load4(xrow + 64 * NB);
+                        vt[s] = make_float4(real ? t.x : 0.f, real ? t.y : 0.f, real ? t.z : 0.f, real ? t.w : 0.f);
+                    }
                 }
 #pragma unroll
                 for (int s = 0; s < STEPS; ++s)
@@ -182,6 +193,15 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
                         acc[b][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], v[s][b].z, acc[b][2], 0, 0, 0);
                         acc[b][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], v[s][b].w, acc[b][3], 0, 0, 0);
                     }
+                if constexpr (TAIL) {
+#pragma unroll
+                    for (int s = 0; s < STEPS; ++s) {
+                        ta0 += w[s] * vt[s].x;
+                        ta1 += w[s] * vt[s].y;
+                        ta2 += w[s] * vt[s].z;
+                        ta3 += w[s] * vt[s].w;
+                    }
+                }
             }
         }
         // D layout: register r of lane (hsub, j) = kernel point 4*hsub + r, channel group j
@@ -208,6 +228,17 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
                         else *reinterpret_cast<v4f*>(o + (long)k * cin + c) = val;
                     }
                 }
+            }
+        }
+        if constexpr (TAIL) {
+            ta0 += __shfl_xor(ta0, 16, 64); ta1 += __shfl_xor(ta1, 16, 64); ta2 += __shfl_xor(ta2, 16, 64); ta3 += __shfl_xor(ta3, 16, 64);
+            ta0 += __shfl_xor(ta0, 32, 64); ta1 += __shfl_xor(ta1, 32, 64); ta2 += __shfl_xor(ta2, 32, 64); ta3 += __shfl_xor(ta3, 32, 64);
+            if (hsub == 0 && jvalid) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f val = {ta0, ta1, ta2, ta3};
+                v4f* dst = reinterpret_cast<v4f*>(reinterpret_cast<float*>(wf) + (long)q * K * cin + (long)j * cin + 64 * NB);
+                if (NT_STORE) __builtin_nontemporal_store(val, dst);
+                else *dst = val;
             }
         }
         if (chunk == 0 && lane == 0) inv_n[q] = 1.0f / (float)(npos > 1 ? npos : 1);
@@ -453,6 +484,19 @@ int kpconv_aggregate_rows(const float* q_pts, int nq, const float* s_pts, int ns
     if (!aligned) {
         hipLaunchKernelGGL(k_kpconv_generic, dim3(blocks_for(nq)), dim3(kWavesPerBlock * 64), 0, st, q_pts, nq, s_pts,
                            ns, idx_ll, h, ld_idx, x, cin, kp, extent, pos, wf, inv_n);
+        PCRCG_CHECK_LAUNCH();
+        return PCRCG_OK;
+    }
+    // cin = 64 nb + 4 (PCR-CG's 129 channels in rows of 132): one wavefront per query, the last float4 on the vector units
+    if (cin == 68 || cin == 132) {
+        const int blocks = blocks_for((long)nq);
+#define LAUNCH_T(NBV, NT)                                                                                                        \
+        hipExtLaunchKernelGGL((k_kpconv_mfma<NBV, NT, float, true>), dim3(blocks), dim3(kWavesPerBlock * 64), 0, st, prof_scope.a, \
+                              prof_scope.b, 0, q_pts, nq, s_pts, ns, idx_ll, h, ld_idx, x, cin, kp, extent,                      \
+                              (const float4*)pk, wf, inv_n, 1)
+        if (cin == 132) { if (stream_out) LAUNCH_T(2, true); else LAUNCH_T(2, false); }
+        else { if (stream_out) LAUNCH_T(1, true); else LAUNCH_T(1, false); }
+#undef LAUNCH_T
         PCRCG_CHECK_LAUNCH();
         return PCRCG_OK;
     }

@@ -404,15 +404,21 @@ def kpconv(q_pts, s_pts, idx, x, kernel_points, weights, extent):
     return gemm(wf, w2, row_scale=inv_n)
 
 
-def inject_image_features(n_points, len_src, images, channels=128):
+def inject_image_features(n_points, len_src, images, channels=128, width=None):
     """PCR-CG's image-feature injection (ref:models/architectures.py:195-514): -> x [n_points, channels + 1] f32 = ones
     with the 2-D features of the projected points written in.  `images`: list, IN THE REFERENCE'S WRITE ORDER (the last
     entry wins where projections overlap), of dicts with fmap [C,H,W] f32, inds2d [n,2] i64 (column, row), inds3d [n]
-    i64, target (bool: indices are relative to the target cloud) and optionally valid [W,H] f32."""
+    i64, target (bool: indices are relative to the target cloud) and optionally valid [W,H] f32.
+    width > channels + 1: the rows are that wide, the extra columns zero -- the form the network runners take the
+    129-channel input in (132: the first KPConv's gather kernel wants rows of whole float4s; zero columns against
+    zero-padded weights change nothing)."""
     L = _lib.lib()
     dev = images[0]["fmap"].device
-    x = torch.empty((n_points, channels + 1), dtype=_F32, device=dev)
-    _lib.check(L.pcrcg_fill2d(x.data_ptr(), channels + 1, n_points, channels + 1, 1.0, _stream()), "pcrcg_fill2d")
+    width = channels + 1 if width is None else int(width)
+    if width < channels + 1:
+        raise RuntimeError("pcrcg_amd.inject_image_features: width must be at least channels + 1")
+    x = (torch.zeros if width > channels + 1 else torch.empty)((n_points, width), dtype=_F32, device=dev)
+    _lib.check(L.pcrcg_fill2d(x.data_ptr(), width, n_points, channels + 1, 1.0, _stream()), "pcrcg_fill2d")
     for im in images:
         fmap = _dev(im["fmap"], _F32, "fmap").contiguous()
         if fmap.dim() != 3 or fmap.shape[0] != channels:
@@ -427,7 +433,7 @@ def inject_image_features(n_points, len_src, images, channels=128):
         _lib.check(L.pcrcg_inject_image_features(fmap.data_ptr(), channels, fmap.shape[1], fmap.shape[2], _ptr(valid),
                                                  i2.data_ptr(), i3.data_ptr(), i3.shape[0],
                                                  int(len_src) if im.get("target") else 0, n_points, x.data_ptr(),
-                                                 channels + 1, _stream()), "pcrcg_inject_image_features")
+                                                 width, _stream()), "pcrcg_inject_image_features")
     return x
 
 

@@ -291,7 +291,7 @@ class PairStreams:
             posted = 0                                            # jobs of this build already handed to a model thread
             try:
                 with torch.cuda.stream(front), torch.no_grad():
-                    for _, points, lengths, ready in items:
+                    for _, points, lengths, ready, _images in items:
                         front.wait_event(ready)                   # inputs may still be in flight on the caller's stream
                         points.record_stream(front)
                         lengths.record_stream(front)
@@ -321,8 +321,9 @@ class PairStreams:
                 start = 0
                 for j, n in enumerate(sizes):
                     seqs = [it[0] for it in items[start:start + n]]
+                    imgs = [it[4] for it in items[start:start + n]]
                     self._mid[(job0 + j) % len(self.models)].put(job0 + j, (seqs, (batches, start, n), arena, built, pyr, slot,
-                                                                             deferred, f, a))
+                                                                             deferred, f, a, (lens_h, imgs)))
                     start += n
                     posted = j + 1
             except BaseException as e:                            # surfaced by result()
@@ -363,7 +364,7 @@ class PairStreams:
                 for q in seqs:
                     self._results.put(q, item[1])
                 continue
-            _, b, arena, built, pyr, slot, deferred, f, a = item
+            _, b, arena, built, pyr, slot, deferred, f, a, (lens_h, imgs) = item
             try:
                 with torch.cuda.stream(stream), torch.no_grad():
                     stream.wait_event(built)
@@ -373,6 +374,7 @@ class PairStreams:
                     if deferred is not None:
                         pyr.restore(deferred, slot)
                     batches, start, n = b
+                    feats = self._image_inputs(batches, start, n, lens_h, imgs)
                     if n >= 2:
                         outs = self.runner.launch_group(batches, n, self.device, start)     # these pairs in ONE call
                     else:
@@ -386,7 +388,7 @@ class PairStreams:
                     out["_tie_status"] = (pyr.status, slot)
                     with self._lock:
                         self._pending.append((pyr.status, slot, done))
-                    out["_keep"] = (b, arena)
+                    out["_keep"] = (b, arena, feats)
                     self._results.put(q, (out, done))
             except BaseException as e:
                 for q in seqs:
@@ -397,13 +399,39 @@ class PairStreams:
                     self._queued[m] -= 1
 
     # ---- caller --------------------------------------------------------------------------------
-    def submit(self, points, lengths):
-        """Queue one pair (points [N,3] f32, lengths [2] i32 on the device) for pyramid build + forward."""
+    def _image_inputs(self, batches, start, n, lens_h, imgs):
+        """PCR-CG's shipped configuration (image_feature: ref:configs/test/indoor.yaml:21-34, ref:models/architectures.py:
+        195-514): the [N, 129] input of every pair of a forward job, injected on the job's model stream from the pair's
+        2-D feature maps and projections (pcrcg_inject_image_features) in rows of KPFCNN.IMAGE_WIDTH floats, and handed to
+        the runner in place of the pyramid's all-ones [N, 1] features.  -> the tensors (kept alive with the outputs)."""
+        if not getattr(self.net, "image_feature", False):
+            if any(im is not None for im in imgs):
+                raise RuntimeError("PairStreams.submit(images=...): the network was built without image_feature")
+            return None
+        from . import ops
+        keep = []
+        for g in range(n):
+            im = imgs[g]
+            if im is None:
+                raise RuntimeError("PairStreams.submit(): this network takes image features -- pass images=[...] with every pair")
+            bt = batches[start + g]
+            first = 2 * (start + g) if len(lens_h[0]) > 2 else 0       # the pair's first cloud in a grouped build
+            x = ops.inject_image_features(int(bt.n_points[0]), int(lens_h[0][first]), im, channels=128, width=self.net.IMAGE_WIDTH)
+            bt.features, bt.feat_dim = x.data_ptr(), int(x.shape[1])
+            keep.append(x)
+        return keep
+
+    def submit(self, points, lengths, images=None):
+        """Queue one pair (points [N,3] f32, lengths [2] i32 on the device) for pyramid build + forward.
+        images: for a network with image_feature (PCR-CG's shipped configuration) the pair's projections as
+        ops.inject_image_features takes them -- a list, in the reference's write order (KPFCNN.image_list builds it from a
+        reference batch dict), of dicts with fmap [128,H,W] f32, inds2d [n,2] i64, inds3d [n] i64, target (bool) and
+        optionally valid [W,H] f32, all on the device.  The 2-D backbone that produces the maps is the caller's."""
         seq = self._submitted
         self._submitted += 1
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))
-        self._in.put((seq, points, lengths, ready))
+        self._in.put((seq, points, lengths, ready, images))
 
     def result(self, wait=True):
         """Outputs of the oldest submitted pair, plus out["done_event"] (a torch.cuda.Event recorded behind their last

@@ -97,3 +97,24 @@ def lomatch_pair(recipe="S30k", seed=0, overlap=0.2):
     tgt_src = np.concatenate([src[keep], fresh], 0).astype(np.float64)
     tgt = (rot @ tgt_src.T + trans).T.astype(np.float32)
     return src, tgt, rot.astype(np.float32), trans.astype(np.float32)
+
+
+def image_inputs(n_src, n_tgt, seed=0, img_num=2, h=120, w=160, frac=0.45, channels=128):
+    """Synthetic stand-ins for what PCR-CG's 2-D branch hands to KPFCNN.forward (ref:models/architectures.py:195-514,
+    ref:datasets/indoor.py:192-829): per cloud and image a [channels, h, w] feature map (the ResUNet's output shape for the
+    3DMatch frames: 128 x 120 x 160), the projected points' pixel coordinates `inds2d` [k, 2] (column, row) and point
+    indices `inds3d` [k] -- a random `frac` of the cloud per image, overlapping between images, so the write order matters
+    -- and, for img_num < 3, a [w, h] valid mask.  Keys as in the reference's batch dict, with the maps under
+    '{side}{i}_feature2d' (what pcrcg_amd.KPFCNN takes in place of a backbone).  numpy arrays, seeded: the same inputs in the
+    fixture generator (scripts/make_golden_image_s30k.py), the tests and bench.py."""
+    rng = np.random.RandomState(1000 + seed)
+    out = {}
+    for side, n in (("src", n_src), ("tgt", n_tgt)):
+        for i in range(1, img_num + 1):
+            k = int(n * frac)
+            out[f"{side}{i}_feature2d"] = rng.rand(channels, h, w).astype(np.float32)
+            out[f"{side}{i}_inds3d"] = rng.permutation(n)[:k].astype(np.int64)
+            out[f"{side}{i}_inds2d"] = np.stack([rng.randint(0, w, k), rng.randint(0, h, k)], 1).astype(np.int64)
+            if img_num < 3:
+                out[f"{side}_valid_map{i}"] = (rng.rand(w, h) > 0.2).astype(np.float32)
+    return out

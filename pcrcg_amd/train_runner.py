@@ -141,11 +141,21 @@ class TrainRunner:
                               grad=bool(with_grad and param.requires_grad and not transpose_cols)))
 
         def kp_block(bv, bg, kp):
-            if kp.in_channels != 1 and kp.in_channels % 4 != 0:
-                raise RuntimeError("pcrcg_amd.train_runner: KPConv input widths must be 1 or a multiple of 4")
             bv.extent = float(kp.KP_extent)
             keep.append(kp.kernel_points.data)
             bv.kp = kp.kernel_points.data.contiguous().data_ptr()
+            if kp.in_channels != 1 and kp.in_channels % 4 != 0:
+                # PCR-CG's 129-channel first layer (round 6): the runner is handed the input in rows of cp = 132 floats (three
+                # zero columns, KPFCNN.IMAGE_WIDTH) and the weights as [15, cp, cout] with zero rows for them -- a derived
+                # layout like the others: refreshed from the parameter every step, its gradient folded back through the
+                # inverse map (the zero rows' gradients, products with zero columns, are dropped)
+                kk, cin, cout = kp.weights.shape
+                cp = (cin + 3) // 4 * 4
+                ix = torch.full((kk, cp, cout), -1, dtype=torch.int32, device=dev)
+                ix[:, :cin] = index_of(kp.weights)
+                derived(bv, bg, "kp_w", kp.weights, ix)
+                derived(bv, bg, "kp_wt", kp.weights, ix.reshape(kk * cp, cout).t().contiguous(), with_grad=False)
+                return
             direct(bv, bg, "kp_w", kp.weights, lambda t: t.reshape(-1, t.shape[-1]))
             # a K-contiguous copy [cout, 15 cin] for the FORWARD contraction (value only: the gradient belongs to kp_w): the
             # k-contiguous product instead of the k-major one

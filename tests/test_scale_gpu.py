@@ -378,3 +378,49 @@ def test_secondary_workloads_forward_runner_equals_mirror(cuda, recipe):
     torch.cuda.synchronize()
     for k in ref:
         assert torch.isfinite(out[k]).all() and rel(out[k], ref[k]) < 1e-5, (recipe, k)
+
+
+def test_s30k_image129_shipped_configuration_vs_reference(cuda, golden_dir):
+    """PCR-CG's SHIPPED configuration at full width and full size (ref:configs/test/indoor.yaml:21-34: image_feature True,
+    img_num 2, in_feats_dim 129; ref:models/architectures.py:195-514): the reference model's outputs on the S30k pair with the
+    synthetic 2-D inputs of pcrcg_amd.synthetic.image_inputs (tests/golden/model_s30k_img129.pt, scripts/
+    make_golden_image_s30k.py) against this path -- the injected [N, 129] matrix bit for bit, the runner's outputs (first
+    KPConv over rows of 132 floats) at 1e-4 on the strided rows and through every row's projections, and the pair engine
+    carrying the same pair (submit(images=...)) equal to the direct forward."""
+    from pcrcg_amd.pairstream import PairStreams
+    gold = torch.load(os.path.join(golden_dir, "model_s30k_img129.pt"))
+    cfg = indoor_config(image_feature=True, img_num=2, in_feats_dim=129)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = KPFCNN(cfg).eval()
+    for k, v in gold["weights_check"].items():          # same seeds -> the reference's weights, bit for bit
+        assert torch.equal(net.state_dict()[k], v), k
+    net = net.to(cuda)
+    src, tgt = synthetic.pair("S30k", 0)
+    pts, lens = _stack(src, tgt, cuda)
+    batch = build_pyramid(pts, lens, cfg, gold["limits"])
+    assert [int(p.shape[0]) for p in batch["points"]] == gold["levels"]
+    for k, v in synthetic.image_inputs(len(src), len(tgt), 0, img_num=2).items():
+        batch[k] = torch.from_numpy(v).to(cuda)
+    batch["src_pcd_raw"], batch["tgt_pcd_raw"] = pts[:len(src)], pts[len(src):]
+    s = gold["stride"]
+    x = net.image_features(batch)
+    assert torch.equal(x[::s].cpu(), gold["x_rows"])
+    assert int((x[:, :128] != 1).any(1).sum()) == gold["x_rows_with_image_features"]
+    with torch.no_grad():
+        out = net(batch)
+    torch.cuda.synchronize()
+    for k, want in gold["rows"].items():
+        assert rel(out[k][::s], want) < TOL, k
+        assert abs(float(out[k].double().mean()) - gold["means"][k]) < TOL, k
+    _check_every_row(out, gold)
+    _, _, images = net.image_list(batch)
+    eng = PairStreams(net, cfg, gold["limits"], cuda)
+    for _ in range(5):
+        eng.submit(pts, lens, images=images)
+    outs = [eng.result() for _ in range(5)]
+    eng.drain()
+    eng.close()
+    for o in outs:
+        for k in gold["rows"]:
+            assert float((o[k] - out[k]).abs().max()) <= 1e-5 * float(out[k].abs().max()), k
