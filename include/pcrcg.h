@@ -68,6 +68,11 @@ int pcrcg_abi_version(void);
  *                      outputs are a function of the inputs alone.
  * Returns PCRCG_EBADARG (and changes nothing) on an unknown name. */
 int pcrcg_debug_set(const char* spec);
+/* deterministic=1 allocates its scratch itself (partial tiles of split-K products, 64-bit fixed-point sums of the train
+ * step's scatters): one buffer per stream it has run on, keyed by the stream handle, grown on demand and kept until the
+ * process ends.  This frees all of it (after a device-wide synchronise): call it before destroying streams the mode has
+ * used -- a recycled handle would otherwise inherit a stale entry -- or to get the memory back. */
+int pcrcg_debug_release(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Front end: grid subsampling

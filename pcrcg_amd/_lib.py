@@ -112,6 +112,7 @@ SIGNATURES = {
     "pcrcg_pyramid_build_parts": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcrcg_pyramid_restore_run": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "pcrcg_debug_release": (c_int, []),
     "pcrcg_stream_pipe_classes": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "pcrcg_thread_shares_gpu": (None, [c_int]),
     "pcrcg_stream_create": (c_int, [c_void_p, c_int]),

@@ -51,6 +51,10 @@ int instnorm_apply_pack(const float* x, int n, int c, int ldx, const float* stat
 // kpconv.hip: where the support records live inside a pcrcg_kpconv_ws_bytes(ns) workspace
 float4* kpconv_pk_ptr(void* ws, size_t ws_bytes, int ns);
 
+// the deterministic debug mode's scratch (gemm_x6.hip, trainops.hip): freed by pcrcg_debug_release()
+void gemm_x6_release_det();
+void trainops_release_det();
+
 // tieorder.hip: pcrcg_kdforest_build over clouds that are LEVELS of per_level clouds each, level l's rows starting at row
 // level_base[l] of sup (per_level = 0: one contiguous stack, the public entry point)
 int kdforest_build_levels(const float* sup, int ns, const int* slen, int nb, int per_level, const int* level_base, void* forest,

@@ -870,12 +870,12 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
 thread_local long g_split_stride = 0;
 thread_local bool g_det_pass = false;
 // the deterministic mode's partial-tile buffer: one per stream, grown on demand (a debugging mode: synchronous allocation)
+struct DetBuf { float* p = nullptr; size_t n = 0; };
+std::mutex g_det_mu;
+std::map<hipStream_t, DetBuf> g_det_bufs;
 float* det_partials(hipStream_t st, size_t floats) {
-    struct Buf { float* p = nullptr; size_t n = 0; };
-    static std::mutex mu;
-    static std::map<hipStream_t, Buf> bufs;
-    std::lock_guard<std::mutex> g(mu);
-    Buf& b = bufs[st];
+    std::lock_guard<std::mutex> g(g_det_mu);
+    DetBuf& b = g_det_bufs[st];
     if (b.n < floats) {
         if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
         if (b.p) (void)hipFree(b.p);
@@ -1001,6 +1001,14 @@ int gemm_x6_redo_counts(unsigned long long* out, int reset) {
 
 // the split-K factor gemm_x6_dispatch uses for an [m, n, k] product (> 1: it accumulates into a zeroed C)
 int gemm_x6_splits(int m, int n, int k, long m_total) { return (m > 0 && n > 0) ? x6_plan(m, n, k, false, false, m_total).splits : 1; }
+
+// pcrcg_debug_release(): the deterministic mode's partial-tile buffers of every stream (the caller has drained them)
+void gemm_x6_release_det() {
+    std::lock_guard<std::mutex> g(g_det_mu);
+    for (auto& kv : g_det_bufs)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    g_det_bufs.clear();
+}
 
 // Called by gemm_dispatch (gemm.hip) for C = A * B^T products when the split-bf16 mode is on.  c_zeroed: C is
 // already all zeros (the runner's zero arena), so a split-K product needs no memset of its own.

@@ -291,6 +291,16 @@ int pcrcg_debug_set(const char* spec) {
     return pcrcg::debug_parse(spec, cur) ? PCRCG_OK : PCRCG_EBADARG;
 }
 
+// The deterministic debug mode (deterministic=1) allocates its scratch itself, one buffer per stream it has been used on,
+// keyed by the stream handle and kept until the process ends.  A host that destroys streams (a recycled handle would inherit
+// a stale entry) or wants the memory back calls this with those streams DRAINED; the next deterministic call allocates anew.
+int pcrcg_debug_release(void) {
+    PCRCG_CHECK_HIP(hipDeviceSynchronize());
+    pcrcg::gemm_x6_release_det();
+    pcrcg::trainops_release_det();
+    return PCRCG_OK;
+}
+
 int pcrcg_check_status(const int* status, void* stream) {
     PCRCG_CHECK_ARG(status != nullptr);
     int h = 0;

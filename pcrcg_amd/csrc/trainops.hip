@@ -165,9 +165,16 @@ struct FixAcc {
     const unsigned* maxbits;   // bit pattern of the largest |source gradient| (k_absmax_bits)
     int fan_log2;              // log2 of (contributions per element x the largest factor a contribution carries)
 };
+// An all-zero source gradient (maxbits == 0: e.g. an output nobody differentiated) has nothing to add: scale 0, every
+// contribution rounds to the integer 0 and the flush skips its (still zero) sums.  Tiny gradients would ask for a scale
+// beyond fp32's range: the exponent is clamped (the resolution is then coarser than 2^-39 of the magnitude but still far
+// below fp32's).  (Round 5 returned +inf for both: 0 * inf = NaN into __float2ll_rn.)
 __device__ __forceinline__ float fix_scale(const FixAcc& f) {
-    const int e = (int)((*f.maxbits >> 23) & 0xff) - 127;          // largest magnitude < 2^(e + 1)
-    return ldexpf(1.0f, 62 - f.fan_log2 - (e + 1));
+    const unsigned bits = *f.maxbits;
+    if (bits == 0u) return 0.0f;
+    const int e = (int)((bits >> 23) & 0xff) - 127;                // largest magnitude < 2^(e + 1)
+    const int s = 62 - f.fan_log2 - (e + 1);
+    return ldexpf(1.0f, s > 126 ? 126 : s);
 }
 template <bool DET>
 __device__ __forceinline__ void scatter_add(float* dst, long off, float v, const FixAcc& f, float scale) {
@@ -190,7 +197,7 @@ __global__ void __launch_bounds__(256) k_fix_flush(long long* __restrict__ acc, 
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
     const long long v = acc[t];
-    if (v != 0) {
+    if (v != 0) {                                                  // (a zero scale leaves only zero sums: never here)
         dst[t] += (float)((double)v / (double)fix_scale(f));
         acc[t] = 0;
     }
@@ -693,6 +700,19 @@ int det_begin(hipStream_t st, size_t elems, const float* src, long rows, int col
     out->fan_log2 = fan_log2;
     return PCRCG_OK;
 }
+}  // namespace
+namespace pcrcg {
+// pcrcg_debug_release(): the deterministic mode's fixed-point scratch of every stream (the caller has drained them)
+void trainops_release_det() {
+    std::lock_guard<std::mutex> g(g_det_lock);
+    for (auto& kv : g_det) {
+        if (kv.second.acc) (void)hipFree(kv.second.acc);
+        if (kv.second.word) (void)hipFree(kv.second.word);
+    }
+    g_det.clear();
+}
+}  // namespace pcrcg
+namespace {
 int det_end(hipStream_t st, const FixAcc& fx, float* dst, size_t elems) {
     hipLaunchKernelGGL(k_fix_flush, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, fx.acc, dst, (long)elems, fx);
     PCRCG_CHECK_LAUNCH();

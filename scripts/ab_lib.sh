@@ -6,6 +6,9 @@ STEPS=480; ROUNDS=2; ARGS=""
 while [ "${1#-}" != "$1" ]; do case $1 in -s) STEPS=$2;; -r) ROUNDS=$2;; -a) ARGS=$2;; esac; shift 2; done
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cp $R/pcrcg_amd/libpcrcg_hip.so /tmp/cur.so
+# whatever happens below (a failed run, an interrupt), the in-tree library is put back: later tests and benchmarks must not
+# run against a variant build (pcrcg_amd/_lib.py loads the in-tree file and nothing else)
+trap 'cp /tmp/cur.so $R/pcrcg_amd/libpcrcg_hip.so' EXIT
 for round in $(seq $ROUNDS); do
   for name in "$@"; do
     if [ "$name" = "cur" ]; then cp /tmp/cur.so $R/pcrcg_amd/libpcrcg_hip.so; else cp $R/ab/$name.so $R/pcrcg_amd/libpcrcg_hip.so; fi
@@ -13,4 +16,3 @@ for round in $(seq $ROUNDS); do
     echo "[$name] $v"
   done
 done
-cp /tmp/cur.so $R/pcrcg_amd/libpcrcg_hip.so
