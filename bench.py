@@ -845,14 +845,14 @@ def main():
             extras["K120k"] = {"error": repr(e)}
         torch.cuda.empty_cache()
         try:
-            extras["S30k_img129"] = secondary_image129(dev, 96, 8, WORKERS, 4, 4)
-        except Exception as e:
-            extras["S30k_img129"] = {"error": repr(e)}
-        torch.cuda.empty_cache()
-        try:
             extras["train_step"] = secondary_train_step(dev, 12)
         except Exception as e:
             extras["train_step"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            extras["S30k_img129"] = secondary_image129(dev, 96, 8, WORKERS, 4, 4)
+        except Exception as e:
+            extras["S30k_img129"] = {"error": repr(e)}
 
     if rank == 0:
         gather, fused = kpconv_roofline(events, cout_of)

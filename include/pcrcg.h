@@ -59,6 +59,8 @@ int pcrcg_abi_version(void);
  * except PCRCG_GEMM_MODE (pcrcg_gemm_set_mode).  Every switch defaults to the product behaviour:
  *   zero_arena=1 stat_sums=1 stat_sums_rows=2^30 fuse_norm=1 fuse_pack=1 fuse_upsample=1 gnn_merge=1 edge_rows=1 att_mfma=1   network runner fusions
  *   radius_blocks=0 radius_eager_redo=0 radius_cells=1 radius_prof=0 pyr_wait=1 pyr_trace=0 kd_spin_limit=0 kd_blocks=0   front end
+ *   pyr_morton=0   1: MEASUREMENT AID -- every subsampled level sorted along a Z curve before anything reads it; the level rows
+ *                  are then not the reference's (a knock-out that prices an internal spatial order: csrc/morton_knock.hip)
  *   att_tq=16                                                                              attention tile
  *   gemm_log=0 x6_tile=-1 x6_splitk=0 x6_t1=32 x6_t2=128 x6_order=-1 x6_big=0 x6_h2=1 gemm_tile=-1 gemm_splitk=0 gemm_split_target=768   GEMM plans
  *   train_side_stream=1 bwd_mfma=1                                                         train-step backward

@@ -51,6 +51,10 @@ int instnorm_apply_pack(const float* x, int n, int c, int ldx, const float* stat
 // kpconv.hip: where the support records live inside a pcrcg_kpconv_ws_bytes(ns) workspace
 float4* kpconv_pk_ptr(void* ws, size_t ws_bytes, int ns);
 
+// morton_knock.hip (measurement aid, DebugOpts::pyr_morton): a subsampled level's rows into Z order, in place
+size_t morton_knock_ws_bytes(int cap);
+int morton_knock_level(float* pts, int cap, const int* len, int nb, void* ws, size_t ws_bytes, hipStream_t st);
+
 // the deterministic debug mode's scratch (gemm_x6.hip, trainops.hip): freed by pcrcg_debug_release()
 void gemm_x6_release_det();
 void trainops_release_det();
@@ -180,6 +184,8 @@ struct DebugOpts {
     int radius_cells = 1;      // pyramid builder: cell-cooperative LDS-staged search (0: the per-query kernel of rounds 1-3)
     int pyr_wait = 1;          // pyramid builder host round trip: 0 stream sync, 1 event, 2 device-posted flag
     int pyr_trace = 0;         // pyramid builder: host enqueue / wait microseconds at exit
+    int pyr_morton = 0;        // MEASUREMENT AID: every subsampled level sorted along a Z curve before anything reads it (the level
+                               // rows are then not the reference's: a knock-out that prices an internal spatial order, morton_knock.hip)
     int att_tq = 16;           // attention kernel: queries per workgroup (8 or 16)
     int kd_spin_limit = 0;     // KD-forest task queue: spin bound (0: default)
     int gemm_log = 0;          // print every GEMM's shape and grid

@@ -328,6 +328,9 @@ static int pyramid_run(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg*
     // most).  It is NOT handed back to the arena: beside the searches on another stream nothing may share its memory.
     const size_t sub_wsb = L > 1 ? pcrcg_grid_subsample_ws_bytes(cap[0], nb) : 0;
     void* sub_ws = L > 1 ? A.raw(sub_wsb) : nullptr;
+    const bool knock_morton = debug_opts().pyr_morton != 0 && L > 1;       // measurement aid (morton_knock.hip)
+    const size_t mk_wsb = knock_morton ? morton_knock_ws_bytes(cap[1]) : 0;
+    void* mk_ws = knock_morton ? A.raw(mk_wsb) : nullptr;
     if (!A.ok()) return PCRCG_EWORKSPACE;
 
     void* carried = nullptr;
@@ -351,6 +354,8 @@ static int pyramid_run(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg*
         if (pooled && !dry)
             PCRCG_PROPAGATE(grid_subsample_bound(pts, n, lens, nb, cfg->dl[l], 0, level_pts[l + 1], lens + nb, m_dev + l, cap[l + 1],
                                                  overflow, sub_ws, sub_wsb, sub_st));
+        if (pooled && !dry && knock_morton)
+            PCRCG_PROPAGATE(morton_knock_level(level_pts[l + 1], cap[l + 1], lens + nb, nb, mk_ws, mk_wsb, sub_st));
         if (pooled && l + 2 == L) PCRCG_PROPAGATE(build_forest(1));      // the last subsampled level exists: the upper levels' forest
         if (cfg->has_conv[l]) {
             if (carried && carried_r == r_conv) { grid = carried; grid_r = carried_r; }
