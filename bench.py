@@ -448,7 +448,7 @@ def secondary_image129(dev, steps, warmup, workers, ppf, ppb, isolated=6):
                         "128 x 120 x 160 maps resident in HBM, 45 % of the points projected per image), image_feature=True, img_num=2, "
                         "in_feats_dim=129; pyramid build + feature injection + KPFCNN+GCN forward",
             "steps": steps, "value": round(steps / dt, 2), "unit": "fragment-pairs/s", "ms_per_step": round(1e3 * dt / steps, 3),
-            "forward_alone_ms": round(iso_ms, 3),
+            "forward_alone_ms": round(iso_ms, 3), "engine_streams_by_dispatcher": pipe.pipe_classes,
             "first_kpconv_gather": {"alone": first_layer(ev_iso), "in_engine": first_layer(ev)},
             "kpconv_gathers_all_layers": {"alone_GBs": round(g_iso["bytes"] / (g_iso["ms"] * 1e-3) / 1e9, 1) if g_iso["ms"] > 0 else None,
                                           "in_engine_GBs": round(gbs, 1), "in_engine_frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
@@ -774,7 +774,12 @@ def main():
     pipe.reset_stats()
     if not args.no_kernel_events:
         ops.kpconv_profile_start()        # HIP events around every KPConv gather/aggregate launch from here on
+    cpu0 = os.times()
     regions = [region(pipe) for _ in range(R)]
+    cpu1 = os.times()
+    # user + system CPU seconds of THIS process (the submitting thread, the front thread, the model threads, the runtime's
+    # own threads) per pair over the timed regions: what a rank costs its host -- eight ranks need eight times that
+    cpu_s_per_pair = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(R * args.steps, 1)
     events = ops.kpconv_profile_stop()
     stats = pipe.stats_snapshot()
     own = sorted(r[2] for r in regions)[len(regions) // 2]      # this rank's own clock, median region
@@ -838,21 +843,21 @@ def main():
     if not args.no_extras and rank == 0 and world == 1 and RECIPE == "S30k" and not BF16:
         # (d) configs[4] and configs[2] on this GPU, bounded (a dozen steps each): driver-visible numbers for both
         del pipe
-        torch.cuda.empty_cache()
-        try:
-            extras["K120k"] = secondary_k120k(dev, 96, 6, WORKERS, 3, 3)
-        except Exception as e:       # secondary figures never fail the headline
-            extras["K120k"] = {"error": repr(e)}
-        torch.cuda.empty_cache()
-        try:
-            extras["train_step"] = secondary_train_step(dev, 12)
-        except Exception as e:
-            extras["train_step"] = {"error": repr(e)}
-        torch.cuda.empty_cache()
-        try:
-            extras["S30k_img129"] = secondary_image129(dev, 96, 8, WORKERS, 4, 4)
-        except Exception as e:
-            extras["S30k_img129"] = {"error": repr(e)}
+        legs = os.environ.get("PCRCG_BENCH_LEGS", "K120k,train_step,S30k_img129").split(",")     # (a measurement aid: which legs, in which order)
+        for leg in legs:
+            if os.environ.get("PCRCG_BENCH_KEEP_CACHE") != "1":
+                torch.cuda.empty_cache()
+            try:       # secondary figures never fail the headline
+                if leg == "K120k":
+                    extras[leg] = secondary_k120k(dev, 96, 6, WORKERS, 3, 3)
+                elif leg == "train_step":
+                    extras[leg] = secondary_train_step(dev, 12)
+                elif leg == "S30k_img129":
+                    extras[leg] = secondary_image129(dev, 96, 8, WORKERS, 4, 4)
+            except Exception as e:
+                import traceback
+                extras[leg] = {"error": repr(e), "traceback": traceback.format_exc()[-1500:]}
+                print("bench.py: secondary leg %s failed: %r" % (leg, e), file=sys.stderr)
 
     if rank == 0:
         gather, fused = kpconv_roofline(events, cout_of)
@@ -969,7 +974,12 @@ def main():
                                 "trips) / enqueueing the restore step + pcrcg_kpfcnn_forward",
                         "front_thread_build_ms_per_pair": round(1e3 * stats["build_s"] / n, 3),
                         "model_threads_enqueue_ms_per_pair": round(1e3 * stats["launch_s"] / n, 3),
-                        "pairs_per_pyramid_build": round(ppb, 2)}
+                        "pairs_per_pyramid_build": round(ppb, 2),
+                        "cpu_s_per_pair": round(cpu_s_per_pair, 6),
+                        "cpu_cores_busy": round(cpu_s_per_pair * args.steps * R / max(sum(r[0] for r in regions), 1e-9), 2),
+                        "cpu_note": "user + system seconds of this whole process per pair over the timed regions (submitting thread, "
+                                    "front thread, three model threads, HIP runtime threads); cpu_cores_busy = the same as cores kept "
+                                    "busy while a region runs -- the per-rank host budget of an N-GPU run"}
         if BF16:
             line["variant"] = {"name": "bf16 feature storage", "max_abs_error_over_max_abs_vs_fp32_path": variant_error,
                                "note": "outside the 1e-4 parity bound of the fp32 path by construction; "

@@ -92,7 +92,13 @@ struct SideStream {
     hipEvent_t joined = nullptr;
     unsigned next = 0;
 };
-static SideStream* side_stream() {
+// The side stream must not share the main stream's hardware DISPATCHER (round 6, profiles/r06_queue_pipes.txt: gfx950 has
+// four; two busy streams on one take turns kernel by kernel -- the weight-gradient products would then run BETWEEN the
+// activation-gradient kernels instead of beside them: 14.2 instead of 12.3 ms per step, which is what the step cost whenever
+// a few engines had created streams in the process before the first backward and the runtime's round-robin put the new stream
+// on the main stream's dispatcher).  So: up to six candidates, classified against the main stream by measurement
+// (pcrcg_stream_pipe_classes, once per device, ~10 ms; the first backward pays it), the first one of another class is kept.
+static SideStream* side_stream(hipStream_t main_stream) {
     static std::mutex mu;
     static SideStream* per_device[64] = {nullptr};
     int dev = 0;
@@ -100,7 +106,27 @@ static SideStream* side_stream() {
     std::lock_guard<std::mutex> lock(mu);
     if (!per_device[dev]) {
         SideStream* s = new SideStream();
-        if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) { delete s; return nullptr; }
+        constexpr int kCand = 6;
+        hipStream_t cand[kCand] = {};
+        int made = 0;
+        for (; made < kCand; ++made)
+            if (hipStreamCreateWithFlags(&cand[made], hipStreamNonBlocking) != hipSuccess) break;
+        if (made == 0) { delete s; return nullptr; }
+        int pick = 0;
+        void* scratch = nullptr;
+        if (hipMalloc(&scratch, 64) == hipSuccess) {
+            void* all[kCand + 1];
+            int cls[kCand + 1];
+            all[0] = main_stream;
+            for (int i = 0; i < made; ++i) all[i + 1] = cand[i];
+            if (pcrcg_stream_pipe_classes(all, made + 1, cls, scratch) == PCRCG_OK)
+                for (int i = 0; i < made; ++i)
+                    if (cls[i + 1] != cls[0]) { pick = i; break; }
+            (void)hipFree(scratch);
+        }
+        s->st = cand[pick];
+        for (int i = 0; i < made; ++i)
+            if (i != pick) (void)hipStreamDestroy(cand[i]);
         s->ev.resize(64);
         bool ok = hipEventCreateWithFlags(&s->joined, hipEventDisableTiming) == hipSuccess;
         for (auto& e : s->ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -714,7 +740,7 @@ int pcrcg_kpfcnn_train_backward(void* tape, const float* d_feats_f, const float*
     Tape& t = *static_cast<Tape*>(tape);
     t.st = as_stream(stream);
     t.rc = PCRCG_OK;
-    t.side = debug_opts().train_side_stream ? side_stream() : nullptr;
+    t.side = debug_opts().train_side_stream ? side_stream(t.st) : nullptr;
     t.forked = false;
     PCRCG_CHECK_HIP(hipMemsetAsync(t.grad.base, 0, t.grad.off, t.st));
     // heads: the gradients of the three outputs into the gradient of x_final

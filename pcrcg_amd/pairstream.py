@@ -26,9 +26,9 @@ candidates by measurement (pcrcg_stream_pipe_classes, ~50 ms at construction) an
 class and the three model streams from the other three (_pick_streams; `pipe_classes` records the choice, a
 RuntimeWarning says when it could not be made).  That holds with the runtime's default of four hardware queues and with
 GPU_MAX_HW_QUEUES=8 alike; rounds 1-5 took streams in creation order and needed the variable set before the first HIP
-call.  ONE engine per process and device: a second engine -- even the closed, not yet collected one of an earlier
-measurement -- puts more busy streams on the same four dispatchers and both slow down.  Reuse the engine
-(set_up_nearest() exists for that reason)."""
+call.  It also lifted the "one engine per process" rule of those rounds (a fresh engine 453 pairs/s, the third one created
+in the same process 355): four engines created one after the other in one process run at 586-592 pairs/s each
+(scripts/engines_in_one_process.py).  Two engines ACTIVE at once still share the four dispatchers."""
 import os
 import queue
 import threading
@@ -164,14 +164,25 @@ class PairStreams:
         from . import ops
         cands = [torch.cuda.Stream(device=dev) for _ in range(12)]
         fcands = cands if front_priority == 0 else [torch.cuda.Stream(device=dev, priority=front_priority) for _ in range(4)]
-        cls = ops.stream_pipe_classes(cands + (fcands if fcands is not cands else []))
+        try:
+            cls = ops.stream_pipe_classes(cands + (fcands if fcands is not cands else []))
+        except RuntimeError as e:       # the probe is a measurement: if it cannot be made, run as rounds 1-5 did and say so
+            import warnings
+            warnings.warn("pcrcg_amd.PairStreams: could not classify streams by dispatcher (%s); taking them in creation order" % e,
+                          RuntimeWarning)
+            return self._pick_streams(n_front, n_model, want_side, front_priority, "off")
         ccls, fcls = cls[:len(cands)], (cls[len(cands):] if fcands is not cands else cls[:len(cands)])
         by = {}
         for s_, c in zip(cands, ccls):
             by.setdefault(c, []).append(s_)
-        front_class = fcls[0]
+        # the front end's class: the one that offers most streams (it needs 1 + want_side per front-end stream; the probe's
+        # classes are not evenly filled: torch hands out pool streams, and the runtime maps them to hardware queues as it likes)
+        if fcands is cands:
+            front_class = max(sorted(by), key=lambda c: len(by[c]))
+        else:
+            front_class = fcls[0]
         self.fronts, used = [], set()
-        for s_, c in zip(fcands, fcls):                       # front-end streams: all from the first one's class
+        for s_, c in zip(fcands, fcls):                       # front-end streams: all from that class
             if c == front_class and len(self.fronts) < n_front:
                 self.fronts.append(s_)
                 used.add(id(s_))
@@ -179,10 +190,18 @@ class PairStreams:
             self.fronts.append(self.fronts[-1])
         free_front = [s_ for s_ in by.get(front_class, []) if id(s_) not in used]
         self.sides = []
-        if want_side:                                         # (beyond what the class offers: whatever torch hands out)
-            spare = iter(free_front + [torch.cuda.Stream(device=dev) for _ in range(2 * len(self.fronts))])
+        if want_side:
+            # side streams come from the front end's class or not at all: a stream of unknown class may sit on a model
+            # stream's dispatcher (seen: the fourth engine of a process got two candidates of its class, took a third stream
+            # blindly for the KD-forests, and ran 13 % slower).  Too few: the forests share the subsamplings' stream, or
+            # everything stays in line.
+            spare = list(free_front)
             for i in range(len(self.fronts)):
-                self.sides.append((next(spare), next(spare) if want_side > 1 else None))
+                sub = spare.pop(0) if spare else None
+                forest = spare.pop(0) if (spare and want_side > 1) else None
+                self.sides.append((sub, forest) if sub is not None else None)
+            if any(p_ is None for p_ in self.sides):
+                self.sides = []
         others = [c for c in sorted(by) if c != front_class] or [front_class]
         if pipes == "front4":                                 # measurement aid: model streams on ALL classes, the front end's too
             others = sorted(by)
@@ -208,7 +227,8 @@ class PairStreams:
                           "kernel by kernel (pcrcg_stream_pipe_classes, profiles/r06_queue_pipes.txt)"
                           % (sorted(by), front_class, mcls), RuntimeWarning)
         self.pipe_classes = {"candidates": ccls, "front": front_class, "model": mcls, "distinct": bool(distinct),
-                             "side_streams": want_side, "side_class": front_class if want_side else None,
+                             "side_streams": sum(1 for x in (self.sides[0] if self.sides else ()) if x is not None),
+                             "side_class": front_class if self.sides else None,
                              "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "(unset: the runtime's default, 4)")}
 
     def set_up_nearest(self, on):

@@ -7,6 +7,7 @@ O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json                       # (the default: 480-step regions)
 python3 $R/bench.py --steps 48 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_48_step_regions.json
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/${TAG}_bench_driver_setting_20_steps.json     # the driver's command, extras included
 db() { find "$1" -name "*results.db" | head -1; }
 # 1. the timed bench under the kernel tracer
 rm -rf /tmp/p1; rocprofv3 --kernel-trace --stats -d /tmp/p1 -o p -- python3 $R/bench.py --steps 48 --warmup 5 --repeats 1 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprof.json

@@ -1,7 +1,7 @@
 # GPU box: the round's final evidence in one call (every leg bounded)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-TAG=${1:-r05}
+TAG=${1:-r06}
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "^E  |passed|failed|FAILED|rror" | tail -8 > gpurun_out/${TAG}_gpu_tests.log
 timeout 1500 bash scripts/collect_profiles.sh $TAG all > gpurun_out/${TAG}_collect.log 2>&1
 # the price of deterministic=1: the engine with a fixed pairing, and the train step
