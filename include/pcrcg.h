@@ -58,6 +58,11 @@ int pcrcg_abi_version(void);
  * read once from the environment variable PCRCG_DEBUG at first use; nothing else in the library reads the environment
  * except PCRCG_GEMM_MODE (pcrcg_gemm_set_mode).  Every switch defaults to the product behaviour:
  *   zero_arena=1 stat_sums=1 stat_sums_rows=2^30 fuse_norm=1 fuse_pack=1 fuse_upsample=1 gnn_merge=1 edge_rows=1 att_mfma=1   network runner fusions
+ *                  (gnn_merge: the source and target clouds of a self-attention layer through one pass and both query
+ *                  projections of a cross layer in one launch -- applies to forward calls of ONE or TWO pairs: the merged
+ *                  pass holds 2 x pairs clouds and the multi-cloud kernels take four; with four pairs per call the two
+ *                  sides run as two passes of four clouds.  The fused key / value projection and the once-per-forward kNN
+ *                  graphs apply at every group size.)
  *   radius_blocks=0 radius_eager_redo=0 radius_cells=1 radius_prof=0 pyr_wait=1 pyr_trace=0 kd_spin_limit=0 kd_blocks=0   front end
  *   pyr_morton=0   1: MEASUREMENT AID -- every subsampled level sorted along a Z curve before anything reads it; the level rows
  *                  are then not the reference's (a knock-out that prices an internal spatial order: csrc/morton_knock.hip)

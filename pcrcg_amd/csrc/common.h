@@ -174,7 +174,8 @@ struct DebugOpts {
     int fuse_norm = 1;         // runner: normalise-on-load inside the consuming product
     int fuse_pack = 1;         // runner: the normalisation that feeds a KPConv also packs its support records
     int fuse_upsample = 1;     // runner: nearest_upsample -> cat(skip) -> unary as two products into one output
-    int gnn_merge = 1;         // runner: source and target clouds of a self-attention layer through ONE pass (round 5)
+    int gnn_merge = 1;         // runner: source and target clouds of a self-attention layer through ONE pass (round 5); needs
+                               // 2 x pairs <= 4 clouds per launch, i.e. forward calls of one or two pairs (include/pcrcg.h)
     int edge_rows = 1;         // edge convolution: the row-parallel multi-cloud kernel (0: the per-cloud chunked kernel)
     int att_mfma = 1;          // attention: the fp32-MFMA kernel, all clouds of a call in one launch (0: the VALU kernel per cloud)
     int radius_blocks = 0;     // radius search grid (0: 512 workgroups)
