@@ -52,6 +52,8 @@ def test_bad_arguments_are_rejected_before_any_launch():
     assert rc == -1
     rc = lib.pcrcg_kpconv_aggregate(None, 5, None, 5, None, 0, 0, None, 1, None, 0.1, None, None, None, 0, None)
     assert rc == -1
+    rc = lib.pcrcg_stream_pipe_classes(None, 4, None, None)        # (checked before the probe touches the GPU)
+    assert rc == -1 and b"bad argument" in lib.pcrcg_last_error()
 
 
 def test_struct_mirrors_match_the_header(tmp_path):

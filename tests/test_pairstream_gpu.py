@@ -337,3 +337,36 @@ def test_engine_streams_sit_on_distinct_dispatchers(cuda, queues):
     assert rec["finite"] and c["distinct"] and not rec["warnings"], rec
     assert len(set([c["front"]] + c["model"])) == 4, c
     assert c["side_class"] == c["front"]
+
+
+def test_stream_pipe_classes_finds_four_dispatchers(cuda):
+    """pcrcg_stream_pipe_classes (the measurement the engine's stream choice rests on): among sixteen library-created
+    streams it finds gfx950's four hardware dispatchers -- four classes, each with several members --, gives the same answer
+    twice, puts a stream in its own class when it is listed twice, and rejects bad arguments before touching the GPU."""
+    import ctypes
+    from pcrcg_amd import _lib
+    L = _lib.lib()
+    streams = []
+    for _ in range(16):
+        h = ctypes.c_void_p()
+        _lib.check(L.pcrcg_stream_create(ctypes.byref(h), 0), "pcrcg_stream_create")
+        streams.append(h.value)
+    scratch = torch.zeros(16, dtype=torch.int32, device=cuda)
+    torch.cuda.synchronize()
+    arr = (ctypes.c_void_p * 17)(*(streams + [streams[3]]))
+    runs = []
+    for _ in range(2):
+        cls = (ctypes.c_int * 17)()
+        _lib.check(L.pcrcg_stream_pipe_classes(arr, 17, cls, scratch.data_ptr()), "pcrcg_stream_pipe_classes")
+        runs.append(list(cls))
+    assert runs[0] == runs[1], runs
+    cls = runs[0]
+    assert cls[0] == 0 and cls[16] == cls[3]
+    assert sorted(set(cls)) == [0, 1, 2, 3], cls                      # four dispatchers, no more, no fewer
+    assert min(cls.count(c) for c in range(4)) >= 2, cls              # and every one serves several of sixteen streams
+    out = (ctypes.c_int * 17)()
+    assert L.pcrcg_stream_pipe_classes(arr, 0, out, scratch.data_ptr()) == -1
+    assert L.pcrcg_stream_pipe_classes(None, 4, out, scratch.data_ptr()) == -1
+    assert L.pcrcg_stream_pipe_classes(arr, 4, out, None) == -1
+    for h in streams:
+        _lib.check(L.pcrcg_stream_destroy(ctypes.c_void_p(h)), "pcrcg_stream_destroy")
