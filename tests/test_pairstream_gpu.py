@@ -370,3 +370,49 @@ def test_stream_pipe_classes_finds_four_dispatchers(cuda):
     assert L.pcrcg_stream_pipe_classes(arr, 4, out, None) == -1
     for h in streams:
         _lib.check(L.pcrcg_stream_destroy(ctypes.c_void_p(h)), "pcrcg_stream_destroy")
+
+
+def test_a_level_that_outgrows_its_bound_is_reported_and_rebuilt(cuda):
+    """Round 6 sizes every level from the bound pcrcg_pyramid_cfg::shrink.  Clouds whose subsampled levels keep nearly all
+    their rows (dl far below the point spacing) outgrow the default bound of one half: the library reports PCRCG_EWORKSPACE
+    at the end of the chain -- with side streams and several pairs per chain as well --, nothing is corrupted, and the same
+    builder, asked again with shrink = 1, returns the tables of a builder that started with shrink = 1."""
+    import ctypes
+    from pcrcg_amd import _lib
+    cfg = indoor_config(first_subsampling_dl=0.0005)
+    rng = np.random.RandomState(1)
+    limits = [8, 8, 8, 8]
+    pts = [torch.from_numpy(rng.rand(3000, 3).astype(np.float32)).to(cuda) for _ in range(3)]
+    lens = [torch.tensor([1500, 1500], dtype=torch.int32, device=cuda) for _ in range(3)]
+    sub, forest = torch.cuda.Stream(device=cuda), torch.cuda.Stream(device=cuda)
+    want = NativePyramid(cfg, limits, "auto")
+    want.shrink = 1.0
+    wb, warena, wlens, wslot = want.build(pts, lens, group=2)
+    torch.cuda.synchronize()
+    nat = NativePyramid(cfg, limits, "auto")
+    nat.set_side_streams(sub, forest)
+    # the raw call with the default bound: the status code, not an exception, and a message that names the bound
+    nat.cfg.shrink, nat.cfg.group = 0.5, 2
+    L = _lib.lib()
+    need = L.pcrcg_pyramid_ws_bytes(9000, 6, ctypes.byref(nat.cfg))
+    arena = torch.empty(int(need), dtype=torch.uint8, device=cuda)
+    from pcrcg_amd.runner import Batch
+    b = (Batch * 3)()
+    h_len = (ctypes.c_int * (4 * 6))()
+    pp = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in pts])
+    lp = (ctypes.c_void_p * 3)(*[l.data_ptr() for l in lens])
+    pn, ln = (ctypes.c_int * 3)(3000, 3000, 3000), (ctypes.c_int * 3)(2, 2, 2)
+    rc = L.pcrcg_pyramid_build_parts(pp, pn, lp, ln, 3, ctypes.byref(nat.cfg), arena.data_ptr(), arena.numel(), nat.scratch.data_ptr(),
+                                     ctypes.byref(b), h_len, nat.status.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    assert rc == -2 and b"shrink" in L.pcrcg_last_error()
+    torch.cuda.synchronize()
+    # the Python builder repeats the call with the bound that always fits
+    gb, garena, glens, gslot = nat.build(pts, lens, group=2)
+    torch.cuda.synchronize()
+    assert nat.shrink == 1.0 and glens == wlens and glens[1] == [1500] * 6
+    for i in range(3):
+        got, ref = nat.as_dict(gb[i], garena, glens, part=(2 * i, 2)), want.as_dict(wb[i], warena, wlens, part=(2 * i, 2))
+        for l in range(4):
+            assert torch.equal(got["points"][l].view(torch.int32), ref["points"][l].view(torch.int32))
+            for key in ("neighbors", "pools", "upsamples"):
+                assert torch.equal(got[key][l], ref[key][l]), (i, key, l)
