@@ -92,10 +92,13 @@ class PairStreams:
         # front_streams / front_priority (< 0: the front-end chain ahead of the forwards) exist for measurements: more
         # than one front-end stream, and a prioritised one, both measured slower
         # side streams of the front end (round 6: the chain is a DAG -- the subsamplings and the KD-forests of the tie-order
-        # restore step need nothing from the searches): forest_stream = 2 (default; PCRCG_FOREST_STREAM) one stream for the
-        # subsamplings and one for the forests, 1 both on one, 0 everything in line on the front-end stream
+        # restore step need nothing from the searches): forest_stream (PCRCG_FOREST_STREAM) = 0 (default) everything in line on
+        # the front-end stream, 1 subsamplings + forests on one side stream, 2 on one each.  Alone on the GPU a chain spread
+        # over streams of OTHER dispatchers takes half the time (profiles/r06_chain_latency_alone.txt); inside the engine the
+        # other dispatchers belong to the forwards, side streams of the front end's own dispatcher add no concurrency, and the
+        # chain in line measures 1.5-2 % better at 20-step regions, equal at 480 (profiles/r06_ab_fill_streams.txt)
         if forest_stream is None:
-            forest_stream = int(os.environ.get("PCRCG_FOREST_STREAM", "2"))
+            forest_stream = int(os.environ.get("PCRCG_FOREST_STREAM", "0"))
         self._pick_streams(max(1, int(front_streams)), max(1, int(model_streams)), int(forest_stream), int(front_priority),
                            os.environ.get("PCRCG_ENGINE_PIPES", "auto") if pipes is None else pipes)
         self.front = self.fronts[0]

@@ -88,7 +88,7 @@ def test_runners_take_the_input_in_rows_of_132_floats(cuda, golden_dir):
         out129 = net.runner().forward({**batch, "features": x129})         # the runner's own pad copy of [N, 129]
     for k, want in gold["outputs"].items():
         assert MR.rel_err(out[k].cpu(), want) < 1e-4, k
-        assert MR.rel_err(out[k].cpu(), out129[k].cpu()) < 1e-6, k
+        assert MR.rel_err(out[k].cpu(), out129[k].cpu()) < 1e-5, k      # (equal up to the order of the products' fp32 atomics)
 
 
 def test_pair_engine_carries_image_features(cuda, golden_dir):

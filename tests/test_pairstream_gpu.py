@@ -163,7 +163,8 @@ def test_pair_engine_matches_sequential(cuda):
     for workers, fronts, per_build, per_fwd in ((1, 1, 2, 1), (3, 2, 2, 2), (2, 1, 4, 4), (2, 1, 3, 2)):
         eng = PairStreams(net, cfg, limits, cuda, model_streams=workers, front_threads=fronts, up_nearest=(workers == 3),
                           pairs_per_build=per_build, pairs_per_forward=per_fwd,
-                          adaptive_jobs=(workers == 3))      # the timing-dependent grouping in ONE configuration only
+                          adaptive_jobs=(workers == 3),      # the timing-dependent grouping in ONE configuration only
+                          forest_stream=(2 if per_build == 4 else (1 if per_build == 3 else 0)))   # chains as a DAG over side streams, and in line
         outs, submitted, total = [], 0, 3 * len(pairs)
         for i in range(total):
             while submitted < min(total, i + 5):
@@ -327,6 +328,7 @@ def test_engine_streams_sit_on_distinct_dispatchers(cuda, queues):
     import sys
     env = dict(os.environ)
     env.pop("GPU_MAX_HW_QUEUES", None)
+    env["PCRCG_FOREST_STREAM"] = "2"            # with the engine's side streams (off by default), so that their class is checked too
     if queues:
         env["GPU_MAX_HW_QUEUES"] = queues
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
