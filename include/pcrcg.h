@@ -611,9 +611,12 @@ typedef struct pcrcg_pyramid_cfg {
                        level when it first reads it.  side_stream2: the KD-forests (tie_order = 1) -- level 0's at once, the
                        subsampled levels' when the last of them exists; NULL: behind the subsamplings on side_stream.
                        `stream` waits for all of it before the call returns.  Both NULL: one stream, one line of kernels.
-                       Take streams that share `stream`'s hardware dispatcher (pcrcg_stream_pipe_classes): these are small
-                       latency-bound kernels whose dispatch is over at once, they do not hold each other up -- on a
-                       dispatcher that also serves a stream of large kernels they would stand behind every one of those. */
+                       Which streams: gfx950 has four hardware dispatchers and a dispatcher hands out one kernel's workgroups at
+                       a time (pcrcg_stream_pipe_classes).  Side streams on OTHER dispatchers than `stream`'s -- idle ones --
+                       halve the chain (one 2 x 30 000-point pair 1.01 against 1.65 ms, four pairs 1.85 against 3.17:
+                       profiles/r06_chain_latency_alone.txt); side streams on `stream`'s own dispatcher gain nothing; side
+                       streams on a dispatcher that also serves a stream of large kernels stand behind every one of those
+                       (the pair engine, whose other three dispatchers run the forwards, builds its chains in line). */
 } pcrcg_pyramid_cfg;
 typedef struct pcrcg_pyramid_restore {
     int njobs;                                   /* 0: no row holds a tie, nothing to do but post the status word */
