@@ -212,6 +212,25 @@ def stream_pipe_classes(streams):
     return [int(c) for c in cls]
 
 
+def streams_on_other_dispatchers(n=2, reference=None, candidates=12):
+    """-> n torch streams that sit on n DIFFERENT hardware dispatchers, none of them the dispatcher of `reference` (default:
+    the current stream): what build_pyramid(side_streams=...) / NativePyramid.set_side_streams want on a GPU that is
+    otherwise idle.  Classified by measurement (stream_pipe_classes): call it once, at start-up, with the GPU idle; fewer
+    than n such streams among the candidates raises RuntimeError."""
+    ref = reference if reference is not None else torch.cuda.current_stream()
+    cands = [torch.cuda.Stream(device=ref.device) for _ in range(candidates)]
+    cls = stream_pipe_classes([ref] + cands)
+    out, seen = [], {cls[0]}
+    for s, c in zip(cands, cls[1:]):
+        if c not in seen:
+            out.append(s)
+            seen.add(c)
+        if len(out) == n:
+            return out
+    raise RuntimeError("pcrcg_amd.ops.streams_on_other_dispatchers: only %d dispatcher classes beside the reference stream's "
+                       "among %d candidates" % (len(out), candidates))
+
+
 MAX_REORDER_JOBS = 12     # PCRCG_MAX_REORDER_JOBS
 
 

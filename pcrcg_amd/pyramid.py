@@ -55,7 +55,7 @@ def check_tie_status(code):
 
 
 def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=False, tie_order=None,
-                  defer_tie_check=False, mirror=False):
+                  defer_tie_check=False, mirror=False, side_streams=None):
     """points [N0,3] f32 and lengths [B] i32 on the device -> the reference's batch dict
     (ref:datasets/dataloader.py:363-380) restricted to the keys KPFCNN.forward reads, all on the
     device: points, neighbors, pools, upsamples (int64, shadow = support count), stack_lengths,
@@ -77,14 +77,19 @@ def build_pyramid(points, lengths, config, neighborhood_limits, want_counts=Fals
     None) and the CALLER must pass its value to check_tie_status() once the stream has finished (a pipelining caller
     does).
 
-    The build needs four host round trips (three subsampled row counts, one for all table widths); this function
-    waits for each of them.  pyramid_steps() is the same build as a generator that YIELDS at those points, so that a
-    caller can keep the stream busy with another pair's pyramid meanwhile (a pipelining caller does)."""
+    side_streams: (subsampling stream, KD-forest stream) -- two torch streams on hardware dispatchers OTHER than the current
+    stream's and otherwise idle (pcrcg_amd.ops.streams_on_other_dispatchers() finds such): the C++ builder then runs the
+    chain as a DAG over the three streams, which halves it on an otherwise idle GPU (one 2 x 30 000-point pair: 1.01
+    against 1.65 ms; profiles/r06_chain_latency_alone.txt).  None: one line of kernels on the current stream.
+
+    The C++ builder (the default path) sizes its levels from a row bound and waits for the stream once, at the end of the
+    chain.  The Python mirror needs four host round trips (three subsampled row counts, one for all table widths);
+    pyramid_steps() is that build as a generator that YIELDS at those points."""
     if not points.is_cuda:
         raise RuntimeError("pcrcg_amd.build_pyramid: points must be on a HIP device (no CPU path)")
     mode = tie_order if tie_order is not None else os.environ.get("PCRCG_TIE_ORDER", "auto")
     if not want_counts and not defer_tie_check and mode in ("auto", "index") and not mirror:
-        return build_pyramid_native(points, lengths, config, neighborhood_limits, mode)
+        return build_pyramid_native(points, lengths, config, neighborhood_limits, mode, side_streams)
     steps = pyramid_steps(points, lengths, config, neighborhood_limits, want_counts, tie_order, defer_tie_check)
     try:
         while True:
@@ -370,9 +375,11 @@ class NativePyramid:
         return out
 
 
-def build_pyramid_native(points, lengths, config, neighborhood_limits, tie_order=None):
+def build_pyramid_native(points, lengths, config, neighborhood_limits, tie_order=None, side_streams=None):
     """build_pyramid through the C++ builder (one FFI call); same dict, same tables entry for entry."""
     nat = NativePyramid(config, neighborhood_limits, tie_order)
+    if side_streams is not None:
+        nat.set_side_streams(*side_streams)
     b, arena, lens_h, slot = nat.build(points, lengths, fresh_arena=True)
     torch.cuda.current_stream().synchronize()
     check_tie_status(int(nat.status[slot]))
@@ -403,9 +410,9 @@ def _node_visibility(nodes, points, visible_idx):
     return vis / tot, p2n
 
 
-def collate_fn_descriptor(list_data, config, neighborhood_limits, device=None):
+def collate_fn_descriptor(list_data, config, neighborhood_limits, device=None, side_streams=None):
     """Same contract as ref:datasets/dataloader.py:203-400 (one pair per batch, :207), with the result
-    already on the device.  Image-feature keys (:383-398) are passed through untouched."""
+    already on the device.  Image-feature keys (:383-398) are passed through untouched.  side_streams: see build_pyramid."""
     assert len(list_data) == 1
     device = torch.device(device if device is not None else "cuda")
     item = list_data[0]
@@ -413,7 +420,7 @@ def collate_fn_descriptor(list_data, config, neighborhood_limits, device=None):
     tgt = torch.as_tensor(np.asarray(item["tgt_pcd"]), dtype=torch.float32).to(device)
     points = torch.cat([src, tgt], 0)
     lengths = torch.tensor([src.shape[0], tgt.shape[0]], dtype=_I32, device=device)
-    out = build_pyramid(points, lengths, config, neighborhood_limits)
+    out = build_pyramid(points, lengths, config, neighborhood_limits, side_streams=side_streams)
     feats = np.concatenate([np.asarray(item["src_feats"]), np.asarray(item["tgt_feats"])], 0)
     out["features"] = torch.as_tensor(feats, dtype=torch.float32).to(device)
     out["rot"] = torch.as_tensor(np.asarray(item["rot"])).to(device)

@@ -418,3 +418,23 @@ def test_a_level_that_outgrows_its_bound_is_reported_and_rebuilt(cuda):
             assert torch.equal(got["points"][l].view(torch.int32), ref["points"][l].view(torch.int32))
             for key in ("neighbors", "pools", "upsamples"):
                 assert torch.equal(got[key][l], ref[key][l]), (i, key, l)
+
+
+def test_build_pyramid_over_streams_of_other_dispatchers(cuda):
+    """build_pyramid(side_streams=ops.streams_on_other_dispatchers()): the drop-in, one-pair-at-a-time path with its chain as a
+    DAG over three dispatchers -- the same dict, entry for entry, as the chain in line."""
+    from pcrcg_amd import ops
+    cfg = indoor_config()
+    limits = synthetic.LIMITS["C1"]
+    sides = ops.streams_on_other_dispatchers(2)
+    cls = ops.stream_pipe_classes([torch.cuda.current_stream()] + sides)
+    assert len(set(cls)) == 3, cls
+    for recipe in ("C1", "T8k"):
+        pts, lens = _pair(recipe, 0, cuda)
+        want = build_pyramid(pts, lens, cfg, limits)
+        got = build_pyramid(pts, lens, cfg, limits, side_streams=tuple(sides))
+        assert got["stack_lengths_host"] == want["stack_lengths_host"]
+        for l in range(cfg.num_layers):
+            assert torch.equal(got["points"][l].view(torch.int32), want["points"][l].view(torch.int32))
+            for key in ("neighbors", "pools", "upsamples"):
+                assert torch.equal(got[key][l], want[key][l]), (recipe, key, l)
