@@ -57,7 +57,7 @@ int pcrcg_abi_version(void);
  * the defaults, or what PCRCG_DEBUG made of them).  The same string is
  * read once from the environment variable PCRCG_DEBUG at first use; nothing else in the library reads the environment
  * except PCRCG_GEMM_MODE (pcrcg_gemm_set_mode).  Every switch defaults to the product behaviour:
- *   zero_arena=1 stat_sums=1 stat_sums_rows=2^30 fuse_norm=1 fuse_pack=1 fuse_upsample=1 gnn_merge=1 edge_rows=1 att_mfma=1   network runner fusions
+ *   zero_arena=1 stat_sums=1 stat_sums_rows=2^30 fuse_norm=1 fuse_pack=1 fuse_upsample=1 gnn_merge=1 edge_rows=1 att_mfma=1 c1_rows16=1   network runner fusions
  *                  (gnn_merge: the source and target clouds of a self-attention layer through one pass and both query
  *                  projections of a cross layer in one launch -- applies to forward calls of ONE or TWO pairs: the merged
  *                  pass holds 2 x pairs clouds and the multi-cloud kernels take four; with four pairs per call the two
@@ -465,7 +465,8 @@ typedef struct pcrcg_block {
     float extent;        /* KP_extent of the block's KPConv */
     const float* kp;     /* [15,3]  ...KPConv.kernel_points */
     const float* kp_w;   /* [15*cin, cout]  ...KPConv.weights */
-    const float* kp_wt;  /* [cout, 15*cin]  K-contiguous copy: the contraction then is a C = A * B^T product, or NULL */
+    const float* kp_wt;  /* [cout, 15*cin]  K-contiguous copy: the contraction then is a C = A * B^T product, or NULL.
+                            cin = 1: [cout, 16], the 16th column zero (the gather kernel then writes rows of 16 floats) */
     const float* kp_w_pad; /* [15*cin_pad, cout]: kp_w with the input channels zero-padded to cin_pad (a multiple of
                               4), or NULL.  Set when cin % 4 != 0 (PCR-CG's 129-channel first layer,
                               ref:models/architectures.py:195-514): the runner pads the features likewise, so the

@@ -120,7 +120,7 @@ int kpconv_pack(const float* x, int ns, int cin, const float* s_pts, void* ws, s
                 unsigned short* x_bf16 = nullptr);
 int kpconv_aggregate_rows(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h, int ld_idx,
                           const float* x, int cin, const float* kp, float extent, float* wf, float* inv_n, void* ws,
-                          size_t ws_bytes, hipStream_t st, bool pack, bool stream_out);
+                          size_t ws_bytes, hipStream_t st, bool pack, bool stream_out, int c1_ld = 0);   // c1_ld = 16: cin = 1 with wf rows of 16 floats (15 + a zero)
 int kpconv_aggregate_bf16(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h, int ld_idx,
                           const float* x, unsigned short* x_bf16, int cin, const float* kp, float extent,
                           unsigned short* wf_bf16, float* inv_n, void* ws, size_t ws_bytes, hipStream_t st);
@@ -174,6 +174,8 @@ struct DebugOpts {
     int fuse_norm = 1;         // runner: normalise-on-load inside the consuming product
     int fuse_pack = 1;         // runner: the normalisation that feeds a KPConv also packs its support records
     int fuse_upsample = 1;     // runner: nearest_upsample -> cat(skip) -> unary as two products into one output
+    int c1_rows16 = 1;         // runner: the first layer's (cin = 1) aggregate in rows of 16 floats, its contraction the grouped A B^T
+                               // product with epilogue statistics (round 6); 0: rows of 15, one k-major launch per pair + a column-sum pass
     int gnn_merge = 1;         // runner: source and target clouds of a self-attention layer through ONE pass (round 5); needs
                                // 2 x pairs <= 4 clouds per launch, i.e. forward calls of one or two pairs (include/pcrcg.h)
     int edge_rows = 1;         // edge convolution: the row-parallel multi-cloud kernel (0: the per-cloud chunked kernel)

@@ -255,7 +255,7 @@ constexpr int C1_PARTS = 4, C1_BATCH = 6;
 __global__ void __launch_bounds__(256) k_kpconv_c1(
     const float* __restrict__ q_pts, int nq, const float* __restrict__ s_pts, int ns,
     const long long* __restrict__ idx, int H, int ld_idx, const float4* __restrict__ pk, const float* __restrict__ kp,
-    float extent, float* __restrict__ wf, float* __restrict__ inv_n) {
+    float extent, float* __restrict__ wf, float* __restrict__ inv_n, int ld_wf) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int part = t & (C1_PARTS - 1);
     const int qraw = t / C1_PARTS;
@@ -310,7 +310,8 @@ __global__ void __launch_bounds__(256) k_kpconv_c1(
     if (qraw >= nq) return;
 #pragma unroll
     for (int k = 0; k < K; ++k)
-        if ((k & (C1_PARTS - 1)) == part) wf[(long)q * K + k] = acc[k];
+        if ((k & (C1_PARTS - 1)) == part) wf[(long)q * ld_wf + k] = acc[k];
+    if (ld_wf > K && part == C1_PARTS - 1) wf[(long)q * ld_wf + K] = 0.f;      // rows of 16 floats: the contraction's k-steps are whole
     if (part == 0) inv_n[q] = 1.0f / (float)(npos > 1 ? npos : 1);
 }
 
@@ -428,7 +429,7 @@ int pcrcg_kpconv_aggregate(const float* q_pts, int nq, const float* s_pts, int n
                            int h, int ld_idx, const float* x, int cin, const float* kp, float extent,
                            float* wf, float* inv_n, void* ws, size_t ws_bytes, void* stream) {
     return kpconv_aggregate_rows(q_pts, nq, s_pts, ns, idx, h, ld_idx, x, cin, kp, extent, wf, inv_n, ws, ws_bytes,
-                                 as_stream(stream), true, true);
+                                 as_stream(stream), true, true, 0);
 }
 
 // The bf16 feature-storage variant of pcrcg_kpconv_aggregate: x stays fp32 at the boundary; `x_bf16` ([ns, cin] u16
@@ -450,8 +451,8 @@ namespace pcrcg {
 // (a row chunk whose wf the contraction reads back from L2 / Infinity Cache right away)
 int kpconv_aggregate_rows(const float* q_pts, int nq, const float* s_pts, int ns, const int64_t* idx, int h, int ld_idx,
                           const float* x, int cin, const float* kp, float extent, float* wf, float* inv_n, void* ws,
-                          size_t ws_bytes, hipStream_t st, bool pack, bool stream_out) {
-    PCRCG_CHECK_ARG(nq >= 0 && ns >= 0 && h >= 1 && ld_idx >= h && cin >= 1);
+                          size_t ws_bytes, hipStream_t st, bool pack, bool stream_out, int c1_ld) {
+    PCRCG_CHECK_ARG(nq >= 0 && ns >= 0 && h >= 1 && ld_idx >= h && cin >= 1 && (c1_ld == 0 || c1_ld == K || c1_ld == K + 1));
     PCRCG_CHECK_ARG(extent > 0.0f);
     if (nq == 0) return PCRCG_OK;
     PCRCG_CHECK_ARG(q_pts && s_pts && idx && x && kp && wf && inv_n && ws);
@@ -471,7 +472,7 @@ int kpconv_aggregate_rows(const float* q_pts, int nq, const float* s_pts, int ns
         KpProfScope prof_scope(st, nq, h, cin, 0, 0);
         hipExtLaunchKernelGGL(k_kpconv_c1, dim3((int)(((long)nq * C1_PARTS + 255) / 256)), dim3(256), 0, st, prof_scope.a,
                               prof_scope.b, 0, q_pts, nq, s_pts, ns, idx_ll, h, ld_idx, (const float4*)pk, kp, extent, wf,
-                              inv_n);
+                              inv_n, c1_ld > 0 ? c1_ld : K);
         PCRCG_CHECK_LAUNCH();
         return PCRCG_OK;
     }

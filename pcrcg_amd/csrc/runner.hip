@@ -392,11 +392,17 @@ void kpconv(Ctx& c, const Batches& B, const pcrcg_block& blk, const Mat& x, cons
         wsb[g] = pcrcg_kpconv_ws_bytes(ns[g]);
         ws[g] = (packed_ws && packed_ws[g]) ? packed_ws[g] : c.raw(wsb[g]);
     }
-    const int kk = PCRCG_KPOINTS * cin;
+    // cin = 1 (the first layer of the geometry-only configurations) with a K-contiguous weight copy: that copy has rows of 16
+    // floats (the 16th zero, pcrcg_amd/runner.py) and the gather kernel writes wf in rows of 16 -- whole k-steps, so the
+    // contraction is the grouped fp16 A B^T product with the statistics in its epilogue like every other layer's (round 6;
+    // before: one k-major six-product launch per pair and a column-sum pass over its output)
+    const bool c1_16 = cin == 1 && blk.kp_wt != nullptr && debug_opts().c1_rows16 != 0;
+    const float* const kp_wt = (cin == 1 && !c1_16) ? nullptr : blk.kp_wt;     // (cin = 1: the copy is the 16-float form or nothing)
+    const int kk = c1_16 ? 16 : PCRCG_KPOINTS * cin;
     // bf16 feature storage (pcrcg_model.feature_bf16): the gathers read a bf16 copy of x and wf is bf16 in HBM -- half
     // the bytes of the two streams that bound the encoder; the contraction takes wf as the (single-term) bf16 operand
     // against the exact three-term split of the fp32 weights, fp32 accumulate and fp32 output.
-    if (c.bf16 && blk.kp_wt && cin % 32 == 0) {
+    if (c.bf16 && kp_wt && cin % 32 == 0) {
         for (int g = 0; g < c.G; ++g) {
             const pcrcg_batch& b = *B.b[g];
             void* xb = c.raw(sizeof(unsigned short) * (size_t)(ns[g] > 0 ? ns[g] : 1) * cin);
@@ -404,7 +410,7 @@ void kpconv(Ctx& c, const Batches& B, const pcrcg_block& blk, const Mat& x, cons
             if (c.live()) {
                 c.check(pcrcg_kpconv_aggregate_bf16(q[g], nq[g], b.points[l], ns[g], tab[g]->idx, tab[g]->cols, tab[g]->ld, xin.p[g],
                                                     cin, blk.kp, blk.extent, xb, wfb, inv_n[g], ws[g], wsb[g], c.st));
-                c.check(gemm_bf16a_bt_colstats(wfb, kk, blk.kp_wt, kk, y.p[g], y.ld, nq[g], y.cols, kk, inv_n[g], nullptr,
+                c.check(gemm_bf16a_bt_colstats(wfb, kk, kp_wt, kk, y.p[g], y.ld, nq[g], y.cols, kk, inv_n[g], nullptr,
                                                st ? st->partials[g] : nullptr, st ? st->bytes : 0, st ? &st->chunks[g] : nullptr,
                                                c.st, y.zeroed, st && st->sums));
             }
@@ -416,7 +422,11 @@ void kpconv(Ctx& c, const Batches& B, const pcrcg_block& blk, const Mat& x, cons
     if (c.live()) {
         for (int g = 0; g < c.G; ++g) {
             const pcrcg_batch& b = *B.b[g];
-            if (packed_ws && packed_ws[g] && xin.p[g] == x.p[g])
+            if (c1_16)
+                c.check(kpconv_aggregate_rows(q[g], nq[g], b.points[l], ns[g], tab[g]->idx, tab[g]->cols, tab[g]->ld, xin.p[g], cin,
+                                              blk.kp, blk.extent, wf.p[g], inv_n[g], ws[g], wsb[g], c.st, /*pack=*/true,
+                                              /*stream_out=*/true, 16));
+            else if (packed_ws && packed_ws[g] && xin.p[g] == x.p[g])
                 c.check(kpconv_aggregate_rows(q[g], nq[g], b.points[l], ns[g], tab[g]->idx, tab[g]->cols, tab[g]->ld, xin.p[g], cin,
                                               blk.kp, blk.extent, wf.p[g], inv_n[g], ws[g], wsb[g], c.st, /*pack=*/false,
                                               /*stream_out=*/true));
@@ -430,8 +440,8 @@ void kpconv(Ctx& c, const Batches& B, const pcrcg_block& blk, const Mat& x, cons
         // Infinity Cache between the two kernels -- isolated 3.50 vs 3.31 ms per forward with 48 MB chunks; inside the
         // engine 416 / 446 / 459 / 462 pairs/s with 16 / 32 / 64 / 120 MB chunks against 460-464 unchunked: the extra
         // launches cost more than the on-chip re-read saves.)
-        if (blk.kp_wt)
-            linear(c, wf, blk.kp_wt, kk, nullptr, y, st, inv_n);
+        if (kp_wt)
+            linear(c, wf, kp_wt, kk, nullptr, y, st, inv_n);
         else   // (descriptor without the K-contiguous weight copy: the plain entry point knows only the partials layout)
             for (int g = 0; g < c.G; ++g)
                 c.check(pcrcg_gemm_f32_colstats(wf.p[g], wf.ld, w, y.cols, 0, y.p[g], y.ld, nq[g], y.cols, kk, inv_n[g], nullptr,
@@ -443,6 +453,10 @@ void kpconv(Ctx& c, const Batches& B, const pcrcg_block& blk, const Mat& x, cons
 
 // input channels of the block's KPConv as the gather kernel sees them (padded to a multiple of 4)
 int kp_cin(const pcrcg_block& blk, const Mat& x) { return (blk.kp_w_pad && blk.cin_pad > x.cols) ? blk.cin_pad : x.cols; }
+// length of a wf row (the contraction's K)
+int kp_k(const pcrcg_block& blk, const Mat& x) {
+    return (x.cols == 1 && blk.kp_wt && debug_opts().c1_rows16) ? 16 : PCRCG_KPOINTS * kp_cin(blk, x);
+}
 
 void out_rows(const Ctx& c, const Batches& B, const pcrcg_block& blk, int* rows) {
     for (int g = 0; g < GMAX; ++g)
@@ -455,7 +469,7 @@ Mat simple_block(Ctx& c, const Batches& B, const pcrcg_block& blk, const Mat& x)
     out_rows(c, B, blk, nq);
     Mat y = c.mat(nq, blk.mid_dim);
     const size_t m = c.mark();
-    Mat t = c.gemm_out(nq, y.cols, PCRCG_KPOINTS * kp_cin(blk, x));
+    Mat t = c.gemm_out(nq, y.cols, kp_k(blk, x));
     Stat ts = stat_buffer(c, nq, t.cols);
     kpconv(c, B, blk, x, t, &ts);
     norm_act(c, t, 0.1f, y, &ts);

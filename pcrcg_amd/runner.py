@@ -146,7 +146,7 @@ class Runner:
         """kp_w: the weights as stored, [15, cin, cout].  kp_w_pad: input channels zero-padded to a multiple of 4
         when cin is not one (the 129-channel PCR-CG input), else NULL.  kp_wt: K-contiguous copy
         [cout, 15*cin_eff] of whichever of the two the gather kernel's output matches -- the contraction then is
-        a C = A @ B^T product with both operands k-contiguous."""
+        a C = A @ B^T product with both operands k-contiguous.  cin = 1: [cout, 16], the 16th column zero."""
         cin = kp.in_channels
         blk.kp_w = self._w(kp.weights.data)
         w = kp.weights.data
@@ -158,7 +158,14 @@ class Runner:
             w[:, :cin].copy_(kp.weights.data)
             blk.kp_w_pad, blk.cin_pad = self._w(w), cp
         k = w.shape[0] * w.shape[1]
-        blk.kp_wt = self._w(w.reshape(k, kp.out_channels).t()) if k % 4 == 0 else None
+        if cin == 1:
+            # the first layer of the geometry-only configurations: rows of 16 floats (15 kernel points + a zero), so that its
+            # contraction is the grouped A B^T product with the statistics in the epilogue like every other layer's
+            w16 = torch.zeros((16, kp.out_channels), dtype=torch.float32, device=w.device)
+            w16[:15].copy_(w.reshape(15, kp.out_channels))
+            blk.kp_wt = self._w(w16.t())
+        else:
+            blk.kp_wt = self._w(w.reshape(k, kp.out_channels).t()) if k % 4 == 0 else None
 
     def _fill_block(self, blk, mod):
         if isinstance(mod, SimpleBlock):
