@@ -81,22 +81,26 @@ int wait_mode() {
 }
 
 // words src[0..n) (+ src2[0..n2)) -> h_scratch[1..]; returns when they are there
-int fetch_(int* h_scratch, const int* src, int n, const int* src2, int n2, hipStream_t st);
-int fetch(int* h_scratch, const int* src, int n, const int* src2, int n2, hipStream_t st) {
-    if (!g_trace.on) return fetch_(h_scratch, src, n, src2, n2, st);
+// (`enqueue`: the stream's enqueue lock held by the caller, released once the transfer is in the stream, before the wait)
+int fetch_(int* h_scratch, const int* src, int n, const int* src2, int n2, hipStream_t st, std::unique_lock<std::mutex>* enqueue);
+int fetch(int* h_scratch, const int* src, int n, const int* src2, int n2, hipStream_t st,
+          std::unique_lock<std::mutex>* enqueue = nullptr) {
+    if (!g_trace.on) return fetch_(h_scratch, src, n, src2, n2, st, enqueue);
     const double t0 = now_us();
-    const int rc = fetch_(h_scratch, src, n, src2, n2, st);
+    const int rc = fetch_(h_scratch, src, n, src2, n2, st, enqueue);
     g_trace.wait += now_us() - t0;      // (racy across threads: a tuning aid)
     g_trace.waits += 1;
     return rc;
 }
-int fetch_(int* h_scratch, const int* src, int n, const int* src2, int n2, hipStream_t st) {
+int fetch_(int* h_scratch, const int* src, int n, const int* src2, int n2, hipStream_t st, std::unique_lock<std::mutex>* enqueue) {
     const int mode = wait_mode();
+    auto let_go = [&] { if (enqueue && enqueue->owns_lock()) enqueue->unlock(); };
     if (mode == 2) {
         volatile int* flag = h_scratch;
         const int tag = (*flag & 0x7fffffff) + 1;
         hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, st, h_scratch, src, n, src2, n2, tag);
         PCRCG_CHECK_LAUNCH();
+        let_go();
         long spins = 0;
         while (*flag != tag) {
             if (++spins > 64) sched_yield();
@@ -111,11 +115,13 @@ int fetch_(int* h_scratch, const int* src, int n, const int* src2, int n2, hipSt
         hipEvent_t ev;
         PCRCG_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         hipError_t e = hipEventRecord(ev, st);
+        let_go();
         if (e == hipSuccess) e = hipEventSynchronize(ev);
         (void)hipEventDestroy(ev);
         PCRCG_CHECK_HIP(e);
     } else {
-        PCRCG_CHECK_HIP(hipStreamSynchronize(st));
+        let_go();
+        PCRCG_CHECK_HIP(hipStreamSynchronize(st));      // (waits for everything in the stream: a later call's chain too)
     }
     return PCRCG_OK;
 }
@@ -196,9 +202,28 @@ static void level_caps(int n0, const pcrcg_pyramid_cfg* cfg, int* cap) {
     }
 }
 
+// Builders on several host threads may share ONE stream (the pair engine's pipelined front end): a call holds the stream's
+// enqueue lock while it enqueues its chain and lets go of it before it waits for its round trip, so the chains stay whole
+// (one after the other in the stream, never interleaved) while one call's wait overlaps the next call's enqueue.
+struct EnqueueLocks {
+    std::mutex mu;
+    hipStream_t key[16];
+    std::mutex lock[16];
+    int n = 0;
+    std::mutex* of(hipStream_t st) {
+        std::lock_guard<std::mutex> g(mu);
+        for (int i = 0; i < n; ++i)
+            if (key[i] == st) return &lock[i];
+        if (n == 16) return &lock[15];
+        key[n] = st;
+        return &lock[n++];
+    }
+};
+static EnqueueLocks g_enqueue;
+
 static int pyramid_run(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg* cfg, Arena& A,
                        int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status, pcrcg_pyramid_restore* deferred,
-                       hipStream_t st) {
+                       hipStream_t st, std::unique_lock<std::mutex>* enqueue = nullptr) {
     const int L = cfg->n_levels;
     const bool dry = A.dry;
     const bool want_ties = cfg->tie_order != 0;
@@ -394,7 +419,7 @@ static int pyramid_run(const Parts& in, int n0, int nb, const pcrcg_pyramid_cfg*
     // ---- the ONE round trip of the call: column counts, capacity status, rows holding ties, row counts, cloud lengths ----
     const int nt = (int)tables.size();
     const int meta_words = MS * max_tables + L + 1;
-    PCRCG_PROPAGATE(fetch(h_scratch, metas, meta_words, lens_all, L * nb, st));
+    PCRCG_PROPAGATE(fetch(h_scratch, metas, meta_words, lens_all, L * nb, st, enqueue));
     // whatever follows on `st` (the reorder step, the caller's readers, a second attempt in the same arena) comes after the forests
     if (forests_done) PCRCG_CHECK_HIP(hipStreamWaitEvent(st, forests_done, 0));
     const int* hm = h_scratch + 1;
@@ -591,7 +616,8 @@ static int pyramid_build_checked(const Parts& in, int n0, int nb, const pcrcg_py
     Arena A(ws, ws_bytes, false);
     hipStream_t st = as_stream(stream);
     const double t0 = g_trace.on ? now_us() : 0.0, w0 = g_trace.wait;
-    const int rc = pyramid_run(in, n0, nb, cfg, A, h_scratch, out, h_lengths, h_status, deferred, st);
+    std::unique_lock<std::mutex> enqueue(*g_enqueue.of(st));
+    const int rc = pyramid_run(in, n0, nb, cfg, A, h_scratch, out, h_lengths, h_status, deferred, st, &enqueue);
     if (g_trace.on) { g_trace.enq += now_us() - t0 - (g_trace.wait - w0); g_trace.calls += 1; }
     if (rc == PCRCG_EWORKSPACE)
         if (A.off > ws_bytes) set_error("pcrcg_pyramid_build: arena too small (%zu needed so far, %zu given): size it with pcrcg_pyramid_ws_bytes for this cfg", A.off, ws_bytes);

@@ -103,6 +103,9 @@ class PairStreams:
                            os.environ.get("PCRCG_ENGINE_PIPES", "auto") if pipes is None else pipes)
         self.front = self.fronts[0]
         nf = max(1, int(front_threads))
+        # overlapped builds: the front threads share one stream; pcrcg_pyramid_build keeps the chains whole (the stream's
+        # enqueue lock) and one thread's round trip + host work overlaps the next chain
+        self._overlap = nf > 1 and len(self.fronts) == 1 and not self.sides
         # every front thread owns a ring of builders (arena + pinned scratch each)
         self.up_nearest = bool(up_nearest)
         self._pyr = [[NativePyramid(config, neighborhood_limits, tie_order, up_nearest=self.up_nearest)
@@ -328,10 +331,19 @@ class PairStreams:
                     claimed = True
                     pyr = self._pyr[f][a]
                     t1 = time.perf_counter()
+                    built = None
                     if k == 1:
                         # one pair: its tie-order restore step goes to the pair's model stream
                         b, arena, lens_h, slot, deferred = pyr.build(items[0][1], items[0][2], defer_restore=True)
                         batches = [b]
+                    elif self._overlap and len(sizes) == 1:
+                        # overlapped builds (two front threads, one stream): when build() returns, its round trip has seen
+                        # the chain through -- the tables are complete, nothing of this build is left in the front-end
+                        # stream, and what IS in that stream by now is the other thread's next chain: no event from it.
+                        # The restore step goes to the model stream of the build's one forward job.
+                        batches, arena, lens_h, slot, deferred = pyr.build([it[1] for it in items], [it[2] for it in items],
+                                                                           group=2, defer_restore=True)
+                        built = False
                     else:
                         # several pairs stacked into ONE kernel chain (the chain is latency-bound: k pairs cost little
                         # more than one); the restore step covers all of them and runs here
@@ -339,8 +351,9 @@ class PairStreams:
                         batches, arena, lens_h, slot = pyr.build([it[1] for it in items], [it[2] for it in items], group=2)
                         deferred = None
                     self._stat(arena_wait_s=t1 - t0, build_s=time.perf_counter() - t1, pairs=k, builds=1)
-                    built = torch.cuda.Event()
-                    built.record(front)
+                    if built is None:
+                        built = torch.cuda.Event()
+                        built.record(front)
                 start = 0
                 for j, n in enumerate(sizes):
                     seqs = [it[0] for it in items[start:start + n]]
@@ -390,7 +403,8 @@ class PairStreams:
             _, b, arena, built, pyr, slot, deferred, f, a, (lens_h, imgs) = item
             try:
                 with torch.cuda.stream(stream), torch.no_grad():
-                    stream.wait_event(built)
+                    if built:
+                        stream.wait_event(built)
                     t0 = time.perf_counter()
                     # the reference's order inside tie groups (KD-forest + reorder), here rather than on the front-end
                     # stream: that stream's serial kernel chain is the pipeline's bottleneck, the model streams have slack
