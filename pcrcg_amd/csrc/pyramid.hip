@@ -557,19 +557,25 @@ int pcrcg_stream_pipe_classes(void* const* streams, int n, int* cls, void* scrat
     }
     int reps[8], nrep = 0;
     auto shares = [&](int a, int b, bool* out) -> int {      // does streams[b] wait for a dispatch on streams[a]?
-        int votes = 0;
-        for (int rep = 0; rep < 2; ++rep) {
+        // best of three, and a trial counts only if the host got from the big launch to the tiny one in time (a preempted
+        // host thread finds the dispatch over and would report "another dispatcher")
+        int yes = 0, no = 0;
+        for (int trial = 0; trial < 10 && yes < 2 && no < 2; ++trial) {
+            const double launch = now_us();
             hipLaunchKernelGGL(k_probe_many, dim3(blocks), dim3(64), 0, as_stream(streams[a]), sink, 64);
             const double start = now_us();
             while (now_us() - start < 150.0) {}
             const double a0 = now_us();
             hipLaunchKernelGGL(k_probe_tiny, dim3(1), dim3(64), 0, as_stream(streams[b]), sink);
+            const double a1 = now_us();
             PCRCG_CHECK_HIP(hipStreamSynchronize(as_stream(streams[b])));
             const double d = now_us() - a0;
             PCRCG_CHECK_HIP(hipDeviceSynchronize());
-            votes += d > (big_us - 150.0) / 3.0 ? 1 : 0;
+            if (a1 - launch > 0.6 * big_us) continue;
+            (d > (big_us - 150.0) / 3.0 ? yes : no) += 1;
         }
-        *out = votes == 2;
+        if (yes < 2 && no < 2) { set_error("pcrcg_stream_pipe_classes: the host is too busy for the probe's timing"); return PCRCG_ELAUNCH; }
+        *out = yes == 2;
         return PCRCG_OK;
     };
     for (int i = 0; i < n; ++i) {
