@@ -626,6 +626,11 @@ typedef struct pcrcg_pyramid_restore {
                                                     enqueued their builds -- they exist once `stream`'s work has passed */
     int* tie_status;                             /* device status word */
 } pcrcg_pyramid_restore;
+/* Threads: calls from several host threads are independent (arena, h_scratch and outputs are the caller's).  Calls that name
+ * the SAME stream hold that stream's enqueue lock while they enqueue their chain and release it before they wait for their
+ * round trip: the chains stay whole, one behind the other, and one call's wait overlaps the next call's enqueue (with
+ * `deferred` set nothing of a call is left in the stream when it returns; without it the restore step follows whatever
+ * another thread has enqueued meanwhile).  profiles/r06_ab_overlapped_builds.txt. */
 size_t pcrcg_pyramid_ws_bytes(int n0, int nb, const pcrcg_pyramid_cfg* cfg);
 int pcrcg_pyramid_build(const float* pts, int n0, const int* len, int nb, const pcrcg_pyramid_cfg* cfg, void* ws,
                         size_t ws_bytes, int* h_scratch, pcrcg_batch* out, int* h_lengths, int* h_status,
