@@ -174,6 +174,7 @@ struct DebugOpts {
     int fuse_norm = 1;         // runner: normalise-on-load inside the consuming product
     int fuse_pack = 1;         // runner: the normalisation that feeds a KPConv also packs its support records
     int fuse_upsample = 1;     // runner: nearest_upsample -> cat(skip) -> unary as two products into one output
+    int knock_tail = 0;        // MEASUREMENT AID (wrong results): resnet blocks of layers < knock_tail skip the shortcut product and its half of the closing pass -- the traffic a fused block tail would save
     int c1_rows16 = 1;         // runner: the first layer's (cin = 1) aggregate in rows of 16 floats, its contraction the grouped A B^T
                                // product with epilogue statistics (round 6); 0: rows of 15, one k-major launch per pair + a column-sum pass
     int gnn_merge = 1;         // runner: source and target clouds of a self-attention layer through ONE pass (round 5); needs

@@ -572,7 +572,9 @@ Mat resnet_block(Ctx& c, const Batches& B, const pcrcg_block& blk, const Mat& fe
                 c.check(pcrcg_gather_max(feats.p[g], feats.rows[g], feats.cols, t.idx, nq[g], t.cols, t.ld, sc.p[g], c.st));
             }
     }
-    if (blk.shortcut) {
+    if (blk.shortcut && blk.layer < debug_opts().knock_tail) {
+        norm_act(c, u2, 0.1f, y, &u2s);
+    } else if (blk.shortcut) {
         Mat s2 = c.gemm_out(nq, blk.out_dim, sc.cols);
         Stat s2s = stat_buffer(c, nq, blk.out_dim);
         linear(c, sc, blk.shortcut, sc.cols, nullptr, s2, &s2s);

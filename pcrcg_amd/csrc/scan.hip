@@ -213,7 +213,7 @@ const DebugName kDebugNames[] = {
     {"fuse_norm", &DebugOpts::fuse_norm}, {"fuse_pack", &DebugOpts::fuse_pack}, {"fuse_upsample", &DebugOpts::fuse_upsample}, {"gnn_merge", &DebugOpts::gnn_merge}, {"edge_rows", &DebugOpts::edge_rows}, {"att_mfma", &DebugOpts::att_mfma},
     {"radius_blocks", &DebugOpts::radius_blocks}, {"radius_eager_redo", &DebugOpts::radius_eager_redo},
     {"radius_cells", &DebugOpts::radius_cells}, {"kd_blocks", &DebugOpts::kd_blocks}, {"radius_prof", &DebugOpts::radius_prof},
-    {"pyr_wait", &DebugOpts::pyr_wait}, {"pyr_trace", &DebugOpts::pyr_trace}, {"pyr_morton", &DebugOpts::pyr_morton}, {"c1_rows16", &DebugOpts::c1_rows16}, {"att_tq", &DebugOpts::att_tq},
+    {"pyr_wait", &DebugOpts::pyr_wait}, {"pyr_trace", &DebugOpts::pyr_trace}, {"pyr_morton", &DebugOpts::pyr_morton}, {"c1_rows16", &DebugOpts::c1_rows16}, {"knock_tail", &DebugOpts::knock_tail}, {"att_tq", &DebugOpts::att_tq},
     {"kd_spin_limit", &DebugOpts::kd_spin_limit}, {"gemm_log", &DebugOpts::gemm_log}, {"x6_tile", &DebugOpts::x6_tile}, {"x6_order", &DebugOpts::x6_order}, {"x6_big", &DebugOpts::x6_big}, {"x6_h2", &DebugOpts::x6_h2}, {"train_side_stream", &DebugOpts::train_side_stream},
     {"x6_splitk", &DebugOpts::x6_splitk}, {"x6_t1", &DebugOpts::x6_t1}, {"x6_t2", &DebugOpts::x6_t2},
     {"gemm_tile", &DebugOpts::gemm_tile}, {"gemm_splitk", &DebugOpts::gemm_splitk},
