@@ -520,9 +520,9 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
     const int nfast = (vec_a && vec_b) ? (k_end - k_begin) / BK : 0;
     // Wait until only the other set's loads are in flight, then split this set into LDS.  `live` = 0 zeroes the tile
     // (the phantom second half of an odd tile count).
-    auto consume = [&](Item<ALAY>* qa, Item<BLAY>* qb, bool live, int k0) {
-        if constexpr (!(KNOCK & 1)) vm_wait<TILE_LOADS>();
-        else vm_wait<0>();
+    auto consume = [&](auto last, Item<ALAY>* qa, Item<BLAY>* qb, bool live, int k0) {
+        if constexpr (!(KNOCK & 1) && !decltype(last)::value) vm_wait<TILE_LOADS>();
+        else vm_wait<0>();                                                // the last tile: no other set in flight behind it
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) {
             if constexpr (ATERMS == 1) pin(qa[it].v[0]);
@@ -628,8 +628,9 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
                     }
             }
         };
-        auto consume_h = [&](Item<ALAY>* qa, Item<BLAY>* qb, bool live, int k0) {
-            vm_wait<TILE_LOADS>();
+        auto consume_h = [&](auto last, Item<ALAY>* qa, Item<BLAY>* qb, bool live, int k0) {
+            if constexpr (decltype(last)::value) vm_wait<0>();            // the last tile: no other set in flight behind it
+            else vm_wait<TILE_LOADS>();
 #pragma unroll
             for (int it = 0; it < A_ITERS; ++it) qa[it].hold();
             if constexpr (!ANORM) {
@@ -681,19 +682,30 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
         if (nfast > 0) {
             std::true_type fast;
             const int k_last = k_begin + (nfast - 1) * BK;
+            std::false_type more;
+            std::true_type last;
             load_tiles(fast, k_begin, ra[0], rb[0]);
             load_tiles(fast, min(k_begin + BK, k_last), ra[1], rb[1]);
-            for (int s = 0; s < nfast; s += 2) {
-                consume_h(ra[0], rb[0], true, k_begin + s * BK);
-                load_tiles(fast, min(k_begin + (s + 2) * BK, k_last), ra[0], rb[0]);
+            // Tiles s, s + 1 are consumed while s + 2, s + 3 are fetched -- as long as there ARE tiles to fetch: the last two
+            // tiles run outside the loop with nothing behind them (round 6; before, every product re-read its last tile
+            // twice as "prefetch": with K = 64 that was half of all tile loads of a kernel bound by its L1 fills).
+            int s = 0;
+            for (; s + 2 < nfast; s += 2) {
+                consume_h(more, ra[0], rb[0], true, k_begin + s * BK);
+                load_tiles(fast, k_begin + (s + 2) * BK, ra[0], rb[0]);
                 __syncthreads();
                 multiply_h();
-                consume_h(ra[1], rb[1], s + 1 < nfast, k_begin + (s + 1) * BK);
-                load_tiles(fast, min(k_begin + (s + 3) * BK, k_last), ra[1], rb[1]);
+                consume_h(more, ra[1], rb[1], true, k_begin + (s + 1) * BK);
+                load_tiles(fast, min(k_begin + (s + 3) * BK, k_last), ra[1], rb[1]);   // (an odd count: the phantom's load)
                 __syncthreads();
                 multiply_h();
             }
-            vm_wait<0>();
+            consume_h(more, ra[0], rb[0], true, k_begin + s * BK);
+            __syncthreads();
+            multiply_h();
+            consume_h(last, ra[1], rb[1], s + 1 < nfast, k_begin + (s + 1) * BK);
+            __syncthreads();
+            multiply_h();
         }
         // The range check costs the loop nothing: an operand at or beyond fp16's range became +-inf in BOTH of its terms
         // (h = inf, l = (x - inf) * 2^11 = -inf), and inf times anything -- zero included -- leaves inf or NaN in every
@@ -767,19 +779,27 @@ __global__ void __launch_bounds__((x6_threads<BM, BN>()), MINB) k_gemm_x6(const 
         // an odd tile count is rounded up with a zeroed phantom tile, and nothing is peeled.
         std::true_type fast;
         const int k_last = k_begin + (nfast - 1) * BK;
+        std::false_type more;
+        std::true_type last;
         load_tiles(fast, k_begin, ra[0], rb[0]);
         load_tiles(fast, min(k_begin + BK, k_last), ra[1], rb[1]);
-        for (int s = 0; s < nfast; s += 2) {
-            consume(ra[0], rb[0], true, k_begin + s * BK);
-            if constexpr (!(KNOCK & 1)) load_tiles(fast, min(k_begin + (s + 2) * BK, k_last), ra[0], rb[0]);   // tile s+2 into the freed set
+        int s = 0;
+        for (; s + 2 < nfast; s += 2) {              // (as in the fp16 loop: the last two tiles have nothing to prefetch behind them)
+            consume(more, ra[0], rb[0], true, k_begin + s * BK);
+            if constexpr (!(KNOCK & 1)) load_tiles(fast, k_begin + (s + 2) * BK, ra[0], rb[0]);   // tile s+2 into the freed set
             if constexpr (!(KNOCK & 32)) __syncthreads();
             multiply();
-            consume(ra[1], rb[1], s + 1 < nfast, k_begin + (s + 1) * BK);
+            consume(more, ra[1], rb[1], true, k_begin + (s + 1) * BK);
             if constexpr (!(KNOCK & 1)) load_tiles(fast, min(k_begin + (s + 3) * BK, k_last), ra[1], rb[1]);
             if constexpr (!(KNOCK & 32)) __syncthreads();
             multiply();
         }
-        vm_wait<0>();                                                     // the two unused trailing prefetches
+        consume(more, ra[0], rb[0], true, k_begin + s * BK);
+        if constexpr (!(KNOCK & 32)) __syncthreads();
+        multiply();
+        consume(last, ra[1], rb[1], s + 1 < nfast, k_begin + (s + 1) * BK);
+        if constexpr (!(KNOCK & 32)) __syncthreads();
+        multiply();
     }
     for (int s = nfast; s < nsteps; ++s) {       // k tail / unaligned operands: guarded loads hipcc counts itself
         std::false_type slow;
