@@ -41,7 +41,9 @@ def mini(golden_dir):
 
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,k", [(1, 1, 1), (37, 5, 19), (128, 64, 16), (763, 512, 7680), (3000, 34, 384),
-                                   (2000, 257, 1538), (60000, 64, 960), (381, 382, 512), (100, 1, 512)])
+                                   (2000, 257, 1538), (60000, 64, 960), (381, 382, 512), (100, 1, 512),
+                                   # one, two, three and five 32-wide k tiles: the pipelined loop's last two tiles run outside it
+                                   (500, 64, 32), (5000, 256, 64), (700, 96, 96), (900, 128, 160), (300, 64, 100)])
 def test_gemm_vs_torch(cuda, m, n, k):
     g = torch.Generator().manual_seed(m * 7 + n)
     a = torch.randn(m, k, generator=g)
