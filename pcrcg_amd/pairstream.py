@@ -6,7 +6,11 @@ libpcrcg_hip.so that releases the GIL.
                 ONCE, at the end of the chain, for the row and column counts).  One stream on purpose: the front-end
                 kernels are latency-bound and partly persistent (the KD-forest's task queue); several pyramids side
                 by side, or pyramids on the model streams, slow everything down (measured: every pair on its own
-                stream, 4 streams: 217 pairs/s; this topology: see DESIGN.md).
+                stream, 4 streams: 217 pairs/s; this topology: see DESIGN.md).  F = 1 by default.  F > 1 on the one stream =
+                OVERLAPPED builds: the library keeps the chains whole (a per-stream enqueue lock, released before a call
+                waits for its round trip), so one thread's host turn overlaps the next chain and the stream never
+                stands idle between chains -- which buys nothing (585 against 591 pairs/s): the rate is the chip's, not
+                the front thread's (profiles/r06_ab_overlapped_builds.txt).
   model stage   M threads, one HIP stream each, enqueue the forwards (pcrcg_kpfcnn_forward) of pairs k, k+M, ...;
                 the coarse levels of one pair overlap the fine levels of the next.  M = 3: a fourth stream with
                 forwards is slower again on this GPU.
