@@ -945,7 +945,10 @@ def main():
                          "algorithmic_bytes_per_pair": int(k_bytes / max(args.steps * R, 1)),
                          "note": "durations are the kernels' own start/stop events (hipExtLaunchKernel); achieved/frac "
                                  "are measured inside the timed regions, where several HIP streams share the GPU; `isolated` "
-                                 "is the same launches run alone right after them",
+                                 "is the same launches run alone right after them.  Beside other streams the event pair of a "
+                                 "launch also spans its wait for the dispatcher: it reads 10-25 % above rocprofv3's kernel "
+                                 "duration for the same launches (profiles/*_kernel_stats.csv states both populations), so "
+                                 "frac is the conservative figure; alone the two agree",
                          "isolated": {"achieved": round(iso_gbs, 1), "frac": round(iso_gbs / HBM_PEAK_GBS, 4),
                                       "avg_launch_us": round(iso_ms * 1e3 / max(len(iso), 1), 2),
                                       "per_launch": iso_rows},
