@@ -175,7 +175,12 @@ class PairStreams:
         cands = [torch.cuda.Stream(device=dev) for _ in range(12)]
         fcands = cands if front_priority == 0 else [torch.cuda.Stream(device=dev, priority=front_priority) for _ in range(4)]
         try:
-            cls = ops.stream_pipe_classes(cands + (fcands if fcands is not cands else []))
+            try:
+                cls = ops.stream_pipe_classes(cands + (fcands if fcands is not cands else []))
+            except RuntimeError:        # other work on the GPU while the probe ran (an engine just closed, another thread's kernels):
+                torch.cuda.synchronize(dev)         # its timing means nothing then -- once more on a drained device
+                time.sleep(0.05)
+                cls = ops.stream_pipe_classes(cands + (fcands if fcands is not cands else []))
         except RuntimeError as e:       # the probe is a measurement: if it cannot be made, run as rounds 1-5 did and say so
             import warnings
             warnings.warn("pcrcg_amd.PairStreams: could not classify streams by dispatcher (%s); taking them in creation order" % e,
