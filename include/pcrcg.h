@@ -67,7 +67,7 @@ int pcrcg_abi_version(void);
  *   pyr_morton=0   1: MEASUREMENT AID -- every subsampled level sorted along a Z curve before anything reads it; the level rows
  *                  are then not the reference's (a knock-out that prices an internal spatial order: csrc/morton_knock.hip)
  *   att_tq=16                                                                              attention tile
- *   gemm_log=0 x6_tile=-1 x6_splitk=0 x6_t1=32 x6_t2=128 x6_order=-1 x6_big=0 x6_h2=1 gemm_tile=-1 gemm_splitk=0 gemm_split_target=768   GEMM plans
+ *   gemm_log=0 x6_tile=-1 x6_splitk=0 x6_t1=1 x6_t2=1 x6_order=-1 x6_big=0 x6_h2=1 gemm_tile=-1 gemm_splitk=0 gemm_split_target=768   GEMM plans
  *   train_side_stream=1 bwd_mfma=1                                                         train-step backward
  *   deterministic=0    1: bit-reproducible results -- no floating-point atomics (split-K partial tiles stored and added in
  *                      split order by a second pass, InstanceNorm statistics from stored partials, fixed-point scatter sums
@@ -329,10 +329,11 @@ int pcrcg_gemm_get_mode(void);
  * clears the counters afterwards.  out2 may be NULL (reset only). */
 int pcrcg_gemm_redo_counts(unsigned long long* out2, int reset);
 /* Declares that the CALLING HOST THREAD enqueues its network calls beside other streams that keep the GPU busy (on = 1;
- * 0 takes it back; per thread, default off).  The products of such a thread are planned with far fewer split-K slices:
+ * 0 takes it back; per thread, default off).  The products of such a thread are planned WITHOUT split-K:
  * alone on the GPU a small product is split until ~200 workgroups exist, which fills the chip; beside other streams
- * their kernels fill the idle CUs anyway and every slice only costs fp32 atomics and a zeroed output (+4.5 % pairs/s in
- * the four-stream pair engine, whose model threads make this call; -1.9 % for a forward that does run alone).  Results
+ * their kernels fill the idle CUs anyway and every slice only costs fp32 atomics, a zeroed output and the column statistics
+ * its epilogue could have left (+5 % pairs/s in the four-stream pair engine, whose model threads make this call; -1.9 %
+ * for a forward that does run alone; round 4-5: a few slices, x6_t1 / x6_t2 = 32 / 128; round 6: none, 1 / 1).  Results
  * differ by summation order only.  No reference counterpart (ref:main.py:15 one process, one stream). */
 void pcrcg_thread_shares_gpu(int on);
 

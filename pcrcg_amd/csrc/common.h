@@ -193,7 +193,7 @@ struct DebugOpts {
     int att_tq = 16;           // attention kernel: queries per workgroup (8 or 16)
     int kd_spin_limit = 0;     // KD-forest task queue: spin bound (0: default)
     int gemm_log = 0;          // print every GEMM's shape and grid
-    int x6_tile = -1, x6_splitk = 0, x6_t1 = 32, x6_t2 = 128, x6_order = -1, x6_big = 0, x6_h2 = 1;   // split-bf16 GEMM plan overrides
+    int x6_tile = -1, x6_splitk = 0, x6_t1 = 1, x6_t2 = 1, x6_order = -1, x6_big = 0, x6_h2 = 1;   // split-bf16 GEMM plan overrides
     int train_side_stream = 1; // train-step backward: weight-gradient products on a second stream
     int gemm_tile = -1, gemm_splitk = 0, gemm_split_target = 768;        // fp32-MFMA GEMM plan overrides
     // deterministic=1: results that are a function of the inputs alone, bit for bit, run after run -- no floating-point

@@ -977,11 +977,14 @@ static X6Plan x6_plan_for(int pick, int m, int n, int k, bool reduce_rows) {
     // Split targets.  Alone on the GPU a product wants ~200 workgroups before it stops splitting (and 1024 while K is very
     // long).  Beside the pair engine's other streams the idle CUs of a small product are filled by their kernels anyway,
     // while every split costs fp32 atomics and a zeroed output: a host thread that has declared the GPU shared
-    // (pcrcg_thread_shares_gpu) gets the targets 32 / 128 -- +4.5 % in the engine (483 -> 505 pairs/s; no splitting at all:
-    // 506), where the same targets cost a forward running alone 1.9 % (3.24 -> 3.30 ms) and the train step 4 % (15.4 ->
-    // 16.1 ms).  dW = X^T dY (reduce_rows: a handful of tiles, K = all points) always keeps the lone-stream targets.
+    // (pcrcg_thread_shares_gpu) does not split at all (targets 1 / 1).  Round 4: 32 / 128, +4.5 % in the engine (483 -> 505
+    // pairs/s; no splitting at all: 506), where the same targets cost a forward running alone 1.9 % (3.24 -> 3.30 ms) and the
+    // train step 4 % (15.4 -> 16.1 ms).  Round 6, after the k-loop stopped loading behind its last tile: 577.0 with 32 / 128,
+    // 581 with 16 / 64, 582.7-583.2 with no splits (574 with 64 / 256; profiles/r06_ab_splitk_targets.txt) -- and an unsplit
+    // product leaves its column statistics in its epilogue and needs neither atomics nor a zeroed output.
+    // dW = X^T dY (reduce_rows: a handful of tiles, K = all points) always keeps the lone-stream targets.
     int t1 = 200, t2 = 1024;
-    if (gemm_x6_shared() && !reduce_rows) { t1 = debug_opts().x6_t1; t2 = debug_opts().x6_t2; }   // tuning aids (defaults 32 / 128)
+    if (gemm_x6_shared() && !reduce_rows) { t1 = debug_opts().x6_t1; t2 = debug_opts().x6_t2; }   // tuning aids (defaults 1 / 1: no splits)
     while ((long)p.gx * p.gy * splits < t1 && k / (2 * splits) >= 256 && splits < max_splits) splits *= 2;
     while ((long)p.gx * p.gy * splits < t2 && k / splits > 1024 && splits < max_splits) splits *= 2;
     if (debug_opts().x6_splitk > 0) splits = debug_opts().x6_splitk;        // tuning aid

@@ -393,7 +393,7 @@ class PairStreams:
     def _serve_model(self, m):
         torch.cuda.set_device(self.device)
         from . import _lib
-        _lib.lib().pcrcg_thread_shares_gpu(1)      # this thread's forwards run beside the other streams': fewer split-K slices
+        _lib.lib().pcrcg_thread_shares_gpu(1)      # this thread's forwards run beside the other streams': no split-K
         stream, job = self.models[m], m
         while True:
             t0 = time.perf_counter()
