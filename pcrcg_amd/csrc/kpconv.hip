@@ -151,7 +151,13 @@ __global__ void __launch_bounds__(kWavesPerBlock * 64) k_kpconv_mfma(
             const float4 sp = pk[ic];                                      // coordinates + row-positive flag
             const float px = sp.x - qx, py = sp.y - qy, pz = sp.z - qz;
             if (chunk == 0) npos += __popcll(__ballot(i >= 0 && sp.w != 0.f));
-            const int hn = H - hc < 64 ? H - hc : 64;
+            // the table pads a short row with shadow entries at its END: the groups behind the last real neighbour would
+            // load (a clamped row), take 15 square roots and multiply by zero weights -- the loop stops at the last real one
+            // (round 6; a row usually holds fewer neighbours than the table is wide: the limits sit at a high percentile)
+            const unsigned long long real_lanes = __ballot(i >= 0);
+            const int hn_all = H - hc < 64 ? H - hc : 64;
+            const int hn_real = real_lanes ? 64 - (int)__clzll(real_lanes) : 0;
+            const int hn = hn_real < hn_all ? hn_real : hn_all;
             // STEPS groups of 4 neighbours at a time: all their row reads are issued before the first
             // MFMA needs one (STEPS x NB KiB in flight per wavefront)
             for (int h0 = 0; h0 < hn; h0 += 4 * STEPS) {
