@@ -752,6 +752,15 @@ struct ReorderJobs {
 };
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// the first 32 bytes of a node (left, right, divfeat, divlow, divhigh, child1, child2, is_root) through the SCALAR cache: the
+// walk below is one dependent node fetch after the other, the node is the same for all lanes, and nothing in this kernel
+// writes nodes (the forest kernel did, before this launch)
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i32x8 node_head(const KdNode* p) {
+    i32x8 r;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    return r;
+}
 __device__ __forceinline__ float unif(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
 __global__ void __launch_bounds__(kReorderWaves * 64) k_reorder(const ReorderJobs jobs, int W, int* __restrict__ status) {
@@ -811,10 +820,10 @@ __global__ void __launch_bounds__(kReorderWaves * 64) k_reorder(const ReorderJob
             const float mind = unif(st_min[sp]);
             d0 = unif(st_d[3 * sp]); d1 = unif(st_d[3 * sp + 1]); d2 = unif(st_d[3 * sp + 2]);
             for (;;) {                                                     // searchLevel :1348-1410
-                const KdNode* nd = &v.nodes[node];
-                const int feat = uni(nd->divfeat);
+                const i32x8 nh = node_head(&v.nodes[node]);
+                const int feat = nh[2];
                 if (feat < 0) {
-                    const int l = uni(nd->left), r = uni(nd->right);
+                    const int l = nh[0], r = nh[1];
                     for (int base = l; base < r; base += 64) {             // the leaf's points in vind order
                         const int i = base + lane;
                         bool hit = false;
@@ -836,8 +845,8 @@ __global__ void __launch_bounds__(kReorderWaves * 64) k_reorder(const ReorderJob
                     break;
                 }
                 const float val = feat == 0 ? vx : (feat == 1 ? vy : vz);
-                const float divlow = unif(nd->divlow), divhigh = unif(nd->divhigh);
-                const int child1 = uni(nd->child1), child2 = uni(nd->child2);
+                const float divlow = __int_as_float(nh[3]), divhigh = __int_as_float(nh[4]);
+                const int child1 = nh[5], child2 = nh[6];
                 const float diff1 = val - divlow, diff2 = val - divhigh;
                 int best, other;
                 float cut_dist;
